@@ -1,0 +1,609 @@
+"""CPU oracle for the FovVideoVDP per-frame visible-difference path.
+
+THIS IS TEST INFRASTRUCTURE, NOT PRODUCT CODE.  It is a numpy (fp32) restatement of the reference algorithm
+(gfxdisp/FovVideoVDP v1.2.3, PyTorch path) written from its behaviour; every function cites the reference
+file:line it follows (paths relative to the reference root).  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may import it.  The product (`fovvideovdp_amd`) never does.
+
+Parity status: PINNED.  `tools/gen_golden.py` imports the real reference in the build container and stores its
+stage captures under `tests/golden/`; `tests/test_oracle_golden.py` checks this file against them (<=1e-6
+relative per stage, 1e-5 on JOD) together with the README known answer 8.693 JOD (README.md:138).
+
+All arithmetic is float32 unless stated; quirks of the reference that change numbers are reproduced on purpose:
+  * `gausspyr_reduce` picks the right-edge fix-up of the horizontal pass by the parity of the ROW count
+    (pyfvvdp/fvvdp_lpyr_dec.py:202),
+  * `+1e-6` in the LUT interpolation denominator (pyfvvdp/interp.py:16),
+  * `circular` temporal padding never places frame 0 in the first window (pyfvvdp/fvvdp.py:267).
+"""
+import json
+import math
+import os
+
+import numpy as np
+
+_F = np.float32
+_DATA = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fovvideovdp_amd", "data")
+
+
+# --------------------------------------------------------------------------------------------------------
+# data (calibration constants, display models, CSF LUT)
+# --------------------------------------------------------------------------------------------------------
+def load_defaults():
+    with open(os.path.join(_DATA, "defaults.json"), "r") as f:
+        return json.load(f)
+
+
+def cache_key(omega, sigma, k_cm):
+    """pyfvvdp/fvvdp.py:502-503"""
+    return ("o%g_s%g_cm%f" % (omega, sigma, k_cm)).replace("-", "n").replace(".", "_")
+
+
+def load_lut(omega, sigma, k_cm):
+    """pyfvvdp/fvvdp.py:505-518 (the .mat content is shipped as fovvideovdp_amd/data/csf_lut.npz)."""
+    z = np.load(os.path.join(_DATA, "csf_lut.npz"))
+    key = cache_key(omega, sigma, k_cm)
+    names = [n for n in z.files if n.startswith(key + "/")]
+    if not names:
+        raise RuntimeError("Error: cache file for %s not found" % key)
+    return {n.split("/", 1)[1]: z[n].astype(_F) for n in names}
+
+
+# --------------------------------------------------------------------------------------------------------
+# display photometry  (pyfvvdp/fvvdp_display_model.py)
+# --------------------------------------------------------------------------------------------------------
+class Photometry:
+    """fvvdp_display_photo_eotf, pyfvvdp/fvvdp_display_model.py:114-176 (+ loader :52-98)."""
+
+    def __init__(self, Y_peak, contrast=1000, EOTF="sRGB", gamma=2.2, E_ambient=0, k_refl=0.005):
+        self.Y_peak, self.contrast, self.EOTF = Y_peak, contrast, EOTF
+        self.gamma, self.E_ambient, self.k_refl = gamma, E_ambient, k_refl
+
+    @classmethod
+    def load(cls, display_name, models=None):
+        models = models if models is not None else load_defaults()["display_models.json"]
+        if display_name not in models:
+            raise RuntimeError('Unknown display model: "' + display_name + '"')
+        m = models[display_name]
+        Y_peak = m["max_luminance"]
+        if "min_luminance" in m:
+            contrast = Y_peak / m["min_luminance"]
+        elif "contrast" in m:
+            contrast = m["contrast"]
+        else:
+            contrast = 500
+        return cls(Y_peak, contrast=contrast, EOTF=m.get("EOTF", "sRGB"), gamma=m.get("gamma", 2.2),
+                   E_ambient=m.get("E_ambient", 0), k_refl=m.get("k_refl", 0.005))
+
+    def get_black_level(self):
+        """:172-176"""
+        return self.E_ambient / math.pi * self.k_refl + self.Y_peak / self.contrast
+
+    def forward(self, V):
+        """:147-165.  Returns (L, out_of_range_flag)."""
+        V = np.asarray(V, dtype=_F)
+        oob = False
+        if self.EOTF != "linear" and (np.any(V > 1) or np.any(V < 0)):
+            oob = True
+            V = np.clip(V, _F(0.0), _F(1.0))
+        Yb = self.get_black_level()
+        if self.EOTF == "sRGB":
+            L = _F(self.Y_peak - Yb) * srgb2lin(V) + _F(Yb)
+        elif self.EOTF == "gamma":
+            L = _F(self.Y_peak - Yb) * np.power(V, _F(self.gamma)) + _F(Yb)
+        elif self.EOTF == "PQ":
+            L = np.clip(pq2lin(V), _F(0.005), _F(self.Y_peak)) + _F(Yb)
+        elif self.EOTF == "linear":
+            L = np.clip(V, _F(0.005), _F(self.Y_peak)) + _F(Yb)
+        else:
+            raise RuntimeError("Unknown EOTF '%s'" % self.EOTF)
+        return L.astype(_F), oob
+
+
+def srgb2lin(p):
+    """pyfvvdp/fvvdp_display_model.py:17-19"""
+    p = np.asarray(p, dtype=_F)
+    with np.errstate(invalid="ignore"):
+        hi = np.power((p + _F(0.055)) / _F(1.055), _F(2.4))
+    return np.where(p > _F(0.04045), hi, p / _F(12.92)).astype(_F)
+
+
+def pq2lin(V):
+    """pyfvvdp/fvvdp_display_model.py:100-112"""
+    V = np.asarray(V, dtype=_F)
+    n, m = 0.15930175781250000, 78.843750000000000
+    c1, c2, c3 = 0.83593750000000000, 18.851562500000000, 18.687500000000000
+    im_t = np.power(V, _F(1 / m))
+    L = _F(10000) * np.power(np.maximum(im_t - _F(c1), _F(0)) / (_F(c2) - _F(c3) * im_t), _F(1 / n))
+    return L.astype(_F)
+
+
+# --------------------------------------------------------------------------------------------------------
+# display geometry  (pyfvvdp/fvvdp_display_model.py:383-568)
+# --------------------------------------------------------------------------------------------------------
+class Geometry:
+    def __init__(self, resolution, distance_m=None, distance_display_heights=None, fov_horizontal=None,
+                 fov_vertical=None, fov_diagonal=None, diagonal_size_inches=None):
+        """:385-436"""
+        self.resolution = resolution
+        ar = resolution[0] / resolution[1]
+        self.display_size_m = None
+        if diagonal_size_inches is not None:
+            height_mm = math.sqrt((diagonal_size_inches * 25.4) ** 2 / (1 + ar ** 2))
+            self.display_size_m = (ar * height_mm / 1000, height_mm / 1000)
+        if distance_m is not None and distance_display_heights is not None:
+            raise RuntimeError("You can pass only one of: distance_m, distance_display_heights.")
+        if distance_m is not None:
+            self.distance_m = distance_m
+        elif distance_display_heights is not None:
+            if self.display_size_m is None:
+                raise RuntimeError("diagonal_size_inches is needed with distance_display_heights")
+            self.distance_m = distance_display_heights * self.display_size_m[1]
+        elif fov_horizontal is not None or fov_vertical is not None or fov_diagonal is not None:
+            self.distance_m = 3
+        else:
+            raise RuntimeError("Viewing distance must be specified as distance_m or distance_display_heights.")
+        if (fov_horizontal is not None) + (fov_vertical is not None) + (fov_diagonal is not None) > 1:
+            raise RuntimeError("You can pass only one of fov_horizontal, fov_vertical, fov_diagonal.")
+        if fov_horizontal is not None:
+            width_m = 2 * math.tan(math.radians(fov_horizontal / 2)) * self.distance_m
+            self.display_size_m = (width_m, width_m / ar)
+        elif fov_vertical is not None:
+            height_m = 2 * math.tan(math.radians(fov_vertical / 2)) * self.distance_m
+            self.display_size_m = (height_m * ar, height_m)
+        elif fov_diagonal is not None:
+            distance_px = math.sqrt(resolution[0] ** 2 + resolution[1] ** 2) / (2.0 * math.tan(math.radians(fov_diagonal * 0.5)))
+            height_deg = math.degrees(math.atan(resolution[1] / 2 / distance_px)) * 2
+            height_m = 2 * math.tan(math.radians(height_deg / 2)) * self.distance_m
+            self.display_size_m = (height_m * ar, height_m)
+        self.ppd_centre = 1 / (2 * math.degrees(math.atan(0.5 * self.display_size_m[0] / resolution[0] / self.distance_m)))
+
+    @classmethod
+    def load(cls, display_name, models=None):
+        """:539-568"""
+        models = models if models is not None else load_defaults()["display_models.json"]
+        if display_name not in models:
+            raise RuntimeError("Error: Display model '%s' not found in display_models.json" % display_name)
+        m = models[display_name]
+        W, H = m["resolution"]
+        if "viewing_distance_meters" in m:
+            distance_m = m["viewing_distance_meters"]
+        elif "viewing_distance_inches" in m:
+            distance_m = m["viewing_distance_inches"] * 0.0254
+        else:
+            distance_m = None
+        if "diagonal_size_meters" in m:
+            diag = m["diagonal_size_meters"] / 0.0254
+        else:
+            diag = m.get("diagonal_size_inches")
+        return cls((W, H), distance_m=distance_m, fov_diagonal=m.get("fov_diagonal"), diagonal_size_inches=diag)
+
+    def get_ppd(self):
+        return self.ppd_centre
+
+    def pix2view_direction(self, res, x_pix, y_pix):
+        """:498-510  (fp32 like the reference when fed fp32 pixel coordinates)."""
+        x_rel = np.asarray(x_pix, dtype=_F) + _F(-res[0] / 2)
+        y_rel = np.asarray(y_pix, dtype=_F) + _F(-res[1] / 2)
+        x_m = x_rel * _F(self.display_size_m[0]) / _F(res[0])
+        y_m = -y_rel * _F(self.display_size_m[1]) / _F(res[1])
+        vx = np.rad2deg(np.arctan(x_m / _F(self.distance_m))).astype(_F)
+        vy = np.rad2deg(np.arctan(y_m / _F(self.distance_m))).astype(_F)
+        return vx, vy
+
+    def resolution_magnification(self, vx, vy):
+        """get_ppd(view_dir)/get_ppd()  :475-488, :512-526"""
+        va = np.sqrt(vx * vx + vy * vy).astype(_F)
+        va = np.minimum(va, _F(89.9))
+        delta = (1 / self.ppd_centre) / 2
+        tan_delta = math.tan(math.radians(delta))
+        tan_a = np.tan(np.deg2rad(va)).astype(_F)
+        ppd = _F(self.ppd_centre) * (np.tan(np.deg2rad(va + _F(delta))).astype(_F) - tan_a) / _F(tan_delta)
+        return (ppd / _F(self.ppd_centre)).astype(_F)
+
+
+# --------------------------------------------------------------------------------------------------------
+# frame supply  (pyfvvdp/video_source.py)
+# --------------------------------------------------------------------------------------------------------
+def reshuffle_dims(T, in_dims, out_dims="BCFHW"):
+    """pyfvvdp/video_source.py:43-69"""
+    in_dims, out_dims = in_dims.upper(), out_dims.upper()
+    inter = "".join(d for d in out_dims if d in in_dims)
+    perm = [in_dims.find(d) for d in inter]
+    Tp = np.transpose(T, perm)
+    out_sh = [Tp.shape[inter.find(d)] if d in inter else 1 for d in out_dims]
+    return Tp.reshape(out_sh)
+
+
+def frame_to_unit(arr_bcfhw, f):
+    """Integer/float unpacking of frame f -> fp32 in [0,1]  (pyfvvdp/video_source.py:184-200)."""
+    fr = arr_bcfhw[:, :, f:f + 1]
+    if fr.dtype == np.float32:
+        return fr.astype(_F)
+    if fr.dtype == np.uint16:          # the reference carries it as int16 and masks; same value
+        return fr.astype(_F) / _F(65535)
+    if fr.dtype == np.int16:
+        return (fr.astype(np.int32) & 0xFFFF).astype(_F) / _F(65535)
+    if fr.dtype == np.uint8:
+        return fr.astype(_F) / _F(255)
+    raise RuntimeError("Only uint8, uint16 and float32 is currently supported")
+
+
+def frame_luminance(arr_bcfhw, f, photometry, rgb2y):
+    """_get_frame: unpack -> photometry -> luminance  (pyfvvdp/video_source.py:180-208).  Returns ([H,W], oob)."""
+    V = frame_to_unit(arr_bcfhw, f)
+    L, oob = photometry.forward(V)
+    if L.shape[1] == 3:
+        L = L[:, 0:1] * _F(rgb2y[0]) + L[:, 1:2] * _F(rgb2y[1]) + L[:, 2:3] * _F(rgb2y[2])
+    return L[0, 0, 0].astype(_F), oob
+
+
+# --------------------------------------------------------------------------------------------------------
+# temporal filters and sliding window  (pyfvvdp/fvvdp.py:228-230, 258-300, 609-630)
+# --------------------------------------------------------------------------------------------------------
+def filter_len(fps):
+    """pyfvvdp/fvvdp.py:228"""
+    return int(np.ceil(250.0 / (1000.0 / fps)))
+
+
+def temporal_filters(fps, sustained_sigma=0.5, sustained_beta=0.06, fl=None):
+    """pyfvvdp/fvvdp.py:609-630.  Returns F[2, fl] fp32."""
+    fl = filter_len(fps) if fl is None else fl
+    t = np.linspace(0.0, fl / fps, fl, dtype=np.float64).astype(_F)   # torch.linspace(fp32)
+    # torch computes start + i*step in fp32; reproduce that rather than numpy's fp64 path
+    step = _F((_F(fl / fps) - _F(0.0)) / _F(fl - 1)) if fl > 1 else _F(0)
+    half = fl // 2
+    idx = np.arange(fl)
+    t_lo = (_F(0.0) + step * idx.astype(_F)).astype(_F)
+    t_hi = (_F(fl / fps) - step * (fl - 1 - idx).astype(_F)).astype(_F)
+    t = np.where(idx < half, t_lo, t_hi).astype(_F)
+    F = np.zeros((2, fl), dtype=_F)
+    sigma, beta = _F(sustained_sigma), _F(sustained_beta)
+    e = -np.power(np.log(t + _F(1e-4)) - np.log(beta), _F(2.0)) / (_F(2.0) * (sigma ** _F(2.0)))
+    F[0] = np.exp(e.astype(_F))
+    F[0] = F[0] / np.sum(F[0], dtype=_F)
+    k2 = 0.062170507756932
+    Fdiff = F[0, 1:] - F[0, :-1]
+    F[1, :-1] = _F(k2) * (Fdiff / (t[1] - t[0]))
+    F[1, -1] = 0
+    return F
+
+
+def window_frame_indices(N, fl, temp_padding):
+    """Source-frame index for every slot of the sliding window.
+
+    Returns idx[N, fl]: idx[ff, k] is the source frame in slot k (oldest first) of the window used for output
+    frame ff (pyfvvdp/fvvdp.py:258-291).  Slot fl-1 is the newest frame and is weighted by F[cc][0] (:298).
+    """
+    if temp_padding == "replicate":
+        first = [0] * fl                                                    # :259-262
+    elif temp_padding == "circular":
+        first = [(N - 1 - fl + kk) % N for kk in range(fl)]                # :263-269 (quirk: frame 0 absent)
+    elif temp_padding == "pingpong":
+        pingpong = list(range(0, N)) + list(range(N - 2, 0, -1))           # :274-278
+        indices = []
+        while len(indices) < (fl - 1):
+            indices = indices + pingpong
+        first = (indices[-(fl - 1):] if fl > 1 else []) + [0]
+    else:
+        raise RuntimeError('Unknown padding method "{}"'.format(temp_padding))
+    idx = np.zeros((N, fl), dtype=np.int64)
+    win = list(first)
+    idx[0] = win
+    for ff in range(1, N):
+        win = win[1:] + [ff]                                                # :290-291
+        idx[ff] = win
+    return idx
+
+
+def temporal_channels(win_T, win_R, F):
+    """R[2cc+s] = sum_k win[s][k] * F[cc][fl-1-k]   (pyfvvdp/fvvdp.py:294-300).  win_*: [fl,H,W] oldest first."""
+    H, W = win_T.shape[-2:]
+    R = np.zeros((4, H, W), dtype=_F)
+    for cc in range(2):
+        corr = F[cc][::-1].reshape(-1, 1, 1).astype(_F)
+        R[2 * cc + 0] = np.sum(win_T * corr, axis=0, dtype=_F)
+        R[2 * cc + 1] = np.sum(win_R * corr, axis=0, dtype=_F)
+    return R
+
+
+# --------------------------------------------------------------------------------------------------------
+# pyramid  (pyfvvdp/fvvdp_lpyr_dec.py)
+# --------------------------------------------------------------------------------------------------------
+def band_frequencies(W, H, ppd):
+    """fvvdp_lpyr_dec.__init__  pyfvvdp/fvvdp_lpyr_dec.py:15-49.  Returns (height, band_freqs[height+1])."""
+    max_levels = int(np.floor(np.log2(min(H, W)))) - 1
+    bands = np.concatenate([[1.0], np.power(2.0, -np.arange(0.0, 14.0)) * 0.3228], 0) * ppd / 2.0
+    invalid = np.nonzero(bands <= 0.5)[0]
+    max_band = max_levels if invalid.size == 0 else int(invalid[0])
+    height = int(np.clip(max_band + 1, 0, max_levels))
+    freqs = np.array([1.0] + [0.3228 * 2.0 ** (-f) for f in range(height)]) * ppd / 2.0
+    return height, freqs
+
+
+_K = np.array([0.25 - 0.4 / 2.0, 0.25, 0.4, 0.25, 0.25 - 0.4 / 2.0]).astype(_F)   # :176 built in fp32 by torch.tensor
+
+
+def _k():
+    # torch.tensor([...python floats...], dtype=float32): each entry rounded from fp64
+    return np.array([0.25 - 0.4 / 2.0, 0.25, 0.4, 0.25, 0.25 - 0.4 / 2.0], dtype=np.float64).astype(_F)
+
+
+def gausspyr_reduce(x):
+    """pyfvvdp/fvvdp_lpyr_dec.py:183-207.  x: [P,H,W] fp32 -> [P,ceil(H/2),ceil(W/2)]."""
+    K = _k()
+    P, H, W = x.shape
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    # vertical: zero-padded 5-tap, stride 2  (:188)
+    xp = np.zeros((P, H + 4 + 1, W), dtype=_F)
+    xp[:, 2:2 + H] = x
+    ya = np.zeros((P, Ho, W), dtype=_F)
+    for k in range(5):
+        ya += K[k] * xp[:, k:k + 2 * Ho:2]
+    ya[:, 0] += x[:, 0] * K[1] + x[:, 1] * K[0]                     # :191
+    if H % 2 == 1:                                                    # :192-195
+        ya[:, -1] += x[:, -1] * K[3] + x[:, -2] * K[4]
+    else:
+        ya[:, -1] += x[:, -1] * K[4]
+    # horizontal on the result (:198)
+    yp = np.zeros((P, Ho, W + 4 + 1), dtype=_F)
+    yp[:, :, 2:2 + W] = ya
+    y = np.zeros((P, Ho, Wo), dtype=_F)
+    for k in range(5):
+        y += K[k] * yp[:, :, k:k + 2 * Wo:2]
+    y[:, :, 0] += ya[:, :, 0] * K[1] + ya[:, :, 1] * K[0]           # :201
+    if H % 2 == 1:       # QUIRK (:202): parity of the ROW count of x selects the column fix-up
+        y[:, :, -1] += ya[:, :, -1] * K[3] + ya[:, :, -2] * K[4]
+    else:
+        y[:, :, -1] += ya[:, :, -1] * K[4]
+    return y
+
+
+def _expand_axis(x, n_out, axis):
+    """One axis of gausspyr_expand: zero-stuff, edge pad, valid conv with 2K (:126-142, :225-233).
+
+    Closed form: even i -> 2K0*x[c-1] + 2K2*x[c] + 2K4*x[c+1] (c=i/2), odd i -> 2K1*x[(i-1)/2] + 2K3*x[(i+1)/2],
+    neighbour indices clamped to the valid range.
+    """
+    K2 = (_k() * _F(2)).astype(_F)
+    x = np.moveaxis(x, axis, -1)
+    n = x.shape[-1]
+    i = np.arange(n_out)
+    c = i // 2
+    cm, cp = np.clip(c - 1, 0, n - 1), np.clip(c + 1, 0, n - 1)
+    c0 = np.clip(c, 0, n - 1)
+    even = (K2[0] * x[..., cm] + K2[2] * x[..., c0]) + K2[4] * x[..., cp]
+    odd = K2[1] * x[..., c0] + K2[3] * x[..., cp]
+    out = np.where((i % 2) == 0, even, odd).astype(_F)
+    return np.moveaxis(out, -1, axis)
+
+
+def gausspyr_expand(x, sz):
+    """pyfvvdp/fvvdp_lpyr_dec.py:219-235: vertical first, then horizontal."""
+    return _expand_axis(_expand_axis(x, sz[0], -2), sz[1], -1)
+
+
+def gaussian_pyramid(image, levels):
+    """pyfvvdp/fvvdp_lpyr_dec.py:144-158"""
+    res = [image]
+    for _ in range(1, levels):
+        res.append(gausspyr_reduce(res[-1]))
+    return res
+
+
+def contrast_pyr_decompose(image, height):
+    """fvvdp_contrast_pyr.decompose  pyfvvdp/fvvdp_lpyr_dec.py:248-273.  image: [P,H,W].
+
+    Returns (contrast bands (list of [P,h,w], base band last), L_bkg bands (list of [h,w])).
+    """
+    gpyr = gaussian_pyramid(image, height + 1)
+    lpyr, lbkg = [], []
+    for i in range(len(gpyr) - 1):
+        ex = gausspyr_expand(gpyr[i + 1], gpyr[i].shape[-2:])
+        layer = gpyr[i] - ex
+        L_bkg = np.maximum(ex[1], _F(0.1))                                   # :265 plane 1 = reference(-sustained)
+        contrast = np.minimum(layer / L_bkg[None], _F(1000.0))               # :266
+        lpyr.append(contrast.astype(_F))
+        lbkg.append(L_bkg.astype(_F))
+    lpyr.append(gpyr[-1])
+    return lpyr, lbkg
+
+
+# --------------------------------------------------------------------------------------------------------
+# CSF LUT interpolation  (pyfvvdp/interp.py, pyfvvdp/fvvdp.py:520-537)
+# --------------------------------------------------------------------------------------------------------
+def get_interpolants_v1(x_q, x):
+    """pyfvvdp/interp.py:11-20"""
+    imax = np.searchsorted(x, x_q, side="left")          # torch.bucketize(right=False): first x[i] >= q
+    imax = np.minimum(imax, x.shape[0] - 1)
+    imin = np.clip(imax - 1, 0, x.shape[0] - 1)
+    ifrc = (x_q - x[imin]) / (x[imax] - x[imin] + _F(0.000001))
+    ifrc = np.where(imax == imin, _F(0), ifrc)
+    ifrc = np.where(ifrc < 0, _F(0), ifrc).astype(_F)
+    return imin, imax, ifrc
+
+
+def interp3(x, y, z, v, x_q, y_q, z_q):
+    """pyfvvdp/interp.py:43-59  (v indexed [y, x, z])."""
+    shp = x_q.shape
+    x_q, y_q, z_q = x_q.ravel(), y_q.ravel(), z_q.ravel()
+    imin, imax, ifrc = get_interpolants_v1(x_q, x)
+    jmin, jmax, jfrc = get_interpolants_v1(y_q, y)
+    kmin, kmax, kfrc = get_interpolants_v1(z_q, z)
+    one = _F(1.0)
+    filtered = (
+        ((v[jmin, imin, kmin] * (one - ifrc) + v[jmin, imax, kmin] * ifrc) * (one - jfrc) +
+         (v[jmax, imin, kmin] * (one - ifrc) + v[jmax, imax, kmin] * ifrc) * jfrc) * (one - kfrc) +
+        ((v[jmin, imin, kmax] * (one - ifrc) + v[jmin, imax, kmax] * ifrc) * (one - jfrc) +
+         (v[jmax, imin, kmax] * (one - ifrc) + v[jmax, imax, kmax] * ifrc) * jfrc) * kfrc)
+    return filtered.reshape(shp).astype(_F)
+
+
+def cached_sensitivity(lut, rho, L_bkg, ecc):
+    """pyfvvdp/fvvdp.py:520-537.  rho, L_bkg, ecc broadcastable fp32 arrays -> S."""
+    rho, L_bkg, ecc = np.broadcast_arrays(np.asarray(rho, _F), np.asarray(L_bkg, _F), np.asarray(ecc, _F))
+    rho_q = np.log2(np.clip(rho, lut["rho"][0], lut["rho"][-1])).astype(_F)
+    Y_q = np.log2(np.clip(L_bkg, lut["Y"][0], lut["Y"][-1])).astype(_F)
+    ecc_q = np.sqrt(np.clip(ecc, lut["ecc"][0], lut["ecc"][-1])).astype(_F)
+    interpolated = interp3(lut["rho_log"], lut["Y_log"], lut["ecc_sqrt"], lut["S_log"], rho_q, Y_q, ecc_q)
+    return np.power(_F(2.0), interpolated).astype(_F)
+
+
+# --------------------------------------------------------------------------------------------------------
+# masking, pooling, JOD  (pyfvvdp/fvvdp.py:337-357, 574-607)
+# --------------------------------------------------------------------------------------------------------
+def apply_masking_model(T, R, N, cc, prm):
+    """pyfvvdp/fvvdp.py:574-596 with phase_uncertainty :550-556 (pu_dilate=0) and mask_func_perc_norm2 :569-572."""
+    p = _F(prm["mask_p"])
+    q = _F(prm["mask_q_sust"] if cc == 0 else prm["mask_q_trans"])
+    T = T / N
+    R = R / N
+    k = np.power(_F(10.0), _F(prm["mask_c"]))
+    M = np.minimum(np.abs(T), np.abs(R)) * k
+    D = np.power(np.abs(T - R), p) / (_F(1.0) + np.power(M, q))
+    return np.minimum(D, _F(1e4)).astype(_F)
+
+
+def lp_norm(x, p, axis=0, normalize=True):
+    """pyfvvdp/fvvdp.py:598-607 (torch.norm accumulates wider than fp32 on CPU; fp64 here)."""
+    N = x.shape[axis] if normalize else 1.0
+    s = np.sum(np.power(np.abs(x.astype(np.float64)), p), axis=axis, keepdims=True)
+    return (np.power(s, 1.0 / p) / (float(N) ** (1.0 / p))).astype(_F)
+
+
+def do_pooling_and_jods(Q_per_ch, prm):
+    """pyfvvdp/fvvdp.py:337-357.  Q_per_ch: [height, 2, N]."""
+    if Q_per_ch.shape[1] == 2:
+        w = np.array([1.0, prm["w_transient"]], dtype=_F).reshape(1, 2, 1)
+    else:
+        w = _F(1)
+    Q_sc = lp_norm(Q_per_ch * w, prm["beta_sch"], 0, False)
+    Q_tc = lp_norm(Q_sc, prm["beta_tch"], 1, False)
+    Q = float(lp_norm(Q_tc, prm["beta_t"], 2, True).squeeze())
+    beta_jod = 10.0 ** prm["log_jod_exp"]
+    a = prm["jod_a"]
+    sign = -1 if a < 0 else 1
+    return _F(sign * ((abs(a) ** (1.0 / beta_jod)) * _F(Q)) ** beta_jod + 10.0)
+
+
+# --------------------------------------------------------------------------------------------------------
+# per-frame core and the frame loop  (pyfvvdp/fvvdp.py:190-334, 359-478)
+# --------------------------------------------------------------------------------------------------------
+class Oracle:
+    """Mirror of `class fvvdp` restricted to the live branch (local_adapt=gpyr, contrast=weber, pu_dilate=0)."""
+
+    def __init__(self, display_name="standard_4k", photometry=None, geometry=None, color_space="sRGB",
+                 foveated=False, temp_padding="replicate"):
+        d = load_defaults()
+        self.prm = d["fvvdp_parameters.json"]
+        self.photometry = photometry if photometry is not None else Photometry.load(display_name, d["display_models.json"])
+        self.geometry = geometry if geometry is not None else Geometry.load(display_name, d["display_models.json"])
+        if color_space not in d["color_spaces.json"]:
+            raise RuntimeError('Unknown color space: "' + color_space + '"')
+        self.rgb2y = d["color_spaces.json"][color_space]["RGB2Y"]
+        self.foveated = foveated
+        self.temp_padding = temp_padding
+        self.ppd = self.geometry.get_ppd()
+        self.lut = [load_lut(om, self.prm["csf_sigma"], self.prm["k_cm"]) for om in (0, 5)]
+        self.capture = None            # optional dict of lists filled with stage outputs
+
+    # -- foveated maps, pyfvvdp/fvvdp.py:416-437 ----------------------------------------------------------
+    def _fov_maps(self, w_band, h_band, w_frame, h_frame, fix):
+        xv = np.linspace(0.5, w_band - 0.5, w_band).astype(_F)
+        yv = np.linspace(0.5, h_band - 0.5, h_band).astype(_F)
+        xx, yy = np.meshgrid(xv, yv, indexing="xy")
+        vx, vy = self.geometry.pix2view_direction((w_band, h_band), xx, yy)
+        gx, gy = self.geometry.pix2view_direction((w_frame, h_frame), _F(fix[0]) + _F(0.5), _F(fix[1]) + _F(0.5))
+        ecc = np.sqrt((vx - gx) ** 2 + (vy - gy) ** 2).astype(_F)
+        res_mag = self.geometry.resolution_magnification(vx, vy)
+        return ecc, res_mag
+
+    def process_frame(self, ff, R, height, rho_band, temp_ch, fixation, frame_size):
+        """process_block_of_frames, pyfvvdp/fvvdp.py:359-478.  R: [P,H,W].  Returns Q[height,2]."""
+        prm = self.prm
+        bands, lbkg = contrast_pyr_decompose(R, height)
+        Q = np.zeros((height, 2), dtype=_F)
+        sens = _F(10.0 ** (prm["sensitivity_correction"] / 20.0))
+        for cc in range(temp_ch):
+            for bb in range(height):
+                m = _F(1.0 if bb == 0 else 2.0)                       # get_band, fvvdp_lpyr_dec.py:57-63
+                T_f = bands[bb][2 * cc + 0] * m
+                R_f = bands[bb][2 * cc + 1] * m
+                L_bkg = lbkg[bb]
+                h, w = T_f.shape
+                if self.foveated:
+                    fix = fixation[ff] if np.ndim(fixation) == 2 else fixation
+                    ecc, res_mag = self._fov_maps(w, h, frame_size[1], frame_size[0], fix)
+                else:
+                    res_mag = np.ones((h, w), dtype=_F)
+                    ecc = np.zeros((h, w), dtype=_F)
+                rho = (_F(rho_band[bb]) * res_mag).astype(_F)         # fvvdp.py:442 (numpy fp64 scalar * fp32 tensor -> fp32)
+                S_raw = cached_sensitivity(self.lut[cc], rho, L_bkg, ecc)
+                S = S_raw * sens                                      # fvvdp.py:447
+                N_nCSF = (_F(1.0) / S).astype(_F)                     # fvvdp.py:451
+                D = apply_masking_model(T_f, R_f, N_nCSF, cc, prm)
+                if self.capture is not None:
+                    self.capture.setdefault("S", []).append(S_raw)
+                    self.capture.setdefault("D", []).append(D)
+                Q[bb, cc] = lp_norm(D.ravel(), prm["beta"], 0, True)[0]
+        if self.capture is not None:
+            self.capture.setdefault("bands", []).append(bands)
+            self.capture.setdefault("L_bkg", []).append(lbkg)
+            self.capture.setdefault("R", []).append(R)
+        return Q
+
+    def predict(self, test, ref, dim_order="BCFHW", frames_per_second=0, fixation_point=None, frames=None):
+        """fvvdp.predict / predict_video_source, pyfvvdp/fvvdp.py:181-334.
+
+        `frames` (optional iterable) restricts the OUTPUT frames that are evaluated (used for bounded CPU
+        timing); pooling then runs over those frames only.
+        """
+        test = reshuffle_dims(np.asarray(test), dim_order)
+        ref = reshuffle_dims(np.asarray(ref), dim_order)
+        if test.shape != ref.shape:
+            raise RuntimeError("Test and reference image/video tensors must be exactly the same shape")
+        B, C, N, H, W = test.shape
+        if frames_per_second == 0 and N > 1:
+            raise RuntimeError("When passing video sequences, you must set frames_per_second parameter")
+        if C not in (1, 3):
+            raise RuntimeError("The content must have either 1 or 3 colour channels.")
+        height, rho_band = band_frequencies(W, H, self.ppd)
+        if fixation_point is None:
+            fixation_point = np.array([W // 2, H // 2])
+        fixation_point = np.asarray(fixation_point)
+        is_image = N == 1
+        oob = False
+        lum_cache = {}
+
+        def lum(arr, tag, f):
+            nonlocal oob
+            if (tag, f) not in lum_cache:
+                L, o = frame_luminance(arr, f, self.photometry, self.rgb2y)
+                oob = oob or o
+                lum_cache[(tag, f)] = L
+            return lum_cache[(tag, f)]
+
+        out_frames = list(range(N)) if frames is None else list(frames)
+        Q_per_ch = np.zeros((height, 2, len(out_frames)), dtype=_F)
+        if is_image:
+            temp_ch = 1
+        else:
+            temp_ch = 2
+            fl = filter_len(frames_per_second)
+            F = temporal_filters(frames_per_second, self.prm["sustained_sigma"], self.prm["sustained_beta"], fl)
+            widx = window_frame_indices(N, fl, self.temp_padding)
+            self.F = F
+        for oi, ff in enumerate(out_frames):
+            if is_image:
+                R = np.stack([lum(test, "t", 0), lum(ref, "r", 0)], 0)
+            else:
+                win_T = np.stack([lum(test, "t", int(j)) for j in widx[ff]], 0)
+                win_R = np.stack([lum(ref, "r", int(j)) for j in widx[ff]], 0)
+                R = temporal_channels(win_T, win_R, F)
+                keep = set(int(j) for j in widx[min(ff + 1, N - 1)])
+                for key in [k for k in lum_cache if k[1] not in keep]:
+                    del lum_cache[key]
+            Q_per_ch[:, :, oi] = self.process_frame(ff, R, height, rho_band, temp_ch, fixation_point, (H, W))
+        jod = do_pooling_and_jods(Q_per_ch, self.prm)
+        stats = {"Q_per_ch": Q_per_ch, "rho_band": rho_band, "frames_per_second": frames_per_second,
+                 "width": W, "height": H, "N_frames": N, "oob": oob}
+        return jod, stats

@@ -1,0 +1,198 @@
+"""Pins the CPU oracle (oracle/fvvdp_oracle.py) against vectors captured from the real reference
+(tools/gen_golden.py).
+
+Tolerances (fp32 rounding noise between two correct implementations, measured while writing the oracle):
+  * R, Gaussian levels, L_bkg, S (non-foveated): a few ulp -> <= 3e-6 relative to the plane's scale;
+  * contrast bands are (G - expand(G'))/L_bkg, a difference of nearly equal numbers: absolute error ~1 ulp of G
+    divided by L_bkg -> <= 1e-5 of the band's max;
+  * D = |dC*S|^2.4/(1+M^q): dC (test minus reference contrast) is itself tiny, so 1-ulp noise on the contrasts is
+    a 1e-4..1e-3 RELATIVE error per pixel -> per-pixel 5e-3 (+1e-4 of the map's max as floor), pooled sum 1e-4;
+  * Q_per_ch: see check_q; JOD 1e-5 absolute;
+  * PQ EOTF at the dark end and the foveated resolution magnification are finite differences of nearly equal
+    fp32 numbers in the reference's own formulas (pq2lin: V^(1/m)-c1; get_ppd: tan(a+delta)-tan(a)) -> 2e-4 / 1e-3."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import fvvdp_oracle as orc
+from fovvideovdp_amd.synth import synth_video_pair
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+def relerr(a, b, floor=0.0):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / (np.abs(b) + floor)))
+
+
+def check_q(q, gq):
+    """Q_per_ch [height,2,N]: 1e-3 everywhere (the coarse bands pool only tens of pixels, so per-pixel rounding
+    noise does not average out), 1e-4 on the three finest bands."""
+    q, gq = np.asarray(q, np.float64), np.asarray(gq, np.float64)
+    assert q.shape == gq.shape
+    assert np.all(np.abs(q - gq) <= 1e-3 * np.abs(gq) + 1e-6 * np.max(np.abs(gq)))
+    nb = min(3, q.shape[0])
+    assert np.all(np.abs(q[:nb] - gq[:nb]) <= 1e-4 * np.abs(gq[:nb]) + 1e-7 * np.max(np.abs(gq)))
+
+
+def gaussblur(img, sigma):
+    from scipy.ndimage import gaussian_filter
+    out = np.zeros_like(img)
+    for cc in range(img.shape[2]):
+        out[..., cc] = gaussian_filter(img[..., cc], sigma, mode="nearest", truncate=2.0)
+    return out
+
+
+def test_units_pyramid():
+    z = load("g5_units")
+    for (h, w) in ((12, 16), (13, 16), (12, 17), (13, 17), (4, 5), (5, 4)):
+        x = z[f"pyr_x_{h}x{w}"]
+        r = orc.gausspyr_reduce(x)
+        assert r.shape == z[f"pyr_reduce_{h}x{w}"].shape
+        assert relerr(r, z[f"pyr_reduce_{h}x{w}"]) < 1e-6
+        e = orc.gausspyr_expand(r, (h, w))
+        assert relerr(e, z[f"pyr_expand_{h}x{w}"]) < 1e-6
+
+
+def test_units_csf_interp():
+    z = load("g5_units")
+    prm = orc.load_defaults()["fvvdp_parameters.json"]
+    for i, om in enumerate((0, 5)):
+        lut = orc.load_lut(om, prm["csf_sigma"], prm["k_cm"])
+        S = orc.cached_sensitivity(lut, z["csf_rho"], z["csf_Y"], z["csf_ecc"])
+        assert relerr(S, z[f"csf_S_o{om}"]) < 5e-6      # exp2 of a value up to ~13: a few ulp of the exponent
+
+
+def test_units_eotf():
+    z = load("g5_units")
+    V = z["eotf_V"]
+    for disp in ("standard_4k", "standard_hdr_pq", "standard_hdr_linear"):
+        ph = orc.Photometry.load(disp)
+        Vin = V * (np.float32(1500.0) if disp == "standard_hdr_linear" else np.float32(1.0))
+        L, oob = ph.forward(Vin.astype(np.float32))
+        assert relerr(L, z[f"eotf_{disp}"]) < (2e-4 if disp == "standard_hdr_pq" else 2e-6), disp
+        assert oob == (disp != "standard_hdr_linear")
+    gm = orc.Photometry(300, contrast=2000, EOTF="gamma", gamma=2.4, E_ambient=100)
+    L, _ = gm.forward(V)
+    assert relerr(L, z["eotf_gamma24"]) < 2e-6
+
+
+def test_units_temporal_filters():
+    z = load("g5_units")
+    for fps in (24, 30, 60, 90, 120):
+        F = orc.temporal_filters(fps)
+        ref = z[f"F_fps{fps}"]
+        assert F.shape == ref.shape
+        assert np.max(np.abs(F - ref)) < 2e-6 * np.max(np.abs(ref)), fps
+
+
+def test_units_geometry():
+    z = load("g5_units")
+    for disp in ("standard_4k", "standard_hmd", "standard_phone"):
+        g = orc.Geometry.load(disp)
+        assert abs(g.get_ppd() - float(z[f"geom_ppd_{disp}"])) < 1e-9
+        xv = np.linspace(0.5, 47.5, 48).astype(np.float32)
+        yv = np.linspace(0.5, 26.5, 27).astype(np.float32)
+        xx, yy = np.meshgrid(xv, yv, indexing="xy")
+        vx, vy = g.pix2view_direction((48, 27), xx, yy)
+        vd = z[f"geom_viewdir_{disp}"]
+        assert np.max(np.abs(vx - vd[0])) < 1e-4 and np.max(np.abs(vy - vd[1])) < 1e-4
+        rm = g.resolution_magnification(vx, vy)
+        assert relerr(rm, z[f"geom_resmag_{disp}"]) < 1e-3      # fp32 tan differences amplified by the finite difference
+
+
+def check_stages(o, cap, z, frames, height, temp_ch):
+    """cap: oracle capture dict, z: golden npz."""
+    for fi, ff in enumerate(frames):
+        gR = z[f"R_f{ff}"]
+        assert np.max(np.abs(cap["R"][fi] - gR)) < 1e-6 * np.max(np.abs(gR))
+        for b in range(height + 1):
+            key = f"band_f{ff}_b{b}"
+            if key in z.files:
+                gb = z[key]
+                scale = float(np.max(np.abs(gb)))
+                assert np.max(np.abs(cap["bands"][fi][b] - gb)) < 1e-5 * max(scale, 1e-3), key
+        for b in range(height):
+            key = f"lbkg_f{ff}_b{b}"
+            if key in z.files:
+                assert relerr(cap["L_bkg"][fi][b], z[key]) < 2e-6, key
+        for i in range(temp_ch * height):
+            key = f"S_f{ff}_i{i}"
+            if key in z.files:
+                assert relerr(cap["S"][fi * temp_ch * height + i], z[key]) < 3e-6, key
+            key = f"D_f{ff}_i{i}"
+            if key in z.files:
+                gd = z[key]
+                d = cap["D"][fi * temp_ch * height + i]
+                assert np.max(np.abs(d - gd) / (np.abs(gd) + 1e-4 * np.max(gd) + 1e-12)) < 5e-3, key
+                # pooled quantity is far tighter than the worst pixel (pow amplifies ulp noise on tiny contrasts)
+                assert abs(d.astype(np.float64).sum() / gd.astype(np.float64).sum() - 1) < 1e-4, key
+
+
+def test_readme_known_answer_g0():
+    """README.md:138 of the reference: 8.693 JOD."""
+    z = load("g0_wavy_facade_blur_4k")
+    ref = z["ref_u16"]
+    test = gaussblur(ref, 2)
+    o = orc.Oracle("standard_4k")
+    jod, stats = o.predict(test, ref, dim_order="HWC")
+    assert abs(float(jod) - 8.693) < 5e-4
+    assert abs(float(jod) - float(z["jod"])) < 1e-5
+    assert relerr(stats["Q_per_ch"][:, 0, 0], z["Q_per_ch"][:, 0, 0]) < 1e-4
+    assert np.allclose(stats["rho_band"], z["rho_band"], rtol=1e-12)
+
+
+def test_config1_crop512_g1():
+    z = load("g1_crop512_blur_fhd")
+    z0 = load("g0_wavy_facade_blur_4k")
+    ref = z0["ref_u16"][85:597, 256:768]
+    test = z["test_u16"]
+    o = orc.Oracle("standard_fhd")
+    o.capture = {}
+    jod, stats = o.predict(test, ref, dim_order="HWC")
+    assert abs(float(jod) - float(z["jod"])) < 1e-5
+    assert relerr(stats["Q_per_ch"][:, 0, 0], z["Q_per_ch"][:, 0, 0]) < 1e-4
+    check_stages(o, o.capture, z, [0], 6, 1)
+    sl = (slice(192, 320), slice(192, 320))
+    assert np.max(np.abs(o.capture["bands"][0][0][(slice(None),) + sl] - z["crop_band_f0_b0"])) < 1e-5
+    assert relerr(o.capture["S"][0][sl], z["crop_S_f0_i0"]) < 3e-6
+
+
+@pytest.mark.parametrize("H,W,N,fps", [(135, 240, 10, 30), (68, 121, 12, 60)])
+def test_tiny_video_stages_g2(H, W, N, fps):
+    test, ref = synth_video_pair(N, H, W)
+    test, ref = test.numpy(), ref.numpy()
+    for pad in ("replicate", "circular", "pingpong"):
+        z = load(f"g2_video_{H}x{W}_{pad}")
+        o = orc.Oracle("standard_fhd", temp_padding=pad)
+        jod, stats = o.predict(test, ref, frames_per_second=fps)
+        assert np.max(np.abs(o.F - z["F"])) < 2e-6 * np.max(np.abs(z["F"]))
+        assert abs(float(jod) - float(z["jod"])) < 1e-5, pad
+        check_q(stats["Q_per_ch"], z["Q_per_ch"])
+        if pad == "replicate":
+            frames = (0, 1, N - 1)
+            o2 = orc.Oracle("standard_fhd", temp_padding=pad)
+            o2.capture = {}
+            o2.predict(test, ref, frames_per_second=fps, frames=frames)
+            height = z["Q_per_ch"].shape[0]
+            check_stages(o2, o2.capture, z, frames, height, 2)
+
+
+def test_f32_gray_and_u16_inputs_g2():
+    test, ref = synth_video_pair(6, 68, 121, C=1)
+    z = load("g2_video_68x121_f32gray")
+    o = orc.Oracle("standard_4k")
+    jod, stats = o.predict(test.float().numpy() / np.float32(255), ref.float().numpy() / np.float32(255), frames_per_second=30)
+    assert abs(float(jod) - float(z["jod"])) < 1e-5
+    z = load("g2_image_68x121_u16gray")
+    t16 = test[0, 0, 0].numpy().astype(np.uint16) * 257
+    r16 = ref[0, 0, 0].numpy().astype(np.uint16) * 257
+    o = orc.Oracle("standard_phone")
+    jod, stats = o.predict(t16, r16, dim_order="HW")
+    assert abs(float(jod) - float(z["jod"])) < 1e-5
+    assert relerr(stats["Q_per_ch"][:, 0, 0], z["Q_per_ch"][:, 0, 0]) < 2e-4

@@ -1,0 +1,349 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REAL reference (build container only: needs /root/reference).
+
+The reference is imported read-only with stub modules for its absent optional dependencies (imageio, ffmpeg);
+its hot path then runs on torch-CPU.  Stage captures are taken by wrapping instance attributes
+(SURVEY.md section 8(c)).  Only DATA (inputs / expected outputs) is written to tests/golden/*.npz.
+
+usage: tools/gen_golden.py [g0] [g1] [g2] [g3fhd] [g3uhd] [g4small] [g4uhd] [g5]     (default: g0 g1 g2 g5)
+"""
+import os
+import struct
+import sys
+import time
+import types
+import zlib
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("FVVDP_REFERENCE", "/root/reference")
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.path.insert(0, ROOT)
+
+
+def import_reference():
+    for name in ("imageio", "imageio.v2", "ffmpeg"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["imageio"].v2 = sys.modules["imageio.v2"]
+    sys.path.insert(0, REF)
+    import pyfvvdp
+    return pyfvvdp
+
+
+def read_png16(path):
+    """Minimal PNG reader for 8/16-bit non-interlaced gray/RGB/RGBA -> uint16/uint8 [H,W,C]."""
+    with open(path, "rb") as f:
+        data = f.read()
+    assert data[:8] == b"\x89PNG\r\n\x1a\n"
+    pos, idat, ihdr = 8, [], None
+    while pos < len(data):
+        (ln,) = struct.unpack(">I", data[pos:pos + 4])
+        typ = data[pos + 4:pos + 8]
+        body = data[pos + 8:pos + 8 + ln]
+        pos += 12 + ln
+        if typ == b"IHDR":
+            ihdr = struct.unpack(">IIBBBBB", body)
+        elif typ == b"IDAT":
+            idat.append(body)
+        elif typ == b"IEND":
+            break
+    W, H, depth, ctype, _, _, interlace = ihdr
+    assert interlace == 0 and depth in (8, 16) and ctype in (0, 2, 6)
+    ch = {0: 1, 2: 3, 6: 4}[ctype]
+    bpp = ch * depth // 8
+    raw = zlib.decompress(b"".join(idat))
+    stride = W * bpp
+    out = np.zeros((H, stride), dtype=np.uint8)
+    prev = np.zeros(stride, dtype=np.int32)
+    p = 0
+    for y in range(H):
+        ft = raw[p]
+        line = np.frombuffer(raw, dtype=np.uint8, count=stride, offset=p + 1).astype(np.int32)
+        p += 1 + stride
+        if ft == 0:
+            cur = line
+        elif ft == 1:
+            cur = line.copy()
+            cur2 = cur.reshape(-1, bpp)
+            cur2[:] = np.cumsum(cur2, axis=0) & 0xFF
+            cur = cur2.reshape(-1)
+        elif ft == 2:
+            cur = (line + prev) & 0xFF
+        else:                      # 3 (average) and 4 (paeth) need the serial recurrence
+            cur = np.zeros(stride, dtype=np.int32)
+            for i in range(stride):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i]
+                c = prev[i - bpp] if i >= bpp else 0
+                if ft == 3:
+                    pred = (a + b) >> 1
+                else:
+                    pa, pb, pc = abs(b - c), abs(a - c), abs(a + b - 2 * c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                cur[i] = (line[i] + pred) & 0xFF
+        out[y] = cur
+        prev = cur
+    if depth == 16:
+        img = out.reshape(H, W, ch, 2).astype(np.uint16)
+        img = (img[..., 0] << 8) | img[..., 1]
+    else:
+        img = out.reshape(H, W, ch)
+    return img
+
+
+def gaussblur(img, sigma):
+    """Same operation as the reference example helper (scipy gaussian_filter, mode nearest, truncate 2)."""
+    from scipy.ndimage import gaussian_filter
+    out = np.zeros_like(img)
+    for cc in range(img.shape[2]):
+        out[..., cc] = gaussian_filter(img[..., cc], sigma, mode="nearest", truncate=2.0)
+    return out
+
+
+class Capture:
+    """Wrap the reference metric's stage functions and record what flows through them."""
+
+    def __init__(self, fv, frames=None, keep_maps=True):
+        self.fv, self.frames, self.keep_maps = fv, frames, keep_maps
+        self.R, self.bands, self.lbkg, self.S, self.D, self.dsum = {}, {}, {}, {}, {}, {}
+        self._ff = None
+        self._cnt = 0
+        self._orig_pb = fv.process_block_of_frames
+        self._orig_cs = fv.cached_sensitivity
+        self._orig_mm = fv.apply_masking_model
+        fv.process_block_of_frames = self._pb
+        fv.cached_sensitivity = self._cs
+        fv.apply_masking_model = self._mm
+
+    def _want(self):
+        return self.keep_maps and (self.frames is None or self._ff in self.frames)
+
+    def _pb(self, ff, R, vid_sz, temp_ch, fixation_point, heatmap):
+        self._ff, self._cnt = ff, 0
+        if self._want():
+            self.R[ff] = R[0, :, 0].numpy().copy()
+            orig_dec = self.fv.lpyr.decompose
+
+            def dec(image):
+                b, g = orig_dec(image)
+                self.bands[ff] = [x[:, 0].numpy().copy() for x in b]
+                self.lbkg[ff] = [x[0, 0].numpy().copy() for x in g]
+                return b, g
+            self.fv.lpyr.decompose = dec
+            try:
+                return self._orig_pb(ff, R, vid_sz, temp_ch, fixation_point, heatmap)
+            finally:
+                self.fv.lpyr.decompose = orig_dec
+        return self._orig_pb(ff, R, vid_sz, temp_ch, fixation_point, heatmap)
+
+    def _cs(self, rho, omega, L_bkg, ecc, sigma):
+        S = self._orig_cs(rho, omega, L_bkg, ecc, sigma)
+        if self._want():
+            self.S.setdefault(self._ff, []).append(S.reshape(S.shape[-2:]).numpy().copy())
+        return S
+
+    def _mm(self, T, R, N, cc):
+        D = self._orig_mm(T, R, N, cc)
+        d64 = D.double()
+        self.dsum.setdefault(self._ff, []).append(
+            (float(d64.sum()), float((d64 * d64).sum()), float(D.max())))
+        if self._want():
+            self.D.setdefault(self._ff, []).append(D.numpy().copy())
+        return D
+
+    def pack(self, out, prefix=""):
+        for ff in sorted(self.R):
+            out[f"{prefix}R_f{ff}"] = self.R[ff]
+            for i, b in enumerate(self.bands[ff]):
+                out[f"{prefix}band_f{ff}_b{i}"] = b
+            for i, g in enumerate(self.lbkg[ff]):
+                out[f"{prefix}lbkg_f{ff}_b{i}"] = g
+            for i, s in enumerate(self.S.get(ff, [])):
+                out[f"{prefix}S_f{ff}_i{i}"] = s
+            for i, d in enumerate(self.D.get(ff, [])):
+                out[f"{prefix}D_f{ff}_i{i}"] = d
+        fr = sorted(self.dsum)
+        out[prefix + "dsum"] = np.array([self.dsum[f] for f in fr], dtype=np.float64)   # [N, n_calls, 3]
+
+
+def save(name, out):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **out)
+    print("wrote %s (%.2f MB)" % (path, os.path.getsize(path) / 1e6), flush=True)
+
+
+def run_case(pyfvvdp, test, ref, dim_order, fps, display, frames=None, keep_maps=True, foveated=False,
+             fixation=None, temp_padding="replicate"):
+    fv = pyfvvdp.fvvdp(display_name=display, heatmap=None, device=torch.device("cpu"), foveated=foveated,
+                       temp_padding=temp_padding, quiet=True)
+    cap = Capture(fv, frames=frames, keep_maps=keep_maps)
+    t0 = time.time()
+    with torch.no_grad():
+        q, stats = fv.predict(test, ref, dim_order=dim_order, frames_per_second=fps, fixation_point=fixation)
+    dt = time.time() - t0
+    out = {"jod": np.float32(q.item()), "Q_per_ch": stats["Q_per_ch"], "rho_band": np.asarray(stats["rho_band"]),
+           "seconds": np.float64(dt)}
+    if fps > 0:
+        out["F"] = fv.F.numpy()
+        out["filter_len"] = np.int64(fv.filter_len)
+    cap.pack(out)
+    return out
+
+
+def g0(pyfvvdp):
+    """README known answer (README.md:135-138): wavy_facade.png vs Gaussian blur sigma=2, standard_4k."""
+    ref = read_png16(os.path.join(REF, "example_media", "wavy_facade.png"))
+    assert ref.dtype == np.uint16 and ref.shape == (683, 1024, 3)
+    test = gaussblur(ref, 2)
+    out = run_case(pyfvvdp, test, ref, "HWC", 0, "standard_4k", keep_maps=False)
+    out["ref_u16"] = ref
+    print("g0 JOD", out["jod"], "README 8.693")
+    save("g0_wavy_facade_blur_4k", out)
+
+
+def g1(pyfvvdp):
+    """BASELINE config 1: 512x512 crop, standard_fhd, full stage captures (small planes kept as is)."""
+    z = np.load(os.path.join(OUT, "g0_wavy_facade_blur_4k.npz"))
+    ref = z["ref_u16"][85:597, 256:768]
+    test = gaussblur(z["ref_u16"], 2)[85:597, 256:768]
+    out = run_case(pyfvvdp, test, ref, "HWC", 0, "standard_fhd")
+    # the big level-0 maps are dropped to keep the fixture small; levels >=1 and all scalars are kept
+    for k in list(out):
+        if any(k.startswith(p) for p in ("band_f0_b0", "lbkg_f0_b0", "S_f0_i0", "D_f0_i0")):
+            arr = out.pop(k)
+            out["crop_" + k] = arr[..., 192:320, 192:320]
+    out["test_u16"] = test
+    print("g1 JOD", out["jod"])
+    save("g1_crop512_blur_fhd", out)
+
+
+def g2(pyfvvdp):
+    """Tiny odd-size videos: both reduce-quirk parities, all three temporal paddings."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    for (H, W, N, fps) in ((135, 240, 10, 30), (68, 121, 12, 60)):
+        test, ref = synth_video_pair(N, H, W)
+        for pad in ("replicate", "circular", "pingpong"):
+            out = run_case(pyfvvdp, test, ref, "BCFHW", fps, "standard_fhd", frames=(0, 1, N - 1),
+                           keep_maps=(pad == "replicate"), temp_padding=pad)
+            print("g2", H, W, pad, "JOD", out["jod"])
+            save(f"g2_video_{H}x{W}_{pad}", out)
+    # fp32 gray input path on the odd-size case
+    test, ref = synth_video_pair(6, 68, 121, C=1)
+    out = run_case(pyfvvdp, test.float() / 255, ref.float() / 255, "BCFHW", 30, "standard_4k", keep_maps=False)
+    save("g2_video_68x121_f32gray", out)
+    # uint16 image path
+    t16 = (test[0, 0, 0].numpy().astype(np.uint16) * 257)
+    r16 = (ref[0, 0, 0].numpy().astype(np.uint16) * 257)
+    out = run_case(pyfvvdp, t16, r16, "HW", 0, "standard_phone", keep_maps=False)
+    save("g2_image_68x121_u16gray", out)
+
+
+def g3(pyfvvdp, H, W, tag):
+    from fovvideovdp_amd.synth import synth_video_pair
+    N = 60
+    test, ref = synth_video_pair(N, H, W)
+    out = run_case(pyfvvdp, test, ref, "BCFHW", 30, "standard_fhd" if H == 1080 else "standard_4k", keep_maps=False)
+    print("g3", tag, "JOD", out["jod"], "seconds", out["seconds"])
+    save(f"g3_synth_{tag}_60f", out)
+
+
+def g4(pyfvvdp, H, W, N, tag, keep):
+    from fovvideovdp_amd.synth import synth_video_pair, synth_gaze
+    test, ref = synth_video_pair(N, H, W)
+    gaze = synth_gaze(N, H, W)
+    out = run_case(pyfvvdp, test, ref, "BCFHW", 30, "standard_hdr_pq", frames=(0, N // 2, N - 1), keep_maps=keep,
+                   foveated=True, fixation=gaze)
+    out["gaze"] = gaze.numpy()
+    print("g4", tag, "JOD", out["jod"], "seconds", out["seconds"])
+    save(f"g4_foveated_{tag}", out)
+
+
+def g5(pyfvvdp):
+    """Unit vectors for the building blocks."""
+    from pyfvvdp.fvvdp_lpyr_dec import fvvdp_lpyr_dec
+    from pyfvvdp.interp import interp3
+    from pyfvvdp.fvvdp_display_model import fvvdp_display_photometry
+    out = {}
+    rng = np.random.RandomState(7)
+    pyr = fvvdp_lpyr_dec(64, 64, 30.0, torch.device("cpu"))
+    for (h, w) in ((12, 16), (13, 16), (12, 17), (13, 17), (4, 5), (5, 4)):
+        x = rng.rand(3, 1, h, w).astype(np.float32) * 100
+        r = pyr.gausspyr_reduce(torch.tensor(x))
+        e = pyr.gausspyr_expand(r, [h, w])
+        out[f"pyr_x_{h}x{w}"] = x[:, 0]
+        out[f"pyr_reduce_{h}x{w}"] = r[:, 0].numpy()
+        out[f"pyr_expand_{h}x{w}"] = e[:, 0].numpy()
+    fv = pyfvvdp.fvvdp(display_name="standard_4k", device=torch.device("cpu"), quiet=True)
+    lut = fv.csf_cache[fv.get_cache_key(0, fv.csf_sigma, fv.k_cm)]["lut"]
+    n = 4096
+    rho = np.exp(rng.uniform(np.log(0.01), np.log(200), n)).astype(np.float32)
+    Y = np.exp(rng.uniform(np.log(1e-4), np.log(1e5), n)).astype(np.float32)
+    ecc = rng.uniform(-5, 150, n).astype(np.float32)
+    # exact knots as queries too
+    rho[:32], Y[32:64], ecc[64:96] = lut["rho"].numpy(), lut["Y"].numpy(), lut["ecc"].numpy()
+    for om in (0, 5):
+        S = fv.cached_sensitivity(torch.tensor(rho), torch.tensor(om), torch.tensor(Y), torch.tensor(ecc), fv.csf_sigma)
+        out[f"csf_S_o{om}"] = S.numpy()
+    out["csf_rho"], out["csf_Y"], out["csf_ecc"] = rho, Y, ecc
+    V = np.linspace(-0.1, 1.1, 1201).astype(np.float32)
+    for disp in ("standard_4k", "standard_hdr_pq", "standard_hdr_linear", "sdr_4k_30"):
+        try:
+            dm = fvvdp_display_photometry.load(disp)
+        except RuntimeError:
+            continue
+        Vin = V * (1500.0 if disp == "standard_hdr_linear" else 1.0)
+        out[f"eotf_{disp}"] = dm.forward(torch.tensor(Vin.astype(np.float32))).numpy()
+    out["eotf_V"] = V
+    import pyfvvdp.fvvdp_display_model as dmm
+    gm = dmm.fvvdp_display_photo_eotf(300, contrast=2000, EOTF="gamma", gamma=2.4, E_ambient=100)
+    out["eotf_gamma24"] = gm.forward(torch.tensor(V)).numpy()
+    for fps in (24, 30, 60, 90, 120):
+        fv.filter_len = int(np.ceil(250.0 / (1000.0 / fps)))
+        F, _ = fv.get_temporal_filters(fps)
+        out[f"F_fps{fps}"] = F.numpy()
+    # geometry helpers for the foveated path
+    for disp in ("standard_4k", "standard_hmd", "standard_phone"):
+        g = dmm.fvvdp_display_geometry.load(disp)
+        xv = torch.linspace(0.5, 47.5, 48)
+        yv = torch.linspace(0.5, 26.5, 27)
+        xx, yy = torch.meshgrid(xv, yv, indexing="xy")
+        vd = g.pix2view_direction(torch.tensor((48, 27)), xx, yy)
+        out[f"geom_viewdir_{disp}"] = vd.numpy()
+        out[f"geom_resmag_{disp}"] = g.get_resolution_magnification(vd).numpy()
+        out[f"geom_ppd_{disp}"] = np.float64(g.get_ppd())
+    save("g5_units", out)
+
+
+def main():
+    which = sys.argv[1:] or ["g0", "g1", "g2", "g5"]
+    torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
+    pyfvvdp = import_reference()
+    for w in which:
+        t0 = time.time()
+        if w == "g0":
+            g0(pyfvvdp)
+        elif w == "g1":
+            g1(pyfvvdp)
+        elif w == "g2":
+            g2(pyfvvdp)
+        elif w == "g3fhd":
+            g3(pyfvvdp, 1080, 1920, "fhd")
+        elif w == "g3uhd":
+            g3(pyfvvdp, 2160, 3840, "uhd")
+        elif w == "g4small":
+            g4(pyfvvdp, 270, 480, 12, "270x480", True)
+        elif w == "g4uhd":
+            g4(pyfvvdp, 2160, 3840, 120, "uhd_120f", False)
+        elif w == "g5":
+            g5(pyfvvdp)
+        else:
+            raise SystemExit("unknown case " + w)
+        print(w, "done in %.1f s" % (time.time() - t0), flush=True)
+
+
+if __name__ == "__main__":
+    main()
