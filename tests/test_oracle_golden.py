@@ -6,7 +6,7 @@ Tolerances (fp32 rounding noise between two correct implementations, measured wh
   * contrast bands are (G - expand(G'))/L_bkg, a difference of nearly equal numbers: absolute error ~1 ulp of G
     divided by L_bkg -> <= 1e-5 of the band's max;
   * D = |dC*S|^2.4/(1+M^q): dC (test minus reference contrast) is itself tiny, so 1-ulp noise on the contrasts is
-    a 1e-4..1e-3 RELATIVE error per pixel -> per-pixel 1e-2 (+1e-3 of the map's max as floor), pooled sum 1e-4;
+    a 1e-4..1e-3 RELATIVE error per pixel -> per-pixel 1e-2 (+1e-3 of the map's max as floor), pooled sum 1e-4 (1e-3 for maps under 4096 px, where the noise does not average out);
   * Q_per_ch: see check_q; JOD 1e-5 absolute;
   * PQ EOTF at the dark end and the foveated resolution magnification are finite differences of nearly equal
     fp32 numbers in the reference's own formulas (pq2lin: V^(1/m)-c1; get_ppd: tan(a+delta)-tan(a)) -> 2e-4 / 1e-3."""
@@ -131,7 +131,7 @@ def check_stages(o, cap, z, frames, height, temp_ch):
                 d = cap["D"][fi * temp_ch * height + i]
                 assert np.max(np.abs(d - gd) / (np.abs(gd) + 1e-3 * np.max(gd) + 1e-12)) < 1e-2, key
                 # pooled quantity is far tighter than the worst pixel (pow amplifies ulp noise on tiny contrasts)
-                assert abs(d.astype(np.float64).sum() / gd.astype(np.float64).sum() - 1) < 1e-4, key
+                assert abs(d.astype(np.float64).sum() / gd.astype(np.float64).sum() - 1) < (1e-4 if gd.size >= 4096 else 1e-3), key
 
 
 def test_readme_known_answer_g0():
