@@ -1,0 +1,1237 @@
+// libfvvdp_hip: FovVideoVDP per-frame visible-difference path for MI355X (gfx950 / CDNA4).
+//
+// Written for gfx950 only: wave64, single-wave workgroups that stream down the image for the fused pyramid
+// kernel, 16-byte-per-lane coalesced HBM access on pixel-interleaved planes, LDS for neighbour exchange, no MFMA
+// (5-tap stencils + pointwise + LUT: there is no contraction to feed a matrix core).  See DESIGN.md.
+//
+// Data layout in HBM (context scratch): Gaussian level i of frame slot s is an array [h_i][w_i][P] fp32 --
+// the P temporal-channel planes of one pixel are adjacent (one aligned float4 for video, float2 for images), so
+// one lane = one pixel, every load/store is 16 B (8 B) wide and all per-pixel math is thread-local.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "fvvdp_hip.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) return fail(FVVDP_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" const char* fvvdp_last_error(void) { return g_err; }
+
+// ------------------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------------------
+template <int P>
+struct Pix {
+    float v[P];
+};
+
+template <int P>
+__device__ __forceinline__ Pix<P> ld_pix(const float* p);
+template <>
+__device__ __forceinline__ Pix<4> ld_pix<4>(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    return Pix<4>{{t.x, t.y, t.z, t.w}};
+}
+template <>
+__device__ __forceinline__ Pix<2> ld_pix<2>(const float* p) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    return Pix<2>{{t.x, t.y}};
+}
+__device__ __forceinline__ void st_pix(float* p, const Pix<4>& a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
+}
+__device__ __forceinline__ void st_pix(float* p, const Pix<2>& a) {
+    *reinterpret_cast<float2*>(p) = make_float2(a.v[0], a.v[1]);
+}
+
+__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// stage 1: unpack + display photometry + luminance + temporal FIR  ->  pyramid level 0 (interleaved planes)
+// ------------------------------------------------------------------------------------------------------------
+enum { SRC_U8 = 0, SRC_U16 = 1, SRC_F32 = 2 };
+
+struct EotfDev {
+    int kind;
+    float scale;    // Y_peak - Y_black
+    float y_black;
+    float y_peak;
+    float gamma;
+    float l_min, l_max;
+    const float* lut;
+};
+
+// Per-channel display model on a float sample V (fvvdp_display_model.py:147-165).  `bad` is set when V was
+// outside [0,1] for an EOTF that clamps.
+__device__ __forceinline__ float eotf_f32(float V, const EotfDev& e, bool& bad) {
+    switch (e.kind) {
+        case FVVDP_EOTF_SRGB: {
+            bad = bad || (V > 1.0f) || (V < 0.0f);
+            V = fminf(fmaxf(V, 0.0f), 1.0f);
+            const float hi = fast_exp2(2.4f * fast_log2((V + 0.055f) / 1.055f));
+            const float lin = V > 0.04045f ? hi : V / 12.92f;
+            return __fadd_rn(__fmul_rn(e.scale, lin), e.y_black);
+        }
+        case FVVDP_EOTF_GAMMA: {
+            bad = bad || (V > 1.0f) || (V < 0.0f);
+            V = fminf(fmaxf(V, 0.0f), 1.0f);
+            const float lin = V > 0.0f ? fast_exp2(e.gamma * fast_log2(V)) : 0.0f;
+            return __fadd_rn(__fmul_rn(e.scale, lin), e.y_black);
+        }
+        case FVVDP_EOTF_PQ: {
+            bad = bad || (V > 1.0f) || (V < 0.0f);
+            V = fminf(fmaxf(V, 0.0f), 1.0f);
+            const float m = 78.843750000000000f, n = 0.15930175781250000f;
+            const float c1 = 0.83593750000000000f, c2 = 18.851562500000000f, c3 = 18.687500000000000f;
+            const float im_t = V > 0.0f ? fast_exp2(fast_log2(V) * (1.0f / m)) : 0.0f;
+            const float r = fmaxf(im_t - c1, 0.0f) / (c2 - c3 * im_t);
+            const float L = r > 0.0f ? 10000.0f * fast_exp2(fast_log2(r) * (1.0f / n)) : 0.0f;
+            return fminf(fmaxf(L, 0.005f), e.y_peak) + e.y_black;
+        }
+        case FVVDP_EOTF_LINEAR:
+            return fminf(fmaxf(V, 0.005f), e.y_peak) + e.y_black;
+        case FVVDP_EOTF_ABSOLUTE:
+            return fminf(fmaxf(V, e.l_min), e.l_max);
+        default:
+            return V;
+    }
+}
+
+// Luminance of PX consecutive pixels of one frame of one stream.
+//   U8 : LDS table lutw[c][code] = lut[code]*w[c] (same products and same summation order as the reference:
+//        (Lr*w0 + Lg*w1) + Lb*w2, video_source.py:206)
+template <int SRC, int PX>
+struct Sampler {
+    const void* base;
+    size_t chan_stride;
+    int C;
+    const float* lutw;     // LDS, [3][256], SRC_U8 only
+    const float* lut16;    // global, SRC_U16 only
+    float w0, w1, w2;
+    EotfDev e;
+
+    __device__ __forceinline__ void chan(const void* p, size_t off, float (&o)[PX], int c, bool& bad) const {
+        if constexpr (SRC == SRC_U8) {
+            const unsigned char* q = reinterpret_cast<const unsigned char*>(p) + off;
+            unsigned char code[PX];
+            if constexpr (PX == 4) {
+                const uchar4 t = *reinterpret_cast<const uchar4*>(q);
+                code[0] = t.x; code[1] = t.y; code[2] = t.z; code[3] = t.w;
+            } else if constexpr (PX == 2) {
+                const uchar2 t = *reinterpret_cast<const uchar2*>(q);
+                code[0] = t.x; code[1] = t.y;
+            } else {
+                code[0] = *q;
+            }
+#pragma unroll
+            for (int i = 0; i < PX; ++i) o[i] = lutw[c * 256 + code[i]];
+        } else if constexpr (SRC == SRC_U16) {
+            const unsigned short* q = reinterpret_cast<const unsigned short*>(p) + off;
+            unsigned short code[PX];
+            if constexpr (PX == 4) {
+                const ushort4 t = *reinterpret_cast<const ushort4*>(q);
+                code[0] = t.x; code[1] = t.y; code[2] = t.z; code[3] = t.w;
+            } else if constexpr (PX == 2) {
+                const ushort2 t = *reinterpret_cast<const ushort2*>(q);
+                code[0] = t.x; code[1] = t.y;
+            } else {
+                code[0] = *q;
+            }
+            const float wc = (c == 0) ? w0 : ((c == 1) ? w1 : w2);
+#pragma unroll
+            for (int i = 0; i < PX; ++i) o[i] = __fmul_rn(lut16[code[i]], wc);
+        } else {
+            const float* q = reinterpret_cast<const float*>(p) + off;
+            float V[PX];
+            if constexpr (PX == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(q);
+                V[0] = t.x; V[1] = t.y; V[2] = t.z; V[3] = t.w;
+            } else if constexpr (PX == 2) {
+                const float2 t = *reinterpret_cast<const float2*>(q);
+                V[0] = t.x; V[1] = t.y;
+            } else {
+                V[0] = *q;
+            }
+            const float wc = (c == 0) ? w0 : ((c == 1) ? w1 : w2);
+#pragma unroll
+            for (int i = 0; i < PX; ++i) o[i] = __fmul_rn(eotf_f32(V[i], e, bad), wc);
+        }
+    }
+
+    // frame offset `foff` (elements) already includes f*frame_stride + pixel index
+    __device__ __forceinline__ void lum(size_t foff, float (&L)[PX], bool& bad) const {
+        if (C == 3) {
+            float a[PX], b[PX], c[PX];
+            chan(base, foff, a, 0, bad);
+            chan(base, foff + chan_stride, b, 1, bad);
+            chan(base, foff + 2 * chan_stride, c, 2, bad);
+#pragma unroll
+            for (int i = 0; i < PX; ++i) L[i] = __fadd_rn(__fadd_rn(a[i], b[i]), c[i]);
+        } else {
+            chan(base, foff, L, 0, bad);
+        }
+    }
+};
+
+#define T_MAX_IDX 320   // history + outputs of one launch
+struct TemporalArgs {
+    const void* src[2];
+    size_t chan_stride, frame_stride;
+    int C, HW;
+    EotfDev e;
+    float w[3];
+    int n_out;
+    int fl;                // true filter length (<= FL)
+    float* out;            // level 0 of the first output slot: [n_out][HW][4]
+    int* oob;
+    float taps[2][32];
+    int idx[T_MAX_IDX];    // [FL-1+n_out], entries before the true history are padded with a valid frame
+};
+
+__device__ __forceinline__ void build_lutw(float* lutw, const float* lut, int C, const float* w, int tid, int nthreads) {
+    for (int i = tid; i < 256; i += nthreads) {
+        const float l = lut[i];
+        if (C == 3) {
+            lutw[i] = __fmul_rn(l, w[0]);
+            lutw[256 + i] = __fmul_rn(l, w[1]);
+            lutw[512 + i] = __fmul_rn(l, w[2]);
+        } else {
+            lutw[i] = l;
+        }
+    }
+}
+
+// Temporally tiled FIR: one thread owns PX pixels for the whole launch and keeps the last FL luminance values of
+// both streams in registers (ring with compile-time slot indices), so every source frame is read exactly once and
+// every output pixel is written once as one float4 (test-sust, ref-sust, test-trans, ref-trans).
+// Reference: fvvdp.py:294-300 (R[:,2cc+s] = sum_k window[s][k] * F[cc].flip(0)[k]).
+template <int FL, int PX, int SRC>
+__global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a) {
+    __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
+    if constexpr (SRC == SRC_U8) {
+        build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 256);
+        __syncthreads();
+    }
+    const int p = (blockIdx.x * 256 + threadIdx.x) * PX;
+    if (p >= a.HW) return;
+    Sampler<SRC, PX> S[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        S[s].base = a.src[s];
+        S[s].chan_stride = a.chan_stride;
+        S[s].C = a.C;
+        S[s].lutw = lutw;
+        S[s].lut16 = a.e.lut;
+        S[s].w0 = a.C == 3 ? a.w[0] : 1.0f;
+        S[s].w1 = a.w[1];
+        S[s].w2 = a.w[2];
+        S[s].e = a.e;
+    }
+    bool bad = false;
+    float ring[2][FL][PX];
+#pragma unroll
+    for (int u = 0; u < FL - 1; ++u) {
+        const size_t off = (size_t)a.idx[u] * a.frame_stride + p;
+        S[0].lum(off, ring[0][u], bad);
+        S[1].lum(off, ring[1][u], bad);
+    }
+    for (int t0 = 0; t0 < a.n_out; t0 += FL) {
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+            const int t = t0 + u;
+            if (t < a.n_out) {
+                const int slot = (FL - 1 + u) % FL;
+                const size_t off = (size_t)a.idx[FL - 1 + t] * a.frame_stride + p;
+                S[0].lum(off, ring[0][slot], bad);
+                S[1].lum(off, ring[1][slot], bad);
+                float acc[4][PX];
+#pragma unroll
+                for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
+                // oldest tap first, like the reference's sum over the window dimension
+#pragma unroll
+                for (int k = FL - 1; k >= 0; --k) {
+                    const int sl = (slot - k + 2 * FL) % FL;
+                    const float f0 = a.taps[0][k], f1 = a.taps[1][k];
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) {
+                        acc[0][i] = fmaf(ring[0][sl][i], f0, acc[0][i]);
+                        acc[1][i] = fmaf(ring[1][sl][i], f0, acc[1][i]);
+                        acc[2][i] = fmaf(ring[0][sl][i], f1, acc[2][i]);
+                        acc[3][i] = fmaf(ring[1][sl][i], f1, acc[3][i]);
+                    }
+                }
+                float* o = a.out + ((size_t)t * a.HW + p) * 4;
+#pragma unroll
+                for (int i = 0; i < PX; ++i)
+                    *reinterpret_cast<float4*>(o + 4 * i) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+            }
+        }
+    }
+    if (bad && a.oob) atomicOr(a.oob, 1);
+}
+
+// Generic (any fl, any frame size) version: one thread per pixel per output frame, the window is re-read from
+// the source (L2-served).  Used for fl > 32, for frame sizes that are not a multiple of 4 pixels and for still
+// images (P == 2: out = (L_test, L_ref), fvvdp.py:251-253).
+struct GenericArgs {
+    const void* src[2];
+    size_t chan_stride, frame_stride;
+    int C, HW;
+    EotfDev e;
+    float w[3];
+    int n_out, fl;
+    float* out;
+    int* oob;
+    const float* taps;   // device [2][fl]
+    const int* idx;      // device [fl-1+n_out]
+};
+
+template <int SRC, int P>
+__global__ __launch_bounds__(256) void temporal_generic_kernel(const GenericArgs a) {
+    __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
+    if constexpr (SRC == SRC_U8) {
+        build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 256);
+        __syncthreads();
+    }
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int t = blockIdx.y;
+    if (p >= a.HW) return;
+    Sampler<SRC, 1> S[2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        S[s].base = a.src[s];
+        S[s].chan_stride = a.chan_stride;
+        S[s].C = a.C;
+        S[s].lutw = lutw;
+        S[s].lut16 = a.e.lut;
+        S[s].w0 = a.C == 3 ? a.w[0] : 1.0f;
+        S[s].w1 = a.w[1];
+        S[s].w2 = a.w[2];
+        S[s].e = a.e;
+    }
+    bool bad = false;
+    if constexpr (P == 2) {
+        float lt[1], lr[1];
+        const size_t off = (size_t)a.idx[t] * a.frame_stride + p;
+        S[0].lum(off, lt, bad);
+        S[1].lum(off, lr, bad);
+        *reinterpret_cast<float2*>(a.out + ((size_t)t * a.HW + p) * 2) = make_float2(lt[0], lr[0]);
+    } else {
+        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        for (int k = a.fl - 1; k >= 0; --k) {
+            const size_t off = (size_t)a.idx[a.fl - 1 + t - k] * a.frame_stride + p;
+            float lt[1], lr[1];
+            S[0].lum(off, lt, bad);
+            S[1].lum(off, lr, bad);
+            const float f0 = a.taps[k], f1 = a.taps[a.fl + k];
+            acc[0] = fmaf(lt[0], f0, acc[0]);
+            acc[1] = fmaf(lr[0], f0, acc[1]);
+            acc[2] = fmaf(lt[0], f1, acc[2]);
+            acc[3] = fmaf(lr[0], f1, acc[3]);
+        }
+        *reinterpret_cast<float4*>(a.out + ((size_t)t * a.HW + p) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    }
+    if (bad && a.oob) atomicOr(a.oob, 1);
+}
+
+// planar [n][P][HW] <-> interleaved [n][HW][P]
+template <int P>
+__global__ void interleave_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int to_interleaved) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int f = blockIdx.y;
+    if (p >= HW) return;
+#pragma unroll
+    for (int k = 0; k < P; ++k) {
+        if (to_interleaved)
+            out[((size_t)f * HW + p) * P + k] = in[((size_t)f * P + k) * HW + p];
+        else
+            out[((size_t)f * P + k) * HW + p] = in[((size_t)f * HW + p) * P + k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// stage 2: fused pyramid level
+//   read Gaussian level i once, write level i+1 once, and in the same pass expand level i+1, form the contrast
+//   band, weight by the CSF, apply mutual masking and accumulate sum(D^beta)  (nothing else touches HBM).
+// ------------------------------------------------------------------------------------------------------------
+#define STRIP_J 60          // coarse columns produced per wave (64 lanes - 2 halo lanes each side)
+
+struct BandArgs {
+    const float* Gf;        // fine level   [n][h][w][P]
+    float* Gc;              // coarse level [n][hc][wc][P]
+    int w, h, wc, hc;
+    int n_strips, n_chunks, cr;
+    float band_mul;
+    const float4* csf;      // [32] records {Y_log[i], 1/(Y_log[i+1]-Y_log[i]+1e-6), S_log0[i], S_log1[i]}
+    float y_first, y_inv_step;
+    float y_lo, y_hi;       // clamp range of L_bkg (lut Y[0], Y[-1])
+    float lg_gain, lg_k;    // log2(sens_gain), log2(mask_k)
+    float p, q0, q1, beta, lbkg_min, cmax, lg_dmax;
+    float* partial;         // [n][n_strips*n_chunks][2]
+    float* dD;
+    float* dC;
+    float* dL;
+    float* dS;
+    // foveated (FOV == true)
+    const float* lut3[2];   // [32][32][32] S_log per temporal channel
+    const float* ax_rho;    // [32] rho_log
+    const float* ax_ecc;    // [32] ecc_sqrt
+    const float* fix;       // device [n][2] gaze in frame pixels
+    float size_m0, size_m1, dist_m, ppd_c, tan_delta, delta_deg;
+    float rho_band, rho_lo, rho_hi, ecc_lo, ecc_hi;
+    int frame_w, frame_h;
+};
+
+template <int P>
+__device__ __forceinline__ Pix<P> lds_ld(const float* base, int slot) {
+    return ld_pix<P>(base + slot * P);
+}
+
+__device__ __forceinline__ void interp_axis(const float* __restrict__ x, float q, int& i0, int& i1, float& f) {
+    // get_interpolants_v1 (interp.py:11-20): imax = first knot >= q (clamped), imin = max(imax-1,0),
+    // f = (q-x[imin])/(x[imax]-x[imin]+1e-6), 0 if imax==imin, clamped at 0
+    int lo = 0, hi = FVVDP_LUT_N;     // bucketize: first index with x[i] >= q
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+        const int mid = (lo + hi) >> 1;
+        const bool go = (lo < hi) && (x[min(mid, FVVDP_LUT_N - 1)] < q);
+        const bool stay = (lo < hi) && !go;
+        lo = go ? mid + 1 : lo;
+        hi = stay ? mid : hi;
+    }
+    i1 = min(lo, FVVDP_LUT_N - 1);
+    i0 = max(i1 - 1, 0);
+    const float den = x[i1] - x[i0] + 0.000001f;
+    f = (i1 == i0) ? 0.0f : fmaxf((q - x[i0]) / den, 0.0f);
+}
+
+template <int P, bool DBG, bool FOV>
+__global__ __launch_bounds__(64) void band_kernel(const BandArgs a) {
+    constexpr int TC = P / 2;   // temporal channels
+    __shared__ __attribute__((aligned(16))) float s_vE[64 * P];
+    __shared__ __attribute__((aligned(16))) float s_vO[64 * P];
+    __shared__ __attribute__((aligned(16))) float s_eE[64 * P];
+    __shared__ __attribute__((aligned(16))) float s_eO[64 * P];
+    __shared__ float4 s_csf[FVVDP_LUT_N];
+
+    const int lane = threadIdx.x;
+    int bid = blockIdx.x;
+    const int strip = bid % a.n_strips;
+    bid /= a.n_strips;
+    const int chunk = bid % a.n_chunks;
+    const int frame = bid / a.n_chunks;
+    const int blk = chunk * a.n_strips + strip;
+
+    const int w = a.w, h = a.h, wc = a.wc, hc = a.hc;
+    const int Ja = strip * STRIP_J;
+    const int Jb = min(Ja + STRIP_J, wc);
+    const int J = Ja - 2 + lane;
+    const int ca = chunk * a.cr;
+    const int cb = min(ca + a.cr, hc);
+    const bool active = (lane >= 2) && (lane < 62) && (J < Jb);
+    const int X0 = 2 * J, X1 = 2 * J + 1;
+    const int xc0 = min(max(X0, 0), w - 1), xc1 = min(max(X1, 0), w - 1);
+    const bool col1_ok = X1 < w;
+
+    if (!FOV && lane < FVVDP_LUT_N) s_csf[lane] = a.csf[lane];
+
+    // horizontal 5-tap weights of this lane's coarse column incl. the reference's edge fix-ups
+    // (gausspyr_reduce, fvvdp_lpyr_dec.py:198-205; the right-edge branch is selected by the parity of the ROW
+    // count, :202, reproduced here on purpose)
+    const float K0 = 0.05f, K1 = 0.25f, K2 = 0.4f, K3 = 0.25f, K4 = 0.05f;
+    float wq0 = K0, wq1 = K1, wq2 = K2, wq3 = K3, wq4 = K4;
+    if (J == 0) {
+        wq2 += K1;
+        wq3 += K0;
+        wq0 = 0.0f;
+        wq1 = 0.0f;
+    }
+    if (J == wc - 1) {
+        const bool hodd = (h & 1) != 0;
+        if (w & 1) {   // own columns: X0 = w-1 (slot 2), X1 = w (outside)
+            wq3 = 0.0f;
+            wq4 = 0.0f;
+            if (hodd) { wq2 += K3; wq1 += K4; } else { wq2 += K4; }
+        } else {       // own columns: w-2 (slot 2), w-1 (slot 3); slot 4 = w is outside
+            wq4 = 0.0f;
+            if (hodd) { wq3 += K3; wq2 += K4; } else { wq3 += K4; }
+        }
+    }
+    const int lm = max(lane - 1, 0), lp = min(lane + 1, 63);
+    // expand neighbours: coarse columns clamp(J-1), clamp(J+1) (gausspyr_expand edge rule, fvvdp_lpyr_dec.py:126-142)
+    const int jl = min(max(J - 1, 0), wc - 1) - (Ja - 2);
+    const int jr = min(max(J + 1, 0), wc - 1) - (Ja - 2);
+    const int sl = min(max(jl, 0), 63), sr = min(max(jr, 0), 63);
+
+    const float* Gf = a.Gf + (size_t)frame * h * w * P;
+    float* Gc = a.Gc + (size_t)frame * hc * wc * P;
+
+    auto load_row = [&](int r, Pix<P>& p0, Pix<P>& p1) {
+        int rr = r < 0 ? -1 - r : (r >= h ? 2 * h - 1 - r : r);   // symmetric padding (fvvdp_lpyr_dec.py:190-195)
+        rr = min(max(rr, 0), h - 1);
+        const float* row = Gf + (size_t)rr * w * P;
+        p0 = ld_pix<P>(row + (size_t)xc0 * P);
+        p1 = ld_pix<P>(row + (size_t)xc1 * P);
+    };
+
+    Pix<P> W[5][2];
+
+    // one coarse row from the current window: vertical 5-tap in registers, horizontal 5-tap through LDS
+    auto coarse_step = [&]() -> Pix<P> {
+        Pix<P> va, vb;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            va.v[k] = K0 * W[0][0].v[k] + K1 * W[1][0].v[k] + K2 * W[2][0].v[k] + K3 * W[3][0].v[k] + K4 * W[4][0].v[k];
+            vb.v[k] = K0 * W[0][1].v[k] + K1 * W[1][1].v[k] + K2 * W[2][1].v[k] + K3 * W[3][1].v[k] + K4 * W[4][1].v[k];
+        }
+        __syncthreads();
+        st_pix(s_vE + lane * P, va);
+        st_pix(s_vO + lane * P, vb);
+        __syncthreads();
+        const Pix<P> em = lds_ld<P>(s_vE, lm), om = lds_ld<P>(s_vO, lm), ep = lds_ld<P>(s_vE, lp);
+        Pix<P> c;
+#pragma unroll
+        for (int k = 0; k < P; ++k)
+            c.v[k] = wq0 * em.v[k] + wq1 * om.v[k] + wq2 * va.v[k] + wq3 * vb.v[k] + wq4 * ep.v[k];
+        return c;
+    };
+    auto shift_window = [&](const Pix<P> (&n0)[2], const Pix<P> (&n1)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            W[0][j] = W[2][j];
+            W[1][j] = W[3][j];
+            W[2][j] = W[4][j];
+            W[3][j] = n0[j];
+            W[4][j] = n1[j];
+        }
+    };
+
+    // ---- prologue: coarse rows ca-1 and ca --------------------------------------------------------------
+    {
+        const int r0 = 2 * (ca - 1) - 2;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) load_row(r0 + k, W[k][0], W[k][1]);
+    }
+    const Pix<P> cA = coarse_step();
+    Pix<P> nx0[2], nx1[2];
+    load_row(2 * ca + 1, nx0[0], nx0[1]);
+    load_row(2 * ca + 2, nx1[0], nx1[1]);
+    shift_window(nx0, nx1);
+    const Pix<P> cB = coarse_step();
+    if (active) st_pix(Gc + ((size_t)ca * wc + J) * P, cB);
+    Pix<P> Gm1 = (ca > 0) ? cA : cB;
+    Pix<P> G0 = cB;
+    load_row(2 * ca + 3, nx0[0], nx0[1]);
+    load_row(2 * ca + 4, nx1[0], nx1[1]);
+
+    float acc[2] = {0.0f, 0.0f};
+
+    // foveated constants of this lane's two fine columns
+    float vxa = 0.0f, vxb = 0.0f, gx = 0.0f, gy = 0.0f;
+    if constexpr (FOV) {
+        // pix2view_direction (fvvdp_display_model.py:498-510) on the band grid, pixel centres at +0.5
+        const float xa = ((float)X0 + 0.5f) + (-(float)w / 2.0f);
+        const float xb = ((float)X1 + 0.5f) + (-(float)w / 2.0f);
+        vxa = atanf(xa * a.size_m0 / (float)w / a.dist_m) * 57.29577951308232f;
+        vxb = atanf(xb * a.size_m0 / (float)w / a.dist_m) * 57.29577951308232f;
+        const float fxp = a.fix[2 * frame + 0] + 0.5f, fyp = a.fix[2 * frame + 1] + 0.5f;
+        const float gxm = (fxp + (-(float)a.frame_w / 2.0f)) * a.size_m0 / (float)a.frame_w;
+        const float gym = -(fyp + (-(float)a.frame_h / 2.0f)) * a.size_m1 / (float)a.frame_h;
+        gx = atanf(gxm / a.dist_m) * 57.29577951308232f;
+        gy = atanf(gym / a.dist_m) * 57.29577951308232f;
+    }
+
+    // per-pixel tail: contrast, CSF, masking, pooling  (fvvdp_lpyr_dec.py:259-269, fvvdp.py:395-467)
+    auto band_px = [&](const Pix<P>& g, const Pix<P>& e, bool valid, int y, int x, float vx) {
+        const float lb = fmaxf(e.v[1], a.lbkg_min);
+        const float inv = fast_rcp(lb);
+        float c[P];
+#pragma unroll
+        for (int k = 0; k < P; ++k) c[k] = fminf((g.v[k] - e.v[k]) * inv, a.cmax) * a.band_mul;
+        const float yq = fast_log2(fminf(fmaxf(lb, a.y_lo), a.y_hi));
+        float slog[2] = {0.0f, 0.0f};
+        if constexpr (!FOV) {
+            int i = (int)floorf((yq - a.y_first) * a.y_inv_step);
+            i = min(max(i, 0), FVVDP_LUT_N - 2);
+            const float4 r0 = s_csf[i];
+            const float4 r1 = s_csf[i + 1];
+            // the uniform-grid guess can be off by one knot at a knot boundary: step to the bracketing interval
+            const bool up = yq > r1.x && i < FVVDP_LUT_N - 2;
+            const bool dn = yq < r0.x && i > 0;
+            float4 ra = r0, rb = r1;
+            if (up) { ra = r1; rb = s_csf[i + 2]; }
+            if (dn) { rb = r0; ra = s_csf[i - 1]; }
+            const float f = fmaxf((yq - ra.x) * ra.y, 0.0f);
+            slog[0] = ra.z * (1.0f - f) + rb.z * f;
+            slog[1] = ra.w * (1.0f - f) + rb.w * f;
+        } else {
+            // eccentricity and resolution magnification (fvvdp.py:424-437, fvvdp_display_model.py:475-526)
+            const float yp = ((float)y + 0.5f) + (-(float)h / 2.0f);
+            const float vy = atanf(-yp * a.size_m1 / (float)h / a.dist_m) * 57.29577951308232f;
+            const float dx = vx - gx, dy = vy - gy;
+            const float ecc = sqrtf(dx * dx + dy * dy);
+            const float va = fminf(sqrtf(vx * vx + vy * vy), 89.9f);
+            const float ta = tanf(va * 0.017453292519943295f);
+            const float tb = tanf((va + a.delta_deg) * 0.017453292519943295f);
+            const float res_mag = a.ppd_c * (tb - ta) / a.tan_delta / a.ppd_c;
+            const float rho = a.rho_band * res_mag;
+            const float rq = fast_log2(fminf(fmaxf(rho, a.rho_lo), a.rho_hi));
+            const float eq = sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
+            int i0, i1, j0, j1, k0, k1;
+            float fi, fj, fk;
+            interp_axis(a.ax_rho, rq, i0, i1, fi);
+            {   // Y axis knots live in the first 32 records' .x of a.csf
+                int lo = 0, hi = FVVDP_LUT_N;
+#pragma unroll
+                for (int it = 0; it < 6; ++it) {
+                    const int mid = (lo + hi) >> 1;
+                    const bool go = (lo < hi) && (a.csf[min(mid, FVVDP_LUT_N - 1)].x < yq);
+                    const bool stay = (lo < hi) && !go;
+                    lo = go ? mid + 1 : lo;
+                    hi = stay ? mid : hi;
+                }
+                j1 = min(lo, FVVDP_LUT_N - 1);
+                j0 = max(j1 - 1, 0);
+                const float den = a.csf[j1].x - a.csf[j0].x + 0.000001f;
+                fj = (j1 == j0) ? 0.0f : fmaxf((yq - a.csf[j0].x) / den, 0.0f);
+            }
+            interp_axis(a.ax_ecc, eq, k0, k1, fk);
+#pragma unroll
+            for (int cc = 0; cc < TC; ++cc) {
+                const float* v = a.lut3[cc];
+                auto at = [&](int j, int i, int k) { return v[(j * FVVDP_LUT_N + i) * FVVDP_LUT_N + k]; };
+                // interp3 (interp.py:53-57), same association
+                const float lo_k = (at(j0, i0, k0) * (1.0f - fi) + at(j0, i1, k0) * fi) * (1.0f - fj) +
+                                   (at(j1, i0, k0) * (1.0f - fi) + at(j1, i1, k0) * fi) * fj;
+                const float hi_k = (at(j0, i0, k1) * (1.0f - fi) + at(j0, i1, k1) * fi) * (1.0f - fj) +
+                                   (at(j1, i0, k1) * (1.0f - fi) + at(j1, i1, k1) * fi) * fj;
+                slog[cc] = lo_k * (1.0f - fk) + hi_k * fk;
+            }
+        }
+#pragma unroll
+        for (int cc = 0; cc < TC; ++cc) {
+            const float T = c[2 * cc], R = c[2 * cc + 1];
+            const float ls = slog[cc] + a.lg_gain;                      // log2(S), S = 2^interp * gain (fvvdp.py:447)
+            const float q = cc == 0 ? a.q0 : a.q1;
+            // D = |T'-R'|^p / (1 + (k*min(|T'|,|R'|))^q), T' = T*S   (fvvdp.py:585-595), in the log2 domain
+            const float ld = a.p * (fast_log2(fabsf(T - R)) + ls);
+            const float mq = fast_exp2(q * (fast_log2(fminf(fabsf(T), fabsf(R))) + ls + a.lg_k));
+            const float ldd = fminf(ld - fast_log2(1.0f + mq), a.lg_dmax);
+            const float term = fast_exp2(a.beta * ldd);                  // D^beta for the spatial pooling (fvvdp.py:467,607)
+            acc[cc] += valid ? term : 0.0f;
+            if constexpr (DBG) {
+                if (valid) {
+                    const size_t o = (((size_t)frame * 2 + cc) * h + y) * w + x;
+                    if (a.dD) a.dD[o] = fast_exp2(ldd);
+                    if (a.dS) a.dS[o] = fast_exp2(slog[cc]);
+                }
+            }
+        }
+        if constexpr (DBG) {
+            if (valid) {
+                if (a.dC) {
+#pragma unroll
+                    for (int k = 0; k < P; ++k) a.dC[(((size_t)frame * P + k) * h + y) * w + x] = c[k];
+                }
+                if (a.dL) a.dL[((size_t)frame * h + y) * w + x] = lb;
+            }
+        }
+    };
+
+    // ---- main loop: band rows 2c, 2c+1 for c in [ca, cb) ------------------------------------------------
+    const float E0 = 0.1f, E1 = 0.8f, E2 = 0.1f, O0 = 0.5f, O1 = 0.5f;   // 2*K (gausspyr_expand, :228,:233)
+    for (int c = ca; c < cb; ++c) {
+        shift_window(nx0, nx1);               // window = fine rows 2c .. 2c+4
+        if (c + 1 < cb) {                     // prefetch the two rows of the next step
+            load_row(2 * c + 5, nx0[0], nx0[1]);
+            load_row(2 * c + 6, nx1[0], nx1[1]);
+        }
+        const Pix<P> cN = coarse_step();      // coarse row c+1
+        const bool has_next = (c + 1) <= (hc - 1);
+        Pix<P> Gp1 = has_next ? cN : G0;      // index clamp of the expand (fvvdp_lpyr_dec.py:134,138)
+        if (has_next && (c + 1) < cb && active) st_pix(Gc + ((size_t)(c + 1) * wc + J) * P, cN);
+        // vertical expand on the coarse column (even fine row 2c, odd fine row 2c+1)
+        Pix<P> evE, evO;
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            evE.v[k] = (E0 * Gm1.v[k] + E1 * G0.v[k]) + E2 * Gp1.v[k];
+            evO.v[k] = O0 * G0.v[k] + O1 * Gp1.v[k];
+        }
+        st_pix(s_eE + lane * P, evE);
+        st_pix(s_eO + lane * P, evO);
+        __syncthreads();
+        const Pix<P> eEl = lds_ld<P>(s_eE, sl), eEr = lds_ld<P>(s_eE, sr);
+        const Pix<P> eOl = lds_ld<P>(s_eO, sl), eOr = lds_ld<P>(s_eO, sr);
+        Pix<P> x00, x01, x10, x11;            // expanded level at (row 2c|2c+1, col X0|X1)
+#pragma unroll
+        for (int k = 0; k < P; ++k) {
+            x00.v[k] = (E0 * eEl.v[k] + E1 * evE.v[k]) + E2 * eEr.v[k];
+            x01.v[k] = O0 * evE.v[k] + O1 * eEr.v[k];
+            x10.v[k] = (E0 * eOl.v[k] + E1 * evO.v[k]) + E2 * eOr.v[k];
+            x11.v[k] = O0 * evO.v[k] + O1 * eOr.v[k];
+        }
+        const bool row1_ok = (2 * c + 1) < h;
+        band_px(W[0][0], x00, active, 2 * c, X0, vxa);
+        band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vxb);
+        band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vxa);
+        band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vxb);
+        Gm1 = G0;
+        G0 = Gp1;
+    }
+
+    const float s0 = wave_sum(acc[0]);
+    const float s1 = wave_sum(acc[1]);
+    if (lane == 0) {
+        float* o = a.partial + ((size_t)frame * (a.n_strips * a.n_chunks) + blk) * 2;
+        o[0] = s0;
+        o[1] = s1;
+    }
+}
+
+// Q[band][cc][slot] = (sum D^beta / n_px)^(1/beta)   (lp_norm, fvvdp.py:598-607); fixed summation order.
+struct FinalizeArgs {
+    const float* partial;
+    float* Q;
+    int n_bands, n, q_stride, q_col0, tc;
+    float inv_beta;
+    int nblk[FVVDP_MAX_BANDS];
+    long long off[FVVDP_MAX_BANDS];
+    float npx[FVVDP_MAX_BANDS];
+};
+
+__global__ void finalize_kernel(const FinalizeArgs a) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int total = a.n_bands * 2 * a.n;
+    if (i >= total) return;
+    const int s = i % a.n;
+    const int cc = (i / a.n) % 2;
+    const int b = i / (2 * a.n);
+    float q = 0.0f;
+    if (cc < a.tc) {
+        const float* p = a.partial + a.off[b] + (size_t)s * a.nblk[b] * 2 + cc;
+        double sum = 0.0;
+        for (int k = 0; k < a.nblk[b]; ++k) sum += (double)p[2 * k];
+        q = (float)pow(sum / (double)a.npx[b], (double)a.inv_beta);
+    }
+    a.Q[((size_t)b * 2 + cc) * a.q_stride + a.q_col0 + s] = q;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// context
+// ------------------------------------------------------------------------------------------------------------
+struct fvvdp_ctx {
+    int W = 0, H = 0, n_bands = 0, P = 0, max_frames = 0;
+    fvvdp_params prm{};
+    double rho_band[FVVDP_MAX_BANDS + 1]{};
+    int lw[FVVDP_MAX_BANDS + 1]{}, lh[FVVDP_MAX_BANDS + 1]{};
+    float* level[FVVDP_MAX_BANDS + 1]{};
+    float* partial = nullptr;
+    long long partial_off[FVVDP_MAX_BANDS]{};
+    int max_blk[FVVDP_MAX_BANDS]{};
+    size_t partial_floats = 0;
+    float4* csf = nullptr;        // [n_bands][32]
+    bool csf_set = false;
+    float y_first = 0, y_inv_step = 0, y_lo = 0, y_hi = 0;
+    float* lut3[2] = {nullptr, nullptr};
+    float* ax_rho = nullptr;
+    float* ax_ecc = nullptr;
+    float rho_lo = 0, rho_hi = 0, ecc_lo = 0, ecc_hi = 0;
+    bool lut3_set[2] = {false, false};
+    float* d_fix = nullptr;       // [max_frames][2]
+    float* d_taps = nullptr;      // [2][FVVDP_MAX_TAPS]
+    int* d_idx = nullptr;         // [max_frames + FVVDP_MAX_TAPS]
+    size_t scratch = 0;
+    // timing
+    bool timing = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[FVVDP_MAX_BANDS + 2];
+    float t_ms[FVVDP_MAX_BANDS + 2]{};
+    int t_cnt[FVVDP_MAX_BANDS + 2]{};
+};
+
+template <typename T>
+static int dev_alloc(fvvdp_ctx* c, T** p, size_t count) {
+    void* q = nullptr;
+    hipError_t e = hipMalloc(&q, count * sizeof(T));
+    if (e != hipSuccess) return fail(FVVDP_ENOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    *p = reinterpret_cast<T*>(q);
+    c->scratch += count * sizeof(T);
+    return FVVDP_OK;
+}
+
+struct Timed {
+    fvvdp_ctx* c;
+    int id;
+    hipStream_t st;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    Timed(fvvdp_ctx* c_, int id_, hipStream_t st_) : c(c_), id(id_), st(st_) {
+        if (c->timing) {
+            (void)hipEventCreate(&e0);
+            (void)hipEventCreate(&e1);
+            (void)hipEventRecord(e0, st);
+        }
+    }
+    ~Timed() {
+        if (c->timing) {
+            (void)hipEventRecord(e1, st);
+            c->ev[id].push_back({e0, e1});
+        }
+    }
+};
+
+static void chunking(int hc, int n_strips, int n, int& n_chunks, int& cr) {
+    // enough single-wave workgroups to fill 256 CUs several times over, but chunks of at least 8 coarse rows so
+    // the 7-row vertical halo stays a small fraction of the traffic
+    const long long target = 12288;
+    long long want = (target + (long long)n * n_strips - 1) / ((long long)n * n_strips);
+    if (want < 1) want = 1;
+    cr = (int)((hc + want - 1) / want);
+    if (cr < 8) cr = 8;
+    if (cr > hc) cr = hc;
+    n_chunks = (hc + cr - 1) / cr;
+}
+
+extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_bands, int planes, int max_frames,
+                                const double* h_rho_band, const fvvdp_params* prm) {
+    if (!out || !prm || !h_rho_band) return fail(FVVDP_EINVAL, "null argument");
+    if (planes != 2 && planes != 4) return fail(FVVDP_EINVAL, "planes must be 2 (image) or 4 (video), got %d", planes);
+    if (n_bands < 1 || n_bands > FVVDP_MAX_BANDS) return fail(FVVDP_EINVAL, "n_bands %d out of range", n_bands);
+    if (max_frames < 1) return fail(FVVDP_EINVAL, "max_frames must be >= 1");
+    if (width < 4 || height < 4) return fail(FVVDP_EINVAL, "frame %dx%d too small", width, height);
+    fvvdp_ctx* c = new fvvdp_ctx();
+    c->W = width;
+    c->H = height;
+    c->n_bands = n_bands;
+    c->P = planes;
+    c->max_frames = max_frames;
+    c->prm = *prm;
+    int w = width, h = height;
+    for (int i = 0; i <= n_bands; ++i) {
+        c->lw[i] = w;
+        c->lh[i] = h;
+        c->rho_band[i] = h_rho_band[i];
+        if (i < n_bands && (w < 2 || h < 2)) {
+            delete c;
+            return fail(FVVDP_EINVAL, "pyramid level %d is %dx%d: too many bands for this frame size", i, w, h);
+        }
+        w = (w + 1) / 2;
+        h = (h + 1) / 2;
+    }
+    int rc = FVVDP_OK;
+    for (int i = 0; i <= n_bands && rc == FVVDP_OK; ++i)
+        rc = dev_alloc(c, &c->level[i], (size_t)max_frames * c->lw[i] * c->lh[i] * planes);
+    size_t off = 0;
+    for (int b = 0; b < n_bands; ++b) {
+        const int n_strips = (c->lw[b + 1] + STRIP_J - 1) / STRIP_J;
+        const int max_chunks = (c->lh[b + 1] + 7) / 8;
+        c->max_blk[b] = n_strips * max_chunks;
+        c->partial_off[b] = (long long)off;
+        off += (size_t)max_frames * c->max_blk[b] * 2;
+    }
+    c->partial_floats = off;
+    if (rc == FVVDP_OK) rc = dev_alloc(c, &c->partial, off);
+    if (rc == FVVDP_OK) rc = dev_alloc(c, &c->csf, (size_t)n_bands * FVVDP_LUT_N);
+    if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_fix, (size_t)max_frames * 2);
+    if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_taps, (size_t)2 * FVVDP_MAX_TAPS);
+    if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_idx, (size_t)max_frames + FVVDP_MAX_TAPS);
+    if (rc != FVVDP_OK) {
+        fvvdp_ctx_destroy(c);
+        return rc;
+    }
+    *out = c;
+    return FVVDP_OK;
+}
+
+extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
+    if (!c) return;
+    for (int i = 0; i <= FVVDP_MAX_BANDS; ++i)
+        if (c->level[i]) (void)hipFree(c->level[i]);
+    if (c->partial) (void)hipFree(c->partial);
+    if (c->csf) (void)hipFree(c->csf);
+    if (c->d_fix) (void)hipFree(c->d_fix);
+    if (c->d_taps) (void)hipFree(c->d_taps);
+    if (c->d_idx) (void)hipFree(c->d_idx);
+    for (int k = 0; k < 2; ++k)
+        if (c->lut3[k]) (void)hipFree(c->lut3[k]);
+    if (c->ax_rho) (void)hipFree(c->ax_rho);
+    if (c->ax_ecc) (void)hipFree(c->ax_ecc);
+    for (auto& v : c->ev)
+        for (auto& pr : v) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+    delete c;
+}
+
+extern "C" int fvvdp_ctx_level_size(const fvvdp_ctx* c, int level, int* w, int* h) {
+    if (!c || level < 0 || level > c->n_bands) return fail(FVVDP_EINVAL, "bad level %d", level);
+    if (w) *w = c->lw[level];
+    if (h) *h = c->lh[level];
+    return FVVDP_OK;
+}
+
+extern "C" size_t fvvdp_ctx_scratch_bytes(const fvvdp_ctx* c) { return c ? c->scratch : 0; }
+
+extern "C" int fvvdp_ctx_set_csf_1d(fvvdp_ctx* c, const float* h_Y_log, const float* h_S_log) {
+    if (!c || !h_Y_log || !h_S_log) return fail(FVVDP_EINVAL, "null argument");
+    std::vector<float4> rec((size_t)c->n_bands * FVVDP_LUT_N);
+    for (int b = 0; b < c->n_bands; ++b)
+        for (int i = 0; i < FVVDP_LUT_N; ++i) {
+            float inv = 0.0f;
+            if (i + 1 < FVVDP_LUT_N) inv = 1.0f / (h_Y_log[i + 1] - h_Y_log[i] + 0.000001f);   // interp.py:16
+            rec[(size_t)b * FVVDP_LUT_N + i] =
+                make_float4(h_Y_log[i], inv, h_S_log[((size_t)b * 2 + 0) * FVVDP_LUT_N + i],
+                            h_S_log[((size_t)b * 2 + 1) * FVVDP_LUT_N + i]);
+        }
+    HIP_TRY(hipMemcpy(c->csf, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
+    c->y_first = h_Y_log[0];
+    c->y_inv_step = (float)(FVVDP_LUT_N - 1) / (h_Y_log[FVVDP_LUT_N - 1] - h_Y_log[0]);
+    c->y_lo = exp2f(h_Y_log[0]);
+    c->y_hi = exp2f(h_Y_log[FVVDP_LUT_N - 1]);
+    c->csf_set = true;
+    return FVVDP_OK;
+}
+
+extern "C" int fvvdp_ctx_set_csf_3d(fvvdp_ctx* c, int tc, const float* h_S_log, const float* h_Y_log,
+                                    const float* h_rho_log, const float* h_ecc_sqrt) {
+    if (!c || !h_S_log || !h_Y_log || !h_rho_log || !h_ecc_sqrt) return fail(FVVDP_EINVAL, "null argument");
+    if (tc < 0 || tc > 1) return fail(FVVDP_EINVAL, "temporal_channel must be 0 or 1");
+    const size_t n3 = (size_t)FVVDP_LUT_N * FVVDP_LUT_N * FVVDP_LUT_N;
+    int rc = FVVDP_OK;
+    if (!c->lut3[tc]) rc = dev_alloc(c, &c->lut3[tc], n3);
+    if (rc == FVVDP_OK && !c->ax_rho) rc = dev_alloc(c, &c->ax_rho, (size_t)FVVDP_LUT_N);
+    if (rc == FVVDP_OK && !c->ax_ecc) rc = dev_alloc(c, &c->ax_ecc, (size_t)FVVDP_LUT_N);
+    if (rc != FVVDP_OK) return rc;
+    HIP_TRY(hipMemcpy(c->lut3[tc], h_S_log, n3 * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->ax_rho, h_rho_log, FVVDP_LUT_N * sizeof(float), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(c->ax_ecc, h_ecc_sqrt, FVVDP_LUT_N * sizeof(float), hipMemcpyHostToDevice));
+    // the Y axis records double as the knot table of the foveated kernel
+    if (!c->csf_set) {
+        std::vector<float4> rec((size_t)c->n_bands * FVVDP_LUT_N);
+        for (int b = 0; b < c->n_bands; ++b)
+            for (int i = 0; i < FVVDP_LUT_N; ++i) rec[(size_t)b * FVVDP_LUT_N + i] = make_float4(h_Y_log[i], 0.f, 0.f, 0.f);
+        HIP_TRY(hipMemcpy(c->csf, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
+        c->y_lo = exp2f(h_Y_log[0]);
+        c->y_hi = exp2f(h_Y_log[FVVDP_LUT_N - 1]);
+    }
+    c->rho_lo = exp2f(h_rho_log[0]);
+    c->rho_hi = exp2f(h_rho_log[FVVDP_LUT_N - 1]);
+    c->ecc_lo = h_ecc_sqrt[0] * h_ecc_sqrt[0];
+    c->ecc_hi = h_ecc_sqrt[FVVDP_LUT_N - 1] * h_ecc_sqrt[FVVDP_LUT_N - 1];
+    c->lut3_set[tc] = true;
+    return FVVDP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// stage 1 launchers
+// ------------------------------------------------------------------------------------------------------------
+static EotfDev make_eotf(const fvvdp_eotf* e) {
+    EotfDev d;
+    d.kind = e->kind;
+    d.scale = e->Y_peak - e->Y_black;
+    d.y_black = e->Y_black;
+    d.y_peak = e->Y_peak;
+    d.gamma = e->gamma;
+    d.l_min = e->L_min;
+    d.l_max = e->L_max;
+    d.lut = e->d_lut;
+    return d;
+}
+
+template <int FL, int PX>
+static void launch_ring(int dtype, const TemporalArgs& a, hipStream_t st) {
+    const int threads = (a.HW / PX + 255) / 256;
+    dim3 grid(threads), block(256);
+    if (dtype == FVVDP_U8)
+        hipLaunchKernelGGL((temporal_ring_kernel<FL, PX, SRC_U8>), grid, block, 0, st, a);
+    else if (dtype == FVVDP_U16)
+        hipLaunchKernelGGL((temporal_ring_kernel<FL, PX, SRC_U16>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((temporal_ring_kernel<FL, PX, SRC_F32>), grid, block, 0, st, a);
+}
+
+template <int P>
+static void launch_generic(int dtype, const GenericArgs& a, hipStream_t st) {
+    dim3 grid((a.HW + 255) / 256, a.n_out), block(256);
+    if (dtype == FVVDP_U8)
+        hipLaunchKernelGGL((temporal_generic_kernel<SRC_U8, P>), grid, block, 0, st, a);
+    else if (dtype == FVVDP_U16)
+        hipLaunchKernelGGL((temporal_generic_kernel<SRC_U16, P>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((temporal_generic_kernel<SRC_F32, P>), grid, block, 0, st, a);
+}
+
+extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const void* d_ref, int dtype, int C,
+                                       size_t chan_stride, size_t frame_stride, const fvvdp_eotf* eotf,
+                                       const float* h_rgb2y, const int32_t* h_frame_idx, const float* h_taps, int fl,
+                                       int n_out, int slot0, int32_t* d_oob_flag, void* stream) {
+    if (!c || !d_test || !d_ref || !eotf || !h_frame_idx || !h_taps) return fail(FVVDP_EINVAL, "null argument");
+    if (dtype < FVVDP_U8 || dtype > FVVDP_F32) return fail(FVVDP_EINVAL, "Only uint8, uint16 and float32 is currently supported");
+    if (C != 1 && C != 3) return fail(FVVDP_EINVAL, "The content must have either 1 or 3 colour channels.");
+    if (C == 3 && !h_rgb2y) return fail(FVVDP_EINVAL, "rgb2y weights required for C == 3");
+    if (fl < 1 || fl > FVVDP_MAX_TAPS) return fail(FVVDP_EINVAL, "filter length %d out of range", fl);
+    if (c->P == 2 && fl != 1) return fail(FVVDP_EINVAL, "still-image context (planes == 2) needs fl == 1");
+    if (n_out < 1 || slot0 < 0 || slot0 + n_out > c->max_frames) return fail(FVVDP_EINVAL, "slots [%d,%d) exceed max_frames %d", slot0, slot0 + n_out, c->max_frames);
+    if (eotf->kind == FVVDP_EOTF_LUT && (dtype == FVVDP_F32 || !eotf->d_lut)) return fail(FVVDP_EINVAL, "FVVDP_EOTF_LUT needs an integer source and a table");
+    if (eotf->kind != FVVDP_EOTF_LUT && dtype != FVVDP_F32) return fail(FVVDP_EINVAL, "integer sources need FVVDP_EOTF_LUT");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int HW = c->W * c->H;
+    Timed tm(c, 0, st);
+    const bool ring_ok = (c->P == 4) && (fl <= 32) && (HW % 4 == 0) && (chan_stride % 4 == 0) && (frame_stride % 4 == 0);
+    if (ring_ok) {
+        const int FL = fl <= 8 ? 8 : (fl <= 16 ? 16 : 32);
+        const int max_out = T_MAX_IDX - (FL - 1);
+        for (int t0 = 0; t0 < n_out; t0 += max_out) {
+            const int nn = (n_out - t0) < max_out ? (n_out - t0) : max_out;
+            TemporalArgs a;
+            memset(&a, 0, sizeof(a));
+            a.src[0] = d_test;
+            a.src[1] = d_ref;
+            a.chan_stride = chan_stride;
+            a.frame_stride = frame_stride;
+            a.C = C;
+            a.HW = HW;
+            a.e = make_eotf(eotf);
+            if (C == 3) { a.w[0] = h_rgb2y[0]; a.w[1] = h_rgb2y[1]; a.w[2] = h_rgb2y[2]; } else { a.w[0] = 1.0f; }
+            a.n_out = nn;
+            a.fl = fl;
+            a.out = c->level[0] + (size_t)(slot0 + t0) * HW * 4;
+            a.oob = d_oob_flag;
+            for (int k = 0; k < fl; ++k) { a.taps[0][k] = h_taps[k]; a.taps[1][k] = h_taps[fl + k]; }
+            // virtual time of h_frame_idx: entry (fl-1+t) is the newest frame of output t; pad older history
+            const int pad = FL - fl;
+            for (int u = 0; u < FL - 1 + nn; ++u) {
+                const int src = t0 + u - pad;         // index into h_frame_idx
+                a.idx[u] = h_frame_idx[src < 0 ? 0 : src];
+            }
+            if (FL == 8) launch_ring<8, 4>(dtype, a, st);
+            else if (FL == 16) launch_ring<16, 4>(dtype, a, st);
+            else launch_ring<32, 2>(dtype, a, st);
+        }
+    } else {
+        // rare path: tables go through device buffers, uploaded synchronously
+        if (fl - 1 + n_out > c->max_frames + FVVDP_MAX_TAPS) return fail(FVVDP_EINVAL, "too many frames for one call");
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(c->d_taps, h_taps, sizeof(float) * 2 * fl, hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(c->d_idx, h_frame_idx, sizeof(int) * (fl - 1 + n_out), hipMemcpyHostToDevice));
+        GenericArgs a;
+        memset(&a, 0, sizeof(a));
+        a.src[0] = d_test;
+        a.src[1] = d_ref;
+        a.chan_stride = chan_stride;
+        a.frame_stride = frame_stride;
+        a.C = C;
+        a.HW = HW;
+        a.e = make_eotf(eotf);
+        if (C == 3) { a.w[0] = h_rgb2y[0]; a.w[1] = h_rgb2y[1]; a.w[2] = h_rgb2y[2]; } else { a.w[0] = 1.0f; }
+        a.n_out = n_out;
+        a.fl = fl;
+        a.out = c->level[0] + (size_t)slot0 * HW * c->P;
+        a.oob = d_oob_flag;
+        a.taps = c->d_taps;
+        a.idx = c->d_idx;
+        if (c->P == 2) launch_generic<2>(dtype, a, st);
+        else launch_generic<4>(dtype, a, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return FVVDP_OK;
+}
+
+extern "C" int fvvdp_load_channels_planar(fvvdp_ctx* c, const float* d_R, int n, int slot0, void* stream) {
+    if (!c || !d_R) return fail(FVVDP_EINVAL, "null argument");
+    if (n < 1 || slot0 < 0 || slot0 + n > c->max_frames) return fail(FVVDP_EINVAL, "slots out of range");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int HW = c->W * c->H;
+    dim3 grid((HW + 255) / 256, n), block(256);
+    float* out = c->level[0] + (size_t)slot0 * HW * c->P;
+    if (c->P == 4) hipLaunchKernelGGL((interleave_kernel<4>), grid, block, 0, st, d_R, out, HW, 1);
+    else hipLaunchKernelGGL((interleave_kernel<2>), grid, block, 0, st, d_R, out, HW, 1);
+    HIP_TRY(hipGetLastError());
+    return FVVDP_OK;
+}
+
+extern "C" int fvvdp_export_level(fvvdp_ctx* c, int level, int n, float* d_out, void* stream) {
+    if (!c || !d_out) return fail(FVVDP_EINVAL, "null argument");
+    if (level < 0 || level > c->n_bands || n < 1 || n > c->max_frames) return fail(FVVDP_EINVAL, "bad level/n");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const int HW = c->lw[level] * c->lh[level];
+    dim3 grid((HW + 255) / 256, n), block(256);
+    if (c->P == 4) hipLaunchKernelGGL((interleave_kernel<4>), grid, block, 0, st, c->level[level], d_out, HW, 0);
+    else hipLaunchKernelGGL((interleave_kernel<2>), grid, block, 0, st, c->level[level], d_out, HW, 0);
+    HIP_TRY(hipGetLastError());
+    return FVVDP_OK;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// stage 2 launcher
+// ------------------------------------------------------------------------------------------------------------
+template <int P>
+static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, hipStream_t st) {
+    dim3 grid(nblocks), block(64);
+    if (fov) {
+        if (dbg) hipLaunchKernelGGL((band_kernel<P, true, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((band_kernel<P, false, true>), grid, block, 0, st, a);
+    } else {
+        if (dbg) hipLaunchKernelGGL((band_kernel<P, true, false>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((band_kernel<P, false, false>), grid, block, 0, st, a);
+    }
+}
+
+extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
+                                   const fvvdp_geom* geom, const fvvdp_band_maps* maps, void* stream) {
+    if (!c || !d_Q) return fail(FVVDP_EINVAL, "null argument");
+    if (n < 1 || n > c->max_frames) return fail(FVVDP_EINVAL, "n=%d exceeds max_frames=%d", n, c->max_frames);
+    if (q_col0 < 0 || q_col0 + n > q_stride) return fail(FVVDP_EINVAL, "Q columns out of range");
+    const bool fov = h_fixation != nullptr;
+    if (fov && !geom) return fail(FVVDP_EINVAL, "foveated mode needs the display geometry");
+    if (fov && !(c->lut3_set[0] && (c->P == 2 || c->lut3_set[1]))) return fail(FVVDP_ESTATE, "fvvdp_ctx_set_csf_3d not called");
+    if (!fov && !c->csf_set) return fail(FVVDP_ESTATE, "fvvdp_ctx_set_csf_1d not called");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    if (fov) {
+        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipMemcpy(c->d_fix, h_fixation, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+    }
+    FinalizeArgs fa;
+    memset(&fa, 0, sizeof(fa));
+    for (int b = 0; b < c->n_bands; ++b) {
+        BandArgs a;
+        memset(&a, 0, sizeof(a));
+        a.Gf = c->level[b];
+        a.Gc = c->level[b + 1];
+        a.w = c->lw[b];
+        a.h = c->lh[b];
+        a.wc = c->lw[b + 1];
+        a.hc = c->lh[b + 1];
+        a.n_strips = (a.wc + STRIP_J - 1) / STRIP_J;
+        chunking(a.hc, a.n_strips, n, a.n_chunks, a.cr);
+        a.band_mul = (b == 0) ? 1.0f : 2.0f;                 // lpyr.get_band, fvvdp_lpyr_dec.py:57-63
+        a.csf = c->csf + (size_t)b * FVVDP_LUT_N;
+        a.y_first = c->y_first;
+        a.y_inv_step = c->y_inv_step;
+        a.y_lo = c->y_lo;
+        a.y_hi = c->y_hi;
+        a.lg_gain = log2f(c->prm.sens_gain);
+        a.lg_k = log2f(c->prm.mask_k);
+        a.p = c->prm.mask_p;
+        a.q0 = c->prm.mask_q[0];
+        a.q1 = c->prm.mask_q[1];
+        a.beta = c->prm.beta;
+        a.lbkg_min = c->prm.lbkg_min;
+        a.cmax = c->prm.contrast_max;
+        a.lg_dmax = log2f(c->prm.d_max);
+        a.partial = c->partial + c->partial_off[b];
+        bool dbg = false;
+        if (maps) {
+            a.dD = maps[b].d_D;
+            a.dC = maps[b].d_contrast;
+            a.dL = maps[b].d_lbkg;
+            a.dS = maps[b].d_S;
+            dbg = a.dD || a.dC || a.dL || a.dS;
+        }
+        if (fov) {
+            a.lut3[0] = c->lut3[0];
+            a.lut3[1] = c->lut3[1] ? c->lut3[1] : c->lut3[0];
+            a.ax_rho = c->ax_rho;
+            a.ax_ecc = c->ax_ecc;
+            a.fix = c->d_fix;
+            a.size_m0 = geom->display_size_m[0];
+            a.size_m1 = geom->display_size_m[1];
+            a.dist_m = geom->distance_m;
+            a.ppd_c = geom->ppd_centre;
+            const double delta = (1.0 / (double)geom->ppd_centre) / 2.0;
+            a.delta_deg = (float)delta;
+            a.tan_delta = (float)tan(delta * M_PI / 180.0);
+            a.rho_band = (float)c->rho_band[b];
+            a.rho_lo = c->rho_lo;
+            a.rho_hi = c->rho_hi;
+            a.ecc_lo = c->ecc_lo;
+            a.ecc_hi = c->ecc_hi;
+            a.frame_w = c->W;
+            a.frame_h = c->H;
+        }
+        const int nblk = a.n_strips * a.n_chunks;
+        if (nblk > c->max_blk[b]) return fail(FVVDP_ESTATE, "internal: partial buffer too small");
+        {
+            Timed tm(c, 1 + b, st);
+            if (c->P == 4) launch_band<4>(a, nblk * n, dbg, fov, st);
+            else launch_band<2>(a, nblk * n, dbg, fov, st);
+        }
+        fa.nblk[b] = nblk;
+        fa.off[b] = c->partial_off[b];
+        fa.npx[b] = (float)a.w * (float)a.h;
+    }
+    fa.partial = c->partial;
+    fa.Q = d_Q;
+    fa.n_bands = c->n_bands;
+    fa.n = n;
+    fa.q_stride = q_stride;
+    fa.q_col0 = q_col0;
+    fa.tc = c->P / 2;
+    fa.inv_beta = 1.0f / c->prm.beta;
+    {
+        Timed tm(c, 1 + c->n_bands, st);
+        const int total = c->n_bands * 2 * n;
+        hipLaunchKernelGGL(finalize_kernel, dim3((total + 63) / 64), dim3(64), 0, st, fa);
+    }
+    HIP_TRY(hipGetLastError());
+    return FVVDP_OK;
+}
+
+extern "C" int fvvdp_ctx_timing_enable(fvvdp_ctx* c, int on) {
+    if (!c) return fail(FVVDP_EINVAL, "null context");
+    c->timing = on != 0;
+    return FVVDP_OK;
+}
+
+extern "C" int fvvdp_ctx_timing_read(fvvdp_ctx* c, float* h_ms, int32_t* h_count, int capacity, int reset) {
+    if (!c || !h_ms || !h_count) return fail(FVVDP_EINVAL, "null argument");
+    const int nk = c->n_bands + 2;
+    if (capacity < nk) return fail(FVVDP_EINVAL, "capacity %d < %d kernels", capacity, nk);
+    for (int id = 0; id < nk; ++id) {
+        for (auto& pr : c->ev[id]) {
+            HIP_TRY(hipEventSynchronize(pr.second));
+            float ms = 0.0f;
+            HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+            c->t_ms[id] += ms;
+            c->t_cnt[id] += 1;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        c->ev[id].clear();
+        h_ms[id] = c->t_ms[id];
+        h_count[id] = c->t_cnt[id];
+        if (reset) {
+            c->t_ms[id] = 0.0f;
+            c->t_cnt[id] = 0;
+        }
+    }
+    return FVVDP_OK;
+}

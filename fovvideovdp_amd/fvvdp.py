@@ -1,0 +1,433 @@
+"""`class fvvdp`: the reference's public metric API (pyfvvdp/fvvdp.py:58) on top of the MI355X HIP hot path.
+
+What stays in Python (as in the reference): configuration, display models, temporal-filter taps, the collapse of
+the CSF look-up table to per-band 1-D tables, frame batching, and the final pooling / JOD regression
+(do_pooling_and_jods).  What runs in hand-written HIP kernels (libfvvdp_hip.so, include/fvvdp_hip.h): unpacking +
+display photometry + luminance + temporal filtering, the Gaussian/contrast pyramid, CSF weighting, mutual masking
+and spatial pooling.  There is no CPU implementation of the hot path in this package: without a GPU or without the
+built library `predict*` raises.
+"""
+import ctypes as C
+import json
+import logging
+import math
+import os
+
+import numpy as np
+import torch
+
+from . import _native as nat
+from . import utils
+from .display_model import (fvvdp_display_geometry, fvvdp_display_photometry, native_eotf, native_geometry)
+from .video_source import fvvdp_video_source_array
+
+
+def _interpolants(x_q, x):
+    """Bracketing knots and fraction of the reference's LUT interpolation, incl. its +1e-6 in the denominator."""
+    imax = torch.bucketize(x_q, x)
+    imax[imax >= x.shape[0]] = x.shape[0] - 1
+    imin = (imax - 1).clamp(0, x.shape[0] - 1)
+    ifrc = (x_q - x[imin]) / (x[imax] - x[imin] + 0.000001)
+    ifrc[imax == imin] = 0.
+    ifrc[ifrc < 0.0] = 0.
+    return imin, imax, ifrc
+
+
+def band_frequencies(W, H, ppd):
+    """Number of band-pass levels and their centre frequencies [cpd] for a W x H frame at `ppd` pixels/degree
+    (same rule as the reference's pyramid constructor, pyfvvdp/fvvdp_lpyr_dec.py:15-49)."""
+    max_levels = int(np.floor(np.log2(min(H, W)))) - 1
+    octave = 0.3228 * np.power(2.0, -np.arange(0.0, 14.0))
+    bands = np.concatenate([[1.0], octave]) * ppd / 2.0
+    too_low = np.nonzero(bands <= 0.5)[0]
+    max_band = int(too_low[0]) if too_low.size else max_levels
+    height = int(np.clip(max_band + 1, 0, max_levels))
+    freqs = np.array([1.0] + [0.3228 * 2.0 ** (-f) for f in range(height)]) * ppd / 2.0
+    return height, freqs
+
+
+def window_frame_indices(N, fl, temp_padding):
+    """Source frame for every virtual time step: fl-1 history entries (temporal padding before frame 0) followed
+    by the newest frame of each of the N outputs.  Matches the window the reference builds at frame 0 and then
+    slides (pyfvvdp/fvvdp.py:258-291), including `circular` never showing frame 0 at output 0."""
+    if temp_padding == "replicate":
+        first = [0] * fl
+    elif temp_padding == "circular":
+        first = [(N - 1 - fl + kk) % N for kk in range(fl)]
+    elif temp_padding == "pingpong":
+        seq = list(range(0, N)) + list(range(N - 2, 0, -1))
+        hist = []
+        while len(hist) < (fl - 1):
+            hist = hist + seq
+        first = (hist[-(fl - 1):] if fl > 1 else []) + [0]
+    else:
+        raise RuntimeError('Unknown padding method "{}"'.format(temp_padding))
+    return np.asarray(first + list(range(1, N)), dtype=np.int32)
+
+
+class _Context:
+    """Owns one native context (scratch for `batch` frames of a W x H pyramid)."""
+
+    def __init__(self, W, H, height, planes, batch, rho_band, prm):
+        self.key = (W, H, height, planes, batch)
+        self.handle = C.c_void_p()
+        rb = (C.c_double * (height + 1))(*[float(r) for r in rho_band])
+        nat.check(nat.lib().fvvdp_ctx_create(C.byref(self.handle), W, H, height, planes, batch, rb, C.byref(prm)))
+
+    def close(self):
+        if self.handle:
+            nat.lib().fvvdp_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class fvvdp:
+    def __init__(self, display_name="standard_4k", display_photometry=None, display_geometry=None, color_space="sRGB",
+                 foveated=False, heatmap=None, quiet=False, device=None, temp_padding="replicate",
+                 use_checkpoints=False, batch_frames=None):
+        assert heatmap in [None, "none", "raw", "threshold", "supra-threshold"], "Unsupported heatmap type"
+        assert temp_padding in ["replicate", "circular", "pingpong"], "Unsupported temporal padding method"
+        self.quiet = quiet
+        self.foveated = foveated
+        self.heatmap = heatmap
+        self.color_space = color_space
+        self.temp_padding = temp_padding
+        self.use_checkpoints = use_checkpoints
+        self.do_heatmap = (self.heatmap is not None) and (self.heatmap != "none")
+        if self.do_heatmap:
+            raise RuntimeError("heatmap output is not available in the MI355X path yet (DESIGN.md, 'next' rows)")
+        if use_checkpoints:
+            raise RuntimeError("use_checkpoints (training of the metric) is not supported: the HIP path is forward-only")
+        if device is None:
+            device = torch.device('cuda:0') if (torch.cuda.is_available() and torch.cuda.device_count() > 0) else torch.device('cpu')
+        self.device = torch.device(device)
+        self.batch_frames = batch_frames
+        self.set_display_model(display_name, display_photometry=display_photometry, display_geometry=display_geometry)
+        self.load_config()
+        self.csf_cache_dirs = ["csf_cache"]
+        self.omega = [0, 5]
+        self.csf_lut = [utils.load_csf_lut(om, self.csf_sigma, self.k_cm, self.csf_cache_dirs) for om in self.omega]
+        self._ctx = None
+        self._lut_dev = {}
+        self.timing = None
+
+    # ---- configuration ------------------------------------------------------------------------------------
+    def update_device(self, device):
+        self.device = torch.device(device)
+        self._ctx = None
+        self._lut_dev = {}
+
+    def load_config(self):
+        parameters = utils.config_files.load("fvvdp_parameters.json")
+        self.parameters_file = utils.config_files.find("fvvdp_parameters.json")
+        for name in ("mask_p", "mask_c", "pu_dilate", "w_transient", "beta", "beta_t", "beta_tch", "beta_sch",
+                     "sustained_sigma", "sustained_beta", "csf_sigma", "sensitivity_correction", "masking_model",
+                     "local_adapt", "contrast", "jod_a", "log_jod_exp", "mask_q_sust", "mask_q_trans", "k_cm",
+                     "filter_len", "version"):
+            setattr(self, name, parameters[name])
+        if (self.local_adapt != "gpyr" or self.contrast != "weber" or self.pu_dilate != 0 or
+                self.masking_model != "min_mutual_masking_perc_norm2"):
+            raise RuntimeError("Only the shipped model variant (local_adapt=gpyr, contrast=weber, pu_dilate=0, "
+                               "min_mutual_masking_perc_norm2) is implemented by the HIP path")
+        self.debug = False
+
+    def set_display_model(self, display_name="standard_4k", display_photometry=None, display_geometry=None):
+        if display_photometry is None:
+            self.display_photometry = fvvdp_display_photometry.load(display_name)
+            self.display_name = display_name
+        else:
+            self.display_photometry = display_photometry
+            self.display_name = "unspecified"
+        if display_geometry is None:
+            self.display_geometry = fvvdp_display_geometry.load(display_name)
+        else:
+            self.display_geometry = display_geometry
+        self.pix_per_deg = self.display_geometry.get_ppd()
+
+    # ---- public prediction API ------------------------------------------------------------------------------
+    def predict(self, test_cont, reference_cont, dim_order="BCFHW", frames_per_second=0, fixation_point=None):
+        vs = fvvdp_video_source_array(test_cont, reference_cont, frames_per_second, dim_order=dim_order,
+                                      display_photometry=self.display_photometry, color_space_name=self.color_space)
+        return self.predict_video_source(vs, fixation_point=fixation_point)
+
+    def predict_video_source(self, vid_source, fixation_point=None, frame_range=None, pool=True):
+        """Returns (Q_JOD 0-d tensor on the compute device, stats dict).
+
+        `frame_range=(f0, f1)` (extension used for frame sharding across GPUs) evaluates only output frames
+        [f0, f1); the temporal window of frame f0 is still filled from the frames before it.  With `pool=False`
+        the JOD regression is skipped and Q_JOD is None (the caller pools after combining shards).
+        """
+        if self.device.type != "cuda":
+            raise RuntimeError("fovvideovdp_amd needs an AMD GPU (torch device 'cuda'); there is no CPU fallback")
+        height, width, N_frames = vid_source.get_video_size()
+        f0, f1 = (0, N_frames) if frame_range is None else frame_range
+        if not (0 <= f0 < f1 <= N_frames):
+            raise RuntimeError("frame_range out of bounds")
+        n_bands, rho_band = band_frequencies(width, height, self.pix_per_deg)
+        if n_bands < 1:
+            raise RuntimeError("Frame %dx%d is too small for this display (no band-pass level)" % (width, height))
+        is_image = (N_frames == 1)
+        planes = 2 if is_image else 4
+        if is_image:
+            fl, taps = 1, np.ones((2, 1), dtype=np.float32)
+        else:
+            fps = vid_source.get_frames_per_second()
+            self.filter_len = int(np.ceil(250.0 / (1000.0 / fps)))
+            self.F, _ = self.get_temporal_filters(fps)
+            fl, taps = self.filter_len, np.ascontiguousarray(self.F.numpy(), dtype=np.float32)
+            if fl > nat.MAX_TAPS:
+                raise RuntimeError("frame rate too high: temporal filter longer than %d taps" % nat.MAX_TAPS)
+        fix = self._fixation(fixation_point, width, height, N_frames) if self.foveated else None
+
+        n_out = f1 - f0
+        batch = self._batch_size(width, height, planes, n_out)
+        ctx = self._context(width, height, n_bands, planes, batch, rho_band)
+        stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+        Q = torch.zeros((n_bands, 2, n_out), dtype=torch.float32, device=self.device)
+        oob = torch.zeros(1, dtype=torch.int32, device=self.device)
+        widx = window_frame_indices(N_frames, fl, self.temp_padding) if not is_image else np.zeros(1, np.int32)
+        feeder = self._make_feeder(vid_source, width, height)
+
+        for b0 in range(f0, f1, batch):
+            nb = min(batch, f1 - b0)
+            idx = np.ascontiguousarray(widx[b0:b0 + fl - 1 + nb])          # history + newest frames of this batch
+            feeder(ctx, idx, taps, fl, nb, oob, stream)
+            if self.foveated:
+                fx = np.ascontiguousarray(fix[b0:b0 + nb], dtype=np.float32)
+                g = self._geom_struct()
+                nat.check(nat.lib().fvvdp_bands_forward(ctx.handle, nb, C.c_void_p(Q.data_ptr()), n_out, b0 - f0,
+                                                        nat.fptr(fx), C.byref(g), None, stream))
+            else:
+                nat.check(nat.lib().fvvdp_bands_forward(ctx.handle, nb, C.c_void_p(Q.data_ptr()), n_out, b0 - f0,
+                                                        None, None, None, stream))
+
+        Q_jod = self.do_pooling_and_jods(Q, rho_band[0:-1]) if pool else None
+        stats = {}
+        stats['Q_per_ch'] = Q.detach().cpu().numpy()        # the one host synchronisation of the call
+        stats['rho_band'] = rho_band
+        stats['frames_per_second'] = vid_source.get_frames_per_second()
+        stats['width'] = width
+        stats['height'] = height
+        stats['N_frames'] = N_frames
+        if int(oob.item()) != 0:
+            logging.warning("Pixel outside the valid range 0-1")
+        return (Q_jod.squeeze() if pool else None, stats)
+
+    # ---- pooling and JOD regression (Python, as in the reference) ------------------------------------------
+    def do_pooling_and_jods(self, Q_per_ch, rho_band):
+        """Q_per_ch [bands, temporal channels, frames] -> JOD (0-d tensor).  Minkowski pooling over spatial bands
+        (beta_sch), temporal channels (beta_tch, transient weighted by w_transient) and frames (beta_t, mean)."""
+        Q = Q_per_ch
+        if Q.shape[1] == 2:
+            w = torch.tensor([1.0, self.w_transient], dtype=Q.dtype, device=Q.device).view(1, 2, 1)
+            Q = Q * w
+        Q_sc = self.lp_norm(Q, self.beta_sch, 0, False)
+        Q_tc = self.lp_norm(Q_sc, self.beta_tch, 1, False)
+        Q_all = self.lp_norm(Q_tc, self.beta_t, 2, True).squeeze()
+        beta_jod = 10.0 ** self.log_jod_exp
+        sign = -1 if self.jod_a < 0 else 1
+        Q_jod = sign * ((abs(self.jod_a) ** (1.0 / beta_jod)) * Q_all) ** beta_jod + 10.0
+        return Q_jod.squeeze()
+
+    def lp_norm(self, x, p, dim=0, normalize=True):
+        N = x.shape[dim] if normalize else 1.0
+        return torch.norm(x, p, dim=dim, keepdim=True) / (float(N) ** (1. / p))
+
+    def get_temporal_filters(self, frames_per_s):
+        """Sustained (log-Gaussian) and transient (its scaled derivative) temporal filters, fp32 [2, filter_len];
+        tap k weights the frame k steps in the past.  Evaluated on the host."""
+        t = torch.linspace(0.0, self.filter_len / frames_per_s, self.filter_len)
+        F = torch.zeros((2, t.shape[0]))
+        sigma = torch.tensor([self.sustained_sigma])
+        beta = torch.tensor([self.sustained_beta])
+        F[0] = torch.exp(-torch.pow(torch.log(t + 1e-4) - torch.log(beta), 2.0) / (2.0 * (sigma ** 2.0)))
+        F[0] = F[0] / torch.sum(F[0])
+        k2 = 0.062170507756932
+        Fdiff = F[0, 1:] - F[0, :-1]
+        F[1] = k2 * torch.cat([Fdiff / (t[1] - t[0]), torch.tensor([0.0])], 0)
+        omega = torch.tensor([0, 5])
+        return F, omega
+
+    def short_name(self):
+        return "FovVideoVDP"
+
+    def quality_unit(self):
+        return "JOD"
+
+    def get_info_string(self):
+        standard_str = ', (' + self.display_name + ')' if self.display_name.startswith('standard_') else ''
+        fv_mode = 'foveated' if self.foveated else 'non-foveated'
+        return '"FovVideoVDP v{}, {:.4g} [pix/deg], Lpeak={:.5g}, Lblack={:.4g} [cd/m^2], {}{}"'.format(
+            self.version, self.pix_per_deg, self.display_photometry.get_peak_luminance(),
+            self.display_photometry.get_black_level(), fv_mode, standard_str)
+
+    def write_features_to_json(self, stats, dest_fname):
+        Q_per_ch = stats['Q_per_ch']
+        fmap = {}
+        for key, value in stats.items():
+            if key not in ["Q_per_ch", "heatmap"]:
+                fmap[key] = value.tolist() if isinstance(value, np.ndarray) else value
+        for cc in range(Q_per_ch.shape[1]):
+            for bb in range(Q_per_ch.shape[0]):
+                fmap[f"t{cc}_b{bb}"] = Q_per_ch[bb, cc, :].tolist()
+        with open(dest_fname, 'w', encoding='utf-8') as f:
+            json.dump(fmap, f, ensure_ascii=False, indent=4)
+
+    # ---- host-side preparation for the kernels --------------------------------------------------------------
+    def native_params(self):
+        p = nat.Params()
+        p.mask_p = self.mask_p
+        p.mask_q[0], p.mask_q[1] = self.mask_q_sust, self.mask_q_trans
+        p.mask_k = float(torch.pow(torch.tensor(10.0), torch.tensor(self.mask_c)))
+        p.beta = self.beta
+        p.sens_gain = 10.0 ** (self.sensitivity_correction / 20.0)
+        p.lbkg_min, p.contrast_max, p.d_max = 0.1, 1000.0, 1e4
+        return p
+
+    def csf_tables_1d(self, rho_band, n_bands):
+        """Non-foveated mode: the rho and eccentricity coordinates of the CSF query are constant per band, so the
+        trilinear LUT interpolation reduces to a 1-D table over log2(L_bkg) per (band, temporal channel).  The
+        rho-axis blend is done here with the same fp32 operations the per-pixel interpolation would use."""
+        tab = np.zeros((n_bands, 2, nat.LUT_N), dtype=np.float32)
+        for cc in range(2):
+            lut = {k: torch.from_numpy(v) for k, v in self.csf_lut[cc].items()}
+            for bb in range(n_bands):
+                rho = torch.tensor([rho_band[bb]], dtype=torch.float32)
+                rho_q = torch.log2(torch.clamp(rho, lut["rho"][0], lut["rho"][-1]))
+                imin, imax, ifrc = _interpolants(rho_q, lut["rho_log"])
+                v = lut["S_log"]                       # [Y, rho, ecc]; ecc = 0 sits exactly on knot 0
+                t = v[:, imin[0], 0] * (1.0 - ifrc[0]) + v[:, imax[0], 0] * ifrc[0]
+                tab[bb, cc] = t.numpy()
+        return np.ascontiguousarray(self.csf_lut[0]["Y_log"], dtype=np.float32), tab
+
+    def _context(self, W, H, n_bands, planes, batch, rho_band):
+        key = (W, H, n_bands, planes, batch)
+        if self._ctx is not None and self._ctx.key == key:
+            return self._ctx
+        if self._ctx is not None:
+            self._ctx.close()
+        with torch.cuda.device(self.device):
+            ctx = _Context(W, H, n_bands, planes, batch, rho_band, self.native_params())
+            if self.foveated:
+                for cc in range(2):
+                    l = self.csf_lut[cc]
+                    nat.check(nat.lib().fvvdp_ctx_set_csf_3d(ctx.handle, cc, nat.fptr(l["S_log"]), nat.fptr(l["Y_log"]),
+                                                             nat.fptr(l["rho_log"]), nat.fptr(l["ecc_sqrt"])))
+            else:
+                y_log, tab = self.csf_tables_1d(rho_band, n_bands)
+                nat.check(nat.lib().fvvdp_ctx_set_csf_1d(ctx.handle, nat.fptr(y_log), nat.fptr(tab)))
+            if self.timing is not None:
+                nat.check(nat.lib().fvvdp_ctx_timing_enable(ctx.handle, 1))
+        self._ctx = ctx
+        return ctx
+
+    def _batch_size(self, W, H, planes, n_out):
+        if self.batch_frames is not None:
+            return max(1, min(int(self.batch_frames), n_out))
+        per_frame = W * H * planes * 4 * 1.34          # all Gaussian levels of one frame
+        budget = 24e9                                  # resident pyramid scratch (of 288 GB HBM3E)
+        return max(1, min(n_out, 128, int(budget // per_frame)))
+
+    def _geom_struct(self):
+        d = native_geometry(self.display_geometry)
+        if d is None:
+            raise RuntimeError("foveated mode with a custom fvvdp_display_geometry subclass is not supported by the "
+                               "HIP path yet (only the stock geometry model runs in-kernel)")
+        g = nat.Geom()
+        g.display_size_m[0], g.display_size_m[1] = d["display_size_m"]
+        g.distance_m, g.ppd_centre = d["distance_m"], d["ppd_centre"]
+        return g
+
+    def _fixation(self, fixation_point, width, height, N):
+        if fixation_point is None:
+            fp = np.array([width // 2, height // 2], dtype=np.float32)
+        elif isinstance(fixation_point, torch.Tensor):
+            fp = fixation_point.detach().cpu().numpy().astype(np.float32)
+        else:
+            fp = np.asarray(fixation_point, dtype=np.float32)
+        if fp.ndim == 1:
+            fp = np.tile(fp.reshape(1, 2), (N, 1))
+        if fp.shape != (N, 2):
+            raise RuntimeError("fixation_point must be [x, y] or an [N_frames, 2] array")
+        return np.ascontiguousarray(fp, dtype=np.float32)
+
+    def _code_lut(self, photometry, nbits):
+        """Luminance of every integer code value through the display model, evaluated once per display with the
+        model's own `forward` (so user photometry subclasses work) and kept on the device."""
+        key = (id(photometry), nbits)
+        if key not in self._lut_dev:
+            n = 1 << nbits
+            codes = torch.arange(n, dtype=torch.int32).to(torch.float32) / float(n - 1)
+            lut = photometry.forward(codes.view(1, 1, 1, 1, n)).reshape(-1).to(torch.float32)
+            self._lut_dev[key] = lut.contiguous().to(self.device)
+        return self._lut_dev[key]
+
+    def _make_feeder(self, vs, width, height):
+        """Returns feed(ctx, idx, taps, fl, n_out, oob, stream): fills pyramid level 0 of slots [0, n_out)."""
+        lib = nat.lib()
+        HW = width * height
+        if type(vs) is fvvdp_video_source_array or isinstance(vs, fvvdp_video_source_array):
+            test = vs.test_video
+            ref = vs.reference_video
+            if test.shape[0] != 1:
+                raise RuntimeError("Only batch size 1 is supported (as in the reference's sliding-window code)")
+            dt = test.dtype
+            if dt is torch.uint8:
+                dtype, nbits = nat.FVVDP_U8, 8
+            elif dt is torch.int16:
+                dtype, nbits = nat.FVVDP_U16, 16
+            elif dt is torch.float32:
+                dtype, nbits = nat.FVVDP_F32, 0
+            else:
+                raise RuntimeError("Only uint8, uint16 and float32 is currently supported")
+            C_ch, N = test.shape[1], test.shape[2]
+            desc = native_eotf(vs.dm_photometry) if dtype == nat.FVVDP_F32 else None
+            if dtype != nat.FVVDP_F32 or desc is not None:
+                test_d = test.to(self.device).contiguous()
+                ref_d = ref.to(self.device).contiguous()
+                e = nat.Eotf()
+                if dtype != nat.FVVDP_F32:
+                    lut = self._code_lut(vs.dm_photometry, nbits)
+                    e.kind, e.d_lut = nat.EOTF_LUT, lut.data_ptr()
+                else:
+                    e.kind = desc[0]
+                    e.Y_peak = desc[1].get("Y_peak", 0.0)
+                    e.Y_black = desc[1].get("Y_black", 0.0)
+                    e.gamma = desc[1].get("gamma", 1.0)
+                    e.L_min = desc[1].get("L_min", 0.0)
+                    e.L_max = desc[1].get("L_max", 0.0)
+                    if e.kind == nat.EOTF_ABSOLUTE and float(torch.maximum(test_d.max(), ref_d.max())) < 1:
+                        logging.warning('Pixel values are very low. Perhaps images are not scaled in the absolute units of cd/m^2.')
+                w = np.asarray(vs.color_to_luminance, dtype=np.float32)
+
+                def feed(ctx, idx, taps, fl, n_out, oob, stream):
+                    nat.check(lib.fvvdp_temporal_channels(
+                        ctx.handle, C.c_void_p(test_d.data_ptr()), C.c_void_p(ref_d.data_ptr()), dtype, C_ch,
+                        N * HW, HW, C.byref(e), nat.fptr(w), idx.ctypes.data_as(C.POINTER(C.c_int32)),
+                        nat.fptr(taps), fl, n_out, 0, C.c_void_p(oob.data_ptr()), stream))
+                return feed
+        # generic sources (user subclasses, custom float photometry): luminance frames come from the source's own
+        # get_*_frame (the user's code, run on the device); the kernels take over from the temporal filter on.
+        e = nat.Eotf()
+        e.kind = nat.EOTF_NONE
+
+        def feed(ctx, idx, taps, fl, n_out, oob, stream):
+            uniq = sorted(set(int(i) for i in idx))
+            pos = {f: k for k, f in enumerate(uniq)}
+            Lt = torch.empty((len(uniq), height, width), dtype=torch.float32, device=self.device)
+            Lr = torch.empty_like(Lt)
+            for f, k in pos.items():
+                Lt[k] = vs.get_test_frame(f, device=self.device).reshape(height, width)
+                Lr[k] = vs.get_reference_frame(f, device=self.device).reshape(height, width)
+            ridx = np.asarray([pos[int(i)] for i in idx], dtype=np.int32)
+            nat.check(lib.fvvdp_temporal_channels(
+                ctx.handle, C.c_void_p(Lt.data_ptr()), C.c_void_p(Lr.data_ptr()), nat.FVVDP_F32, 1, 0, HW,
+                C.byref(e), None, ridx.ctypes.data_as(C.POINTER(C.c_int32)), nat.fptr(taps), fl, n_out, 0,
+                C.c_void_p(oob.data_ptr()), stream))
+            torch.cuda.current_stream(self.device).synchronize()     # Lt/Lr are released on return
+        return feed

@@ -1,0 +1,184 @@
+/*
+ * fvvdp_hip.h -- C ABI of libfvvdp_hip.so: the FovVideoVDP per-frame visible-difference path on MI355X (gfx950).
+ *
+ * The reference (gfxdisp/FovVideoVDP v1.2.3) has no native/FFI layer: its boundary is the Python class
+ * `pyfvvdp.fvvdp` (pyfvvdp/fvvdp.py:58).  The natural operator seams inside it are
+ *     fvvdp_video_source_array._get_frame      pyfvvdp/video_source.py:180-208      (unpack + photometry + luminance)
+ *     sliding window + temporal FIR            pyfvvdp/fvvdp.py:258-300
+ *     fvvdp_contrast_pyr.decompose             pyfvvdp/fvvdp_lpyr_dec.py:246-273    (Gaussian/contrast pyramid)
+ *     process_block_of_frames                  pyfvvdp/fvvdp.py:359-478            (CSF, masking, spatial pooling)
+ * and each entry point below replaces one of them (cited per function).  A maintainer of the reference binds
+ * these with ctypes; `fovvideovdp_amd/_native.py` is that binding.
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns 0 on success or a negative FVVDP_E* code and never
+ *     throws; fvvdp_last_error() returns a thread-local message for the last failure.
+ *   - pointers named d_* are DEVICE pointers (e.g. torch tensor.data_ptr() on PyTorch-ROCm); pointers named
+ *     h_* are HOST pointers (small tables, copied during the call).
+ *   - `stream` is a hipStream_t passed as void* (e.g. torch.cuda.current_stream().cuda_stream); all kernels are
+ *     enqueued on it and nothing synchronises except where stated.
+ *   - the context owns only its scratch (pyramid levels, tables, partial sums), allocated once in
+ *     fvvdp_ctx_create; per-call functions never allocate.  One context per (device, stream); not thread-safe.
+ *   - pyramid planes: P = 4 for video (test-sustained, ref-sustained, test-transient, ref-transient;
+ *     pyfvvdp/fvvdp.py:293) or P = 2 for a still image (test, ref; pyfvvdp/fvvdp.py:251-253).
+ */
+#ifndef FVVDP_HIP_H
+#define FVVDP_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FVVDP_OK 0
+#define FVVDP_EINVAL (-1)   /* bad argument */
+#define FVVDP_EHIP (-2)     /* a HIP runtime call failed */
+#define FVVDP_ENOMEM (-3)   /* scratch allocation failed */
+#define FVVDP_ESTATE (-4)   /* call order violated (e.g. CSF table not set) */
+
+#define FVVDP_MAX_BANDS 16
+#define FVVDP_MAX_TAPS 256
+#define FVVDP_LUT_N 32      /* knots per axis of the cached CSF LUT (pyfvvdp/csf_cache) */
+
+typedef struct fvvdp_ctx fvvdp_ctx;
+
+/* Calibration constants of the masking/pooling stage (pyfvvdp/fvvdp_data/fvvdp_parameters.json, read by
+ * fvvdp.load_config pyfvvdp/fvvdp.py:113-145). */
+typedef struct fvvdp_params {
+    float mask_p;        /* 2.4                                   fvvdp.py:585 */
+    float mask_q[2];     /* sustained, transient                  fvvdp.py:586 */
+    float mask_k;        /* 10^mask_c                             fvvdp.py:555 */
+    float beta;          /* spatial pooling exponent              fvvdp.py:467 */
+    float sens_gain;     /* 10^(sensitivity_correction/20)        fvvdp.py:447 */
+    float lbkg_min;      /* 0.1                                   fvvdp_lpyr_dec.py:265 */
+    float contrast_max;  /* 1000                                  fvvdp_lpyr_dec.py:266 */
+    float d_max;         /* 1e4                                   fvvdp.py:595 */
+} fvvdp_params;
+
+/* Source sample types accepted by fvvdp_temporal_channels (pyfvvdp/video_source.py:184-200). */
+enum { FVVDP_U8 = 0, FVVDP_U16 = 1, FVVDP_F32 = 2 };
+
+/* Display photometry applied per colour channel (pyfvvdp/fvvdp_display_model.py:147-165, :203-212). */
+enum {
+    FVVDP_EOTF_LUT = 0,       /* integer sources only: L = d_lut[code], table built by the caller            */
+    FVVDP_EOTF_SRGB = 1,      /* (Y_peak-Y_black)*srgb2lin(V)+Y_black                 :155-156, :17-19        */
+    FVVDP_EOTF_GAMMA = 2,     /* (Y_peak-Y_black)*V^gamma+Y_black                     :157-158                */
+    FVVDP_EOTF_PQ = 3,        /* clip(pq2lin(V),0.005,Y_peak)+Y_black                 :159-160, :100-112      */
+    FVVDP_EOTF_LINEAR = 4,    /* clip(V,0.005,Y_peak)+Y_black                         :161-162                */
+    FVVDP_EOTF_ABSOLUTE = 5,  /* clamp(V,L_min,L_max)  (fvvdp_display_photo_absolute) :203-212                */
+    FVVDP_EOTF_NONE = 6       /* source already holds luminance in cd/m^2 (custom video sources)             */
+};
+
+typedef struct fvvdp_eotf {
+    int32_t kind;
+    float Y_peak;
+    float Y_black;
+    float gamma;
+    float L_min, L_max;      /* FVVDP_EOTF_ABSOLUTE only */
+    const float* d_lut;      /* FVVDP_EOTF_LUT: 256 (U8) or 65536 (U16) luminances per code value */
+} fvvdp_eotf;
+
+/* Display geometry for foveated mode (pyfvvdp/fvvdp_display_model.py:383-526, pyfvvdp/fvvdp.py:416-437). */
+typedef struct fvvdp_geom {
+    float display_size_m[2];  /* width, height in metres              :395,417,420,430 */
+    float distance_m;         /* viewing distance                     :401-408        */
+    float ppd_centre;         /* pixels per degree at the centre      :436            */
+} fvvdp_geom;
+
+/* Optional per-band map outputs of fvvdp_bands_forward (any pointer may be NULL).  Planar fp32, device memory:
+ *   d_D        [n][2][h_b][w_b]  difference map after masking, one plane per temporal channel (fvvdp.py:454)
+ *   d_contrast [n][P][h_b][w_b]  contrast band times the band multiplier (lpyr.get_band, fvvdp_lpyr_dec.py:57-63)
+ *   d_lbkg     [n][h_b][w_b]     background luminance (fvvdp_lpyr_dec.py:265)
+ *   d_S        [n][2][h_b][w_b]  sensitivity before the gain (cached_sensitivity, fvvdp.py:520-537)             */
+typedef struct fvvdp_band_maps {
+    float* d_D;
+    float* d_contrast;
+    float* d_lbkg;
+    float* d_S;
+} fvvdp_band_maps;
+
+/* ---- lifecycle ------------------------------------------------------------------------------------------ */
+
+/* Replaces the per-resolution setup in predict_video_source (pyfvvdp/fvvdp.py:209-213: the pyramid object) and
+ * the per-frame tensor allocations of the hot loop.  `n_bands` = lpyr.height (number of band-pass levels; the
+ * Gaussian pyramid has n_bands+1 levels, fvvdp_lpyr_dec.py:15-49).  `max_frames` = number of frames whose
+ * pyramids are resident at once (frame batch).  h_rho_band: n_bands+1 band frequencies in cpd. */
+int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_bands, int planes, int max_frames,
+                     const double* h_rho_band, const fvvdp_params* prm);
+void fvvdp_ctx_destroy(fvvdp_ctx* ctx);
+const char* fvvdp_last_error(void);
+/* Level geometry: level 0 is the frame; sizes follow ceil(/2) (fvvdp_lpyr_dec.py:198). */
+int fvvdp_ctx_level_size(const fvvdp_ctx* ctx, int level, int* w, int* h);
+/* Bytes of device scratch held by the context. */
+size_t fvvdp_ctx_scratch_bytes(const fvvdp_ctx* ctx);
+
+/* ---- CSF tables ------------------------------------------------------------------------------------------ */
+
+/* Non-foveated mode: rho and eccentricity are constant per band, so the 32^3 LUT collapses exactly to a 1-D
+ * table over log2(L_bkg) per (band, temporal channel) -- the rho/ecc interpolation of interp3
+ * (pyfvvdp/interp.py:43-59) is done once by the caller with the same fp32 operations.
+ *   h_Y_log  [32]               knots of the luminance axis (log2 cd/m^2)
+ *   h_S_log  [n_bands][2][32]   log2 sensitivity at the knots                                           */
+int fvvdp_ctx_set_csf_1d(fvvdp_ctx* ctx, const float* h_Y_log, const float* h_S_log);
+
+/* Foveated mode: full LUT of one temporal channel (cached_sensitivity + interp3, pyfvvdp/fvvdp.py:520-537).
+ *   h_S_log [32(Y)][32(rho)][32(ecc)], axes h_Y_log, h_rho_log, h_ecc_sqrt (32 each).                  */
+int fvvdp_ctx_set_csf_3d(fvvdp_ctx* ctx, int temporal_channel, const float* h_S_log, const float* h_Y_log,
+                         const float* h_rho_log, const float* h_ecc_sqrt);
+
+/* ---- stage 1: frames -> temporal channels --------------------------------------------------------------- */
+
+/* Replaces fvvdp_video_source_array._get_frame (video_source.py:180-208), fvvdp_display_photo_eotf.forward
+ * (fvvdp_display_model.py:147-165) and the sliding-window temporal filter (fvvdp.py:258-300) for `n_out`
+ * consecutive output frames; the result is written into pyramid level 0 of slots [slot0, slot0+n_out).
+ *   d_test, d_ref   source videos, element (c, f, y, x) at  c*chan_stride + f*frame_stride + y*width + x
+ *   dtype, C        FVVDP_U8/U16/F32; C in {1,3}
+ *   h_rgb2y[3]      luminance weights (color_spaces.json RGB2Y), ignored when C == 1
+ *   h_frame_idx     [fl-1+n_out] source frame of every virtual time step: the first fl-1 entries are the
+ *                   history before the first output (temporal padding, or real frames when continuing a
+ *                   video / a frame shard), entry fl-1+t is the newest frame of output t
+ *   h_taps          [2][fl] temporal filters (get_temporal_filters, fvvdp.py:609-630); tap k weights the frame
+ *                   k steps in the past.  planes == 2 (still image): fl must be 1 and only h_taps[0] is used.
+ *   d_oob_flag      optional int: set to 1 if a float sample was outside [0,1] (the caller re-emits the
+ *                   reference's warning "Pixel outside the valid range 0-1")                               */
+int fvvdp_temporal_channels(fvvdp_ctx* ctx, const void* d_test, const void* d_ref, int dtype, int C,
+                            size_t chan_stride, size_t frame_stride, const fvvdp_eotf* eotf,
+                            const float* h_rgb2y, const int32_t* h_frame_idx, const float* h_taps, int fl,
+                            int n_out, int slot0, int32_t* d_oob_flag, void* stream);
+
+/* Alternative entry for callers that already hold the temporal channels in the reference layout
+ * R[n][P][H][W] (planar fp32, fvvdp.py:294): copies them into pyramid level 0 of slots [slot0, slot0+n). */
+int fvvdp_load_channels_planar(fvvdp_ctx* ctx, const float* d_R, int n, int slot0, void* stream);
+
+/* ---- stage 2: pyramid + CSF + masking + spatial pooling --------------------------------------------------- */
+
+/* Replaces process_block_of_frames (fvvdp.py:359-478) incl. lpyr.decompose (fvvdp_lpyr_dec.py:248-273),
+ * cached_sensitivity (fvvdp.py:520-537), apply_masking_model (fvvdp.py:574-596) and lp_norm (fvvdp.py:598-607)
+ * for the frames in slots [0, n).
+ *   d_Q           output, Q_per_ch[band][cc][q_stride] fp32; frame slot s is written at column q_col0+s.
+ *                 cc=1 is written as 0 for planes == 2 (fvvdp.py:465).
+ *   h_fixation    NULL = non-foveated; else [n][2] gaze (x,y) in frame pixels for each slot (fvvdp.py:417-431)
+ *   geom          required when h_fixation != NULL
+ *   maps          NULL or array of n_bands structs with optional per-band map outputs                     */
+int fvvdp_bands_forward(fvvdp_ctx* ctx, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
+                        const fvvdp_geom* geom, const fvvdp_band_maps* maps, void* stream);
+
+/* ---- introspection (tests, profiling) --------------------------------------------------------------------- */
+
+/* Copy Gaussian level `level` of slots [0,n) to planar fp32 d_out[n][P][h][w] (gaussian_pyramid_dec,
+ * fvvdp_lpyr_dec.py:144-158). */
+int fvvdp_export_level(fvvdp_ctx* ctx, int level, int n, float* d_out, void* stream);
+
+/* Per-kernel HIP-event timing of the most recent calls.  When enabled, every kernel launch is bracketed by
+ * events on the caller's stream.  fvvdp_ctx_timing_read synchronises the events and returns, per kernel id,
+ * accumulated milliseconds and launch counts since the last reset.
+ *   ids: 0 = temporal, 1..n_bands = band kernel of level id-1, n_bands+1 = finalize                       */
+int fvvdp_ctx_timing_enable(fvvdp_ctx* ctx, int on);
+int fvvdp_ctx_timing_read(fvvdp_ctx* ctx, float* h_ms, int32_t* h_count, int capacity, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FVVDP_HIP_H */

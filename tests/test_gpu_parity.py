@@ -1,0 +1,280 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
+(libfvvdp_hip.so) and through the reference-shaped Python API, against (a) golden vectors captured from the real
+reference and (b) the CPU oracle on the same seeded inputs.  Tolerances as in tests/test_oracle_golden.py
+(fp32 rounding noise of this algorithm); JOD within 1e-3 (north-star bound), in practice ~1e-5."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+@pytest.fixture(scope="module")
+def fv():
+    import fovvideovdp_amd
+    from fovvideovdp_amd import _native
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    _native.lib()          # fails loudly when the HIP library is missing
+    return fovvideovdp_amd
+
+
+def check_q(q, gq, coarse=1e-3, fine=1e-4):
+    q, gq = np.asarray(q, np.float64), np.asarray(gq, np.float64)
+    assert q.shape == gq.shape
+    assert np.all(np.abs(q - gq) <= coarse * np.abs(gq) + 1e-6 * np.max(np.abs(gq))), np.max(np.abs(q - gq) / (np.abs(gq) + 1e-6 * np.max(np.abs(gq))))
+    nb = min(3, q.shape[0])
+    assert np.all(np.abs(q[:nb] - gq[:nb]) <= fine * np.abs(gq[:nb]) + 1e-7 * np.max(np.abs(gq)))
+
+
+def gaussblur(img, sigma):
+    from scipy.ndimage import gaussian_filter
+    out = np.zeros_like(img)
+    for cc in range(img.shape[2]):
+        out[..., cc] = gaussian_filter(img[..., cc], sigma, mode="nearest", truncate=2.0)
+    return out
+
+
+def test_readme_known_answer(fv):
+    """README.md:138 of the reference: wavy_facade vs blur sigma=2 on standard_4k -> 8.693 JOD."""
+    z = load("g0_wavy_facade_blur_4k")
+    ref = z["ref_u16"]
+    test = gaussblur(ref, 2)
+    m = fv.fvvdp(display_name="standard_4k")
+    q, stats = m.predict(test, ref, dim_order="HWC")
+    assert q.device.type == "cuda" and q.dim() == 0
+    assert abs(float(q) - 8.693) < 1e-3
+    assert abs(float(q) - float(z["jod"])) < 1e-4
+    check_q(stats["Q_per_ch"][:, 0:1, :], z["Q_per_ch"][:, 0:1, :])
+    assert np.all(stats["Q_per_ch"][:, 1, :] == 0)
+    assert np.allclose(stats["rho_band"], z["rho_band"], rtol=1e-12)
+    assert stats["width"] == 1024 and stats["height"] == 683 and stats["N_frames"] == 1
+
+
+def test_config1_crop512(fv):
+    z = load("g1_crop512_blur_fhd")
+    z0 = load("g0_wavy_facade_blur_4k")
+    ref = z0["ref_u16"][85:597, 256:768]
+    m = fv.fvvdp(display_name="standard_fhd")
+    q, stats = m.predict(z["test_u16"], ref, dim_order="HWC")
+    assert abs(float(q) - float(z["jod"])) < 1e-4
+    check_q(stats["Q_per_ch"][:, 0:1, :], z["Q_per_ch"][:, 0:1, :])
+
+
+def stage_check(maps, exported, z, frames, n_bands, P):
+    """maps/exported from the HIP path for the frames in order; z golden npz."""
+    TC = P // 2
+    for fi, ff in enumerate(frames):
+        for b in range(n_bands):
+            key = f"band_f{ff}_b{b}"
+            if key in z.files:
+                gb = z[key] * (1.0 if b == 0 else 2.0)          # kernel output already holds the band multiplier
+                hb = maps[b]["contrast"][fi].cpu().numpy()
+                assert np.max(np.abs(hb - gb)) < 2e-5 * max(float(np.max(np.abs(gb))), 1e-3), key
+            key = f"lbkg_f{ff}_b{b}"
+            if key in z.files:
+                gl, hl = z[key], maps[b]["lbkg"][fi].cpu().numpy()
+                assert np.max(np.abs(hl - gl) / gl) < 5e-6, key
+            for cc in range(TC):
+                i = cc * n_bands + b
+                key = f"S_f{ff}_i{i}"
+                if key in z.files:
+                    gs, hs = z[key], maps[b]["S"][fi, cc].cpu().numpy()
+                    assert np.max(np.abs(hs - gs) / gs) < 2e-5, key
+                key = f"D_f{ff}_i{i}"
+                if key in z.files:
+                    gd, hd = z[key].astype(np.float64), maps[b]["D"][fi, cc].cpu().numpy().astype(np.float64)
+                    assert np.max(np.abs(hd - gd) / (np.abs(gd) + 1e-3 * np.max(gd) + 1e-12)) < 2e-2, key
+                    assert abs(hd.sum() / gd.sum() - 1) < (2e-4 if gd.size >= 4096 else 2e-3), key
+        # Gaussian base band = last golden 'band'
+        key = f"band_f{ff}_b{n_bands}"
+        if key in z.files:
+            gb, hb = z[key], exported[fi].cpu().numpy()
+            assert np.max(np.abs(hb - gb)) < 3e-6 * np.max(np.abs(gb)), key
+
+
+@pytest.mark.parametrize("H,W,N,fps", [(135, 240, 10, 30), (68, 121, 12, 60)])
+def test_stages_from_golden_R(fv, H, W, N, fps):
+    """C ABI, stage 2 only: feed the reference's own temporal channels R (golden) and compare every stage:
+    contrast bands, L_bkg, S, D and the base Gaussian level (both reduce-quirk parities are covered)."""
+    from fovvideovdp_amd.lowlevel import Pipeline
+    z = load(f"g2_video_{H}x{W}_replicate")
+    frames = (0, 1, N - 1)
+    m = fv.fvvdp(display_name="standard_fhd")
+    pipe = Pipeline(m, W, H, 4, len(frames))
+    R = torch.tensor(np.stack([z[f"R_f{ff}"] for ff in frames], 0), device=m.device)
+    pipe.load_planar(R)
+    Q, maps = pipe.bands_forward(len(frames), want_maps=True)
+    base = pipe.export_level(pipe.n_bands, len(frames))
+    torch.cuda.synchronize()
+    assert pipe.n_bands == z["Q_per_ch"].shape[0]
+    stage_check(maps, base, z, frames, pipe.n_bands, 4)
+    check_q(Q.cpu().numpy(), z["Q_per_ch"][:, :, list(frames)])
+    # run-to-run determinism of the two-stage pooled reduction
+    Q2 = pipe.bands_forward(len(frames))
+    assert torch.equal(Q, Q2)
+
+
+@pytest.mark.parametrize("H,W,N,fps", [(135, 240, 10, 30), (68, 121, 12, 60)])
+@pytest.mark.parametrize("pad", ["replicate", "circular", "pingpong"])
+def test_video_end_to_end_golden(fv, H, W, N, fps, pad):
+    from fovvideovdp_amd.synth import synth_video_pair
+    z = load(f"g2_video_{H}x{W}_{pad}")
+    test, ref = synth_video_pair(N, H, W)
+    m = fv.fvvdp(display_name="standard_fhd", temp_padding=pad)
+    q, stats = m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
+    assert np.max(np.abs(m.F.numpy() - z["F"])) < 2e-6 * np.max(np.abs(z["F"]))
+    assert abs(float(q) - float(z["jod"])) < 1e-4, pad
+    check_q(stats["Q_per_ch"], z["Q_per_ch"])
+    # frame batching and device-resident input must not change anything
+    m2 = fv.fvvdp(display_name="standard_fhd", temp_padding=pad, batch_frames=3)
+    q2, stats2 = m2.predict(test.cuda(), ref.cuda(), dim_order="BCFHW", frames_per_second=fps)
+    assert np.array_equal(stats["Q_per_ch"], stats2["Q_per_ch"])
+    assert float(q) == float(q2)
+
+
+def test_temporal_channels_vs_golden_R(fv):
+    """C ABI, stage 1: unpack + sRGB LUT + luminance + FIR against the reference's R, ring and generic kernels."""
+    from fovvideovdp_amd.lowlevel import Pipeline
+    from fovvideovdp_amd import _native as nat
+    from fovvideovdp_amd.synth import synth_video_pair
+    from fovvideovdp_amd.fvvdp import window_frame_indices
+    for (H, W, N, fps) in ((135, 240, 10, 30), (68, 121, 12, 60)):
+        z = load(f"g2_video_{H}x{W}_replicate")
+        test, ref = synth_video_pair(N, H, W)
+        m = fv.fvvdp(display_name="standard_fhd")
+        pipe = Pipeline(m, W, H, 4, N)
+        fl = int(z["filter_len"])
+        m.filter_len = fl
+        F, _ = m.get_temporal_filters(fps)
+        idx = window_frame_indices(N, fl, "replicate")
+        e = nat.Eotf()
+        lut = m._code_lut(m.display_photometry, 8)
+        e.kind, e.d_lut = nat.EOTF_LUT, lut.data_ptr()
+        td, rd = test.cuda(), ref.cuda()
+        pipe.temporal(td, rd, nat.FVVDP_U8, 3, N * H * W, H * W, e, [0.2126729, 0.7151522, 0.0721750], idx, F.numpy(), fl, N)
+        R = pipe.export_level(0, N).cpu().numpy()
+        for ff in (0, 1, N - 1):
+            g = z[f"R_f{ff}"]
+            assert np.max(np.abs(R[ff] - g)) < 2e-6 * np.max(np.abs(g)), (H, W, ff)
+
+
+def test_f32_gray_and_u16_inputs(fv):
+    from fovvideovdp_amd.synth import synth_video_pair
+    test, ref = synth_video_pair(6, 68, 121, C=1)
+    z = load("g2_video_68x121_f32gray")
+    m = fv.fvvdp(display_name="standard_4k")
+    q, stats = m.predict(test.float() / 255, ref.float() / 255, frames_per_second=30)
+    assert abs(float(q) - float(z["jod"])) < 1e-4
+    check_q(stats["Q_per_ch"], z["Q_per_ch"])
+    z = load("g2_image_68x121_u16gray")
+    t16 = test[0, 0, 0].numpy().astype(np.uint16) * 257
+    r16 = ref[0, 0, 0].numpy().astype(np.uint16) * 257
+    m = fv.fvvdp(display_name="standard_phone")
+    q, stats = m.predict(t16, r16, dim_order="HW")
+    assert abs(float(q) - float(z["jod"])) < 1e-4
+    check_q(stats["Q_per_ch"][:, 0:1], z["Q_per_ch"][:, 0:1])
+
+
+def test_identical_inputs_give_10_jod(fv):
+    from fovvideovdp_amd.synth import synth_video_pair
+    _, ref = synth_video_pair(9, 72, 128)
+    m = fv.fvvdp(display_name="standard_fhd")
+    q, stats = m.predict(ref, ref, frames_per_second=30)
+    assert float(q) == 10.0
+    assert np.all(stats["Q_per_ch"] == 0)
+
+
+def test_custom_video_source_and_photometry(fv):
+    """User subclasses keep working: a custom video source goes through its own get_*_frame; a custom photometry on
+    integer input is tabulated through its own forward()."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    N, H, W, fps = 8, 68, 120, 30
+    test, ref = synth_video_pair(N, H, W)
+    m = fv.fvvdp(display_name="standard_fhd")
+    q0, s0 = m.predict(test, ref, frames_per_second=fps)
+    inner = fv.fvvdp_video_source_array(test, ref, fps, display_photometry=m.display_photometry)
+
+    class MySource(fv.fvvdp_video_source):
+        def get_video_size(self):
+            return inner.get_video_size()
+
+        def get_frames_per_second(self):
+            return fps
+
+        def get_test_frame(self, frame, device):
+            return inner.get_test_frame(frame, device)
+
+        def get_reference_frame(self, frame, device):
+            return inner.get_reference_frame(frame, device)
+
+    q1, s1 = m.predict_video_source(MySource())
+    assert abs(float(q1) - float(q0)) < 1e-4
+    check_q(s1["Q_per_ch"], s0["Q_per_ch"])
+
+    class MyPhoto(fv.fvvdp_display_photometry):
+        def forward(self, V):
+            return 150.0 * V ** 2.0 + 0.3
+
+        def get_peak_luminance(self):
+            return 150.3
+
+        def get_black_level(self):
+            return 0.3
+
+    m2 = fv.fvvdp(display_name="standard_fhd", display_photometry=MyPhoto())
+    q2, s2 = m2.predict(test, ref, frames_per_second=fps)
+
+    class OPhoto:
+        def forward(self, V):
+            return (np.float32(150.0) * V ** np.float32(2.0) + np.float32(0.3)).astype(np.float32), False
+
+    o = orc.Oracle("standard_fhd", photometry=OPhoto())
+    oq, os_ = o.predict(test.numpy(), ref.numpy(), frames_per_second=fps)
+    assert abs(float(q2) - float(oq)) < 1e-4
+    check_q(s2["Q_per_ch"], os_["Q_per_ch"])
+
+
+def test_error_behaviour(fv):
+    m = fv.fvvdp(display_name="standard_fhd")
+    a = np.zeros((32, 32, 3), dtype=np.uint8)
+    with pytest.raises(RuntimeError):
+        m.predict(a, np.zeros((32, 33, 3), dtype=np.uint8), dim_order="HWC")
+    with pytest.raises(RuntimeError):
+        m.predict(np.zeros((2, 32, 32), np.uint8), np.zeros((2, 32, 32), np.uint8), dim_order="FHW")   # fps missing
+    with pytest.raises(RuntimeError):
+        m.predict(np.zeros((32, 32, 2), np.uint8), np.zeros((32, 32, 2), np.uint8), dim_order="HWC")   # 2 channels
+    with pytest.raises(RuntimeError):
+        m.predict(np.zeros((32, 32), np.float64), np.zeros((32, 32), np.float64), dim_order="HW")
+    with pytest.raises(RuntimeError):
+        fv.fvvdp(display_name="no_such_display")
+
+
+def test_out_of_range_warning(fv, caplog):
+    import logging
+    m = fv.fvvdp(display_name="standard_fhd")
+    a = np.random.RandomState(0).rand(64, 64).astype(np.float32) * 1.2
+    with caplog.at_level(logging.WARNING):
+        m.predict(a, a * 0.9, dim_order="HW")
+    assert any("Pixel outside the valid range 0-1" in r.message for r in caplog.records)
+
+
+def test_oracle_random_sizes(fv):
+    """HIP vs CPU oracle on seeded inputs of assorted sizes (odd/even in both axes, multi-strip widths)."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    for (N, H, W, fps, disp) in ((5, 97, 263, 24, "standard_4k"), (4, 130, 129, 30, "standard_fhd"), (3, 271, 481, 60, "standard_4k")):
+        test, ref = synth_video_pair(N, H, W)
+        m = fv.fvvdp(display_name=disp)
+        q, stats = m.predict(test, ref, frames_per_second=fps)
+        oq, ostats = orc.Oracle(disp).predict(test.numpy(), ref.numpy(), frames_per_second=fps)
+        assert abs(float(q) - float(oq)) < 1e-4, (H, W)
+        check_q(stats["Q_per_ch"], ostats["Q_per_ch"])
