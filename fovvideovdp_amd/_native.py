@@ -7,7 +7,7 @@ import sys
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
-LIB_PATH = os.path.join(_HERE, "libfvvdp_hip.so")
+LIB_PATH = os.environ.get("FVVDP_LIB", os.path.join(_HERE, "libfvvdp_hip.so"))   # override: A/B builds
 SRC_PATH = os.path.join(_HERE, "csrc", "fvvdp_hip.hip")
 INCLUDE_DIR = os.path.join(ROOT, "include")
 

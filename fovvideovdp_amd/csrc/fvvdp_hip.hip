@@ -12,6 +12,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -234,6 +235,72 @@ __device__ __forceinline__ void build_lutw(float* lutw, const float* lut, int C,
 // both streams in registers (ring with compile-time slot indices), so every source frame is read exactly once and
 // every output pixel is written once as one float4 (test-sust, ref-sust, test-trans, ref-trans).
 // Reference: fvvdp.py:294-300 (R[:,2cc+s] = sum_k window[s][k] * F[cc].flip(0)[k]).
+// PX raw samples of one channel.  A thread's PX pixels are 256 apart (pixel i of thread t in block b is
+// b*256*PX + i*256 + t): every load and every store instruction of a wave then covers one contiguous run of
+// memory (64 x 1/2/4 B loads, 64 x 16 B = 1 KiB stores of finished float4 pixels).
+template <int SRC, int PX>
+struct RawPx {
+    unsigned int wd[PX];
+    __device__ __forceinline__ unsigned int code(int i) const { return wd[i]; }              // integer sources
+    __device__ __forceinline__ float value(int i) const { return __uint_as_float(wd[i]); }   // float source
+};
+
+template <int SRC, int PX>
+__device__ __forceinline__ RawPx<SRC, PX> load_raw(const void* base, size_t off, const int (&px)[PX]) {
+    RawPx<SRC, PX> r;
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        if constexpr (SRC == SRC_U8) r.wd[i] = reinterpret_cast<const unsigned char*>(base)[off + px[i]];
+        else if constexpr (SRC == SRC_U16) r.wd[i] = reinterpret_cast<const unsigned short*>(base)[off + px[i]];
+        else r.wd[i] = reinterpret_cast<const unsigned int*>(base)[off + px[i]];
+    }
+    return r;
+}
+
+// raw samples of all channels of one frame of one stream -> luminance of PX pixels
+template <int SRC, int PX>
+struct RawFrame {
+    RawPx<SRC, PX> ch[3];
+};
+
+template <int SRC, int PX>
+__device__ __forceinline__ RawFrame<SRC, PX> fetch_frame(const void* base, size_t off, size_t chan_stride, int C,
+                                                         const int (&px)[PX]) {
+    RawFrame<SRC, PX> f;
+    f.ch[0] = load_raw<SRC, PX>(base, off, px);
+    if (C == 3) {
+        f.ch[1] = load_raw<SRC, PX>(base, off + chan_stride, px);
+        f.ch[2] = load_raw<SRC, PX>(base, off + 2 * chan_stride, px);
+    } else {
+        f.ch[1] = f.ch[0];
+        f.ch[2] = f.ch[0];
+    }
+    return f;
+}
+
+template <int SRC, int PX>
+__device__ __forceinline__ void frame_lum(const RawFrame<SRC, PX>& f, int C, const float* lutw, const float* lut16,
+                                          const float (&w)[3], const EotfDev& e, float (&L)[PX], bool& bad) {
+    float v[3][PX];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        if (c > 0 && C != 3) break;
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            if constexpr (SRC == SRC_U8) v[c][i] = lutw[c * 256 + f.ch[c].code(i)];
+            else if constexpr (SRC == SRC_U16) v[c][i] = __fmul_rn(lut16[f.ch[c].code(i)], w[c]);
+            else v[c][i] = __fmul_rn(eotf_f32(f.ch[c].value(i), e, bad), w[c]);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < PX; ++i) L[i] = (C == 3) ? __fadd_rn(__fadd_rn(v[0][i], v[1][i]), v[2][i]) : v[0][i];
+}
+
+// Temporally tiled FIR: one thread owns PX pixels for the whole launch and keeps the last FL luminance values of
+// both streams in registers (ring with compile-time slot indices), so every source frame is read exactly once and
+// every output pixel is written once as one float4 (test-sust, ref-sust, test-trans, ref-trans).  The raw samples
+// of the next frame are fetched while the current one is filtered (software prefetch, one frame ahead).
+// Reference: fvvdp.py:294-300 (R[:,2cc+s] = sum_k window[s][k] * F[cc].flip(0)[k]).
 template <int FL, int PX, int SRC>
 __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a) {
     __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
@@ -241,58 +308,66 @@ __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a
         build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 256);
         __syncthreads();
     }
-    const int p = (blockIdx.x * 256 + threadIdx.x) * PX;
-    if (p >= a.HW) return;
-    Sampler<SRC, PX> S[2];
+    int px[PX];          // this thread's pixels (clamped for the loads; stores are predicated on `ok`)
+    bool ok[PX];
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        S[s].base = a.src[s];
-        S[s].chan_stride = a.chan_stride;
-        S[s].C = a.C;
-        S[s].lutw = lutw;
-        S[s].lut16 = a.e.lut;
-        S[s].w0 = a.C == 3 ? a.w[0] : 1.0f;
-        S[s].w1 = a.w[1];
-        S[s].w2 = a.w[2];
-        S[s].e = a.e;
+    for (int i = 0; i < PX; ++i) {
+        const int q = blockIdx.x * (256 * PX) + i * 256 + threadIdx.x;
+        ok[i] = q < a.HW;
+        px[i] = ok[i] ? q : a.HW - 1;
     }
+    const float w[3] = {a.C == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};
     bool bad = false;
     float ring[2][FL][PX];
 #pragma unroll
-    for (int u = 0; u < FL - 1; ++u) {
-        const size_t off = (size_t)a.idx[u] * a.frame_stride + p;
-        S[0].lum(off, ring[0][u], bad);
-        S[1].lum(off, ring[1][u], bad);
+    for (int u = 0; u < FL; ++u)
+#pragma unroll
+        for (int i = 0; i < PX; ++i) ring[0][u][i] = ring[1][u][i] = 0.0f;
+    // virtual time v = 0 .. FL-2 is the history, v = FL-1+t the newest frame of output t; ring slot = v % FL.
+    // The same pipelined loop fills the history and produces the outputs, so at most one frame is in flight.
+    const int total = FL - 1 + a.n_out;
+    RawFrame<SRC, PX> nx[2];
+    {
+        const size_t off = (size_t)a.idx[0] * a.frame_stride;
+        nx[0] = fetch_frame<SRC, PX>(a.src[0], off, a.chan_stride, a.C, px);
+        nx[1] = fetch_frame<SRC, PX>(a.src[1], off, a.chan_stride, a.C, px);
     }
-    for (int t0 = 0; t0 < a.n_out; t0 += FL) {
+    for (int v0 = 0; v0 < total; v0 += FL) {
 #pragma unroll
         for (int u = 0; u < FL; ++u) {
-            const int t = t0 + u;
-            if (t < a.n_out) {
-                const int slot = (FL - 1 + u) % FL;
-                const size_t off = (size_t)a.idx[FL - 1 + t] * a.frame_stride + p;
-                S[0].lum(off, ring[0][slot], bad);
-                S[1].lum(off, ring[1][slot], bad);
-                float acc[4][PX];
-#pragma unroll
-                for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
-                // oldest tap first, like the reference's sum over the window dimension
-#pragma unroll
-                for (int k = FL - 1; k >= 0; --k) {
-                    const int sl = (slot - k + 2 * FL) % FL;
-                    const float f0 = a.taps[0][k], f1 = a.taps[1][k];
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) {
-                        acc[0][i] = fmaf(ring[0][sl][i], f0, acc[0][i]);
-                        acc[1][i] = fmaf(ring[1][sl][i], f0, acc[1][i]);
-                        acc[2][i] = fmaf(ring[0][sl][i], f1, acc[2][i]);
-                        acc[3][i] = fmaf(ring[1][sl][i], f1, acc[3][i]);
-                    }
+            const int v = v0 + u;
+            if (v < total) {
+                const RawFrame<SRC, PX> cur0 = nx[0], cur1 = nx[1];
+                if (v + 1 < total) {
+                    const size_t off = (size_t)a.idx[v + 1] * a.frame_stride;
+                    nx[0] = fetch_frame<SRC, PX>(a.src[0], off, a.chan_stride, a.C, px);
+                    nx[1] = fetch_frame<SRC, PX>(a.src[1], off, a.chan_stride, a.C, px);
                 }
-                float* o = a.out + ((size_t)t * a.HW + p) * 4;
+                frame_lum<SRC, PX>(cur0, a.C, lutw, a.e.lut, w, a.e, ring[0][u], bad);
+                frame_lum<SRC, PX>(cur1, a.C, lutw, a.e.lut, w, a.e, ring[1][u], bad);
+                if (v >= FL - 1) {
+                    float acc[4][PX];
 #pragma unroll
-                for (int i = 0; i < PX; ++i)
-                    *reinterpret_cast<float4*>(o + 4 * i) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+                    for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
+                    // oldest tap first, like the reference's sum over the window dimension
+#pragma unroll
+                    for (int k = FL - 1; k >= 0; --k) {
+                        const int sl = (u - k + 2 * FL) % FL;
+                        const float f0 = a.taps[0][k], f1 = a.taps[1][k];
+#pragma unroll
+                        for (int i = 0; i < PX; ++i) {
+                            acc[0][i] = fmaf(ring[0][sl][i], f0, acc[0][i]);
+                            acc[1][i] = fmaf(ring[1][sl][i], f0, acc[1][i]);
+                            acc[2][i] = fmaf(ring[0][sl][i], f1, acc[2][i]);
+                            acc[3][i] = fmaf(ring[1][sl][i], f1, acc[3][i]);
+                        }
+                    }
+                    float* o = a.out + (size_t)(v - (FL - 1)) * a.HW * 4;
+#pragma unroll
+                    for (int i = 0; i < PX; ++i)
+                        if (ok[i])
+                            *reinterpret_cast<float4*>(o + (size_t)px[i] * 4) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+                }
             }
         }
     }
@@ -382,8 +457,66 @@ __global__ void interleave_kernel(const float* __restrict__ in, float* __restric
 // stage 2: fused pyramid level
 //   read Gaussian level i once, write level i+1 once, and in the same pass expand level i+1, form the contrast
 //   band, weight by the CSF, apply mutual masking and accumulate sum(D^beta)  (nothing else touches HBM).
+//
+//   One single-wave workgroup streams down a strip of 120 fine (60 coarse) columns: lane l owns coarse column
+//   J = Ja-2+l and the two fine columns 2J, 2J+1 (4 fine pixels per step).  Vertical 5-tap reduce and the vertical
+//   half of the expand are thread-local on a register window of 5 fine rows; the horizontal halves take the
+//   neighbour lanes' values through DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1) -- no LDS, no
+//   barriers, so the waves of a CU run completely decoupled and hide each other's HBM latency.  Plane pairs
+//   (test, ref) live in adjacent registers and go through packed fp32 math (v_pk_fma_f32), which also makes the
+//   test and reference planes bit-symmetric (identical inputs give exactly D = 0).
 // ------------------------------------------------------------------------------------------------------------
 #define STRIP_J 60          // coarse columns produced per wave (64 lanes - 2 halo lanes each side)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int P>
+struct Px {                 // one pixel: P/2 (test, ref) pairs
+    v2f h[P / 2];
+};
+
+template <int P>
+__device__ __forceinline__ Px<P> ld_px(const float* p);
+template <>
+__device__ __forceinline__ Px<4> ld_px<4>(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    Px<4> r;
+    r.h[0] = v2f{t.x, t.y};
+    r.h[1] = v2f{t.z, t.w};
+    return r;
+}
+template <>
+__device__ __forceinline__ Px<2> ld_px<2>(const float* p) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    Px<2> r;
+    r.h[0] = v2f{t.x, t.y};
+    return r;
+}
+__device__ __forceinline__ void st_px(float* p, const Px<4>& a) {
+    *reinterpret_cast<float4*>(p) = make_float4(a.h[0].x, a.h[0].y, a.h[1].x, a.h[1].y);
+}
+__device__ __forceinline__ void st_px(float* p, const Px<2>& a) {
+    *reinterpret_cast<float2*>(p) = make_float2(a.h[0].x, a.h[0].y);
+}
+
+__device__ __forceinline__ v2f splat(float s) { return v2f{s, s}; }
+// a*s + c on both halves (v_pk_fma_f32)
+__device__ __forceinline__ v2f pfma(v2f a, float s, v2f c) { return __builtin_elementwise_fma(a, splat(s), c); }
+
+// value held by the lane to the left / right (0 at the wave's ends)
+__device__ __forceinline__ float from_left(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_right(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+}
+// acc + w * neighbour(x), per component (v_fmac_f32 with a DPP source)
+__device__ __forceinline__ v2f fma_left(v2f x, float w, v2f acc) {
+    return v2f{fmaf(from_left(x.x), w, acc.x), fmaf(from_left(x.y), w, acc.y)};
+}
+__device__ __forceinline__ v2f fma_right(v2f x, float w, v2f acc) {
+    return v2f{fmaf(from_right(x.x), w, acc.x), fmaf(from_right(x.y), w, acc.y)};
+}
 
 struct BandArgs {
     const float* Gf;        // fine level   [n][h][w][P]
@@ -391,9 +524,11 @@ struct BandArgs {
     int w, h, wc, hc;
     int n_strips, n_chunks, cr;
     float band_mul;
-    const float4* csf;      // [32] records {Y_log[i], 1/(Y_log[i+1]-Y_log[i]+1e-6), S_log0[i], S_log1[i]}
+    const float4* csf;      // [32] records {S_log0[i], S_log1[i], S_log0[i+1]-S_log0[i], S_log1[i+1]-S_log1[i]}
+    const float4* csf_y;    // [32] records {Y_log[i], ...} (foveated path: knots of the Y axis)
     float y_first, y_inv_step;
     float y_lo, y_hi;       // clamp range of L_bkg (lut Y[0], Y[-1])
+    float ly_lo, ly_hi;     // the same in log2
     float lg_gain, lg_k;    // log2(sens_gain), log2(mask_k)
     float p, q0, q1, beta, lbkg_min, cmax, lg_dmax;
     float* partial;         // [n][n_strips*n_chunks][2]
@@ -410,11 +545,6 @@ struct BandArgs {
     float rho_band, rho_lo, rho_hi, ecc_lo, ecc_hi;
     int frame_w, frame_h;
 };
-
-template <int P>
-__device__ __forceinline__ Pix<P> lds_ld(const float* base, int slot) {
-    return ld_pix<P>(base + slot * P);
-}
 
 __device__ __forceinline__ void interp_axis(const float* __restrict__ x, float q, int& i0, int& i1, float& f) {
     // get_interpolants_v1 (interp.py:11-20): imax = first knot >= q (clamped), imin = max(imax-1,0),
@@ -434,17 +564,30 @@ __device__ __forceinline__ void interp_axis(const float* __restrict__ x, float q
     f = (i1 == i0) ? 0.0f : fmaxf((q - x[i0]) / den, 0.0f);
 }
 
+#ifndef BAND_MIN_WAVES
+#define BAND_MIN_WAVES 1
+#endif
+#ifndef BAND_EXCHANGE_LDS
+#define BAND_EXCHANGE_LDS 0     // 0: neighbour lanes through DPP wave shifts (measured faster), 1: through LDS
+#endif
+
 template <int P, bool DBG, bool FOV>
-__global__ __launch_bounds__(64) void band_kernel(const BandArgs a) {
-    constexpr int TC = P / 2;   // temporal channels
-    __shared__ __attribute__((aligned(16))) float s_vE[64 * P];
-    __shared__ __attribute__((aligned(16))) float s_vO[64 * P];
-    __shared__ __attribute__((aligned(16))) float s_eE[64 * P];
-    __shared__ __attribute__((aligned(16))) float s_eO[64 * P];
+__global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs a) {
+    constexpr int HP = P / 2;   // (test, ref) pairs = temporal channels
     __shared__ float4 s_csf[FVVDP_LUT_N];
+#if BAND_EXCHANGE_LDS
+    __shared__ __attribute__((aligned(16))) float s_x[4][64 * P];   // vE, vO, evE, evO of the 64 lanes
+#endif
 
     const int lane = threadIdx.x;
-    int bid = blockIdx.x;
+    // XCD-aware work order: hardware places workgroup b on XCD b % 8 (speed only, never correctness).  Give each
+    // XCD a contiguous range of work items (strip fastest, then chunk, then frame) so that neighbouring strips,
+    // which share their 4+4 halo columns, run on the same XCD at about the same time and hit in its L2.
+    int bid;
+    {
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
+        bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
+    }
     const int strip = bid % a.n_strips;
     bid /= a.n_strips;
     const int chunk = bid % a.n_chunks;
@@ -462,11 +605,16 @@ __global__ __launch_bounds__(64) void band_kernel(const BandArgs a) {
     const int xc0 = min(max(X0, 0), w - 1), xc1 = min(max(X1, 0), w - 1);
     const bool col1_ok = X1 < w;
 
-    if (!FOV && lane < FVVDP_LUT_N) s_csf[lane] = a.csf[lane];
+    if (!FOV) {
+        if (lane < FVVDP_LUT_N) s_csf[lane] = a.csf[lane];
+        __syncthreads();
+    }
 
     // horizontal 5-tap weights of this lane's coarse column incl. the reference's edge fix-ups
     // (gausspyr_reduce, fvvdp_lpyr_dec.py:198-205; the right-edge branch is selected by the parity of the ROW
-    // count, :202, reproduced here on purpose)
+    // count, :202, reproduced here on purpose).  Taps: E[l-1], O[l-1], E[l], O[l], E[l+1]  (E/O = even/odd fine
+    // column of a lane); taps falling outside the image get weight 0 and their fix-up is folded into the
+    // in-range taps.
     const float K0 = 0.05f, K1 = 0.25f, K2 = 0.4f, K3 = 0.25f, K4 = 0.05f;
     float wq0 = K0, wq1 = K1, wq2 = K2, wq3 = K3, wq4 = K4;
     if (J == 0) {
@@ -477,54 +625,81 @@ __global__ __launch_bounds__(64) void band_kernel(const BandArgs a) {
     }
     if (J == wc - 1) {
         const bool hodd = (h & 1) != 0;
-        if (w & 1) {   // own columns: X0 = w-1 (slot 2), X1 = w (outside)
+        if (w & 1) {   // own columns: X0 = w-1 (tap 2), X1 = w (outside)
             wq3 = 0.0f;
             wq4 = 0.0f;
             if (hodd) { wq2 += K3; wq1 += K4; } else { wq2 += K4; }
-        } else {       // own columns: w-2 (slot 2), w-1 (slot 3); slot 4 = w is outside
+        } else {       // own columns: w-2 (tap 2), w-1 (tap 3); tap 4 = column w is outside
             wq4 = 0.0f;
             if (hodd) { wq3 += K3; wq2 += K4; } else { wq3 += K4; }
         }
     }
-    const int lm = max(lane - 1, 0), lp = min(lane + 1, 63);
-    // expand neighbours: coarse columns clamp(J-1), clamp(J+1) (gausspyr_expand edge rule, fvvdp_lpyr_dec.py:126-142)
-    const int jl = min(max(J - 1, 0), wc - 1) - (Ja - 2);
-    const int jr = min(max(J + 1, 0), wc - 1) - (Ja - 2);
-    const int sl = min(max(jl, 0), 63), sr = min(max(jr, 0), 63);
+    // horizontal expand weights (2K = .1 .8 .1 / .5 .5, gausspyr_expand fvvdp_lpyr_dec.py:126-142,233); a
+    // neighbour outside the coarse row is the clamped (own) column, so its weight moves to the centre tap
+    const bool at_l = (J <= 0), at_r = (J >= wc - 1);
+    const float el = at_l ? 0.0f : 0.1f, er = at_r ? 0.0f : 0.1f;
+    const float ec = 0.8f + (at_l ? 0.1f : 0.0f) + (at_r ? 0.1f : 0.0f);
+    const float orr = at_r ? 0.0f : 0.5f;
+    const float oc = at_r ? 1.0f : 0.5f;
 
     const float* Gf = a.Gf + (size_t)frame * h * w * P;
     float* Gc = a.Gc + (size_t)frame * hc * wc * P;
 
-    auto load_row = [&](int r, Pix<P>& p0, Pix<P>& p1) {
+    auto load_row = [&](int r, Px<P>& p0, Px<P>& p1) {
         int rr = r < 0 ? -1 - r : (r >= h ? 2 * h - 1 - r : r);   // symmetric padding (fvvdp_lpyr_dec.py:190-195)
         rr = min(max(rr, 0), h - 1);
         const float* row = Gf + (size_t)rr * w * P;
-        p0 = ld_pix<P>(row + (size_t)xc0 * P);
-        p1 = ld_pix<P>(row + (size_t)xc1 * P);
+        p0 = ld_px<P>(row + (size_t)xc0 * P);
+        p1 = ld_px<P>(row + (size_t)xc1 * P);
     };
 
-    Pix<P> W[5][2];
+    Px<P> W[5][2];
 
-    // one coarse row from the current window: vertical 5-tap in registers, horizontal 5-tap through LDS
-    auto coarse_step = [&]() -> Pix<P> {
-        Pix<P> va, vb;
+    const int lm = max(lane - 1, 0), lp = min(lane + 1, 63);
+    (void)lm; (void)lp;
+    // one coarse row from the current window: vertical 5-tap in registers, horizontal 5-tap across lanes
+    auto coarse_step = [&]() -> Px<P> {
+        Px<P> c, va, vb;
 #pragma unroll
-        for (int k = 0; k < P; ++k) {
-            va.v[k] = K0 * W[0][0].v[k] + K1 * W[1][0].v[k] + K2 * W[2][0].v[k] + K3 * W[3][0].v[k] + K4 * W[4][0].v[k];
-            vb.v[k] = K0 * W[0][1].v[k] + K1 * W[1][1].v[k] + K2 * W[2][1].v[k] + K3 * W[3][1].v[k] + K4 * W[4][1].v[k];
+        for (int k = 0; k < HP; ++k) {
+            v2f a0 = W[0][0].h[k] * K0;
+            a0 = pfma(W[1][0].h[k], K1, a0);
+            a0 = pfma(W[2][0].h[k], K2, a0);
+            a0 = pfma(W[3][0].h[k], K3, a0);
+            va.h[k] = pfma(W[4][0].h[k], K4, a0);
+            v2f b0 = W[0][1].h[k] * K0;
+            b0 = pfma(W[1][1].h[k], K1, b0);
+            b0 = pfma(W[2][1].h[k], K2, b0);
+            b0 = pfma(W[3][1].h[k], K3, b0);
+            vb.h[k] = pfma(W[4][1].h[k], K4, b0);
         }
+#if BAND_EXCHANGE_LDS
+        __syncthreads();                       // single-wave workgroup: no s_barrier, only orders the LDS accesses
+        st_px(&s_x[0][lane * P], va);
+        st_px(&s_x[1][lane * P], vb);
         __syncthreads();
-        st_pix(s_vE + lane * P, va);
-        st_pix(s_vO + lane * P, vb);
-        __syncthreads();
-        const Pix<P> em = lds_ld<P>(s_vE, lm), om = lds_ld<P>(s_vO, lm), ep = lds_ld<P>(s_vE, lp);
-        Pix<P> c;
+        const Px<P> em = ld_px<P>(&s_x[0][lm * P]), om = ld_px<P>(&s_x[1][lm * P]), ep = ld_px<P>(&s_x[0][lp * P]);
 #pragma unroll
-        for (int k = 0; k < P; ++k)
-            c.v[k] = wq0 * em.v[k] + wq1 * om.v[k] + wq2 * va.v[k] + wq3 * vb.v[k] + wq4 * ep.v[k];
+        for (int k = 0; k < HP; ++k) {
+            v2f acc = em.h[k] * wq0;
+            acc = pfma(om.h[k], wq1, acc);
+            acc = pfma(va.h[k], wq2, acc);
+            acc = pfma(vb.h[k], wq3, acc);
+            c.h[k] = pfma(ep.h[k], wq4, acc);
+        }
+#else
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            v2f acc = va.h[k] * wq2;
+            acc = pfma(vb.h[k], wq3, acc);
+            acc = fma_left(va.h[k], wq0, acc);
+            acc = fma_left(vb.h[k], wq1, acc);
+            c.h[k] = fma_right(va.h[k], wq4, acc);
+        }
+#endif
         return c;
     };
-    auto shift_window = [&](const Pix<P> (&n0)[2], const Pix<P> (&n1)[2]) {
+    auto shift_window = [&](const Px<P> (&n0)[2], const Px<P> (&n1)[2]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             W[0][j] = W[2][j];
@@ -541,15 +716,15 @@ __global__ __launch_bounds__(64) void band_kernel(const BandArgs a) {
 #pragma unroll
         for (int k = 0; k < 5; ++k) load_row(r0 + k, W[k][0], W[k][1]);
     }
-    const Pix<P> cA = coarse_step();
-    Pix<P> nx0[2], nx1[2];
+    const Px<P> cA = coarse_step();
+    Px<P> nx0[2], nx1[2];
     load_row(2 * ca + 1, nx0[0], nx0[1]);
     load_row(2 * ca + 2, nx1[0], nx1[1]);
     shift_window(nx0, nx1);
-    const Pix<P> cB = coarse_step();
-    if (active) st_pix(Gc + ((size_t)ca * wc + J) * P, cB);
-    Pix<P> Gm1 = (ca > 0) ? cA : cB;
-    Pix<P> G0 = cB;
+    const Px<P> cB = coarse_step();
+    if (active) st_px(Gc + ((size_t)ca * wc + J) * P, cB);
+    Px<P> Gm1 = (ca > 0) ? cA : cB;
+    Px<P> G0 = cB;
     load_row(2 * ca + 3, nx0[0], nx0[1]);
     load_row(2 * ca + 4, nx1[0], nx1[1]);
 
@@ -570,29 +745,33 @@ __global__ __launch_bounds__(64) void band_kernel(const BandArgs a) {
         gy = atanf(gym / a.dist_m) * 57.29577951308232f;
     }
 
+    const float lg_bm = __log2f(a.band_mul);
+    const float lg_base = a.lg_gain;              // log2(S) = interp + log2(gain)      (fvvdp.py:447)
+    const float lg_mask = a.lg_gain + a.lg_k;      // log2(k*S)
+
     // per-pixel tail: contrast, CSF, masking, pooling  (fvvdp_lpyr_dec.py:259-269, fvvdp.py:395-467)
-    auto band_px = [&](const Pix<P>& g, const Pix<P>& e, bool valid, int y, int x, float vx) {
-        const float lb = fmaxf(e.v[1], a.lbkg_min);
-        const float inv = fast_rcp(lb);
-        float c[P];
+    auto band_px = [&](const Px<P>& g, const Px<P>& e, bool valid, int y, int x, float vx) {
+        const float lb = fmaxf(e.h[0].y, a.lbkg_min);                  // plane 1 = reference (sustained)
+        // contrast = min((g-e)/lb, cmax) * m.  Dividing by lb>0 commutes with |.|, min and the clamp, so the
+        // division is carried as -log2(lb) in the log domain below: no reciprocal, no per-plane multiply.
+        const float dcap = a.cmax * lb;                                // (g-e)/lb <= cmax  <=>  g-e <= cmax*lb
+        v2f d[HP];
 #pragma unroll
-        for (int k = 0; k < P; ++k) c[k] = fminf((g.v[k] - e.v[k]) * inv, a.cmax) * a.band_mul;
-        const float yq = fast_log2(fminf(fmaxf(lb, a.y_lo), a.y_hi));
+        for (int k = 0; k < HP; ++k) {
+            const v2f t = g.h[k] - e.h[k];
+            d[k] = v2f{fminf(t.x, dcap), fminf(t.y, dcap)};            // upper clamp only (fvvdp_lpyr_dec.py:266)
+        }
+        const float llb = fast_log2(lb);
+        const float yq = fminf(fmaxf(llb, a.ly_lo), a.ly_hi);          // = log2(clamp(lb, Y[0], Y[-1]))  (fvvdp.py:530)
         float slog[2] = {0.0f, 0.0f};
         if constexpr (!FOV) {
-            int i = (int)floorf((yq - a.y_first) * a.y_inv_step);
-            i = min(max(i, 0), FVVDP_LUT_N - 2);
-            const float4 r0 = s_csf[i];
-            const float4 r1 = s_csf[i + 1];
-            // the uniform-grid guess can be off by one knot at a knot boundary: step to the bracketing interval
-            const bool up = yq > r1.x && i < FVVDP_LUT_N - 2;
-            const bool dn = yq < r0.x && i > 0;
-            float4 ra = r0, rb = r1;
-            if (up) { ra = r1; rb = s_csf[i + 2]; }
-            if (dn) { rb = r0; ra = s_csf[i - 1]; }
-            const float f = fmaxf((yq - ra.x) * ra.y, 0.0f);
-            slog[0] = ra.z * (1.0f - f) + rb.z * f;
-            slog[1] = ra.w * (1.0f - f) + rb.w * f;
+            // 1-D table over log2(L_bkg) (uniform knots): interval from the grid, value = v[i] + f*(v[i+1]-v[i])
+            const float t = (yq - a.y_first) * a.y_inv_step;
+            const float fi = fminf(fmaxf(floorf(t), 0.0f), (float)(FVVDP_LUT_N - 2));
+            const float4 r = s_csf[(int)fi];                           // {v0[i], v1[i], v0[i+1]-v0[i], v1[i+1]-v1[i]}
+            const float f = t - fi;
+            slog[0] = fmaf(f, r.z, r.x);
+            slog[1] = fmaf(f, r.w, r.y);
         } else {
             // eccentricity and resolution magnification (fvvdp.py:424-437, fvvdp_display_model.py:475-526)
             const float yp = ((float)y + 0.5f) + (-(float)h / 2.0f);
@@ -609,24 +788,24 @@ __global__ __launch_bounds__(64) void band_kernel(const BandArgs a) {
             int i0, i1, j0, j1, k0, k1;
             float fi, fj, fk;
             interp_axis(a.ax_rho, rq, i0, i1, fi);
-            {   // Y axis knots live in the first 32 records' .x of a.csf
+            {   // Y axis knots: .x of the a.csf_y records
                 int lo = 0, hi = FVVDP_LUT_N;
 #pragma unroll
                 for (int it = 0; it < 6; ++it) {
                     const int mid = (lo + hi) >> 1;
-                    const bool go = (lo < hi) && (a.csf[min(mid, FVVDP_LUT_N - 1)].x < yq);
+                    const bool go = (lo < hi) && (a.csf_y[min(mid, FVVDP_LUT_N - 1)].x < yq);
                     const bool stay = (lo < hi) && !go;
                     lo = go ? mid + 1 : lo;
                     hi = stay ? mid : hi;
                 }
                 j1 = min(lo, FVVDP_LUT_N - 1);
                 j0 = max(j1 - 1, 0);
-                const float den = a.csf[j1].x - a.csf[j0].x + 0.000001f;
-                fj = (j1 == j0) ? 0.0f : fmaxf((yq - a.csf[j0].x) / den, 0.0f);
+                const float den = a.csf_y[j1].x - a.csf_y[j0].x + 0.000001f;
+                fj = (j1 == j0) ? 0.0f : fmaxf((yq - a.csf_y[j0].x) / den, 0.0f);
             }
             interp_axis(a.ax_ecc, eq, k0, k1, fk);
 #pragma unroll
-            for (int cc = 0; cc < TC; ++cc) {
+            for (int cc = 0; cc < HP; ++cc) {
                 const float* v = a.lut3[cc];
                 auto at = [&](int j, int i, int k) { return v[(j * FVVDP_LUT_N + i) * FVVDP_LUT_N + k]; };
                 // interp3 (interp.py:53-57), same association
@@ -637,17 +816,19 @@ __global__ __launch_bounds__(64) void band_kernel(const BandArgs a) {
                 slog[cc] = lo_k * (1.0f - fk) + hi_k * fk;
             }
         }
+        const float vm = valid ? 1.0f : 0.0f;
+        const float lcn = lg_bm - llb;                                   // log2(m / lb)
 #pragma unroll
-        for (int cc = 0; cc < TC; ++cc) {
-            const float T = c[2 * cc], R = c[2 * cc + 1];
-            const float ls = slog[cc] + a.lg_gain;                      // log2(S), S = 2^interp * gain (fvvdp.py:447)
+        for (int cc = 0; cc < HP; ++cc) {
+            const float dT = d[cc].x, dR = d[cc].y;
             const float q = cc == 0 ? a.q0 : a.q1;
+            const float ls = slog[cc] + lcn;                             // log2(S/gain * m / lb)
             // D = |T'-R'|^p / (1 + (k*min(|T'|,|R'|))^q), T' = T*S   (fvvdp.py:585-595), in the log2 domain
-            const float ld = a.p * (fast_log2(fabsf(T - R)) + ls);
-            const float mq = fast_exp2(q * (fast_log2(fminf(fabsf(T), fabsf(R))) + ls + a.lg_k));
+            const float ld = a.p * (fast_log2(fabsf(dT - dR)) + (ls + lg_base));
+            const float mq = fast_exp2(q * (fast_log2(fminf(fabsf(dT), fabsf(dR))) + (ls + lg_mask)));
             const float ldd = fminf(ld - fast_log2(1.0f + mq), a.lg_dmax);
             const float term = fast_exp2(a.beta * ldd);                  // D^beta for the spatial pooling (fvvdp.py:467,607)
-            acc[cc] += valid ? term : 0.0f;
+            acc[cc] = fmaf(term, vm, acc[cc]);
             if constexpr (DBG) {
                 if (valid) {
                     const size_t o = (((size_t)frame * 2 + cc) * h + y) * w + x;
@@ -659,8 +840,12 @@ __global__ __launch_bounds__(64) void band_kernel(const BandArgs a) {
         if constexpr (DBG) {
             if (valid) {
                 if (a.dC) {
+                    const float sc = a.band_mul / lb;
 #pragma unroll
-                    for (int k = 0; k < P; ++k) a.dC[(((size_t)frame * P + k) * h + y) * w + x] = c[k];
+                    for (int k = 0; k < HP; ++k) {
+                        a.dC[(((size_t)frame * P + 2 * k) * h + y) * w + x] = d[k].x * sc;
+                        a.dC[(((size_t)frame * P + 2 * k + 1) * h + y) * w + x] = d[k].y * sc;
+                    }
                 }
                 if (a.dL) a.dL[((size_t)frame * h + y) * w + x] = lb;
             }
@@ -668,42 +853,68 @@ __global__ __launch_bounds__(64) void band_kernel(const BandArgs a) {
     };
 
     // ---- main loop: band rows 2c, 2c+1 for c in [ca, cb) ------------------------------------------------
-    const float E0 = 0.1f, E1 = 0.8f, E2 = 0.1f, O0 = 0.5f, O1 = 0.5f;   // 2*K (gausspyr_expand, :228,:233)
     for (int c = ca; c < cb; ++c) {
         shift_window(nx0, nx1);               // window = fine rows 2c .. 2c+4
         if (c + 1 < cb) {                     // prefetch the two rows of the next step
             load_row(2 * c + 5, nx0[0], nx0[1]);
             load_row(2 * c + 6, nx1[0], nx1[1]);
         }
-        const Pix<P> cN = coarse_step();      // coarse row c+1
+        const Px<P> cN = coarse_step();       // coarse row c+1
         const bool has_next = (c + 1) <= (hc - 1);
-        Pix<P> Gp1 = has_next ? cN : G0;      // index clamp of the expand (fvvdp_lpyr_dec.py:134,138)
-        if (has_next && (c + 1) < cb && active) st_pix(Gc + ((size_t)(c + 1) * wc + J) * P, cN);
-        // vertical expand on the coarse column (even fine row 2c, odd fine row 2c+1)
-        Pix<P> evE, evO;
+        Px<P> Gp1 = has_next ? cN : G0;       // index clamp of the expand (fvvdp_lpyr_dec.py:134,138)
+        if (has_next && (c + 1) < cb && active) st_px(Gc + ((size_t)(c + 1) * wc + J) * P, cN);
+        Px<P> x00, x01, x10, x11;             // expanded level at (row 2c|2c+1, col X0|X1)
+        Px<P> evE, evO;
 #pragma unroll
-        for (int k = 0; k < P; ++k) {
-            evE.v[k] = (E0 * Gm1.v[k] + E1 * G0.v[k]) + E2 * Gp1.v[k];
-            evO.v[k] = O0 * G0.v[k] + O1 * Gp1.v[k];
+        for (int k = 0; k < HP; ++k) {
+            // vertical expand on the coarse column: even fine row 2c (.1 .8 .1), odd fine row 2c+1 (.5 .5)
+            v2f t = Gm1.h[k] * 0.1f;
+            t = pfma(G0.h[k], 0.8f, t);
+            evE.h[k] = pfma(Gp1.h[k], 0.1f, t);
+            evO.h[k] = pfma(Gp1.h[k], 0.5f, G0.h[k] * 0.5f);
         }
-        st_pix(s_eE + lane * P, evE);
-        st_pix(s_eO + lane * P, evO);
+#if BAND_EXCHANGE_LDS
+        st_px(&s_x[2][lane * P], evE);
+        st_px(&s_x[3][lane * P], evO);
         __syncthreads();
-        const Pix<P> eEl = lds_ld<P>(s_eE, sl), eEr = lds_ld<P>(s_eE, sr);
-        const Pix<P> eOl = lds_ld<P>(s_eO, sl), eOr = lds_ld<P>(s_eO, sr);
-        Pix<P> x00, x01, x10, x11;            // expanded level at (row 2c|2c+1, col X0|X1)
+        const Px<P> eEl = ld_px<P>(&s_x[2][lm * P]), eEr = ld_px<P>(&s_x[2][lp * P]);
+        const Px<P> eOl = ld_px<P>(&s_x[3][lm * P]), eOr = ld_px<P>(&s_x[3][lp * P]);
 #pragma unroll
-        for (int k = 0; k < P; ++k) {
-            x00.v[k] = (E0 * eEl.v[k] + E1 * evE.v[k]) + E2 * eEr.v[k];
-            x01.v[k] = O0 * evE.v[k] + O1 * eEr.v[k];
-            x10.v[k] = (E0 * eOl.v[k] + E1 * evO.v[k]) + E2 * eOr.v[k];
-            x11.v[k] = O0 * evO.v[k] + O1 * eOr.v[k];
+        for (int k = 0; k < HP; ++k) {
+            // horizontal expand: even fine column takes J-1, J, J+1; odd fine column J, J+1
+            v2f t = eEl.h[k] * el;
+            t = pfma(evE.h[k], ec, t);
+            x00.h[k] = pfma(eEr.h[k], er, t);
+            x01.h[k] = pfma(eEr.h[k], orr, evE.h[k] * oc);
+            t = eOl.h[k] * el;
+            t = pfma(evO.h[k], ec, t);
+            x10.h[k] = pfma(eOr.h[k], er, t);
+            x11.h[k] = pfma(eOr.h[k], orr, evO.h[k] * oc);
         }
+#else
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            v2f t = evE.h[k] * ec;
+            t = fma_left(evE.h[k], el, t);
+            x00.h[k] = fma_right(evE.h[k], er, t);
+            x01.h[k] = fma_right(evE.h[k], orr, evE.h[k] * oc);
+            t = evO.h[k] * ec;
+            t = fma_left(evO.h[k], el, t);
+            x10.h[k] = fma_right(evO.h[k], er, t);
+            x11.h[k] = fma_right(evO.h[k], orr, evO.h[k] * oc);
+        }
+#endif
         const bool row1_ok = (2 * c + 1) < h;
+#if defined(BAND_ABLATE) && BAND_ABLATE >= 1      // profiling ablation: no per-pixel tail, keep the data flow alive
+        acc[0] += x00.h[0].x + x01.h[0].x + x10.h[0].x + x11.h[0].x + W[0][0].h[0].x + W[0][1].h[0].x + W[1][0].h[0].x + W[1][1].h[0].x;
+        if (false)
+#endif
+        {
         band_px(W[0][0], x00, active, 2 * c, X0, vxa);
         band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vxb);
         band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vxa);
         band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vxb);
+        }
         Gm1 = G0;
         G0 = Gp1;
     }
@@ -758,7 +969,8 @@ struct fvvdp_ctx {
     long long partial_off[FVVDP_MAX_BANDS]{};
     int max_blk[FVVDP_MAX_BANDS]{};
     size_t partial_floats = 0;
-    float4* csf = nullptr;        // [n_bands][32]
+    float4* csf = nullptr;        // [n_bands][32] slope-form records of the 1-D tables
+    float4* csf_y = nullptr;      // [32] {Y_log[i],0,0,0}
     bool csf_set = false;
     float y_first = 0, y_inv_step = 0, y_lo = 0, y_hi = 0;
     float* lut3[2] = {nullptr, nullptr};
@@ -770,6 +982,7 @@ struct fvvdp_ctx {
     float* d_taps = nullptr;      // [2][FVVDP_MAX_TAPS]
     int* d_idx = nullptr;         // [max_frames + FVVDP_MAX_TAPS]
     size_t scratch = 0;
+    long long wave_capacity = 4096;   // resident single-wave workgroups of the band kernel on the whole chip
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[FVVDP_MAX_BANDS + 2];
@@ -807,15 +1020,25 @@ struct Timed {
     }
 };
 
-static void chunking(int hc, int n_strips, int n, int& n_chunks, int& cr) {
-    // enough single-wave workgroups to fill 256 CUs several times over, but chunks of at least 8 coarse rows so
-    // the 7-row vertical halo stays a small fraction of the traffic
-    const long long target = 12288;
-    long long want = (target + (long long)n * n_strips - 1) / ((long long)n * n_strips);
-    if (want < 1) want = 1;
-    cr = (int)((hc + want - 1) / want);
-    if (cr < 8) cr = 8;
-    if (cr > hc) cr = hc;
+static void chunking(int hc, int n_strips, int n, long long capacity, int& n_chunks, int& cr) {
+    // Every single-wave workgroup does the same amount of work (cr steps + ~2.5 steps of prologue for the two
+    // halo coarse rows), so the launch proceeds in "rounds" of `capacity` resident waves.  Pick the chunk height
+    // that minimises rounds x per-wave cost; chunks of at least 8 coarse rows keep the 7-row halo re-read small.
+    double best = 1e300;
+    cr = hc;
+    for (int cand = 8; cand <= hc || cand == 8; ++cand) {
+        const int c = cand > hc ? hc : cand;
+        const long long chunks = (hc + c - 1) / c;
+        const long long waves = (long long)n * n_strips * chunks;
+        const long long rounds = (waves + capacity - 1) / capacity;
+        const double cost = (double)rounds * ((double)c + 2.5) * (1.0 + 1e-4 * (double)chunks);
+        if (cost < best) { best = cost; cr = c; }
+        if (cand >= hc) break;
+    }
+    if (const char* ov = getenv("FVVDP_BAND_CR")) {       // tuning override
+        const int v = atoi(ov);
+        if (v >= 1) cr = v > hc ? hc : v;
+    }
     n_chunks = (hc + cr - 1) / cr;
 }
 
@@ -859,12 +1082,25 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
     c->partial_floats = off;
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->partial, off);
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->csf, (size_t)n_bands * FVVDP_LUT_N);
+    if (rc == FVVDP_OK) rc = dev_alloc(c, &c->csf_y, (size_t)FVVDP_LUT_N);
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_fix, (size_t)max_frames * 2);
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_taps, (size_t)2 * FVVDP_MAX_TAPS);
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_idx, (size_t)max_frames + FVVDP_MAX_TAPS);
     if (rc != FVVDP_OK) {
         fvvdp_ctx_destroy(c);
         return rc;
+    }
+    {
+        int dev = 0, cus = 256, per_cu = 16;
+        if (hipGetDevice(&dev) == hipSuccess) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        }
+        hipError_t e = (planes == 4)
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, band_kernel<4, false, false>, 64, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, band_kernel<2, false, false>, 64, 0);
+        if (e != hipSuccess || per_cu < 1) per_cu = 16;
+        c->wave_capacity = (long long)per_cu * cus;
     }
     *out = c;
     return FVVDP_OK;
@@ -876,6 +1112,7 @@ extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
         if (c->level[i]) (void)hipFree(c->level[i]);
     if (c->partial) (void)hipFree(c->partial);
     if (c->csf) (void)hipFree(c->csf);
+    if (c->csf_y) (void)hipFree(c->csf_y);
     if (c->d_fix) (void)hipFree(c->d_fix);
     if (c->d_taps) (void)hipFree(c->d_taps);
     if (c->d_idx) (void)hipFree(c->d_idx);
@@ -902,14 +1139,15 @@ extern "C" size_t fvvdp_ctx_scratch_bytes(const fvvdp_ctx* c) { return c ? c->sc
 
 extern "C" int fvvdp_ctx_set_csf_1d(fvvdp_ctx* c, const float* h_Y_log, const float* h_S_log) {
     if (!c || !h_Y_log || !h_S_log) return fail(FVVDP_EINVAL, "null argument");
+    // Record i of a band holds the table value at knot i and the step to knot i+1 for both temporal channels:
+    // the kernel evaluates v[i] + f*(v[i+1]-v[i]) with f from the (uniform) knot grid.
     std::vector<float4> rec((size_t)c->n_bands * FVVDP_LUT_N);
     for (int b = 0; b < c->n_bands; ++b)
         for (int i = 0; i < FVVDP_LUT_N; ++i) {
-            float inv = 0.0f;
-            if (i + 1 < FVVDP_LUT_N) inv = 1.0f / (h_Y_log[i + 1] - h_Y_log[i] + 0.000001f);   // interp.py:16
-            rec[(size_t)b * FVVDP_LUT_N + i] =
-                make_float4(h_Y_log[i], inv, h_S_log[((size_t)b * 2 + 0) * FVVDP_LUT_N + i],
-                            h_S_log[((size_t)b * 2 + 1) * FVVDP_LUT_N + i]);
+            const float* v0 = h_S_log + ((size_t)b * 2 + 0) * FVVDP_LUT_N;
+            const float* v1 = h_S_log + ((size_t)b * 2 + 1) * FVVDP_LUT_N;
+            const int j = i + 1 < FVVDP_LUT_N ? i + 1 : i;
+            rec[(size_t)b * FVVDP_LUT_N + i] = make_float4(v0[i], v1[i], v0[j] - v0[i], v1[j] - v1[i]);
         }
     HIP_TRY(hipMemcpy(c->csf, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
     c->y_first = h_Y_log[0];
@@ -933,12 +1171,10 @@ extern "C" int fvvdp_ctx_set_csf_3d(fvvdp_ctx* c, int tc, const float* h_S_log, 
     HIP_TRY(hipMemcpy(c->lut3[tc], h_S_log, n3 * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->ax_rho, h_rho_log, FVVDP_LUT_N * sizeof(float), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(c->ax_ecc, h_ecc_sqrt, FVVDP_LUT_N * sizeof(float), hipMemcpyHostToDevice));
-    // the Y axis records double as the knot table of the foveated kernel
-    if (!c->csf_set) {
-        std::vector<float4> rec((size_t)c->n_bands * FVVDP_LUT_N);
-        for (int b = 0; b < c->n_bands; ++b)
-            for (int i = 0; i < FVVDP_LUT_N; ++i) rec[(size_t)b * FVVDP_LUT_N + i] = make_float4(h_Y_log[i], 0.f, 0.f, 0.f);
-        HIP_TRY(hipMemcpy(c->csf, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
+    {
+        std::vector<float4> rec(FVVDP_LUT_N);
+        for (int i = 0; i < FVVDP_LUT_N; ++i) rec[i] = make_float4(h_Y_log[i], 0.f, 0.f, 0.f);
+        HIP_TRY(hipMemcpy(c->csf_y, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
         c->y_lo = exp2f(h_Y_log[0]);
         c->y_hi = exp2f(h_Y_log[FVVDP_LUT_N - 1]);
     }
@@ -968,8 +1204,7 @@ static EotfDev make_eotf(const fvvdp_eotf* e) {
 
 template <int FL, int PX>
 static void launch_ring(int dtype, const TemporalArgs& a, hipStream_t st) {
-    const int threads = (a.HW / PX + 255) / 256;
-    dim3 grid(threads), block(256);
+    dim3 grid((a.HW + 256 * PX - 1) / (256 * PX)), block(256);
     if (dtype == FVVDP_U8)
         hipLaunchKernelGGL((temporal_ring_kernel<FL, PX, SRC_U8>), grid, block, 0, st, a);
     else if (dtype == FVVDP_U16)
@@ -1005,7 +1240,7 @@ extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const v
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int HW = c->W * c->H;
     Timed tm(c, 0, st);
-    const bool ring_ok = (c->P == 4) && (fl <= 32) && (HW % 4 == 0) && (chan_stride % 4 == 0) && (frame_stride % 4 == 0);
+    const bool ring_ok = (c->P == 4) && (fl <= 32);
     if (ring_ok) {
         const int FL = fl <= 8 ? 8 : (fl <= 16 ? 16 : 32);
         const int max_out = T_MAX_IDX - (FL - 1);
@@ -1131,13 +1366,16 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
         a.wc = c->lw[b + 1];
         a.hc = c->lh[b + 1];
         a.n_strips = (a.wc + STRIP_J - 1) / STRIP_J;
-        chunking(a.hc, a.n_strips, n, a.n_chunks, a.cr);
+        chunking(a.hc, a.n_strips, n, c->wave_capacity, a.n_chunks, a.cr);
         a.band_mul = (b == 0) ? 1.0f : 2.0f;                 // lpyr.get_band, fvvdp_lpyr_dec.py:57-63
         a.csf = c->csf + (size_t)b * FVVDP_LUT_N;
+        a.csf_y = c->csf_y;
         a.y_first = c->y_first;
         a.y_inv_step = c->y_inv_step;
         a.y_lo = c->y_lo;
         a.y_hi = c->y_hi;
+        a.ly_lo = log2f(c->y_lo);
+        a.ly_hi = log2f(c->y_hi);
         a.lg_gain = log2f(c->prm.sens_gain);
         a.lg_k = log2f(c->prm.mask_k);
         a.p = c->prm.mask_p;
