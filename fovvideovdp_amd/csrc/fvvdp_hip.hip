@@ -278,8 +278,8 @@ __device__ __forceinline__ RawFrame<SRC, PX> fetch_frame(const void* base, size_
     return f;
 }
 
-template <int SRC, int PX>
-__device__ __forceinline__ void frame_lum(const RawFrame<SRC, PX>& f, int C, const float* lutw, const float* lut16,
+template <int SRC, int PX, typename FRAME>
+__device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lutw, const float* lut16,
                                           const float (&w)[3], const EotfDev& e, float (&L)[PX], bool& bad) {
     float v[3][PX];
 #pragma unroll
@@ -301,6 +301,9 @@ __device__ __forceinline__ void frame_lum(const RawFrame<SRC, PX>& f, int C, con
 // every output pixel is written once as one float4 (test-sust, ref-sust, test-trans, ref-trans).  The raw samples
 // of the next frame are fetched while the current one is filtered (software prefetch, one frame ahead).
 // Reference: fvvdp.py:294-300 (R[:,2cc+s] = sum_k window[s][k] * F[cc].flip(0)[k]).
+#ifndef TDIST
+#define TDIST 1          // frames of raw samples in flight per thread; 2 and 4 measured slower (VGPRs -> occupancy)
+#endif
 template <int FL, int PX, int SRC>
 __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a) {
     __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
@@ -326,25 +329,26 @@ __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a
     // virtual time v = 0 .. FL-2 is the history, v = FL-1+t the newest frame of output t; ring slot = v % FL.
     // The same pipelined loop fills the history and produces the outputs, so at most one frame is in flight.
     const int total = FL - 1 + a.n_out;
-    RawFrame<SRC, PX> nx[2];
-    {
-        const size_t off = (size_t)a.idx[0] * a.frame_stride;
-        nx[0] = fetch_frame<SRC, PX>(a.src[0], off, a.chan_stride, a.C, px);
-        nx[1] = fetch_frame<SRC, PX>(a.src[1], off, a.chan_stride, a.C, px);
+    RawFrame<SRC, PX> nx[TDIST][2];           // raw samples of the next TDIST frames, in flight
+#pragma unroll
+    for (int d = 0; d < TDIST; ++d) {
+        const size_t off = (size_t)a.idx[d < total ? d : total - 1] * a.frame_stride;
+        nx[d][0] = fetch_frame<SRC, PX>(a.src[0], off, a.chan_stride, a.C, px);
+        nx[d][1] = fetch_frame<SRC, PX>(a.src[1], off, a.chan_stride, a.C, px);
     }
     for (int v0 = 0; v0 < total; v0 += FL) {
 #pragma unroll
         for (int u = 0; u < FL; ++u) {
             const int v = v0 + u;
             if (v < total) {
-                const RawFrame<SRC, PX> cur0 = nx[0], cur1 = nx[1];
-                if (v + 1 < total) {
-                    const size_t off = (size_t)a.idx[v + 1] * a.frame_stride;
-                    nx[0] = fetch_frame<SRC, PX>(a.src[0], off, a.chan_stride, a.C, px);
-                    nx[1] = fetch_frame<SRC, PX>(a.src[1], off, a.chan_stride, a.C, px);
+                const RawFrame<SRC, PX> cur0 = nx[u % TDIST][0], cur1 = nx[u % TDIST][1];
+                if (v + TDIST < total) {
+                    const size_t off = (size_t)a.idx[v + TDIST] * a.frame_stride;
+                    nx[u % TDIST][0] = fetch_frame<SRC, PX>(a.src[0], off, a.chan_stride, a.C, px);
+                    nx[u % TDIST][1] = fetch_frame<SRC, PX>(a.src[1], off, a.chan_stride, a.C, px);
                 }
-                frame_lum<SRC, PX>(cur0, a.C, lutw, a.e.lut, w, a.e, ring[0][u], bad);
-                frame_lum<SRC, PX>(cur1, a.C, lutw, a.e.lut, w, a.e, ring[1][u], bad);
+                frame_lum<SRC, PX, RawFrame<SRC, PX>>(cur0, a.C, lutw, a.e.lut, w, a.e, ring[0][u], bad);
+                frame_lum<SRC, PX, RawFrame<SRC, PX>>(cur1, a.C, lutw, a.e.lut, w, a.e, ring[1][u], bad);
                 if (v >= FL - 1) {
                     float acc[4][PX];
 #pragma unroll
@@ -367,6 +371,134 @@ __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a
                     for (int i = 0; i < PX; ++i)
                         if (ok[i])
                             *reinterpret_cast<float4*>(o + (size_t)px[i] * 4) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+                }
+            }
+        }
+    }
+    if (bad && a.oob) atomicOr(a.oob, 1);
+}
+
+// ---- vector variant of the temporally tiled FIR (the fast path) -------------------------------------------------
+// Single-wave workgroups; a lane owns PX CONSECUTIVE pixels, so one load per channel fetches all of them
+// (4 uint8 = one dword, 4 uint16 = 8 B, 4 fp32 = 16 B: 4x fewer memory instructions than the per-pixel loads of
+// temporal_ring_kernel).  The finished float4 pixels are transposed through LDS (padded rows, conflict-free) so that
+// every store instruction of the wave still writes one contiguous 1 KiB run.  Needs HW % PX == 0 and PX-sample
+// aligned strides; other sizes take temporal_ring_kernel.
+template <int SRC, int PX>
+struct RawVec {
+    static constexpr int ES = (SRC == SRC_U8 ? 1 : (SRC == SRC_U16 ? 2 : 4));
+    static constexpr int WORDS = (ES * PX + 3) / 4;
+    unsigned int wd[WORDS];
+    __device__ __forceinline__ unsigned int code(int i) const {
+        if constexpr (SRC == SRC_U8) return (wd[i / 4] >> (8 * (i % 4))) & 0xFFu;
+        else return (wd[i / 2] >> (16 * (i % 2))) & 0xFFFFu;
+    }
+    __device__ __forceinline__ float value(int i) const { return __uint_as_float(wd[i]); }
+};
+template <int SRC, int PX>
+struct RawVecFrame {
+    RawVec<SRC, PX> ch[3];
+};
+
+template <int SRC, int PX>
+__device__ __forceinline__ RawVec<SRC, PX> load_vec(const void* base, size_t off) {
+    RawVec<SRC, PX> r;
+    constexpr int ES = RawVec<SRC, PX>::ES;
+    constexpr int BYTES = ES * PX;
+    const char* q = reinterpret_cast<const char*>(base) + off * ES;
+    if constexpr (BYTES == 16) {
+        const uint4 t = *reinterpret_cast<const uint4*>(q);
+        r.wd[0] = t.x; r.wd[1] = t.y; r.wd[2] = t.z; r.wd[3] = t.w;
+    } else if constexpr (BYTES == 8) {
+        const uint2 t = *reinterpret_cast<const uint2*>(q);
+        r.wd[0] = t.x; r.wd[1] = t.y;
+    } else if constexpr (BYTES == 4) {
+        r.wd[0] = *reinterpret_cast<const unsigned int*>(q);
+    } else {
+        r.wd[0] = *reinterpret_cast<const unsigned short*>(q);
+    }
+    return r;
+}
+
+template <int SRC, int PX>
+__device__ __forceinline__ RawVecFrame<SRC, PX> fetch_vec(const void* base, size_t off, size_t chan_stride, int C) {
+    RawVecFrame<SRC, PX> f;
+    f.ch[0] = load_vec<SRC, PX>(base, off);
+    if (C == 3) {
+        f.ch[1] = load_vec<SRC, PX>(base, off + chan_stride);
+        f.ch[2] = load_vec<SRC, PX>(base, off + 2 * chan_stride);
+    } else {
+        f.ch[1] = f.ch[0];
+        f.ch[2] = f.ch[0];
+    }
+    return f;
+}
+
+template <int FL, int PX, int SRC>
+__global__ __launch_bounds__(64) void temporal_vec_kernel(const TemporalArgs a) {
+    __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
+    __shared__ float4 s_t[64 * (PX + 1)];          // one padded row of PX float4 per lane
+    const int lane = threadIdx.x;
+    if constexpr (SRC == SRC_U8) build_lutw(lutw, a.e.lut, a.C, a.w, lane, 64);
+    __syncthreads();
+    const int p0 = blockIdx.x * (64 * PX);          // first pixel of this wave
+    const int pl = min(p0 + lane * PX, a.HW - PX);  // this lane's PX consecutive pixels (clamped: loads stay in range)
+    const float w[3] = {a.C == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};
+    bool bad = false;
+    float ring[2][FL][PX];
+#pragma unroll
+    for (int u = 0; u < FL; ++u)
+#pragma unroll
+        for (int i = 0; i < PX; ++i) ring[0][u][i] = ring[1][u][i] = 0.0f;
+    const int total = FL - 1 + a.n_out;
+    RawVecFrame<SRC, PX> nx[2];
+    {
+        const size_t off = (size_t)a.idx[0] * a.frame_stride + pl;
+        nx[0] = fetch_vec<SRC, PX>(a.src[0], off, a.chan_stride, a.C);
+        nx[1] = fetch_vec<SRC, PX>(a.src[1], off, a.chan_stride, a.C);
+    }
+    for (int v0 = 0; v0 < total; v0 += FL) {
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+            const int v = v0 + u;
+            if (v < total) {
+                const RawVecFrame<SRC, PX> cur0 = nx[0], cur1 = nx[1];
+                if (v + 1 < total) {
+                    const size_t off = (size_t)a.idx[v + 1] * a.frame_stride + pl;
+                    nx[0] = fetch_vec<SRC, PX>(a.src[0], off, a.chan_stride, a.C);
+                    nx[1] = fetch_vec<SRC, PX>(a.src[1], off, a.chan_stride, a.C);
+                }
+                frame_lum<SRC, PX, RawVecFrame<SRC, PX>>(cur0, a.C, lutw, a.e.lut, w, a.e, ring[0][u], bad);
+                frame_lum<SRC, PX, RawVecFrame<SRC, PX>>(cur1, a.C, lutw, a.e.lut, w, a.e, ring[1][u], bad);
+                if (v >= FL - 1) {
+                    float acc[4][PX];
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
+#pragma unroll
+                    for (int k = FL - 1; k >= 0; --k) {      // oldest tap first, like the reference's sum over the window
+                        const int sl = (u - k + 2 * FL) % FL;
+                        const float f0 = a.taps[0][k], f1 = a.taps[1][k];
+#pragma unroll
+                        for (int i = 0; i < PX; ++i) {
+                            acc[0][i] = fmaf(ring[0][sl][i], f0, acc[0][i]);
+                            acc[1][i] = fmaf(ring[1][sl][i], f0, acc[1][i]);
+                            acc[2][i] = fmaf(ring[0][sl][i], f1, acc[2][i]);
+                            acc[3][i] = fmaf(ring[1][sl][i], f1, acc[3][i]);
+                        }
+                    }
+                    // transpose through LDS: lane l holds pixels l*PX..l*PX+PX-1, store i writes pixels i*64+l
+                    __syncthreads();                         // single wave: orders the LDS accesses only
+#pragma unroll
+                    for (int i = 0; i < PX; ++i)
+                        s_t[lane * (PX + 1) + i] = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+                    __syncthreads();
+                    float4* o = reinterpret_cast<float4*>(a.out) + (size_t)(v - (FL - 1)) * a.HW + p0;
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) {
+                        const int q = i * 64 + lane;
+                        const float4 val = s_t[(q / PX) * (PX + 1) + (q % PX)];
+                        if (p0 + q < a.HW) o[q] = val;
+                    }
                 }
             }
         }
@@ -459,7 +591,7 @@ __global__ void interleave_kernel(const float* __restrict__ in, float* __restric
 //   band, weight by the CSF, apply mutual masking and accumulate sum(D^beta)  (nothing else touches HBM).
 //
 //   One single-wave workgroup streams down a strip of 120 fine (60 coarse) columns: lane l owns coarse column
-//   J = Ja-2+l and the two fine columns 2J, 2J+1 (4 fine pixels per step).  Vertical 5-tap reduce and the vertical
+//   J = 60*strip+l and the two fine columns 2J, 2J+1 (4 fine pixels per step).  Vertical 5-tap reduce and the vertical
 //   half of the expand are thread-local on a register window of 5 fine rows; the horizontal halves take the
 //   neighbour lanes' values through DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1) -- no LDS, no
 //   barriers, so the waves of a CU run completely decoupled and hide each other's HBM latency.  Plane pairs
@@ -595,12 +727,13 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
     const int blk = chunk * a.n_strips + strip;
 
     const int w = a.w, h = a.h, wc = a.wc, hc = a.hc;
-    const int Ja = strip * STRIP_J;
-    const int Jb = min(Ja + STRIP_J, wc);
-    const int J = Ja - 2 + lane;
+    // lane l of strip s owns coarse column J = 60*s + l, i.e. fine columns 120*s + 2l (+1): the 128 fine pixels a
+    // wave reads per row start at byte 1920*s of the row -> aligned to the 128-byte lines.  Lanes 2..61 produce
+    // output; lanes 0,1 and 62,63 only feed their neighbours (in strip 0 the image border makes lanes 0,1 complete).
+    const int J = strip * STRIP_J + lane;
     const int ca = chunk * a.cr;
     const int cb = min(ca + a.cr, hc);
-    const bool active = (lane >= 2) && (lane < 62) && (J < Jb);
+    const bool active = (lane >= 2 || strip == 0) && (lane < 62) && (J < wc);
     const int X0 = 2 * J, X1 = 2 * J + 1;
     const int xc0 = min(max(X0, 0), w - 1), xc1 = min(max(X1, 0), w - 1);
     const bool col1_ok = X1 < w;
@@ -939,10 +1072,10 @@ struct FinalizeArgs {
     float npx[FVVDP_MAX_BANDS];
 };
 
-__global__ void finalize_kernel(const FinalizeArgs a) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    const int total = a.n_bands * 2 * a.n;
-    if (i >= total) return;
+__global__ __launch_bounds__(64) void finalize_kernel(const FinalizeArgs a) {
+    // one wave per (band, cc, slot); lane l adds partials l, l+64, ... in fp64, then a fixed shuffle tree
+    const int i = blockIdx.x;
+    const int lane = threadIdx.x;
     const int s = i % a.n;
     const int cc = (i / a.n) % 2;
     const int b = i / (2 * a.n);
@@ -950,10 +1083,12 @@ __global__ void finalize_kernel(const FinalizeArgs a) {
     if (cc < a.tc) {
         const float* p = a.partial + a.off[b] + (size_t)s * a.nblk[b] * 2 + cc;
         double sum = 0.0;
-        for (int k = 0; k < a.nblk[b]; ++k) sum += (double)p[2 * k];
+        for (int k = lane; k < a.nblk[b]; k += 64) sum += (double)p[2 * k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
         q = (float)pow(sum / (double)a.npx[b], (double)a.inv_beta);
     }
-    a.Q[((size_t)b * 2 + cc) * a.q_stride + a.q_col0 + s] = q;
+    if (lane == 0) a.Q[((size_t)b * 2 + cc) * a.q_stride + a.q_col0 + s] = q;
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -1020,10 +1155,13 @@ struct Timed {
     }
 };
 
+// strips cover coarse columns [0,62), [62,122), ... (see band_kernel)
+static int band_strips(int wc) { return wc <= 62 ? 1 : 1 + (wc - 62 + STRIP_J - 1) / STRIP_J; }
+
 static void chunking(int hc, int n_strips, int n, long long capacity, int& n_chunks, int& cr) {
-    // Every single-wave workgroup does the same amount of work (cr steps + ~2.5 steps of prologue for the two
-    // halo coarse rows), so the launch proceeds in "rounds" of `capacity` resident waves.  Pick the chunk height
-    // that minimises rounds x per-wave cost; chunks of at least 8 coarse rows keep the 7-row halo re-read small.
+    // Every single-wave workgroup does the same amount of work (cr steps + the prologue for the two halo coarse
+    // rows, whose 7 extra fine rows are re-read from HBM: weighted as 8 steps), so the launch proceeds in "rounds"
+    // of `capacity` resident waves.  Pick the chunk height that minimises rounds x per-wave cost.
     double best = 1e300;
     cr = hc;
     for (int cand = 8; cand <= hc || cand == 8; ++cand) {
@@ -1031,7 +1169,7 @@ static void chunking(int hc, int n_strips, int n, long long capacity, int& n_chu
         const long long chunks = (hc + c - 1) / c;
         const long long waves = (long long)n * n_strips * chunks;
         const long long rounds = (waves + capacity - 1) / capacity;
-        const double cost = (double)rounds * ((double)c + 2.5) * (1.0 + 1e-4 * (double)chunks);
+        const double cost = (double)rounds * ((double)c + 8.0) * (1.0 + 1e-4 * (double)chunks);
         if (cost < best) { best = cost; cr = c; }
         if (cand >= hc) break;
     }
@@ -1073,7 +1211,7 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
         rc = dev_alloc(c, &c->level[i], (size_t)max_frames * c->lw[i] * c->lh[i] * planes);
     size_t off = 0;
     for (int b = 0; b < n_bands; ++b) {
-        const int n_strips = (c->lw[b + 1] + STRIP_J - 1) / STRIP_J;
+        const int n_strips = band_strips(c->lw[b + 1]);
         const int max_chunks = (c->lh[b + 1] + 7) / 8;
         c->max_blk[b] = n_strips * max_chunks;
         c->partial_off[b] = (long long)off;
@@ -1213,6 +1351,17 @@ static void launch_ring(int dtype, const TemporalArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((temporal_ring_kernel<FL, PX, SRC_F32>), grid, block, 0, st, a);
 }
 
+template <int FL, int PX>
+static void launch_vec(int dtype, const TemporalArgs& a, hipStream_t st) {
+    dim3 grid((a.HW + 64 * PX - 1) / (64 * PX)), block(64);
+    if (dtype == FVVDP_U8)
+        hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_U8>), grid, block, 0, st, a);
+    else if (dtype == FVVDP_U16)
+        hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_U16>), grid, block, 0, st, a);
+    else
+        hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_F32>), grid, block, 0, st, a);
+}
+
 template <int P>
 static void launch_generic(int dtype, const GenericArgs& a, hipStream_t st) {
     dim3 grid((a.HW + 255) / 256, a.n_out), block(256);
@@ -1267,9 +1416,22 @@ extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const v
                 const int src = t0 + u - pad;         // index into h_frame_idx
                 a.idx[u] = h_frame_idx[src < 0 ? 0 : src];
             }
-            if (FL == 8) launch_ring<8, 4>(dtype, a, st);
-            else if (FL == 16) launch_ring<16, 4>(dtype, a, st);
-            else launch_ring<32, 2>(dtype, a, st);
+            // vector path needs the lane's PX consecutive samples to be naturally aligned
+            const int PXv = FL == 32 ? 2 : 4;
+            const int es = dtype == FVVDP_U8 ? 1 : (dtype == FVVDP_U16 ? 2 : 4);
+            const bool vec_ok = !getenv("FVVDP_TEMPORAL_SCALAR") && (HW % PXv == 0) && (HW >= PXv) &&
+                                (chan_stride % PXv == 0) && (frame_stride % PXv == 0) &&
+                                (reinterpret_cast<uintptr_t>(d_test) % (size_t)(es * PXv) == 0) &&
+                                (reinterpret_cast<uintptr_t>(d_ref) % (size_t)(es * PXv) == 0);
+            if (vec_ok) {
+                if (FL == 8) launch_vec<8, 4>(dtype, a, st);
+                else if (FL == 16) launch_vec<16, 4>(dtype, a, st);
+                else launch_vec<32, 2>(dtype, a, st);
+            } else {
+                if (FL == 8) launch_ring<8, 4>(dtype, a, st);
+                else if (FL == 16) launch_ring<16, 4>(dtype, a, st);
+                else launch_ring<32, 2>(dtype, a, st);
+            }
         }
     } else {
         // rare path: tables go through device buffers, uploaded synchronously
@@ -1365,7 +1527,7 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
         a.h = c->lh[b];
         a.wc = c->lw[b + 1];
         a.hc = c->lh[b + 1];
-        a.n_strips = (a.wc + STRIP_J - 1) / STRIP_J;
+        a.n_strips = band_strips(a.wc);
         chunking(a.hc, a.n_strips, n, c->wave_capacity, a.n_chunks, a.cr);
         a.band_mul = (b == 0) ? 1.0f : 2.0f;                 // lpyr.get_band, fvvdp_lpyr_dec.py:57-63
         a.csf = c->csf + (size_t)b * FVVDP_LUT_N;
@@ -1437,7 +1599,7 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
     {
         Timed tm(c, 1 + c->n_bands, st);
         const int total = c->n_bands * 2 * n;
-        hipLaunchKernelGGL(finalize_kernel, dim3((total + 63) / 64), dim3(64), 0, st, fa);
+        hipLaunchKernelGGL(finalize_kernel, dim3(total), dim3(64), 0, st, fa);
     }
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;

@@ -1,0 +1,128 @@
+// HBM streaming micro-benchmarks used to find the practical ceilings quoted in DESIGN.md (not part of the product).
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void read_f4(const float4* __restrict__ p, size_t n4, float* out) {
+    size_t i = (size_t)blockIdx.x * 256 * UNROLL + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256 * UNROLL;
+    float acc = 0.f;
+    for (; i + 256 * (UNROLL - 1) < n4; i += stride) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = p[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc += v[u].x + v[u].y + v[u].z + v[u].w;
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+template <int UNROLL>
+__global__ __launch_bounds__(256) void copy_f4(const float4* __restrict__ p, float4* __restrict__ q, size_t n4) {
+    size_t i = (size_t)blockIdx.x * 256 * UNROLL + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * 256 * UNROLL;
+    for (; i + 256 * (UNROLL - 1) < n4; i += stride) {
+        float4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = p[i + u * 256];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) q[i + u * 256] = v[u];
+    }
+}
+
+// the band kernel's read pattern: single-wave workgroups, each walks down `rows` rows of a [H][W] float4 image,
+// reading 2 x float4 per lane per row (lane l: pixels 2l, 2l+1 of a 128-pixel strip), 2 rows per step, prefetch 1.
+template <int ACTIVE, int HALO_L>
+__global__ __launch_bounds__(64) void read_strips(const float4* __restrict__ img, int W, int H, int n_strips, int chunk_rows,
+                                                  int n_chunks, float4* __restrict__ coarse, float* out) {
+    int bid;
+    {
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
+        bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
+    }
+    const int strip = bid % n_strips;
+    const int chunk = (bid / n_strips) % n_chunks;
+    const int frame = bid / (n_strips * n_chunks);
+    const int lane = threadIdx.x;
+    const int x0 = min(max(strip * 2 * ACTIVE + 2 * (lane - HALO_L), 0), W - 2);
+    const float4* base = img + (size_t)frame * W * H;
+    const int r0 = chunk * chunk_rows, r1 = min(r0 + chunk_rows, H);
+    float acc = 0.f;
+    float4 a = base[(size_t)r0 * W + x0], b = base[(size_t)r0 * W + x0 + 1];
+    float4 c = base[(size_t)(r0 + 1) * W + x0], d = base[(size_t)(r0 + 1) * W + x0 + 1];
+    for (int r = r0; r < r1; r += 2) {
+        const float4 a0 = a, b0 = b, c0 = c, d0 = d;
+        const int rn = min(r + 2, H - 2);
+        a = base[(size_t)rn * W + x0]; b = base[(size_t)rn * W + x0 + 1];
+        c = base[(size_t)(rn + 1) * W + x0]; d = base[(size_t)(rn + 1) * W + x0 + 1];
+        acc += a0.x + b0.y + c0.z + d0.w;
+        if (coarse && lane >= HALO_L && lane < HALO_L + ACTIVE) {
+            const int Wc = W / 2;
+            const int J = strip * ACTIVE + lane - HALO_L;
+            if (J < Wc) coarse[((size_t)frame * (H / 2) + r / 2) * Wc + J] = make_float4(a0.x, b0.x, c0.x, d0.x);
+        }
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+
+template <typename F>
+static double timeit(F f, int reps = 5) {
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    f(); f();
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < reps; ++i) f();
+    CK(hipEventRecord(e1));
+    CK(hipEventSynchronize(e1));
+    float ms;
+    CK(hipEventElapsedTime(&ms, e0, e1));
+    return ms / reps * 1e-3;
+}
+
+int main() {
+    const int W = 3840, H = 2160, N = 60;
+    const size_t n4 = (size_t)W * H * N;            // 7.96 GB
+    float4 *p, *q; float* out;
+    CK(hipMalloc(&p, n4 * 16)); CK(hipMalloc(&q, n4 * 16)); CK(hipMalloc(&out, 64));
+    CK(hipMemset(p, 1, n4 * 16));
+    const double gb = n4 * 16 / 1e9;
+    for (int blocks : {2048, 4096, 8192, 32768, 131072}) {
+        double t = timeit([&] { hipLaunchKernelGGL(read_f4<4>, dim3(blocks), dim3(256), 0, 0, p, n4, out); });
+        printf("read_f4<4>  blocks %6d: %.2f TB/s\n", blocks, gb / t / 1e3);
+    }
+    for (int blocks : {4096, 32768}) {
+        double t = timeit([&] { hipLaunchKernelGGL(read_f4<8>, dim3(blocks), dim3(256), 0, 0, p, n4, out); });
+        printf("read_f4<8>  blocks %6d: %.2f TB/s\n", blocks, gb / t / 1e3);
+    }
+    for (int blocks : {4096, 32768, 131072}) {
+        double t = timeit([&] { hipLaunchKernelGGL(copy_f4<4>, dim3(blocks), dim3(256), 0, 0, p, q, n4); });
+        printf("copy_f4<4>  blocks %6d: %.2f TB/s (r+w)\n", blocks, 2 * gb / t / 1e3);
+    }
+    for (int chunk_rows : {128, 270}) {
+        const int n_chunks = (H + chunk_rows - 1) / chunk_rows;
+        {
+            const int n_strips = 32, grid = n_strips * n_chunks * N;
+            double t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, (float4*)nullptr, out); });
+            printf("strips 60 active, halo_l 0 (fine aligned), rows/chunk %4d: read only %.2f TB/s", chunk_rows, gb / t / 1e3);
+            t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+            printf("   + coarse write (960 B, offset 0): %.2f TB/s alg\n", 1.25 * gb / t / 1e3);
+            t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 2>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+            printf("   strips 60 active, halo_l 2 (fine misaligned 64B) + coarse write: %.2f TB/s alg\n", 1.25 * gb / t / 1e3);
+        }
+        {
+            const int n_strips = (1920 + 55) / 56, grid = n_strips * n_chunks * N;
+            double t = timeit([&] { hipLaunchKernelGGL((read_strips<56, 4>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+            printf("   strips 56 active, halo_l 4 (fine+coarse aligned, 7 full lines) + coarse write: %.2f TB/s alg\n", 1.25 * gb / t / 1e3);
+        }
+        {
+            const int n_strips = 30, grid = n_strips * n_chunks * N;
+            double t = timeit([&] { hipLaunchKernelGGL((read_strips<64, 0>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+            printf("   strips 64 active, no halo (1 KB aligned writes) + coarse write: %.2f TB/s alg\n", 1.25 * gb / t / 1e3);
+        }
+    }
+    return 0;
+}
