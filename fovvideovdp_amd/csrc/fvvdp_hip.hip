@@ -624,11 +624,14 @@ __device__ __forceinline__ Px<2> ld_px<2>(const float* p) {
     r.h[0] = v2f{t.x, t.y};
     return r;
 }
+// the coarse level is written once and only read by the next launch: non-temporal stores (measured +2-3 % on the
+// read+write mix of this kernel, tools/microbench/membw.hip)
+typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_px(float* p, const Px<4>& a) {
-    *reinterpret_cast<float4*>(p) = make_float4(a.h[0].x, a.h[0].y, a.h[1].x, a.h[1].y);
+    __builtin_nontemporal_store(v4f{a.h[0].x, a.h[0].y, a.h[1].x, a.h[1].y}, reinterpret_cast<v4f*>(p));
 }
 __device__ __forceinline__ void st_px(float* p, const Px<2>& a) {
-    *reinterpret_cast<float2*>(p) = make_float2(a.h[0].x, a.h[0].y);
+    __builtin_nontemporal_store(a.h[0], reinterpret_cast<v2f*>(p));
 }
 
 __device__ __forceinline__ v2f splat(float s) { return v2f{s, s}; }
@@ -699,17 +702,11 @@ __device__ __forceinline__ void interp_axis(const float* __restrict__ x, float q
 #ifndef BAND_MIN_WAVES
 #define BAND_MIN_WAVES 1
 #endif
-#ifndef BAND_EXCHANGE_LDS
-#define BAND_EXCHANGE_LDS 0     // 0: neighbour lanes through DPP wave shifts (measured faster), 1: through LDS
-#endif
 
 template <int P, bool DBG, bool FOV>
 __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs a) {
     constexpr int HP = P / 2;   // (test, ref) pairs = temporal channels
     __shared__ float4 s_csf[FVVDP_LUT_N];
-#if BAND_EXCHANGE_LDS
-    __shared__ __attribute__((aligned(16))) float s_x[4][64 * P];   // vE, vO, evE, evO of the 64 lanes
-#endif
 
     const int lane = threadIdx.x;
     // XCD-aware work order: hardware places workgroup b on XCD b % 8 (speed only, never correctness).  Give each
@@ -788,8 +785,6 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
 
     Px<P> W[5][2];
 
-    const int lm = max(lane - 1, 0), lp = min(lane + 1, 63);
-    (void)lm; (void)lp;
     // one coarse row from the current window: vertical 5-tap in registers, horizontal 5-tap across lanes
     auto coarse_step = [&]() -> Px<P> {
         Px<P> c, va, vb;
@@ -806,21 +801,6 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
             b0 = pfma(W[3][1].h[k], K3, b0);
             vb.h[k] = pfma(W[4][1].h[k], K4, b0);
         }
-#if BAND_EXCHANGE_LDS
-        __syncthreads();                       // single-wave workgroup: no s_barrier, only orders the LDS accesses
-        st_px(&s_x[0][lane * P], va);
-        st_px(&s_x[1][lane * P], vb);
-        __syncthreads();
-        const Px<P> em = ld_px<P>(&s_x[0][lm * P]), om = ld_px<P>(&s_x[1][lm * P]), ep = ld_px<P>(&s_x[0][lp * P]);
-#pragma unroll
-        for (int k = 0; k < HP; ++k) {
-            v2f acc = em.h[k] * wq0;
-            acc = pfma(om.h[k], wq1, acc);
-            acc = pfma(va.h[k], wq2, acc);
-            acc = pfma(vb.h[k], wq3, acc);
-            c.h[k] = pfma(ep.h[k], wq4, acc);
-        }
-#else
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
             v2f acc = va.h[k] * wq2;
@@ -829,7 +809,6 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
             acc = fma_left(vb.h[k], wq1, acc);
             c.h[k] = fma_right(va.h[k], wq4, acc);
         }
-#endif
         return c;
     };
     auto shift_window = [&](const Px<P> (&n0)[2], const Px<P> (&n1)[2]) {
@@ -1006,25 +985,6 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
             evE.h[k] = pfma(Gp1.h[k], 0.1f, t);
             evO.h[k] = pfma(Gp1.h[k], 0.5f, G0.h[k] * 0.5f);
         }
-#if BAND_EXCHANGE_LDS
-        st_px(&s_x[2][lane * P], evE);
-        st_px(&s_x[3][lane * P], evO);
-        __syncthreads();
-        const Px<P> eEl = ld_px<P>(&s_x[2][lm * P]), eEr = ld_px<P>(&s_x[2][lp * P]);
-        const Px<P> eOl = ld_px<P>(&s_x[3][lm * P]), eOr = ld_px<P>(&s_x[3][lp * P]);
-#pragma unroll
-        for (int k = 0; k < HP; ++k) {
-            // horizontal expand: even fine column takes J-1, J, J+1; odd fine column J, J+1
-            v2f t = eEl.h[k] * el;
-            t = pfma(evE.h[k], ec, t);
-            x00.h[k] = pfma(eEr.h[k], er, t);
-            x01.h[k] = pfma(eEr.h[k], orr, evE.h[k] * oc);
-            t = eOl.h[k] * el;
-            t = pfma(evO.h[k], ec, t);
-            x10.h[k] = pfma(eOr.h[k], er, t);
-            x11.h[k] = pfma(eOr.h[k], orr, evO.h[k] * oc);
-        }
-#else
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
             v2f t = evE.h[k] * ec;
@@ -1036,7 +996,6 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
             x10.h[k] = fma_right(evO.h[k], er, t);
             x11.h[k] = fma_right(evO.h[k], orr, evO.h[k] * oc);
         }
-#endif
         const bool row1_ok = (2 * c + 1) < h;
 #if defined(BAND_ABLATE) && BAND_ABLATE >= 1      // profiling ablation: no per-pixel tail, keep the data flow alive
         acc[0] += x00.h[0].x + x01.h[0].x + x10.h[0].x + x11.h[0].x + W[0][0].h[0].x + W[0][1].h[0].x + W[1][0].h[0].x + W[1][1].h[0].x;
@@ -1164,7 +1123,7 @@ static void chunking(int hc, int n_strips, int n, long long capacity, int& n_chu
     // of `capacity` resident waves.  Pick the chunk height that minimises rounds x per-wave cost.
     double best = 1e300;
     cr = hc;
-    for (int cand = 8; cand <= hc || cand == 8; ++cand) {
+    for (int cand = 2; cand <= hc || cand == 2; ++cand) {
         const int c = cand > hc ? hc : cand;
         const long long chunks = (hc + c - 1) / c;
         const long long waves = (long long)n * n_strips * chunks;
@@ -1212,7 +1171,7 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
     size_t off = 0;
     for (int b = 0; b < n_bands; ++b) {
         const int n_strips = band_strips(c->lw[b + 1]);
-        const int max_chunks = (c->lh[b + 1] + 7) / 8;
+        const int max_chunks = (c->lh[b + 1] + 1) / 2;
         c->max_blk[b] = n_strips * max_chunks;
         c->partial_off[b] = (long long)off;
         off += (size_t)max_frames * c->max_blk[b] * 2;

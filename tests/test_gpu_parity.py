@@ -321,3 +321,32 @@ def test_foveated_pq_golden(fv):
     q1, _ = m.predict(test, ref, frames_per_second=30, fixation_point=np.array([W // 2, H // 2]))
     q2, _ = m.predict(test, ref, frames_per_second=30)
     assert float(q1) == float(q2)
+
+
+@pytest.mark.parametrize("fps,N", [(120, 34), (144, 40), (25, 9)])
+def test_other_frame_rates_vs_oracle(fv, fps, N):
+    """Filter lengths that take the other kernel instantiations: 120 fps -> 30 taps (FL=32 ring, 2 px per lane),
+    144 fps -> 36 taps (generic kernel, fl > 32), 25 fps -> 7 taps (zero-padded to FL=8)."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    H, W = 36, 64
+    test, ref = synth_video_pair(N, H, W)
+    for pad in ("replicate", "pingpong"):
+        m = fv.fvvdp(display_name="standard_fhd", temp_padding=pad)
+        q, stats = m.predict(test, ref, frames_per_second=fps)
+        oq, ostats = orc.Oracle("standard_fhd", temp_padding=pad).predict(test.numpy(), ref.numpy(), frames_per_second=fps)
+        assert abs(float(q) - float(oq)) < 1e-4, (fps, pad)
+        check_q(stats["Q_per_ch"], ostats["Q_per_ch"], coarse=4e-3)      # coarsest band is 5x8 px here: rounding noise does not average
+
+
+def test_misaligned_sizes_take_the_scalar_temporal_kernel(fv):
+    """Frame sizes with H*W not a multiple of 4 use per-pixel loads; results must not change."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    N, H, W, fps = 6, 33, 67, 30
+    test, ref = synth_video_pair(N, H, W)
+    m = fv.fvvdp(display_name="standard_fhd")
+    q, stats = m.predict(test, ref, frames_per_second=fps)
+    oq, ostats = orc.Oracle("standard_fhd").predict(test.numpy(), ref.numpy(), frames_per_second=fps)
+    assert abs(float(q) - float(oq)) < 1e-4
+    check_q(stats["Q_per_ch"], ostats["Q_per_ch"])

@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void copy_f4(const float4* __restrict__ p, flo
 
 // the band kernel's read pattern: single-wave workgroups, each walks down `rows` rows of a [H][W] float4 image,
 // reading 2 x float4 per lane per row (lane l: pixels 2l, 2l+1 of a 128-pixel strip), 2 rows per step, prefetch 1.
-template <int ACTIVE, int HALO_L>
+template <int ACTIVE, int HALO_L, int NT>
 __global__ __launch_bounds__(64) void read_strips(const float4* __restrict__ img, int W, int H, int n_strips, int chunk_rows,
                                                   int n_chunks, float4* __restrict__ coarse, float* out) {
     int bid;
@@ -50,18 +50,29 @@ __global__ __launch_bounds__(64) void read_strips(const float4* __restrict__ img
     const float4* base = img + (size_t)frame * W * H;
     const int r0 = chunk * chunk_rows, r1 = min(r0 + chunk_rows, H);
     float acc = 0.f;
-    float4 a = base[(size_t)r0 * W + x0], b = base[(size_t)r0 * W + x0 + 1];
-    float4 c = base[(size_t)(r0 + 1) * W + x0], d = base[(size_t)(r0 + 1) * W + x0 + 1];
+    auto LD = [&](size_t i) -> float4 {
+        typedef float vf4 __attribute__((ext_vector_type(4)));
+        if constexpr (NT & 1) { const vf4 t = __builtin_nontemporal_load(reinterpret_cast<const vf4*>(base + i)); return make_float4(t.x, t.y, t.z, t.w); }
+        else return base[i];
+    };
+    float4 a = LD((size_t)r0 * W + x0), b = LD((size_t)r0 * W + x0 + 1);
+    float4 c = LD((size_t)(r0 + 1) * W + x0), d = LD((size_t)(r0 + 1) * W + x0 + 1);
     for (int r = r0; r < r1; r += 2) {
         const float4 a0 = a, b0 = b, c0 = c, d0 = d;
         const int rn = min(r + 2, H - 2);
-        a = base[(size_t)rn * W + x0]; b = base[(size_t)rn * W + x0 + 1];
-        c = base[(size_t)(rn + 1) * W + x0]; d = base[(size_t)(rn + 1) * W + x0 + 1];
+        a = LD((size_t)rn * W + x0); b = LD((size_t)rn * W + x0 + 1);
+        c = LD((size_t)(rn + 1) * W + x0); d = LD((size_t)(rn + 1) * W + x0 + 1);
         acc += a0.x + b0.y + c0.z + d0.w;
         if (coarse && lane >= HALO_L && lane < HALO_L + ACTIVE) {
             const int Wc = W / 2;
             const int J = strip * ACTIVE + lane - HALO_L;
-            if (J < Wc) coarse[((size_t)frame * (H / 2) + r / 2) * Wc + J] = make_float4(a0.x, b0.x, c0.x, d0.x);
+            if (J < Wc) {
+                float4* dst = coarse + ((size_t)frame * (H / 2) + r / 2) * Wc + J;
+                const float4 val = make_float4(a0.x, b0.x, c0.x, d0.x);
+                typedef float vf4 __attribute__((ext_vector_type(4)));
+                if constexpr (NT & 2) __builtin_nontemporal_store(vf4{val.x, val.y, val.z, val.w}, reinterpret_cast<vf4*>(dst));
+                else *dst = val;
+            }
         }
     }
     if (acc == 123.456f) out[0] = acc;
@@ -102,27 +113,18 @@ int main() {
         double t = timeit([&] { hipLaunchKernelGGL(copy_f4<4>, dim3(blocks), dim3(256), 0, 0, p, q, n4); });
         printf("copy_f4<4>  blocks %6d: %.2f TB/s (r+w)\n", blocks, 2 * gb / t / 1e3);
     }
-    for (int chunk_rows : {128, 270}) {
+    for (int chunk_rows : {270, 1080}) {
         const int n_chunks = (H + chunk_rows - 1) / chunk_rows;
-        {
-            const int n_strips = 32, grid = n_strips * n_chunks * N;
-            double t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, (float4*)nullptr, out); });
-            printf("strips 60 active, halo_l 0 (fine aligned), rows/chunk %4d: read only %.2f TB/s", chunk_rows, gb / t / 1e3);
-            t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
-            printf("   + coarse write (960 B, offset 0): %.2f TB/s alg\n", 1.25 * gb / t / 1e3);
-            t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 2>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
-            printf("   strips 60 active, halo_l 2 (fine misaligned 64B) + coarse write: %.2f TB/s alg\n", 1.25 * gb / t / 1e3);
-        }
-        {
-            const int n_strips = (1920 + 55) / 56, grid = n_strips * n_chunks * N;
-            double t = timeit([&] { hipLaunchKernelGGL((read_strips<56, 4>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
-            printf("   strips 56 active, halo_l 4 (fine+coarse aligned, 7 full lines) + coarse write: %.2f TB/s alg\n", 1.25 * gb / t / 1e3);
-        }
-        {
-            const int n_strips = 30, grid = n_strips * n_chunks * N;
-            double t = timeit([&] { hipLaunchKernelGGL((read_strips<64, 0>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
-            printf("   strips 64 active, no halo (1 KB aligned writes) + coarse write: %.2f TB/s alg\n", 1.25 * gb / t / 1e3);
-        }
+        const int n_strips = 32, grid = n_strips * n_chunks * N;
+        double t;
+        t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 0>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+        printf("rows/chunk %4d: plain ld/st            : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
+        t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 1>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+        printf("rows/chunk %4d: nt loads               : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
+        t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 2>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+        printf("rows/chunk %4d: nt stores              : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
+        t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 3>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+        printf("rows/chunk %4d: nt loads + nt stores   : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
     }
     return 0;
 }
