@@ -8,6 +8,7 @@ import sys
 _HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(_HERE)
 LIB_PATH = os.environ.get("FVVDP_LIB", os.path.join(_HERE, "libfvvdp_hip.so"))   # override: A/B builds
+BUILD_FLAGS_NOTE = "hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -mllvm -pragma-unroll-threshold=1000000"
 SRC_PATH = os.path.join(_HERE, "csrc", "fvvdp_hip.hip")
 INCLUDE_DIR = os.path.join(ROOT, "include")
 
@@ -67,8 +68,10 @@ def build(force=False, verbose=False):
             os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(INCLUDE_DIR, "fvvdp_hip.h"))):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + INCLUDE_DIR, SRC_PATH,
-           "-o", LIB_PATH]
+    # -pragma-unroll-threshold: the temporal kernels keep their filter window in registers and rely on FULL unrolling
+    # of the tap loops (static ring slots); the default size cap silently falls back to scratch-memory indexing
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
+           "-pragma-unroll-threshold=1000000", "-I" + INCLUDE_DIR, SRC_PATH, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
