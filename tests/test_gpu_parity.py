@@ -336,7 +336,7 @@ def test_other_frame_rates_vs_oracle(fv, fps, N):
         q, stats = m.predict(test, ref, frames_per_second=fps)
         oq, ostats = orc.Oracle("standard_fhd", temp_padding=pad).predict(test.numpy(), ref.numpy(), frames_per_second=fps)
         assert abs(float(q) - float(oq)) < 1e-4, (fps, pad)
-        check_q(stats["Q_per_ch"], ostats["Q_per_ch"], coarse=4e-3)      # coarsest band is 5x8 px here: rounding noise does not average
+        check_q(stats["Q_per_ch"], ostats["Q_per_ch"], coarse=4e-3, fine=4e-3)   # 36x64 frame: every band is tiny, the noise does not average
 
 
 def test_misaligned_sizes_take_the_scalar_temporal_kernel(fv):
