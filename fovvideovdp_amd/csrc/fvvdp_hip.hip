@@ -1050,6 +1050,45 @@ __global__ __launch_bounds__(64) void finalize_kernel(const FinalizeArgs a) {
     if (lane == 0) a.Q[((size_t)b * 2 + cc) * a.q_stride + a.q_col0 + s] = q;
 }
 
+// Heat-map reconstruction, one level: out = expand(coarse) + (D0 + w*D1)/m   [then ^beta_jod * |jod_a| on level 0]
+// (heatmap_pyr.set_band / reconstruct, fvvdp_lpyr_dec.py:65-71,94-101; expand closed form as in band_kernel).
+struct HeatArgs {
+    const float* D;        // [n][2][h][w]
+    const float* coarse;   // [n][hc][wc] or nullptr for the coarsest band
+    float* out;            // [n][h][w]
+    int w, h, wc, hc, tc;
+    float w_trans, inv_m, beta_jod, scale;
+    int final_level;
+};
+
+__global__ __launch_bounds__(256) void heat_level_kernel(const HeatArgs a) {
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    const int y = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= a.w) return;
+    const size_t plane = (size_t)a.h * a.w;
+    const size_t o = (size_t)y * a.w + x;
+    float v = a.D[((size_t)f * 2) * plane + o];
+    if (a.tc == 2) v = v + a.w_trans * a.D[((size_t)f * 2 + 1) * plane + o];
+    v = v * a.inv_m;
+    if (a.coarse) {
+        const float* c = a.coarse + (size_t)f * a.hc * a.wc;
+        const int cy = y >> 1, cx = x >> 1;
+        const int r0 = max(cy - 1, 0), r1 = cy, r2 = min(cy + 1, a.hc - 1);
+        const int c0 = max(cx - 1, 0), c1 = cx, c2 = min(cx + 1, a.wc - 1);
+        auto col = [&](int cc) -> float {     // vertical pass first (gausspyr_expand, fvvdp_lpyr_dec.py:225-228)
+            if (y & 1) return 0.5f * c[(size_t)r1 * a.wc + cc] + 0.5f * c[(size_t)r2 * a.wc + cc];
+            return (0.1f * c[(size_t)r0 * a.wc + cc] + 0.8f * c[(size_t)r1 * a.wc + cc]) + 0.1f * c[(size_t)r2 * a.wc + cc];
+        };
+        float e;
+        if (x & 1) e = 0.5f * col(c1) + 0.5f * col(c2);
+        else e = (0.1f * col(c0) + 0.8f * col(c1)) + 0.1f * col(c2);
+        v = e + v;
+    }
+    if (a.final_level) v = powf(v, a.beta_jod) * a.scale;
+    a.out[(size_t)f * plane + o] = v;
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------------------
@@ -1075,6 +1114,7 @@ struct fvvdp_ctx {
     float* d_fix = nullptr;       // [max_frames][2]
     float* d_taps = nullptr;      // [2][FVVDP_MAX_TAPS]
     int* d_idx = nullptr;         // [max_frames + FVVDP_MAX_TAPS]
+    float* heat[FVVDP_MAX_BANDS + 1]{};   // heat-map accumulation images of levels >= 1, allocated on first use
     size_t scratch = 0;
     long long wave_capacity = 4096;   // resident single-wave workgroups of the band kernel on the whole chip
     // timing
@@ -1210,6 +1250,8 @@ extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     if (c->partial) (void)hipFree(c->partial);
     if (c->csf) (void)hipFree(c->csf);
     if (c->csf_y) (void)hipFree(c->csf_y);
+    for (int i = 0; i <= FVVDP_MAX_BANDS; ++i)
+        if (c->heat[i]) (void)hipFree(c->heat[i]);
     if (c->d_fix) (void)hipFree(c->d_fix);
     if (c->d_taps) (void)hipFree(c->d_taps);
     if (c->d_idx) (void)hipFree(c->d_idx);
@@ -1559,6 +1601,41 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
         Timed tm(c, 1 + c->n_bands, st);
         const int total = c->n_bands * 2 * n;
         hipLaunchKernelGGL(finalize_kernel, dim3(total), dim3(64), 0, st, fa);
+    }
+    HIP_TRY(hipGetLastError());
+    return FVVDP_OK;
+}
+
+extern "C" int fvvdp_heatmap_reconstruct(fvvdp_ctx* c, int n, const float* const* h_dD, float w_transient, float beta_jod,
+                                         float jod_a_abs, float* d_out, void* stream) {
+    if (!c || !h_dD || !d_out) return fail(FVVDP_EINVAL, "null argument");
+    if (n < 1 || n > c->max_frames) return fail(FVVDP_EINVAL, "n=%d exceeds max_frames=%d", n, c->max_frames);
+    for (int b = 0; b < c->n_bands; ++b)
+        if (!h_dD[b]) return fail(FVVDP_EINVAL, "missing D map of band %d", b);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    for (int b = 1; b < c->n_bands; ++b)
+        if (!c->heat[b]) {
+            int rc = dev_alloc(c, &c->heat[b], (size_t)c->max_frames * c->lw[b] * c->lh[b]);
+            if (rc != FVVDP_OK) return rc;
+        }
+    for (int b = c->n_bands - 1; b >= 0; --b) {
+        HeatArgs a;
+        memset(&a, 0, sizeof(a));
+        a.D = h_dD[b];
+        a.coarse = (b == c->n_bands - 1) ? nullptr : c->heat[b + 1];   // the base band of a zero image is zero
+        a.out = (b == 0) ? d_out : c->heat[b];
+        a.w = c->lw[b];
+        a.h = c->lh[b];
+        a.wc = c->lw[b + 1];
+        a.hc = c->lh[b + 1];
+        a.tc = c->P / 2;
+        a.w_trans = w_transient;
+        a.inv_m = (b == 0) ? 1.0f : 0.5f;                              // set_band divides by the band multiplier
+        a.beta_jod = beta_jod;
+        a.scale = jod_a_abs;
+        a.final_level = (b == 0);
+        dim3 grid((a.w + 255) / 256, a.h, n), block(256);
+        hipLaunchKernelGGL(heat_level_kernel, grid, block, 0, st, a);
     }
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;

@@ -99,8 +99,6 @@ class fvvdp:
         self.temp_padding = temp_padding
         self.use_checkpoints = use_checkpoints
         self.do_heatmap = (self.heatmap is not None) and (self.heatmap != "none")
-        if self.do_heatmap:
-            raise RuntimeError("heatmap output is not available in the MI355X path yet (DESIGN.md, 'next' rows)")
         if use_checkpoints:
             raise RuntimeError("use_checkpoints (training of the metric) is not supported: the HIP path is forward-only")
         if device is None:
@@ -186,6 +184,11 @@ class fvvdp:
 
         n_out = f1 - f0
         batch = self._batch_size(width, height, planes, n_out)
+        heatmap = None
+        if self.do_heatmap:
+            batch = max(1, min(batch, int(2e9 // (width * height * 4 * 12))))     # D maps + context image per frame
+            dmap_channels = 1 if self.heatmap == "raw" else 3
+            heatmap = torch.zeros([1, dmap_channels, n_out, height, width], dtype=torch.float16, device=torch.device('cpu'))
         ctx = self._context(width, height, n_bands, planes, batch, rho_band)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         Q = torch.zeros((n_bands, 2, n_out), dtype=torch.float32, device=self.device)
@@ -197,14 +200,23 @@ class fvvdp:
             nb = min(batch, f1 - b0)
             idx = np.ascontiguousarray(widx[b0:b0 + fl - 1 + nb])          # history + newest frames of this batch
             feeder(ctx, idx, taps, fl, nb, oob, stream)
+            maps_arr, dmaps = None, None
+            if self.do_heatmap:                      # per-band difference maps as extra kernel outputs
+                maps_arr = (nat.BandMaps * n_bands)()
+                dmaps = []
+                w_l, h_l = width, height
+                for b in range(n_bands):
+                    dmaps.append(torch.empty((nb, 2, h_l, w_l), dtype=torch.float32, device=self.device))
+                    maps_arr[b].d_D = dmaps[b].data_ptr()
+                    w_l, h_l = (w_l + 1) // 2, (h_l + 1) // 2
+            fx, g = None, None
             if self.foveated:
-                fx = np.ascontiguousarray(fix[b0:b0 + nb], dtype=np.float32)
-                g = self._geom_struct()
-                nat.check(nat.lib().fvvdp_bands_forward(ctx.handle, nb, C.c_void_p(Q.data_ptr()), n_out, b0 - f0,
-                                                        nat.fptr(fx), C.byref(g), None, stream))
-            else:
-                nat.check(nat.lib().fvvdp_bands_forward(ctx.handle, nb, C.c_void_p(Q.data_ptr()), n_out, b0 - f0,
-                                                        None, None, None, stream))
+                fxa = np.ascontiguousarray(fix[b0:b0 + nb], dtype=np.float32)
+                fx, g = nat.fptr(fxa), C.byref(self._geom_struct())
+            nat.check(nat.lib().fvvdp_bands_forward(ctx.handle, nb, C.c_void_p(Q.data_ptr()), n_out, b0 - f0,
+                                                    fx, g, maps_arr, stream))
+            if self.do_heatmap:
+                heatmap[:, :, b0 - f0:b0 - f0 + nb] = self._heatmap_batch(ctx, nb, dmaps, planes, width, height, stream)
 
         Q_jod = self.do_pooling_and_jods(Q, rho_band[0:-1]) if pool else None
         stats = {}
@@ -214,9 +226,30 @@ class fvvdp:
         stats['width'] = width
         stats['height'] = height
         stats['N_frames'] = N_frames
+        if self.do_heatmap:
+            stats['heatmap'] = heatmap
         if int(oob.item()) != 0:
             logging.warning("Pixel outside the valid range 0-1")
         return (Q_jod.squeeze() if pool else None, stats)
+
+    def _heatmap_batch(self, ctx, nb, dmaps, planes, width, height, stream):
+        """Difference maps of `nb` frames -> fp16 CPU tensor [1, 1|3, nb, H, W] (fvvdp.py:469-476)."""
+        from .visualize_diff_map import visualize_diff_map
+        ptrs = (C.c_void_p * len(dmaps))(*[d.data_ptr() for d in dmaps])
+        dmap = torch.empty((nb, height, width), dtype=torch.float32, device=self.device)
+        beta_jod = float(np.power(10.0, self.log_jod_exp))
+        nat.check(nat.lib().fvvdp_heatmap_reconstruct(ctx.handle, nb, ptrs, float(self.w_transient), beta_jod,
+                                                      abs(float(self.jod_a)), C.c_void_p(dmap.data_ptr()), stream))
+        if self.heatmap == "raw":
+            return dmap.to(torch.float16).cpu().view(1, 1, nb, height, width)
+        lvl0 = torch.empty((nb, planes, height, width), dtype=torch.float32, device=self.device)
+        nat.check(nat.lib().fvvdp_export_level(ctx.handle, 0, nb, C.c_void_p(lvl0.data_ptr()), stream))
+        out = torch.empty((1, 3, nb, height, width), dtype=torch.float16)
+        for k in range(nb):      # tone mapping is per frame (global histogram of the frame)
+            col = visualize_diff_map(dmap[k].view(1, 1, height, width), context_image=lvl0[k:k + 1, 0:1],
+                                     colormap_type=self.heatmap)
+            out[0, :, k] = col[0].to(torch.float16).cpu()
+        return out
 
     # ---- pooling and JOD regression (Python, as in the reference) ------------------------------------------
     def do_pooling_and_jods(self, Q_per_ch, rho_band):

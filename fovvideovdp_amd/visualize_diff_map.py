@@ -1,0 +1,72 @@
+"""Colouring of difference maps (heat maps): the map modulates a tone-mapped, desaturated copy of the frame.
+Host-side torch code (visualisation, not on the hot path); same results as the reference's
+pyfvvdp/visualize_diff_map.py, which it replaces for `heatmap in {"threshold", "supra-threshold"}`."""
+import torch
+
+_LUMA = (0.212656, 0.715158, 0.072186)
+
+
+def _interp1(x, v, x_q):
+    """Piece-wise linear look-up with the reference's knot search and its +1e-6 in the denominator."""
+    shp = x_q.shape
+    q = x_q.flatten()
+    imax = torch.bucketize(q, x)
+    imax[imax >= x.shape[0]] = x.shape[0] - 1
+    imin = (imax - 1).clamp(0, x.shape[0] - 1)
+    frc = (q - x[imin]) / (x[imax] - x[imin] + 0.000001)
+    frc[imax == imin] = 0.
+    frc[frc < 0.0] = 0.
+    return (v[imin] * (1.0 - frc) + v[imax] * frc).reshape(shp)
+
+
+def luminance_NCHW(x):
+    if x.shape[1] == 3:
+        return x[:, 0:1, ...] * _LUMA[0] + x[:, 1:2, ...] * _LUMA[1] + x[:, 2:3, ...] * _LUMA[2]
+    return x
+
+
+def log_luminance(x):
+    y = luminance_NCHW(x)
+    floor = torch.min(y[y > 0.0])
+    return torch.log(torch.clamp(y, min=floor))
+
+
+def vis_tonemap(b, dr):
+    """Histogram-based tone curve that fits log-luminance `b` into a dynamic range `dr` centred at 0.5."""
+    t = 3.0
+    b_min, b_max = torch.min(b), torch.max(b)
+    if b_max - b_min < dr:
+        return (b - b_min) / (b_max - b_min + 1e-3) * dr + (1 - dr) / 2
+    b_scale = torch.linspace(b_min, b_max, 1024, device=b.device)
+    b_p = torch.histc(b, 1024, b_min, b_max)
+    b_p = b_p / torch.sum(b_p)
+    dy = torch.pow(b_p, 1.0 / t)
+    dy = dy / torch.sum(dy)
+    v = torch.cumsum(dy, 0) * dr + (1.0 - dr) / 2.0
+    return _interp1(b_scale, v, b)
+
+
+_COLOR_MAPS = {
+    "threshold": ([[0.2, 0.2, 1.0], [0.2, 1.0, 1.0], [0.2, 1.0, 0.2], [1.0, 1.0, 0.2], [1.0, 0.2, 0.2]],
+                  [0.00, 0.25, 0.50, 0.75, 1.00]),
+    "supra-threshold": ([[0.2, 1.0, 1.0], [1.0, 1.0, 1.0], [1.0, 1.0, 0.2]], [0.0, 0.5, 1.0]),
+    "monochromatic": ([[1.0, 1.0, 1.0], [1.0, 1.0, 1.0]], [0.0, 1.0]),
+}
+
+
+def visualize_diff_map(diff_map, context_image=None, type="pmap", colormap_type="supra-threshold"):
+    """diff_map [N,1,H,W] in [0,1] -> sRGB-like [N,3,H,W]."""
+    if colormap_type not in _COLOR_MAPS:
+        raise RuntimeError("Unknown colormap: %s" % colormap_type)
+    diff_map = torch.clamp(diff_map, 0.0, 1.0)
+    if context_image is None:
+        tmo_img = torch.ones_like(diff_map) * 0.5
+    else:
+        tmo_img = vis_tonemap(log_luminance(context_image), 0.6)
+    cm, cm_in = _COLOR_MAPS[colormap_type]
+    color_map = torch.tensor(cm, device=diff_map.device)
+    color_map_in = torch.tensor(cm_in, device=diff_map.device)
+    color_map_l = color_map[:, 0:1] * _LUMA[0] + color_map[:, 1:2] * _LUMA[1] + color_map[:, 2:3] * _LUMA[2]
+    color_map_ch = color_map / (torch.cat([color_map_l] * 3, 1) + 0.0001)
+    cmap = torch.cat([_interp1(color_map_in, color_map_ch[:, k], diff_map) for k in range(3)], 1)
+    return (cmap * torch.cat([tmo_img] * 3, dim=1)).clip(0., 1.)

@@ -165,6 +165,17 @@ int fvvdp_load_channels_planar(fvvdp_ctx* ctx, const float* d_R, int n, int slot
 int fvvdp_bands_forward(fvvdp_ctx* ctx, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
                         const fvvdp_geom* geom, const fvvdp_band_maps* maps, void* stream);
 
+/* ---- difference-map (heat-map) reconstruction --------------------------------------------------------------- */
+
+/* Replaces the heat-map branch of process_block_of_frames (fvvdp.py:374-375,458-471) with heatmap_pyr.set_band /
+ * reconstruct (fvvdp_lpyr_dec.py:65-71,94-101): per band b the map (D_sustained + w_transient*D_transient)/band_mul
+ * is accumulated by expand-and-add from the coarsest band up, then dmap = img^beta_jod * |jod_a|.
+ *   h_dD      host array of n_bands DEVICE pointers: the d_D maps written by fvvdp_bands_forward for the same n
+ *             frames ([n][2][h_b][w_b]; for planes == 2 only channel 0 is used)
+ *   d_out     [n][H][W] fp32 (the caller converts to fp16 like the reference, fvvdp.py:473)                  */
+int fvvdp_heatmap_reconstruct(fvvdp_ctx* ctx, int n, const float* const* h_dD, float w_transient, float beta_jod,
+                              float jod_a_abs, float* d_out, void* stream);
+
 /* ---- introspection (tests, profiling) --------------------------------------------------------------------- */
 
 /* Copy Gaussian level `level` of slots [0,n) to planar fp32 d_out[n][P][h][w] (gaussian_pyramid_dec,

@@ -350,3 +350,35 @@ def test_misaligned_sizes_take_the_scalar_temporal_kernel(fv):
     oq, ostats = orc.Oracle("standard_fhd").predict(test.numpy(), ref.numpy(), frames_per_second=fps)
     assert abs(float(q) - float(oq)) < 1e-4
     check_q(stats["Q_per_ch"], ostats["Q_per_ch"])
+
+
+def test_heatmaps_golden(fv):
+    """Difference maps: raw and coloured, video and still image, against the reference."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    z = load("g6_heatmaps")
+    test, ref = synth_video_pair(6, 68, 121)
+    for mode, tag in (("raw", "raw"), ("supra-threshold", "supra")):
+        m = fv.fvvdp(display_name="standard_fhd", heatmap=mode)
+        q, st = m.predict(test, ref, frames_per_second=30)
+        hm, g = st["heatmap"], z[f"video_{tag}"]
+        assert hm.dtype == torch.float16 and hm.device.type == "cpu" and tuple(hm.shape) == g.shape
+        assert abs(float(q) - float(z[f"video_{tag}_jod"])) < 1e-4
+        d = np.abs(hm.float().numpy() - g.astype(np.float32))
+        # fp16 storage: 1 ulp is 1e-3 relative; the map itself carries the per-pixel D noise of DESIGN.md section 5
+        assert np.max(d / (np.abs(g.astype(np.float32)) + 2e-3)) < 2e-2, tag
+        assert np.mean(d) < 2e-4, tag
+    t2, r2 = synth_video_pair(1, 135, 240)
+    for mode, tag in (("raw", "raw"), ("threshold", "thr")):
+        m = fv.fvvdp(display_name="standard_4k", heatmap=mode)
+        q, st = m.predict(t2[0, :, 0], r2[0, :, 0], dim_order="CHW")
+        hm, g = st["heatmap"], z[f"image_{tag}"]
+        assert tuple(hm.shape) == g.shape
+        assert abs(float(q) - float(z[f"image_{tag}_jod"])) < 1e-4
+        d = np.abs(hm.float().numpy() - g.astype(np.float32))
+        assert np.max(d / (np.abs(g.astype(np.float32)) + 2e-3)) < 2e-2, tag
+    # batching must not change the maps
+    m = fv.fvvdp(display_name="standard_fhd", heatmap="raw", batch_frames=4)
+    _, st2 = m.predict(test, ref, frames_per_second=30)
+    m = fv.fvvdp(display_name="standard_fhd", heatmap="raw")
+    _, st1 = m.predict(test, ref, frames_per_second=30)
+    assert torch.equal(st1["heatmap"], st2["heatmap"])

@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     nat.build()                                    # hipcc cross-compiles for gfx950 without a GPU
     L = ctypes.CDLL(nat.LIB_PATH)
     declared = header_functions()
-    assert len(declared) == 13
+    assert len(declared) == 14
     for name in declared:
         assert hasattr(L, name), "libfvvdp_hip.so does not export " + name
     assert sorted(nat.SYMBOLS) == declared         # the ctypes binding covers exactly the header
@@ -54,8 +54,6 @@ def test_no_cpu_fallback():
     a = np.zeros((64, 64), dtype=np.uint8)
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         m.predict(a, a, dim_order="HW")
-    with pytest.raises(RuntimeError):
-        fv.fvvdp(heatmap="threshold")
     with pytest.raises(AssertionError):
         fv.fvvdp(heatmap="bogus")
     with pytest.raises(AssertionError):
@@ -221,3 +219,25 @@ def test_synthetic_generator_is_deterministic():
     assert int(r1.to(torch.int64).sum()) == 444849 or True     # value pinned by the golden JODs that use it
     t3, _ = synth_video_pair(3, 17, 23, pair=1)
     assert not torch.equal(t1, t3)
+
+
+def test_visualize_diff_map_colouring():
+    """Host-side colouring of difference maps: shapes, range, colour-map end points."""
+    from fovvideovdp_amd.visualize_diff_map import visualize_diff_map, vis_tonemap
+    g = torch.Generator().manual_seed(3)
+    ctx = torch.rand(1, 1, 40, 60, generator=g) * 100 + 0.5
+    dm = torch.zeros(1, 1, 40, 60)
+    dm[0, 0, :, 30:] = 1.0
+    for cmap, lo, hi in (("threshold", (0.2, 0.2, 1.0), (1.0, 0.2, 0.2)), ("supra-threshold", (0.2, 1.0, 1.0), (1.0, 1.0, 0.2))):
+        out = visualize_diff_map(dm, context_image=ctx, colormap_type=cmap)
+        assert out.shape == (1, 3, 40, 60) and float(out.min()) >= 0 and float(out.max()) <= 1
+        # hue follows the map: ratios of the channels at d=0 and d=1 equal the colour-map end points
+        for px, col in (((0, 0), lo), ((0, 59), hi)):
+            v = out[0, :, px[0], px[1]]
+            k = int(np.argmax(col))
+            if float(v[k]) < 1.0:           # not clipped
+                assert np.allclose((v / v[k]).numpy(), np.array(col) / col[k], atol=2e-3)
+    with pytest.raises(RuntimeError):
+        visualize_diff_map(dm, colormap_type="nope")
+    t = vis_tonemap(torch.log(ctx), 0.6)
+    assert float(t.min()) >= 0.19 and float(t.max()) <= 0.81

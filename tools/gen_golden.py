@@ -321,6 +321,27 @@ def g5(pyfvvdp):
     save("g5_units", out)
 
 
+def g6(pyfvvdp):
+    """Heat maps (difference maps): raw on a tiny odd-size video, coloured on an image and a video."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    out = {}
+    test, ref = synth_video_pair(6, 68, 121)
+    for mode, tag in (("raw", "raw"), ("supra-threshold", "supra")):
+        fv = pyfvvdp.fvvdp(display_name="standard_fhd", heatmap=mode, device=torch.device("cpu"), quiet=True)
+        with torch.no_grad():
+            q, st = fv.predict(test, ref, dim_order="BCFHW", frames_per_second=30)
+        out[f"video_{tag}"] = st["heatmap"].numpy()
+        out[f"video_{tag}_jod"] = np.float32(q.item())
+    t2, r2 = synth_video_pair(1, 135, 240)
+    for mode, tag in (("raw", "raw"), ("threshold", "thr")):
+        fv = pyfvvdp.fvvdp(display_name="standard_4k", heatmap=mode, device=torch.device("cpu"), quiet=True)
+        with torch.no_grad():
+            q, st = fv.predict(t2[0, :, 0], r2[0, :, 0], dim_order="CHW")
+        out[f"image_{tag}"] = st["heatmap"].numpy()
+        out[f"image_{tag}_jod"] = np.float32(q.item())
+    save("g6_heatmaps", out)
+
+
 def main():
     which = sys.argv[1:] or ["g0", "g1", "g2", "g5"]
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
@@ -343,6 +364,8 @@ def main():
             g4(pyfvvdp, 2160, 3840, 120, "uhd_120f", False)
         elif w == "g5":
             g5(pyfvvdp)
+        elif w == "g6":
+            g6(pyfvvdp)
         else:
             raise SystemExit("unknown case " + w)
         print(w, "done in %.1f s" % (time.time() - t0), flush=True)
