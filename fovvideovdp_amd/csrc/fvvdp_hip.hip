@@ -672,32 +672,15 @@ struct BandArgs {
     float* dL;
     float* dS;
     // foveated (FOV == true)
-    const float* lut3[2];   // [32][32][32] S_log per temporal channel
-    const float* ax_rho;    // [32] rho_log
-    const float* ax_ecc;    // [32] ecc_sqrt
+    const float4* sublut;   // per band: [32 ecc][32 Y][rw] of {S_log0[i], S_log1[i], S_log0[i+1], S_log1[i+1]} (i = rho knot)
+    const float* axes;      // [3][32] knots: Y_log, rho_log, ecc_sqrt
+    int rw, i_lo;           // rho knots covered by the band's sub-LUT: [i_lo, i_lo+rw]
     const float* fix;       // device [n][2] gaze in frame pixels
-    float size_m0, size_m1, dist_m, ppd_c, tan_delta, delta_deg;
+    float size_m0, size_m1, dist_m, cos_delta, delta_rad;
     float rho_band, rho_lo, rho_hi, ecc_lo, ecc_hi;
+    float inv_step[3], first[3];   // uniform-grid estimates of the three axes
     int frame_w, frame_h;
 };
-
-__device__ __forceinline__ void interp_axis(const float* __restrict__ x, float q, int& i0, int& i1, float& f) {
-    // get_interpolants_v1 (interp.py:11-20): imax = first knot >= q (clamped), imin = max(imax-1,0),
-    // f = (q-x[imin])/(x[imax]-x[imin]+1e-6), 0 if imax==imin, clamped at 0
-    int lo = 0, hi = FVVDP_LUT_N;     // bucketize: first index with x[i] >= q
-#pragma unroll
-    for (int it = 0; it < 6; ++it) {
-        const int mid = (lo + hi) >> 1;
-        const bool go = (lo < hi) && (x[min(mid, FVVDP_LUT_N - 1)] < q);
-        const bool stay = (lo < hi) && !go;
-        lo = go ? mid + 1 : lo;
-        hi = stay ? mid : hi;
-    }
-    i1 = min(lo, FVVDP_LUT_N - 1);
-    i0 = max(i1 - 1, 0);
-    const float den = x[i1] - x[i0] + 0.000001f;
-    f = (i1 == i0) ? 0.0f : fmaxf((q - x[i0]) / den, 0.0f);
-}
 
 #ifndef BAND_MIN_WAVES
 #define BAND_MIN_WAVES 1
@@ -735,10 +718,13 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
     const int xc0 = min(max(X0, 0), w - 1), xc1 = min(max(X1, 0), w - 1);
     const bool col1_ok = X1 < w;
 
-    if (!FOV) {
+    __shared__ float s_ax[FOV ? 3 * FVVDP_LUT_N : 1];
+    if constexpr (!FOV) {
         if (lane < FVVDP_LUT_N) s_csf[lane] = a.csf[lane];
-        __syncthreads();
+    } else {
+        for (int i = lane; i < 3 * FVVDP_LUT_N; i += 64) s_ax[i] = a.axes[i];
     }
+    __syncthreads();
 
     // horizontal 5-tap weights of this lane's coarse column incl. the reference's edge fix-ups
     // (gausspyr_reduce, fvvdp_lpyr_dec.py:198-205; the right-edge branch is selected by the parity of the ROW
@@ -862,7 +848,7 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
     const float lg_mask = a.lg_gain + a.lg_k;      // log2(k*S)
 
     // per-pixel tail: contrast, CSF, masking, pooling  (fvvdp_lpyr_dec.py:259-269, fvvdp.py:395-467)
-    auto band_px = [&](const Px<P>& g, const Px<P>& e, bool valid, int y, int x, float vx) {
+    auto band_px = [&](const Px<P>& g, const Px<P>& e, bool valid, int y, int x, float vx, float vy) {
         const float lb = fmaxf(e.h[0].y, a.lbkg_min);                  // plane 1 = reference (sustained)
         // contrast = min((g-e)/lb, cmax) * m.  Dividing by lb>0 commutes with |.|, min and the clamp, so the
         // division is carried as -log2(lb) in the log domain below: no reciprocal, no per-plane multiply.
@@ -885,48 +871,36 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
             slog[0] = fmaf(f, r.z, r.x);
             slog[1] = fmaf(f, r.w, r.y);
         } else {
-            // eccentricity and resolution magnification (fvvdp.py:424-437, fvvdp_display_model.py:475-526)
-            const float yp = ((float)y + 0.5f) + (-(float)h / 2.0f);
-            const float vy = atanf(-yp * a.size_m1 / (float)h / a.dist_m) * 57.29577951308232f;
+            // eccentricity and resolution magnification (fvvdp.py:424-437, fvvdp_display_model.py:475-526).
+            // (tan(a+d)-tan(a))/tan(d) == cos(d)/(cos(a)cos(a+d)): evaluated in this form it needs no slow tan and
+            // does not lose digits to the reference's fp32 finite difference (whose noise, ~5e-4, bounds parity).
             const float dx = vx - gx, dy = vy - gy;
-            const float ecc = sqrtf(dx * dx + dy * dy);
-            const float va = fminf(sqrtf(vx * vx + vy * vy), 89.9f);
-            const float ta = tanf(va * 0.017453292519943295f);
-            const float tb = tanf((va + a.delta_deg) * 0.017453292519943295f);
-            const float res_mag = a.ppd_c * (tb - ta) / a.tan_delta / a.ppd_c;
+            const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
+            const float va = fminf(__builtin_amdgcn_sqrtf(vx * vx + vy * vy), 89.9f) * 0.017453292519943295f;
+            const float res_mag = a.cos_delta * fast_rcp(__cosf(va) * __cosf(va + a.delta_rad));
             const float rho = a.rho_band * res_mag;
             const float rq = fast_log2(fminf(fmaxf(rho, a.rho_lo), a.rho_hi));
-            const float eq = sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
-            int i0, i1, j0, j1, k0, k1;
-            float fi, fj, fk;
-            interp_axis(a.ax_rho, rq, i0, i1, fi);
-            {   // Y axis knots: .x of the a.csf_y records
-                int lo = 0, hi = FVVDP_LUT_N;
-#pragma unroll
-                for (int it = 0; it < 6; ++it) {
-                    const int mid = (lo + hi) >> 1;
-                    const bool go = (lo < hi) && (a.csf_y[min(mid, FVVDP_LUT_N - 1)].x < yq);
-                    const bool stay = (lo < hi) && !go;
-                    lo = go ? mid + 1 : lo;
-                    hi = stay ? mid : hi;
-                }
-                j1 = min(lo, FVVDP_LUT_N - 1);
-                j0 = max(j1 - 1, 0);
-                const float den = a.csf_y[j1].x - a.csf_y[j0].x + 0.000001f;
-                fj = (j1 == j0) ? 0.0f : fmaxf((yq - a.csf_y[j0].x) / den, 0.0f);
-            }
-            interp_axis(a.ax_ecc, eq, k0, k1, fk);
-#pragma unroll
-            for (int cc = 0; cc < HP; ++cc) {
-                const float* v = a.lut3[cc];
-                auto at = [&](int j, int i, int k) { return v[(j * FVVDP_LUT_N + i) * FVVDP_LUT_N + k]; };
-                // interp3 (interp.py:53-57), same association
-                const float lo_k = (at(j0, i0, k0) * (1.0f - fi) + at(j0, i1, k0) * fi) * (1.0f - fj) +
-                                   (at(j1, i0, k0) * (1.0f - fi) + at(j1, i1, k0) * fi) * fj;
-                const float hi_k = (at(j0, i0, k1) * (1.0f - fi) + at(j0, i1, k1) * fi) * (1.0f - fj) +
-                                   (at(j1, i0, k1) * (1.0f - fi) + at(j1, i1, k1) * fi) * fj;
-                slog[cc] = lo_k * (1.0f - fk) + hi_k * fk;
-            }
+            const float eq = __builtin_amdgcn_sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
+            // interval on each (uniform) axis from the grid, fraction from the stored knots incl. interp.py:16's +1e-6
+            auto axis = [&](int ax, float q, int lo, int hi, int& k, float& f) {
+                k = min(max((int)floorf((q - a.first[ax]) * a.inv_step[ax]), lo), hi);
+                const float x0 = s_ax[ax * FVVDP_LUT_N + k], x1 = s_ax[ax * FVVDP_LUT_N + k + 1];
+                f = fmaxf((q - x0) / (x1 - x0 + 0.000001f), 0.0f);
+            };
+            int kY, kR, kE;
+            float fY, fR, fE;
+            axis(0, yq, 0, FVVDP_LUT_N - 2, kY, fY);
+            axis(1, rq, a.i_lo, a.i_lo + a.rw - 1, kR, fR);
+            axis(2, eq, 0, FVVDP_LUT_N - 2, kE, fE);
+            const float4* sb = a.sublut + ((size_t)(kE * FVVDP_LUT_N + kY) * a.rw + (kR - a.i_lo));
+            const size_t sj = a.rw, sk = (size_t)FVVDP_LUT_N * a.rw;
+            const float4 v00 = sb[0], v10 = sb[sj], v01 = sb[sk], v11 = sb[sk + sj];      // v[dj][dk]
+            const float gR = 1.0f - fR, gY = 1.0f - fY, gE = 1.0f - fE;
+            // interp3 (interp.py:53-57), same association: rho blend, then Y, then ecc
+            slog[0] = ((v00.x * gR + v00.z * fR) * gY + (v10.x * gR + v10.z * fR) * fY) * gE +
+                      ((v01.x * gR + v01.z * fR) * gY + (v11.x * gR + v11.z * fR) * fY) * fE;
+            slog[1] = ((v00.y * gR + v00.w * fR) * gY + (v10.y * gR + v10.w * fR) * fY) * gE +
+                      ((v01.y * gR + v01.w * fR) * gY + (v11.y * gR + v11.w * fR) * fY) * fE;
         }
         const float vm = valid ? 1.0f : 0.0f;
         const float lcn = lg_bm - llb;                                   // log2(m / lb)
@@ -1002,10 +976,16 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
         if (false)
 #endif
         {
-        band_px(W[0][0], x00, active, 2 * c, X0, vxa);
-        band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vxb);
-        band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vxa);
-        band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vxb);
+        float vy0 = 0.0f, vy1 = 0.0f;        // vertical view angle of the two fine rows (foveated)
+        if constexpr (FOV) {
+            const float yp0 = ((float)(2 * c) + 0.5f) + (-(float)h / 2.0f), yp1 = yp0 + 1.0f;
+            vy0 = atanf(-yp0 * a.size_m1 / (float)h / a.dist_m) * 57.29577951308232f;
+            vy1 = atanf(-yp1 * a.size_m1 / (float)h / a.dist_m) * 57.29577951308232f;
+        }
+        band_px(W[0][0], x00, active, 2 * c, X0, vxa, vy0);
+        band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vxb, vy0);
+        band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vxa, vy1);
+        band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vxb, vy1);
         }
         Gm1 = G0;
         G0 = Gp1;
@@ -1106,9 +1086,13 @@ struct fvvdp_ctx {
     float4* csf_y = nullptr;      // [32] {Y_log[i],0,0,0}
     bool csf_set = false;
     float y_first = 0, y_inv_step = 0, y_lo = 0, y_hi = 0;
-    float* lut3[2] = {nullptr, nullptr};
-    float* ax_rho = nullptr;
-    float* ax_ecc = nullptr;
+    std::vector<float> h_lut3[2];              // host copies of the full 32^3 LUTs (foveated mode)
+    float h_axes[3][FVVDP_LUT_N]{};            // Y_log, rho_log, ecc_sqrt
+    float* d_axes = nullptr;                   // [3][32]
+    float4* sublut[FVVDP_MAX_BANDS]{};         // per-band rho slices, rebuilt when the geometry changes
+    int sub_rw[FVVDP_MAX_BANDS]{}, sub_ilo[FVVDP_MAX_BANDS]{};
+    fvvdp_geom sub_geom{};
+    bool sub_valid = false;
     float rho_lo = 0, rho_hi = 0, ecc_lo = 0, ecc_hi = 0;
     bool lut3_set[2] = {false, false};
     float* d_fix = nullptr;       // [max_frames][2]
@@ -1255,10 +1239,9 @@ extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     if (c->d_fix) (void)hipFree(c->d_fix);
     if (c->d_taps) (void)hipFree(c->d_taps);
     if (c->d_idx) (void)hipFree(c->d_idx);
-    for (int k = 0; k < 2; ++k)
-        if (c->lut3[k]) (void)hipFree(c->lut3[k]);
-    if (c->ax_rho) (void)hipFree(c->ax_rho);
-    if (c->ax_ecc) (void)hipFree(c->ax_ecc);
+    if (c->d_axes) (void)hipFree(c->d_axes);
+    for (int b = 0; b < FVVDP_MAX_BANDS; ++b)
+        if (c->sublut[b]) (void)hipFree(c->sublut[b]);
     for (auto& v : c->ev)
         for (auto& pr : v) {
             (void)hipEventDestroy(pr.first);
@@ -1303,20 +1286,18 @@ extern "C" int fvvdp_ctx_set_csf_3d(fvvdp_ctx* c, int tc, const float* h_S_log, 
     if (tc < 0 || tc > 1) return fail(FVVDP_EINVAL, "temporal_channel must be 0 or 1");
     const size_t n3 = (size_t)FVVDP_LUT_N * FVVDP_LUT_N * FVVDP_LUT_N;
     int rc = FVVDP_OK;
-    if (!c->lut3[tc]) rc = dev_alloc(c, &c->lut3[tc], n3);
-    if (rc == FVVDP_OK && !c->ax_rho) rc = dev_alloc(c, &c->ax_rho, (size_t)FVVDP_LUT_N);
-    if (rc == FVVDP_OK && !c->ax_ecc) rc = dev_alloc(c, &c->ax_ecc, (size_t)FVVDP_LUT_N);
+    if (!c->d_axes) rc = dev_alloc(c, &c->d_axes, (size_t)3 * FVVDP_LUT_N);
     if (rc != FVVDP_OK) return rc;
-    HIP_TRY(hipMemcpy(c->lut3[tc], h_S_log, n3 * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->ax_rho, h_rho_log, FVVDP_LUT_N * sizeof(float), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(c->ax_ecc, h_ecc_sqrt, FVVDP_LUT_N * sizeof(float), hipMemcpyHostToDevice));
-    {
-        std::vector<float4> rec(FVVDP_LUT_N);
-        for (int i = 0; i < FVVDP_LUT_N; ++i) rec[i] = make_float4(h_Y_log[i], 0.f, 0.f, 0.f);
-        HIP_TRY(hipMemcpy(c->csf_y, rec.data(), rec.size() * sizeof(float4), hipMemcpyHostToDevice));
-        c->y_lo = exp2f(h_Y_log[0]);
-        c->y_hi = exp2f(h_Y_log[FVVDP_LUT_N - 1]);
+    c->h_lut3[tc].assign(h_S_log, h_S_log + n3);
+    for (int i = 0; i < FVVDP_LUT_N; ++i) {
+        c->h_axes[0][i] = h_Y_log[i];
+        c->h_axes[1][i] = h_rho_log[i];
+        c->h_axes[2][i] = h_ecc_sqrt[i];
     }
+    HIP_TRY(hipMemcpy(c->d_axes, c->h_axes, sizeof(c->h_axes), hipMemcpyHostToDevice));
+    c->y_lo = exp2f(h_Y_log[0]);
+    c->y_hi = exp2f(h_Y_log[FVVDP_LUT_N - 1]);
+    c->sub_valid = false;
     c->rho_lo = exp2f(h_rho_log[0]);
     c->rho_hi = exp2f(h_rho_log[FVVDP_LUT_N - 1]);
     c->ecc_lo = h_ecc_sqrt[0] * h_ecc_sqrt[0];
@@ -1491,6 +1472,57 @@ extern "C" int fvvdp_export_level(fvvdp_ctx* c, int level, int n, float* d_out, 
 // ------------------------------------------------------------------------------------------------------------
 // stage 2 launcher
 // ------------------------------------------------------------------------------------------------------------
+// Foveated mode: slice of the 32^3 LUT that band b can reach.  rho = rho_band*res_mag with res_mag in
+// [1, res_mag(corner of the screen)], so only a few rho knots are live per band; the slice is stored as
+// [ecc][Y][rho] of float4 {S0[i], S1[i], S0[i+1], S1[i+1]} so that one aligned 16-byte load returns the two rho
+// corners of both temporal channels and neighbouring pixels (similar ecc, Y) share cache lines.
+static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g) {
+    if (c->sub_valid && memcmp(&c->sub_geom, g, sizeof(*g)) == 0) return FVVDP_OK;
+    const double delta = (1.0 / (double)g->ppd_centre) / 2.0 * M_PI / 180.0;
+    const double ax = atan(0.5 * g->display_size_m[0] / g->distance_m) * 180.0 / M_PI;
+    const double ay = atan(0.5 * g->display_size_m[1] / g->distance_m) * 180.0 / M_PI;
+    double va = sqrt(ax * ax + ay * ay);
+    if (va > 89.9) va = 89.9;
+    va *= M_PI / 180.0;
+    const double mag_max = cos(delta) / (cos(va) * cos(va + delta)) * 1.01;   // 1 % margin over the corner pixel
+    const float* xr = c->h_axes[1];
+    for (int b = 0; b < c->n_bands; ++b) {
+        double r_lo = c->rho_band[b], r_hi = c->rho_band[b] * mag_max;
+        const double lo_c = exp2((double)xr[0]), hi_c = exp2((double)xr[FVVDP_LUT_N - 1]);
+        r_lo = fmin(fmax(r_lo, lo_c), hi_c);
+        r_hi = fmin(fmax(r_hi, lo_c), hi_c);
+        int i_lo = 0, i_hi = FVVDP_LUT_N - 1;
+        while (i_lo + 1 < FVVDP_LUT_N - 1 && xr[i_lo + 1] < log2(r_lo) - 1e-3) ++i_lo;   // last knot <= log2(r_lo)
+        while (i_hi - 1 > i_lo && xr[i_hi - 1] > log2(r_hi) + 1e-3) --i_hi;              // first knot >= log2(r_hi)
+        const int rw = i_hi - i_lo;                                                       // intervals covered
+        if (c->sublut[b] && c->sub_rw[b] != rw) {
+            (void)hipFree(c->sublut[b]);
+            c->sublut[b] = nullptr;
+        }
+        const size_t n = (size_t)FVVDP_LUT_N * FVVDP_LUT_N * rw;
+        if (!c->sublut[b]) {
+            int rc = dev_alloc(c, &c->sublut[b], n);
+            if (rc != FVVDP_OK) return rc;
+        }
+        std::vector<float4> h(n);
+        const float* L0 = c->h_lut3[0].data();
+        const float* L1 = c->h_lut3[1].empty() ? L0 : c->h_lut3[1].data();
+        for (int k = 0; k < FVVDP_LUT_N; ++k)
+            for (int j = 0; j < FVVDP_LUT_N; ++j)
+                for (int i = 0; i < rw; ++i) {
+                    const size_t s0 = ((size_t)j * FVVDP_LUT_N + (i_lo + i)) * FVVDP_LUT_N + k;       // [Y][rho][ecc]
+                    const size_t s1 = ((size_t)j * FVVDP_LUT_N + (i_lo + i + 1)) * FVVDP_LUT_N + k;
+                    h[((size_t)k * FVVDP_LUT_N + j) * rw + i] = make_float4(L0[s0], L1[s0], L0[s1], L1[s1]);
+                }
+        HIP_TRY(hipMemcpy(c->sublut[b], h.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        c->sub_rw[b] = rw;
+        c->sub_ilo[b] = i_lo;
+    }
+    c->sub_geom = *g;
+    c->sub_valid = true;
+    return FVVDP_OK;
+}
+
 template <int P>
 static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, hipStream_t st) {
     dim3 grid(nblocks), block(64);
@@ -1516,6 +1548,8 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
     if (fov) {
         HIP_TRY(hipStreamSynchronize(st));
         HIP_TRY(hipMemcpy(c->d_fix, h_fixation, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
+        int rc = build_sublut(c, geom);
+        if (rc != FVVDP_OK) return rc;
     }
     FinalizeArgs fa;
     memset(&fa, 0, sizeof(fa));
@@ -1558,23 +1592,26 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
             dbg = a.dD || a.dC || a.dL || a.dS;
         }
         if (fov) {
-            a.lut3[0] = c->lut3[0];
-            a.lut3[1] = c->lut3[1] ? c->lut3[1] : c->lut3[0];
-            a.ax_rho = c->ax_rho;
-            a.ax_ecc = c->ax_ecc;
+            a.sublut = c->sublut[b];
+            a.axes = c->d_axes;
+            a.rw = c->sub_rw[b];
+            a.i_lo = c->sub_ilo[b];
             a.fix = c->d_fix;
             a.size_m0 = geom->display_size_m[0];
             a.size_m1 = geom->display_size_m[1];
             a.dist_m = geom->distance_m;
-            a.ppd_c = geom->ppd_centre;
-            const double delta = (1.0 / (double)geom->ppd_centre) / 2.0;
-            a.delta_deg = (float)delta;
-            a.tan_delta = (float)tan(delta * M_PI / 180.0);
+            const double delta = (1.0 / (double)geom->ppd_centre) / 2.0 * M_PI / 180.0;
+            a.delta_rad = (float)delta;
+            a.cos_delta = (float)cos(delta);
             a.rho_band = (float)c->rho_band[b];
             a.rho_lo = c->rho_lo;
             a.rho_hi = c->rho_hi;
             a.ecc_lo = c->ecc_lo;
             a.ecc_hi = c->ecc_hi;
+            for (int ax = 0; ax < 3; ++ax) {
+                a.first[ax] = c->h_axes[ax][0];
+                a.inv_step[ax] = (float)(FVVDP_LUT_N - 1) / (c->h_axes[ax][FVVDP_LUT_N - 1] - c->h_axes[ax][0]);
+            }
             a.frame_w = c->W;
             a.frame_h = c->H;
         }
