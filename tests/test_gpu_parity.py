@@ -395,10 +395,12 @@ def test_full_size_synthetic_video_golden(fv, tag, H, W, disp):
     q, stats = m.predict(test, ref, frames_per_second=30)
     assert abs(float(q) - float(z["jod"])) < 1e-4            # north-star bound: 1e-3
     check_q(stats["Q_per_ch"], z["Q_per_ch"])
-    # frame batching at full size: two batches of 30 give the same numbers
+    # frame batching at full size: two batches of 30.  The work split of the pooled sums depends on the number of
+    # frames per launch, so the fp32 partial sums are grouped differently: equal to rounding, not bit-equal.
     m2 = fv.fvvdp(display_name=disp, batch_frames=30)
     q2, stats2 = m2.predict(test, ref, frames_per_second=30)
-    assert float(q2) == float(q) and np.array_equal(stats["Q_per_ch"], stats2["Q_per_ch"])
+    assert abs(float(q2) - float(q)) < 2e-6
+    assert np.allclose(stats["Q_per_ch"], stats2["Q_per_ch"], rtol=2e-6, atol=0)
 
 
 def test_config4_foveated_uhd_golden(fv):
