@@ -130,6 +130,15 @@ def main():
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": None, "avg_launch_ms": round(t0_ms, 4), "bytes_per_launch": int(b0),
                 "frames_per_launch": frames_per_launch}
+        # HBM bytes per launch from the PMC counters cannot be collected from inside this process; they come from the
+        # committed rocprofv3 --pmc passes of the same kernel and launch shape (tools/pmc_level0.py, profiles/)
+        pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_level0.json")) \
+            if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        if pmc and (W, H, int(frames_per_launch)) == (3840, 2160, 60):
+            with open(os.path.join(ROOT, "profiles", pmc[-1])) as f:
+                pj = json.load(f)
+            roof["traffic"] = int(pj["traffic_bytes"])
+            roof["traffic_source"] = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % pmc[-1]
         # graded pass = all band levels (B_alg of SURVEY section 8(d))
         b_all = sum(4.0 * P * (sizes[i][0] * sizes[i][1] + sizes[i + 1][0] * sizes[i + 1][1]) for i in range(n_bands)) * N * reps
         t_all = sum(ms[1 + i] for i in range(n_bands)) + ms[1 + n_bands]
