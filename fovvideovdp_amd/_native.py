@@ -48,6 +48,7 @@ SYMBOLS = {
     "fvvdp_ctx_set_csf_1d": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "fvvdp_ctx_set_csf_3d": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_float),
                                        C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "fvvdp_ctx_set_view_maps": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
     "fvvdp_temporal_channels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                           C.POINTER(Eotf), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

@@ -675,7 +675,10 @@ struct BandArgs {
     const float4* sublut;   // per band: [32 ecc][32 Y][rw] of {S_log0[i], S_log1[i], S_log0[i+1], S_log1[i+1]} (i = rho knot)
     const float* axes;      // [3][32] knots: Y_log, rho_log, ecc_sqrt
     int rw, i_lo;           // rho knots covered by the band's sub-LUT: [i_lo, i_lo+rw]
-    const float* fix;       // device [n][2] gaze in frame pixels
+    const float* fix;       // device [n][2]: gaze in frame pixels, or gaze view direction in degrees (map mode)
+    const float* mvx;       // map mode (user geometry): view direction x,y [h][w] in degrees and resolution
+    const float* mvy;       //   magnification [h][w] of this band, evaluated by the caller with the user's
+    const float* mrm;       //   geometry object; nullptr = stock geometry computed in-kernel
     float size_m0, size_m1, dist_m, cos_delta, delta_rad;
     float rho_band, rho_lo, rho_hi, ecc_lo, ecc_hi;
     float inv_step[3], first[3];   // uniform-grid estimates of the three axes
@@ -836,11 +839,16 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
         const float xb = ((float)X1 + 0.5f) + (-(float)w / 2.0f);
         vxa = atanf(xa * a.size_m0 / (float)w / a.dist_m) * 57.29577951308232f;
         vxb = atanf(xb * a.size_m0 / (float)w / a.dist_m) * 57.29577951308232f;
-        const float fxp = a.fix[2 * frame + 0] + 0.5f, fyp = a.fix[2 * frame + 1] + 0.5f;
-        const float gxm = (fxp + (-(float)a.frame_w / 2.0f)) * a.size_m0 / (float)a.frame_w;
-        const float gym = -(fyp + (-(float)a.frame_h / 2.0f)) * a.size_m1 / (float)a.frame_h;
-        gx = atanf(gxm / a.dist_m) * 57.29577951308232f;
-        gy = atanf(gym / a.dist_m) * 57.29577951308232f;
+        if (a.mvx) {
+            gx = a.fix[2 * frame + 0];
+            gy = a.fix[2 * frame + 1];
+        } else {
+            const float fxp = a.fix[2 * frame + 0] + 0.5f, fyp = a.fix[2 * frame + 1] + 0.5f;
+            const float gxm = (fxp + (-(float)a.frame_w / 2.0f)) * a.size_m0 / (float)a.frame_w;
+            const float gym = -(fyp + (-(float)a.frame_h / 2.0f)) * a.size_m1 / (float)a.frame_h;
+            gx = atanf(gxm / a.dist_m) * 57.29577951308232f;
+            gy = atanf(gym / a.dist_m) * 57.29577951308232f;
+        }
     }
 
     const float lg_bm = __log2f(a.band_mul);
@@ -849,6 +857,7 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
 
     // per-pixel tail: contrast, CSF, masking, pooling  (fvvdp_lpyr_dec.py:259-269, fvvdp.py:395-467)
     auto band_px = [&](const Px<P>& g, const Px<P>& e, bool valid, int y, int x, float vx, float vy) {
+        (void)x;
         const float lb = fmaxf(e.h[0].y, a.lbkg_min);                  // plane 1 = reference (sustained)
         // contrast = min((g-e)/lb, cmax) * m.  Dividing by lb>0 commutes with |.|, min and the clamp, so the
         // division is carried as -log2(lb) in the log domain below: no reciprocal, no per-plane multiply.
@@ -874,10 +883,19 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
             // eccentricity and resolution magnification (fvvdp.py:424-437, fvvdp_display_model.py:475-526).
             // (tan(a+d)-tan(a))/tan(d) == cos(d)/(cos(a)cos(a+d)): evaluated in this form it needs no slow tan and
             // does not lose digits to the reference's fp32 finite difference (whose noise, ~5e-4, bounds parity).
+            float res_mag;
+            if (a.mvx) {                          // user geometry: maps evaluated by the caller
+                const int yc = min(y, h - 1), xc = min(x, w - 1);
+                const size_t o = (size_t)yc * w + xc;
+                vx = a.mvx[o];
+                vy = a.mvy[o];
+                res_mag = a.mrm[o];
+            } else {
+                const float va = fminf(__builtin_amdgcn_sqrtf(vx * vx + vy * vy), 89.9f) * 0.017453292519943295f;
+                res_mag = a.cos_delta * fast_rcp(__cosf(va) * __cosf(va + a.delta_rad));
+            }
             const float dx = vx - gx, dy = vy - gy;
             const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
-            const float va = fminf(__builtin_amdgcn_sqrtf(vx * vx + vy * vy), 89.9f) * 0.017453292519943295f;
-            const float res_mag = a.cos_delta * fast_rcp(__cosf(va) * __cosf(va + a.delta_rad));
             const float rho = a.rho_band * res_mag;
             const float rq = fast_log2(fminf(fmaxf(rho, a.rho_lo), a.rho_hi));
             const float eq = __builtin_amdgcn_sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
@@ -1092,6 +1110,11 @@ struct fvvdp_ctx {
     float4* sublut[FVVDP_MAX_BANDS]{};         // per-band rho slices, rebuilt when the geometry changes
     int sub_rw[FVVDP_MAX_BANDS]{}, sub_ilo[FVVDP_MAX_BANDS]{};
     fvvdp_geom sub_geom{};
+    const float* map_vx[FVVDP_MAX_BANDS]{};    // user-geometry maps (owned by the caller)
+    const float* map_vy[FVVDP_MAX_BANDS]{};
+    const float* map_rm[FVVDP_MAX_BANDS]{};
+    float map_rm_max[FVVDP_MAX_BANDS]{}, map_rm_min[FVVDP_MAX_BANDS]{};
+    bool maps_set = false;
     bool sub_valid = false;
     float rho_lo = 0, rho_hi = 0, ecc_lo = 0, ecc_hi = 0;
     bool lut3_set[2] = {false, false};
@@ -1477,17 +1500,27 @@ extern "C" int fvvdp_export_level(fvvdp_ctx* c, int level, int n, float* d_out, 
 // [ecc][Y][rho] of float4 {S0[i], S1[i], S0[i+1], S1[i+1]} so that one aligned 16-byte load returns the two rho
 // corners of both temporal channels and neighbouring pixels (similar ecc, Y) share cache lines.
 static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g) {
-    if (c->sub_valid && memcmp(&c->sub_geom, g, sizeof(*g)) == 0) return FVVDP_OK;
-    const double delta = (1.0 / (double)g->ppd_centre) / 2.0 * M_PI / 180.0;
-    const double ax = atan(0.5 * g->display_size_m[0] / g->distance_m) * 180.0 / M_PI;
-    const double ay = atan(0.5 * g->display_size_m[1] / g->distance_m) * 180.0 / M_PI;
-    double va = sqrt(ax * ax + ay * ay);
-    if (va > 89.9) va = 89.9;
-    va *= M_PI / 180.0;
-    const double mag_max = cos(delta) / (cos(va) * cos(va + delta)) * 1.01;   // 1 % margin over the corner pixel
+    fvvdp_geom key;
+    memset(&key, 0, sizeof(key));
+    if (g) key = *g;
+    if (c->sub_valid && memcmp(&c->sub_geom, &key, sizeof(key)) == 0) return FVVDP_OK;
+    double mag_max = 1.0, mag_min = 1.0;
+    if (g) {
+        const double delta = (1.0 / (double)g->ppd_centre) / 2.0 * M_PI / 180.0;
+        const double ax = atan(0.5 * g->display_size_m[0] / g->distance_m) * 180.0 / M_PI;
+        const double ay = atan(0.5 * g->display_size_m[1] / g->distance_m) * 180.0 / M_PI;
+        double va = sqrt(ax * ax + ay * ay);
+        if (va > 89.9) va = 89.9;
+        va *= M_PI / 180.0;
+        mag_max = cos(delta) / (cos(va) * cos(va + delta)) * 1.01;   // 1 % margin over the corner pixel
+    }
     const float* xr = c->h_axes[1];
     for (int b = 0; b < c->n_bands; ++b) {
-        double r_lo = c->rho_band[b], r_hi = c->rho_band[b] * mag_max;
+        if (!g) {                // user geometry: the caller states the range of its magnification map
+            mag_max = c->map_rm_max[b] > 0 ? (double)c->map_rm_max[b] * 1.01 : 1e9;
+            mag_min = c->map_rm_min[b] > 0 ? (double)c->map_rm_min[b] * 0.99 : 0.0;
+        }
+        double r_lo = c->rho_band[b] * mag_min, r_hi = c->rho_band[b] * mag_max;
         const double lo_c = exp2((double)xr[0]), hi_c = exp2((double)xr[FVVDP_LUT_N - 1]);
         r_lo = fmin(fmax(r_lo, lo_c), hi_c);
         r_hi = fmin(fmax(r_hi, lo_c), hi_c);
@@ -1518,7 +1551,7 @@ static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g) {
         c->sub_rw[b] = rw;
         c->sub_ilo[b] = i_lo;
     }
-    c->sub_geom = *g;
+    c->sub_geom = key;
     c->sub_valid = true;
     return FVVDP_OK;
 }
@@ -1541,7 +1574,7 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
     if (n < 1 || n > c->max_frames) return fail(FVVDP_EINVAL, "n=%d exceeds max_frames=%d", n, c->max_frames);
     if (q_col0 < 0 || q_col0 + n > q_stride) return fail(FVVDP_EINVAL, "Q columns out of range");
     const bool fov = h_fixation != nullptr;
-    if (fov && !geom) return fail(FVVDP_EINVAL, "foveated mode needs the display geometry");
+    if (fov && !geom && !c->maps_set) return fail(FVVDP_EINVAL, "foveated mode needs the display geometry (or fvvdp_ctx_set_view_maps)");
     if (fov && !(c->lut3_set[0] && (c->P == 2 || c->lut3_set[1]))) return fail(FVVDP_ESTATE, "fvvdp_ctx_set_csf_3d not called");
     if (!fov && !c->csf_set) return fail(FVVDP_ESTATE, "fvvdp_ctx_set_csf_1d not called");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -1597,12 +1630,19 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
             a.rw = c->sub_rw[b];
             a.i_lo = c->sub_ilo[b];
             a.fix = c->d_fix;
-            a.size_m0 = geom->display_size_m[0];
-            a.size_m1 = geom->display_size_m[1];
-            a.dist_m = geom->distance_m;
-            const double delta = (1.0 / (double)geom->ppd_centre) / 2.0 * M_PI / 180.0;
-            a.delta_rad = (float)delta;
-            a.cos_delta = (float)cos(delta);
+            if (geom) {
+                a.size_m0 = geom->display_size_m[0];
+                a.size_m1 = geom->display_size_m[1];
+                a.dist_m = geom->distance_m;
+                const double delta = (1.0 / (double)geom->ppd_centre) / 2.0 * M_PI / 180.0;
+                a.delta_rad = (float)delta;
+                a.cos_delta = (float)cos(delta);
+            } else {
+                a.size_m0 = a.size_m1 = a.dist_m = 1.0f;
+                a.mvx = c->map_vx[b];
+                a.mvy = c->map_vy[b];
+                a.mrm = c->map_rm[b];
+            }
             a.rho_band = (float)c->rho_band[b];
             a.rho_lo = c->rho_lo;
             a.rho_hi = c->rho_hi;
@@ -1640,6 +1680,28 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
         hipLaunchKernelGGL(finalize_kernel, dim3(total), dim3(64), 0, st, fa);
     }
     HIP_TRY(hipGetLastError());
+    return FVVDP_OK;
+}
+
+extern "C" int fvvdp_ctx_set_view_maps(fvvdp_ctx* c, int band, const float* d_view_x, const float* d_view_y,
+                                       const float* d_res_mag, float res_mag_min, float res_mag_max) {
+    if (!c) return fail(FVVDP_EINVAL, "null context");
+    if (band < 0 || band >= c->n_bands) return fail(FVVDP_EINVAL, "band %d out of range", band);
+    if (!d_view_x || !d_view_y || !d_res_mag) {      // clear
+        for (int b = 0; b < FVVDP_MAX_BANDS; ++b) c->map_vx[b] = c->map_vy[b] = c->map_rm[b] = nullptr;
+        c->maps_set = false;
+        c->sub_valid = false;
+        return FVVDP_OK;
+    }
+    c->map_vx[band] = d_view_x;
+    c->map_vy[band] = d_view_y;
+    c->map_rm[band] = d_res_mag;
+    c->map_rm_max[band] = res_mag_max;
+    c->map_rm_min[band] = res_mag_min;
+    c->maps_set = true;
+    for (int b = 0; b < c->n_bands; ++b)
+        if (!c->map_vx[b]) c->maps_set = false;      // complete only when every band has its maps
+    c->sub_valid = false;
     return FVVDP_OK;
 }
 

@@ -212,7 +212,12 @@ class fvvdp:
             fx, g = None, None
             if self.foveated:
                 fxa = np.ascontiguousarray(fix[b0:b0 + nb], dtype=np.float32)
-                fx, g = nat.fptr(fxa), C.byref(self._geom_struct())
+                if native_geometry(self.display_geometry) is not None:
+                    g = C.byref(self._geom_struct())
+                else:                                # user geometry: maps + gaze view directions (degrees)
+                    self._set_view_maps(ctx, n_bands, width, height)
+                    fxa = self._gaze_view_dirs(fxa, width, height)
+                fx = nat.fptr(fxa)
             nat.check(nat.lib().fvvdp_bands_forward(ctx.handle, nb, C.c_void_p(Q.data_ptr()), n_out, b0 - f0,
                                                     fx, g, maps_arr, stream))
             if self.do_heatmap:
@@ -366,11 +371,41 @@ class fvvdp:
         budget = 24e9                                  # resident pyramid scratch (of 288 GB HBM3E)
         return max(1, min(n_out, 128, int(budget // per_frame)))
 
+    def _set_view_maps(self, ctx, n_bands, width, height):
+        """User geometry model: evaluate its pix2view_direction / get_resolution_magnification once per band on the
+        band's pixel grid (as the reference does per frame, fvvdp.py:424-437) and hand the maps to the kernels."""
+        if getattr(ctx, "view_maps", None) is not None:
+            return
+        maps = []
+        w_b, h_b = width, height
+        for b in range(n_bands):
+            xv = torch.linspace(0.5, w_b - 0.5, w_b, device=self.device)
+            yv = torch.linspace(0.5, h_b - 0.5, h_b, device=self.device)
+            xx, yy = torch.meshgrid(xv, yv, indexing='xy')
+            vd = self.display_geometry.pix2view_direction(torch.tensor((w_b, h_b)), xx, yy)
+            rm = self.display_geometry.get_resolution_magnification(vd)
+            if rm.dim() == 0:
+                rm = rm.expand(h_b, w_b)
+            vx = vd[0].to(torch.float32).contiguous()
+            vy = vd[1].to(torch.float32).contiguous()
+            rm = rm.to(torch.float32).contiguous()
+            maps.append((vx, vy, rm))
+            nat.check(nat.lib().fvvdp_ctx_set_view_maps(ctx.handle, b, C.c_void_p(vx.data_ptr()), C.c_void_p(vy.data_ptr()),
+                                                        C.c_void_p(rm.data_ptr()), float(rm.min()), float(rm.max())))
+            w_b, h_b = (w_b + 1) // 2, (h_b + 1) // 2
+        ctx.view_maps = maps          # keep the tensors alive as long as the context
+
+    def _gaze_view_dirs(self, fix_px, width, height):
+        """Gaze positions [n,2] in frame pixels -> view directions in degrees through the user's geometry."""
+        fx = torch.as_tensor(fix_px[:, 0] + 0.5, device=self.device)
+        fy = torch.as_tensor(fix_px[:, 1] + 0.5, device=self.device)
+        vd = self.display_geometry.pix2view_direction(torch.tensor((width, height)), fx, fy)
+        return np.ascontiguousarray(torch.stack((vd[0], vd[1]), dim=1).to(torch.float32).cpu().numpy())
+
     def _geom_struct(self):
         d = native_geometry(self.display_geometry)
         if d is None:
-            raise RuntimeError("foveated mode with a custom fvvdp_display_geometry subclass is not supported by the "
-                               "HIP path yet (only the stock geometry model runs in-kernel)")
+            raise RuntimeError("internal: user geometry goes through _set_view_maps")
         g = nat.Geom()
         g.display_size_m[0], g.display_size_m[1] = d["display_size_m"]
         g.distance_m, g.ppd_centre = d["distance_m"], d["ppd_centre"]

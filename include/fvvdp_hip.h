@@ -128,6 +128,15 @@ int fvvdp_ctx_set_csf_1d(fvvdp_ctx* ctx, const float* h_Y_log, const float* h_S_
 int fvvdp_ctx_set_csf_3d(fvvdp_ctx* ctx, int temporal_channel, const float* h_S_log, const float* h_Y_log,
                          const float* h_rho_log, const float* h_ecc_sqrt);
 
+/* Foveated mode with a USER geometry model (a subclass of fvvdp_display_geometry with its own pix2view_direction /
+ * get_ppd, e.g. pytorch_examples/ex_custom_ppd.py:38-57): the caller evaluates, once per band, the view direction
+ * of every band pixel and the resolution magnification with the user's object (fvvdp.py:424-437) and hands the maps
+ * over; fvvdp_bands_forward is then called with geom == NULL and h_fixation holding the gaze VIEW DIRECTION in
+ * degrees for each slot.  d_view_x, d_view_y, d_res_mag: [h_b][w_b] fp32, must stay alive; res_mag_min/max = range of
+ * the magnification map (bounds the rho slice of the LUT).  Passing NULL maps clears map mode.             */
+int fvvdp_ctx_set_view_maps(fvvdp_ctx* ctx, int band, const float* d_view_x, const float* d_view_y,
+                            const float* d_res_mag, float res_mag_min, float res_mag_max);
+
 /* ---- stage 1: frames -> temporal channels --------------------------------------------------------------- */
 
 /* Replaces fvvdp_video_source_array._get_frame (video_source.py:180-208), fvvdp_display_photo_eotf.forward

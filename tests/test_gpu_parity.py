@@ -416,3 +416,39 @@ def test_config4_foveated_uhd_golden(fv):
     assert abs(float(q) - float(z["jod"])) < 2e-4
     qq, gq = stats["Q_per_ch"].astype(np.float64), z["Q_per_ch"].astype(np.float64)
     assert np.all(np.abs(qq - gq) <= 3e-3 * np.abs(gq) + 1e-6 * np.max(gq))
+
+
+def test_custom_geometry_subclass_foveated(fv):
+    """User subclass of fvvdp_display_geometry with its own ppd model (like the reference's ex_custom_ppd.py): the
+    kernels take per-band view-direction / magnification maps evaluated with the user's object."""
+    from fovvideovdp_amd.synth import synth_video_pair, synth_gaze
+    from oracle import fvvdp_oracle as orc
+    N, H, W, fps = 5, 120, 160, 30
+
+    class MyGeom(fv.fvvdp_display_geometry):
+        def get_ppd(self, view_dir=None):
+            if view_dir is None:
+                return self.ppd_centre
+            view_angle = torch.sqrt(torch.sum(view_dir ** 2, dim=0, keepdim=False))
+            return self.ppd_centre / (view_angle / 20. + 1.)
+
+    class OGeom(orc.Geometry):
+        def resolution_magnification(self, vx, vy):
+            va = np.sqrt(vx * vx + vy * vy).astype(np.float32)
+            return (np.float32(self.ppd_centre) / (va / np.float32(20.) + np.float32(1.)) / np.float32(self.ppd_centre)).astype(np.float32)
+
+    test, ref = synth_video_pair(N, H, W)
+    gaze = synth_gaze(N, H, W).numpy()
+    g = MyGeom((W, H), distance_m=0.5, fov_diagonal=70.0)
+    m = fv.fvvdp(display_name="standard_hmd", display_geometry=g, foveated=True)
+    q, stats = m.predict(test, ref, frames_per_second=fps, fixation_point=gaze)
+    og = OGeom((W, H), distance_m=0.5, fov_diagonal=70.0)
+    o = orc.Oracle("standard_hmd", geometry=og, foveated=True)
+    oq, ostats = o.predict(test.numpy(), ref.numpy(), frames_per_second=fps, fixation_point=gaze)
+    assert abs(float(q) - float(oq)) < 2e-4
+    qq, gq = stats["Q_per_ch"].astype(np.float64), ostats["Q_per_ch"].astype(np.float64)
+    assert np.all(np.abs(qq - gq) <= 3e-3 * np.abs(gq) + 1e-5 * np.max(gq)), np.max(np.abs(qq - gq) / (np.abs(gq) + 1e-5 * np.max(gq)))
+    # and it differs from the stock model (the custom ppd lowers the resolution away from the centre)
+    m0 = fv.fvvdp(display_name="standard_hmd", display_geometry=fv.fvvdp_display_geometry((W, H), distance_m=0.5, fov_diagonal=70.0), foveated=True)
+    q0, _ = m0.predict(test, ref, frames_per_second=fps, fixation_point=gaze)
+    assert abs(float(q0) - float(q)) > 1e-3
