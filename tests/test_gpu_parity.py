@@ -452,3 +452,46 @@ def test_custom_geometry_subclass_foveated(fv):
     m0 = fv.fvvdp(display_name="standard_hmd", display_geometry=fv.fvvdp_display_geometry((W, H), distance_m=0.5, fov_diagonal=70.0), foveated=True)
     q0, _ = m0.predict(test, ref, frames_per_second=fps, fixation_point=gaze)
     assert abs(float(q0) - float(q)) > 1e-3
+
+
+def test_float_sources_all_eotfs_vs_oracle(fv):
+    """fp32 sources go through the in-kernel display models (sRGB, gamma, PQ, linear, absolute); uint16 video goes
+    through the 65536-entry LUT.  Compared with the oracle; PQ at the dark end is a finite difference of fp32 pows in
+    the reference formula itself (tolerance 1e-3 on Q there)."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    N, H, W, fps = 6, 72, 128, 30
+    test8, ref8 = synth_video_pair(N, H, W)
+    tf, rf = test8.float() / 255, ref8.float() / 255
+
+    cases = []
+    cases.append(("standard_fhd sRGB rgb", dict(display_name="standard_fhd"), orc.Oracle("standard_fhd"), tf, rf, 1.0))
+    cases.append(("hdr pq rgb", dict(display_name="standard_hdr_pq"), orc.Oracle("standard_hdr_pq"), tf, rf, 1.0))
+    cases.append(("hdr linear", dict(display_name="standard_hdr_linear"), orc.Oracle("standard_hdr_linear"), tf * 900.0, rf * 900.0, 1.0))
+    gm = fv.fvvdp_display_photo_eotf(300, contrast=2000, EOTF="gamma", gamma=2.4, E_ambient=100)
+    cases.append(("gamma 2.4", dict(display_name="standard_fhd", display_photometry=gm),
+                  orc.Oracle("standard_fhd", photometry=orc.Photometry(300, contrast=2000, EOTF="gamma", gamma=2.4, E_ambient=100)), tf, rf, 1.0))
+
+    class OAbs:
+        def forward(self, V):
+            return np.clip(V, np.float32(0.005), np.float32(10000)).astype(np.float32), False
+
+    cases.append(("absolute", dict(display_name="standard_4k", display_photometry=fv.fvvdp_display_photo_absolute()),
+                  orc.Oracle("standard_4k", photometry=OAbs()), tf * 400.0 + 0.5, rf * 400.0 + 0.5, 1.0))
+    for name, kw, o, t, r, scale in cases:
+        m = fv.fvvdp(**kw)
+        q, stats = m.predict(t, r, frames_per_second=fps)
+        oq, ostats = o.predict(t.numpy(), r.numpy(), frames_per_second=fps)
+        assert abs(float(q) - float(oq)) < 2e-4, name
+        check_q(stats["Q_per_ch"], ostats["Q_per_ch"], coarse=2e-3, fine=1e-3 if "pq" in name else 2e-4)
+    # uint16 video (int16-packed on the torch side like the reference)
+    t16 = (test8.numpy().astype(np.uint16) * 257)
+    r16 = (ref8.numpy().astype(np.uint16) * 257)
+    m = fv.fvvdp(display_name="standard_fhd")
+    q, stats = m.predict(t16, r16, frames_per_second=fps)
+    oq, ostats = orc.Oracle("standard_fhd").predict(t16, r16, frames_per_second=fps)
+    assert abs(float(q) - float(oq)) < 1e-4
+    check_q(stats["Q_per_ch"], ostats["Q_per_ch"], coarse=2e-3, fine=2e-4)
+    # uint8 codes x257 are the same normalised values: identical luminance, identical result as the uint8 video
+    q8, _ = m.predict(test8, ref8, frames_per_second=fps)
+    assert abs(float(q8) - float(q)) < 1e-5

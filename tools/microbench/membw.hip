@@ -67,7 +67,8 @@ __global__ __launch_bounds__(64) void read_strips(const float4* __restrict__ img
             const int Wc = W / 2;
             const int J = strip * ACTIVE + lane - HALO_L;
             if (J < Wc) {
-                float4* dst = coarse + ((size_t)frame * (H / 2) + r / 2) * Wc + J;
+                float4* dst = (NT & 4) ? coarse + (((size_t)frame * n_strips + strip) * (H / 2) + r / 2) * 64 + lane
+                                       : coarse + ((size_t)frame * (H / 2) + r / 2) * Wc + J;
                 const float4 val = make_float4(a0.x, b0.x, c0.x, d0.x);
                 typedef float vf4 __attribute__((ext_vector_type(4)));
                 if constexpr (NT & 2) __builtin_nontemporal_store(vf4{val.x, val.y, val.z, val.w}, reinterpret_cast<vf4*>(dst));
@@ -117,14 +118,12 @@ int main() {
         const int n_chunks = (H + chunk_rows - 1) / chunk_rows;
         const int n_strips = 32, grid = n_strips * n_chunks * N;
         double t;
-        t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 0>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
-        printf("rows/chunk %4d: plain ld/st            : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
-        t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 1>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
-        printf("rows/chunk %4d: nt loads               : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
         t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 2>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
-        printf("rows/chunk %4d: nt stores              : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
-        t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 3>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
-        printf("rows/chunk %4d: nt loads + nt stores   : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
+        printf("rows/chunk %4d: row-major coarse, nt stores        : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
+        t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 6>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+        printf("rows/chunk %4d: strip-contiguous coarse, nt stores : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
+        t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 4>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+        printf("rows/chunk %4d: strip-contiguous coarse, plain     : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
     }
     return 0;
 }
