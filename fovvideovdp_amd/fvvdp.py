@@ -259,18 +259,21 @@ class fvvdp:
     # ---- pooling and JOD regression (Python, as in the reference) ------------------------------------------
     def do_pooling_and_jods(self, Q_per_ch, rho_band):
         """Q_per_ch [bands, temporal channels, frames] -> JOD (0-d tensor).  Minkowski pooling over spatial bands
-        (beta_sch), temporal channels (beta_tch, transient weighted by w_transient) and frames (beta_t, mean)."""
+        (beta_sch), temporal channels (beta_tch, transient weighted by w_transient) and frames (beta_t, mean).
+        A leading batch dimension [K, bands, channels, frames] pools K videos at once -> [K]."""
         Q = Q_per_ch
-        if Q.shape[1] == 2:
+        d = Q.dim() - 3                        # 0, or 1 with a leading batch of videos
+        if Q.shape[d + 1] == 2:
             w = torch.tensor([1.0, self.w_transient], dtype=Q.dtype, device=Q.device).view(1, 2, 1)
             Q = Q * w
-        Q_sc = self.lp_norm(Q, self.beta_sch, 0, False)
-        Q_tc = self.lp_norm(Q_sc, self.beta_tch, 1, False)
-        Q_all = self.lp_norm(Q_tc, self.beta_t, 2, True).squeeze()
+        Q_sc = self.lp_norm(Q, self.beta_sch, d + 0, False)
+        Q_tc = self.lp_norm(Q_sc, self.beta_tch, d + 1, False)
+        Q_all = self.lp_norm(Q_tc, self.beta_t, d + 2, True)
+        Q_all = Q_all.reshape(Q_all.shape[0]) if d == 1 else Q_all.squeeze()
         beta_jod = 10.0 ** self.log_jod_exp
         sign = -1 if self.jod_a < 0 else 1
         Q_jod = sign * ((abs(self.jod_a) ** (1.0 / beta_jod)) * Q_all) ** beta_jod + 10.0
-        return Q_jod.squeeze()
+        return Q_jod if d == 1 else Q_jod.squeeze()
 
     def lp_norm(self, x, p, dim=0, normalize=True):
         N = x.shape[dim] if normalize else 1.0

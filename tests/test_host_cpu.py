@@ -143,6 +143,13 @@ def test_pooling_and_jod_regression():
         assert jod.dim() == 0
         assert abs(float(jod) - float(z["jod"])) < 2e-6
     assert float(m.do_pooling_and_jods(torch.zeros(7, 2, 5), None)) == 10.0
+    # batched form used by the multi-GPU gather: [K, bands, 2, N] -> [K], same numbers as one by one
+    z = load("g2_video_135x240_replicate")
+    Qb = torch.stack([torch.tensor(z["Q_per_ch"]), torch.tensor(z["Q_per_ch"]) * 0.5, torch.zeros_like(torch.tensor(z["Q_per_ch"]))])
+    jb = m.do_pooling_and_jods(Qb, None)
+    assert jb.shape == (3,)
+    for k in range(3):
+        assert abs(float(jb[k]) - float(m.do_pooling_and_jods(Qb[k], None))) < 1e-6
 
 
 def test_display_models_against_reference_vectors():
