@@ -29,6 +29,10 @@ class Eotf(C.Structure):
                 ("L_min", C.c_float), ("L_max", C.c_float), ("d_lut", C.c_void_p)]
 
 
+class YuvFormat(C.Structure):
+    _fields_ = [("bit_depth", C.c_int32), ("chroma_420", C.c_int32), ("ycbcr2rgb", C.c_float * 9)]
+
+
 class Geom(C.Structure):
     _fields_ = [("display_size_m", C.c_float * 2), ("distance_m", C.c_float), ("ppd_centre", C.c_float)]
 
@@ -52,6 +56,9 @@ SYMBOLS = {
     "fvvdp_temporal_channels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                           C.POINTER(Eotf), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "fvvdp_temporal_channels_yuv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(YuvFormat), C.c_size_t,
+                                              C.POINTER(Eotf), C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                              C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fvvdp_load_channels_planar": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "fvvdp_bands_forward": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
                                       C.POINTER(Geom), C.POINTER(BandMaps), C.c_void_p]),

@@ -506,6 +506,121 @@ __global__ __launch_bounds__(64) void temporal_vec_kernel(const TemporalArgs a) 
     if (bad && a.oob) atomicOr(a.oob, 1);
 }
 
+// ---- planar YUV ingest fused with the temporal filter ---------------------------------------------------------
+// Replaces video_reader_yuv_pytorch.unpack / _fixed2float_upscale (video_source_file.py:219-276) + _prepare_frame
+// (:355-363): limited-range fixed->float (Y: w*Y-16/219 clipped to [0,1]; Cb,Cr: w*c-128/224 clipped to +-0.5),
+// 4:2:0 chroma bilinear x2 (torch interpolate, align_corners=False: source = (dst+0.5)/2-0.5 clamped at 0),
+// YCbCr->RGB matrix, clip to [0,1], display model per channel, RGB->luminance, then the same register-ring FIR
+// as the other temporal kernels.  One thread owns PX pixels 256 apart (coalesced Y loads and float4 stores).
+struct YuvArgs {
+    const void* src[2];
+    size_t frame_stride;     // elements between frames
+    int W, H, uvw, uvh;
+    int chroma420;
+    float wy, wc;            // 1/(2^(b-8)*219), 1/(2^(b-8)*224)
+    float m[9];              // ycbcr2rgb, row-major: R = m0*Y + m1*Cb + m2*Cr ...
+    EotfDev e;
+    float w[3];
+    int n_out, fl;
+    float* out;
+    int* oob;
+    float taps[2][32];
+    int idx[T_MAX_IDX];
+};
+
+template <typename T>
+__device__ __forceinline__ float yuv_lum(const T* __restrict__ f, const YuvArgs& a, int p, bool& bad) {
+    const int HW = a.W * a.H;
+    const int y = p / a.W, x = p - y * a.W;
+    const float Yf = fminf(fmaxf(a.wy * (float)f[p] - (16.0f / 219.0f), 0.0f), 1.0f);
+    const T* U = f + HW;
+    const T* V = U + a.uvw * a.uvh;
+    auto cf = [&](const T* pl, int yy, int xx) {
+        return fminf(fmaxf(a.wc * (float)pl[yy * a.uvw + xx] - (128.0f / 224.0f), -0.5f), 0.5f);
+    };
+    float u, v;
+    if (a.chroma420) {
+        const float sy = fmaxf(((float)y + 0.5f) * 0.5f - 0.5f, 0.0f), sx = fmaxf(((float)x + 0.5f) * 0.5f - 0.5f, 0.0f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = min(y0 + 1, a.uvh - 1), x1 = min(x0 + 1, a.uvw - 1);
+        const float fy = sy - (float)y0, fx = sx - (float)x0;
+        const float gy = 1.0f - fy, gx = 1.0f - fx;
+        u = gy * (gx * cf(U, y0, x0) + fx * cf(U, y0, x1)) + fy * (gx * cf(U, y1, x0) + fx * cf(U, y1, x1));
+        v = gy * (gx * cf(V, y0, x0) + fx * cf(V, y0, x1)) + fy * (gx * cf(V, y1, x0) + fx * cf(V, y1, x1));
+    } else {
+        u = cf(U, y, x);
+        v = cf(V, y, x);
+    }
+    float L = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        float rgb = a.m[3 * c] * Yf + a.m[3 * c + 1] * u + a.m[3 * c + 2] * v;
+        rgb = fminf(fmaxf(rgb, 0.0f), 1.0f);
+        const float l = __fmul_rn(eotf_f32(rgb, a.e, bad), a.w[c]);
+        L = (c == 0) ? l : __fadd_rn(L, l);
+    }
+    return L;
+}
+
+template <int FL, int PX, typename T>
+__global__ __launch_bounds__(256) void temporal_yuv_kernel(const YuvArgs a) {
+    const int HW = a.W * a.H;
+    int px[PX];
+    bool ok[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const int q = blockIdx.x * (256 * PX) + i * 256 + threadIdx.x;
+        ok[i] = q < HW;
+        px[i] = ok[i] ? q : HW - 1;
+    }
+    bool bad = false;
+    float ring[2][FL][PX];
+#pragma unroll
+    for (int u = 0; u < FL; ++u)
+#pragma unroll
+        for (int i = 0; i < PX; ++i) ring[0][u][i] = ring[1][u][i] = 0.0f;
+    const int total = FL - 1 + a.n_out;
+    for (int v0 = 0; v0 < total; v0 += FL) {
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+            const int v = v0 + u;
+            if (v < total) {
+                const size_t off = (size_t)a.idx[v] * a.frame_stride;
+                const T* f0 = reinterpret_cast<const T*>(a.src[0]) + off;
+                const T* f1 = reinterpret_cast<const T*>(a.src[1]) + off;
+#pragma unroll
+                for (int i = 0; i < PX; ++i) {
+                    ring[0][u][i] = yuv_lum<T>(f0, a, px[i], bad);
+                    ring[1][u][i] = yuv_lum<T>(f1, a, px[i], bad);
+                }
+                if (v >= FL - 1) {
+                    float acc[4][PX];
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
+#pragma unroll
+                    for (int k = FL - 1; k >= 0; --k) {
+                        const int sl = (u - k + 2 * FL) % FL;
+                        const float t0 = a.taps[0][k], t1 = a.taps[1][k];
+#pragma unroll
+                        for (int i = 0; i < PX; ++i) {
+                            acc[0][i] = fmaf(ring[0][sl][i], t0, acc[0][i]);
+                            acc[1][i] = fmaf(ring[1][sl][i], t0, acc[1][i]);
+                            acc[2][i] = fmaf(ring[0][sl][i], t1, acc[2][i]);
+                            acc[3][i] = fmaf(ring[1][sl][i], t1, acc[3][i]);
+                        }
+                    }
+                    float* o = a.out + (size_t)(v - (FL - 1)) * HW * 4;
+#pragma unroll
+                    for (int i = 0; i < PX; ++i)
+                        if (ok[i])
+                            *reinterpret_cast<float4*>(o + (size_t)px[i] * 4) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+                }
+            }
+        }
+    }
+    if (bad && a.oob) atomicOr(a.oob, 1);
+}
+
 // Generic (any fl, any frame size) version: one thread per pixel per output frame, the window is re-read from
 // the source (L2-served).  Used for fl > 32, for frame sizes that are not a multiple of 4 pixels and for still
 // images (P == 2: out = (L_test, L_ref), fvvdp.py:251-253).
@@ -1462,6 +1577,66 @@ extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const v
         a.idx = c->d_idx;
         if (c->P == 2) launch_generic<2>(dtype, a, st);
         else launch_generic<4>(dtype, a, st);
+    }
+    HIP_TRY(hipGetLastError());
+    return FVVDP_OK;
+}
+
+template <int FL, int PX>
+static void launch_yuv(int bytes, const YuvArgs& a, hipStream_t st) {
+    const int HW = a.W * a.H;
+    dim3 grid((HW + 256 * PX - 1) / (256 * PX)), block(256);
+    if (bytes == 1) hipLaunchKernelGGL((temporal_yuv_kernel<FL, PX, unsigned char>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((temporal_yuv_kernel<FL, PX, unsigned short>), grid, block, 0, st, a);
+}
+
+extern "C" int fvvdp_temporal_channels_yuv(fvvdp_ctx* c, const void* d_test, const void* d_ref, const fvvdp_yuv_format* fmt,
+                                           size_t frame_stride, const fvvdp_eotf* eotf, const float* h_rgb2y,
+                                           const int32_t* h_frame_idx, const float* h_taps, int fl, int n_out, int slot0,
+                                           int32_t* d_oob_flag, void* stream) {
+    if (!c || !d_test || !d_ref || !fmt || !eotf || !h_rgb2y || !h_frame_idx || !h_taps) return fail(FVVDP_EINVAL, "null argument");
+    if (c->P != 4) return fail(FVVDP_EINVAL, "YUV ingest is for video contexts (planes == 4)");
+    if (fmt->bit_depth < 8 || fmt->bit_depth > 16) return fail(FVVDP_EINVAL, "bit depth %d not supported", fmt->bit_depth);
+    if (fmt->chroma_420 && ((c->W | c->H) & 1)) return fail(FVVDP_EINVAL, "4:2:0 needs even frame dimensions");
+    if (fl < 1 || fl > 32) return fail(FVVDP_EINVAL, "filter length %d out of range for the YUV path (1..32)", fl);
+    if (n_out < 1 || slot0 < 0 || slot0 + n_out > c->max_frames) return fail(FVVDP_EINVAL, "slots out of range");
+    if (eotf->kind == FVVDP_EOTF_LUT) return fail(FVVDP_EINVAL, "YUV sources need a closed-form display model (RGB is fractional after the matrix)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    Timed tm(c, 0, st);
+    const int FL = fl <= 8 ? 8 : (fl <= 16 ? 16 : 32);
+    const int max_out = T_MAX_IDX - (FL - 1);
+    for (int t0 = 0; t0 < n_out; t0 += max_out) {
+        const int nn = (n_out - t0) < max_out ? (n_out - t0) : max_out;
+        YuvArgs a;
+        memset(&a, 0, sizeof(a));
+        a.src[0] = d_test;
+        a.src[1] = d_ref;
+        a.frame_stride = frame_stride;
+        a.W = c->W;
+        a.H = c->H;
+        a.chroma420 = fmt->chroma_420 ? 1 : 0;
+        a.uvw = fmt->chroma_420 ? c->W / 2 : c->W;
+        a.uvh = fmt->chroma_420 ? c->H / 2 : c->H;
+        const float scale = (float)(1 << (fmt->bit_depth - 8));
+        a.wy = 1.0f / (scale * 219.0f);
+        a.wc = 1.0f / (scale * 224.0f);
+        for (int i = 0; i < 9; ++i) a.m[i] = fmt->ycbcr2rgb[i];
+        a.e = make_eotf(eotf);
+        a.w[0] = h_rgb2y[0]; a.w[1] = h_rgb2y[1]; a.w[2] = h_rgb2y[2];
+        a.n_out = nn;
+        a.fl = fl;
+        a.out = c->level[0] + (size_t)(slot0 + t0) * c->W * c->H * 4;
+        a.oob = d_oob_flag;
+        for (int k = 0; k < fl; ++k) { a.taps[0][k] = h_taps[k]; a.taps[1][k] = h_taps[fl + k]; }
+        const int pad = FL - fl;
+        for (int u = 0; u < FL - 1 + nn; ++u) {
+            const int src = t0 + u - pad;
+            a.idx[u] = h_frame_idx[src < 0 ? 0 : src];
+        }
+        const int bytes = fmt->bit_depth > 8 ? 2 : 1;
+        if (FL == 8) launch_yuv<8, 2>(bytes, a, st);
+        else if (FL == 16) launch_yuv<16, 2>(bytes, a, st);
+        else launch_yuv<32, 1>(bytes, a, st);
     }
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;

@@ -20,6 +20,7 @@ from . import _native as nat
 from . import utils
 from .display_model import (fvvdp_display_geometry, fvvdp_display_photometry, native_eotf, native_geometry)
 from .video_source import fvvdp_video_source_array
+from .video_source_yuv import fvvdp_video_source_yuv_frames
 
 
 def _interpolants(x_q, x):
@@ -482,6 +483,33 @@ class fvvdp:
                         N * HW, HW, C.byref(e), nat.fptr(w), idx.ctypes.data_as(C.POINTER(C.c_int32)),
                         nat.fptr(taps), fl, n_out, 0, C.c_void_p(oob.data_ptr()), stream))
                 return feed
+        if isinstance(vs, fvvdp_video_source_yuv_frames) and native_eotf(vs.dm_photometry) is not None:
+            # raw planar YUV: unpacking, chroma upsampling, colour matrix and display model run in the HIP kernel
+            test_d = vs.test_yuv.to(self.device).contiguous()
+            ref_d = vs.reference_yuv.to(self.device).contiguous()
+            desc = native_eotf(vs.dm_photometry)
+            e = nat.Eotf()
+            e.kind = desc[0]
+            e.Y_peak = desc[1].get("Y_peak", 0.0)
+            e.Y_black = desc[1].get("Y_black", 0.0)
+            e.gamma = desc[1].get("gamma", 1.0)
+            e.L_min = desc[1].get("L_min", 0.0)
+            e.L_max = desc[1].get("L_max", 0.0)
+            fmt = nat.YuvFormat()
+            fmt.bit_depth = vs.bit_depth
+            fmt.chroma_420 = 1 if vs.chroma_ss == "420" else 0
+            for i, val in enumerate(np.asarray(vs.ycbcr2rgb, dtype=np.float32).reshape(-1)):
+                fmt.ycbcr2rgb[i] = float(val)
+            w = np.asarray(vs.color_to_luminance, dtype=np.float32)
+
+            def feed_yuv(ctx, idx, taps, fl, n_out, oob, stream):
+                if fl > 32:
+                    raise RuntimeError("frame rate too high for the YUV path (temporal filter longer than 32 taps)")
+                nat.check(lib.fvvdp_temporal_channels_yuv(
+                    ctx.handle, C.c_void_p(test_d.data_ptr()), C.c_void_p(ref_d.data_ptr()), C.byref(fmt), vs.frame_elems,
+                    C.byref(e), nat.fptr(w), idx.ctypes.data_as(C.POINTER(C.c_int32)), nat.fptr(taps), fl, n_out, 0,
+                    C.c_void_p(oob.data_ptr()), stream))
+            return feed_yuv
         # generic sources (user subclasses, custom float photometry): luminance frames come from the source's own
         # get_*_frame (the user's code, run on the device); the kernels take over from the temporal filter on.
         e = nat.Eotf()

@@ -68,3 +68,24 @@ def synth_gaze(N, H, W):
     gx = torch.linspace(0, W - 1, N, dtype=torch.float64)
     gy = torch.linspace(0, H - 1, N, dtype=torch.float64)
     return torch.stack((gx, gy), dim=1).to(torch.float32)
+
+
+def synth_yuv_pair(N, H, W, bit_depth=8, chroma_ss="420", device="cpu", pair=0):
+    """Raw planar limited-range YUV frames (Y plane, then U, then V per frame; [N, frame_elems]) derived from the
+    synthetic RGB pair with integer arithmetic only (bit-identical on CPU and GPU).  uint8 for 8 bit, int32-exact
+    values stored as uint16 (torch.int16 carrier is avoided: returned as int32 tensors to be cast by the caller)."""
+    test, ref = synth_video_pair(N, H, W, device=device, pair=pair)
+    out = []
+    for v in (test, ref):
+        rgb = v[0].permute(1, 0, 2, 3).to(torch.int64)                  # [N,3,H,W]
+        R, G, B = rgb[:, 0], rgb[:, 1], rgb[:, 2]
+        Y = torch.div(66 * R + 129 * G + 25 * B + 128, 256, rounding_mode="floor") + 16
+        U = torch.div(-38 * R - 74 * G + 112 * B + 128, 256, rounding_mode="floor") + 128
+        V = torch.div(112 * R - 94 * G - 18 * B + 128, 256, rounding_mode="floor") + 128
+        if chroma_ss == "420":
+            U = torch.div(U[:, 0::2, 0::2] + U[:, 0::2, 1::2] + U[:, 1::2, 0::2] + U[:, 1::2, 1::2] + 2, 4, rounding_mode="floor")
+            V = torch.div(V[:, 0::2, 0::2] + V[:, 0::2, 1::2] + V[:, 1::2, 0::2] + V[:, 1::2, 1::2] + 2, 4, rounding_mode="floor")
+        sc = 1 << (bit_depth - 8)
+        fr = torch.cat([(Y * sc).reshape(N, -1), (U * sc).reshape(N, -1), (V * sc).reshape(N, -1)], dim=1)
+        out.append(fr.to(torch.uint8) if bit_depth == 8 else fr.to(torch.int32))
+    return out[0], out[1]

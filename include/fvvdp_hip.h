@@ -157,6 +157,24 @@ int fvvdp_temporal_channels(fvvdp_ctx* ctx, const void* d_test, const void* d_re
                             const float* h_rgb2y, const int32_t* h_frame_idx, const float* h_taps, int fl,
                             int n_out, int slot0, int32_t* d_oob_flag, void* stream);
 
+/* Raw planar YUV sources (what video_reader_yuv_pytorch receives from ffmpeg's rawvideo pipe,
+ * video_source_file.py:166-217): every frame is the Y plane [H][W] followed by the U and V planes ([H/2][W/2] for
+ * 4:2:0, [H][W] for 4:4:4), uint8 for bit_depth 8, little-endian uint16 above. */
+typedef struct fvvdp_yuv_format {
+    int32_t bit_depth;       /* 8..16                                        video_source_file.py:196-197       */
+    int32_t chroma_420;      /* 1 = 4:2:0 (bilinear x2 chroma upsampling), 0 = 4:4:4   :199-201, :268-272       */
+    float ycbcr2rgb[9];      /* row-major 3x3, BT.709 or BT.2020nc              :225-235                          */
+} fvvdp_yuv_format;
+
+/* Replaces video_reader_yuv_pytorch.unpack + _fixed2float_upscale (video_source_file.py:219-276),
+ * fvvdp_video_source_video_file._prepare_frame (:355-363) and the temporal filter (fvvdp.py:258-300): like
+ * fvvdp_temporal_channels, but the source frames are raw planar YUV.  frame_stride in elements; the display model
+ * must be closed-form (kind != FVVDP_EOTF_LUT); full-screen resizing is not supported. */
+int fvvdp_temporal_channels_yuv(fvvdp_ctx* ctx, const void* d_test, const void* d_ref, const fvvdp_yuv_format* fmt,
+                                size_t frame_stride, const fvvdp_eotf* eotf, const float* h_rgb2y,
+                                const int32_t* h_frame_idx, const float* h_taps, int fl, int n_out, int slot0,
+                                int32_t* d_oob_flag, void* stream);
+
 /* Alternative entry for callers that already hold the temporal channels in the reference layout
  * R[n][P][H][W] (planar fp32, fvvdp.py:294): copies them into pyramid level 0 of slots [slot0, slot0+n). */
 int fvvdp_load_channels_planar(fvvdp_ctx* ctx, const float* d_R, int n, int slot0, void* stream);

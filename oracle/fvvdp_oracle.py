@@ -237,6 +237,37 @@ def frame_luminance(arr_bcfhw, f, photometry, rgb2y):
     return L[0, 0, 0].astype(_F), oob
 
 
+def yuv_unpack(frame, W, H, bit_depth, chroma_ss, color_space):
+    """video_reader_yuv_pytorch.unpack + _fixed2float_upscale, pyfvvdp/video_source_file.py:219-276.
+    frame: 1-D uint8/uint16 (Y plane, U plane, V plane) -> RGB [H,W,3] fp32 in [0,1]."""
+    ypx = W * H
+    uvh, uvw = (H // 2, W // 2) if chroma_ss == "420" else (H, W)
+    x = frame.astype(_F)
+    sc = 2 ** (bit_depth - 8)
+    Y = np.clip(_F(1 / (sc * 219)) * x[:ypx] - _F(16 / 219), 0, 1).reshape(H, W).astype(_F)                # :246-251
+    uv = np.clip(_F(1 / (sc * 224)) * x[ypx:] - _F(128 / 224), _F(-0.5), _F(0.5)).reshape(2, uvh, uvw).astype(_F)  # :253-258
+    if chroma_ss == "420":                                                                             # :260-262
+        # torch interpolate(scale_factor=2, mode='bilinear', align_corners=False): src = (dst+0.5)/2-0.5, clamped at 0
+        def axis(n_out, n_in):
+            src = np.maximum((np.arange(n_out, dtype=_F) + _F(0.5)) * _F(0.5) - _F(0.5), _F(0))
+            i0 = src.astype(np.int64)
+            i1 = np.minimum(i0 + 1, n_in - 1)
+            f = (src - i0.astype(_F)).astype(_F)
+            return i0, i1, f
+        y0, y1, fy = axis(H, uvh)
+        x0, x1, fx = axis(W, uvw)
+        fy, fx = fy[None, :, None], fx[None, None, :]
+        top = (_F(1) - fx) * uv[:, y0][:, :, x0] + fx * uv[:, y0][:, :, x1]
+        bot = (_F(1) - fx) * uv[:, y1][:, :, x0] + fx * uv[:, y1][:, :, x1]
+        uv = ((_F(1) - fy) * top + fy * bot).astype(_F)
+    Yuv = np.stack((Y, uv[0], uv[1]), axis=-1)
+    if color_space == "bt2020nc":                                                                      # :225-235
+        M = np.array([[1, 0, 1.47460], [1, -0.16455, -0.57135], [1, 1.88140, 0]], dtype=_F)
+    else:
+        M = np.array([[1, 0, 1.402], [1, -0.344136, -0.714136], [1, 1.772, 0]], dtype=_F)
+    return np.clip(Yuv @ M.T, 0, 1).astype(_F)                                                          # :237,244
+
+
 # --------------------------------------------------------------------------------------------------------
 # temporal filters and sliding window  (pyfvvdp/fvvdp.py:228-230, 258-300, 609-630)
 # --------------------------------------------------------------------------------------------------------
@@ -550,6 +581,16 @@ class Oracle:
             self.capture.setdefault("L_bkg", []).append(lbkg)
             self.capture.setdefault("R", []).append(R)
         return Q
+
+    def predict_yuv(self, test_yuv, ref_yuv, frames_per_second, W, H, bit_depth=8, chroma_ss="420", color_space="bt709",
+                    fixation_point=None, frames=None):
+        """Raw planar YUV frames [N, frame_elems] through unpack -> photometry -> luminance
+        (fvvdp_video_source_video_file._prepare_frame, pyfvvdp/video_source_file.py:355-363), then the usual path."""
+        def to_rgb(arr):
+            vid = np.stack([yuv_unpack(arr[f], W, H, bit_depth, chroma_ss, color_space) for f in range(arr.shape[0])], 0)
+            return np.ascontiguousarray(vid.transpose(3, 0, 1, 2)[None])           # [1,3,N,H,W] fp32
+        return self.predict(to_rgb(np.asarray(test_yuv)), to_rgb(np.asarray(ref_yuv)), "BCFHW", frames_per_second,
+                            fixation_point, frames)
 
     def predict(self, test, ref, dim_order="BCFHW", frames_per_second=0, fixation_point=None, frames=None):
         """fvvdp.predict / predict_video_source, pyfvvdp/fvvdp.py:181-334.

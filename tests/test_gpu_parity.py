@@ -495,3 +495,39 @@ def test_float_sources_all_eotfs_vs_oracle(fv):
     # uint8 codes x257 are the same normalised values: identical luminance, identical result as the uint8 video
     q8, _ = m.predict(test8, ref8, frames_per_second=fps)
     assert abs(float(q8) - float(q)) < 1e-5
+
+
+@pytest.mark.parametrize("tag", ["420_8_709", "444_10_2020pq"])
+def test_yuv_ingest_golden(fv, tag):
+    """raw planar YUV frames straight into the fused HIP ingest+temporal kernel, against the
+    reference's video_reader_yuv_pytorch.unpack pipeline (golden g7) and, per stage, its temporal channels."""
+    from fovvideovdp_amd.synth import synth_yuv_pair
+    from oracle import fvvdp_oracle as orc
+    cases = {"420_8_709": (8, 68, 120, 8, "420", "bt709", "standard_fhd", 30),
+             "444_10_2020pq": (6, 54, 96, 10, "444", "bt2020nc", "standard_hdr_pq", 60)}
+    N, H, W, bd, css, cs, disp, fps = cases[tag]
+    z = load("g7_yuv_ingest")
+    ty, ry = synth_yuv_pair(N, H, W, bit_depth=bd, chroma_ss=css)
+    m = fv.fvvdp(display_name=disp)
+    vs = fv.fvvdp_video_source_yuv_frames(ty, ry, fps, W, H, bit_depth=bd, chroma_ss=css, color_space=cs,
+                                          display_photometry=m.display_photometry)
+    q, stats = m.predict_video_source(vs)
+    assert abs(float(q) - float(z[f"{tag}_jod"])) < 2e-4
+    qq, gq = stats["Q_per_ch"].astype(np.float64), z[f"{tag}_Q"].astype(np.float64)
+    assert np.all(np.abs(qq - gq) <= 4e-3 * np.abs(gq) + 1e-6 * np.max(gq))
+    # the same source through its torch get_*_frame (generic path) must agree with the fused kernel
+    class Wrap(fv.fvvdp_video_source):
+        def get_video_size(self):
+            return vs.get_video_size()
+
+        def get_frames_per_second(self):
+            return fps
+
+        def get_test_frame(self, f, device):
+            return vs.get_test_frame(f, device)
+
+        def get_reference_frame(self, f, device):
+            return vs.get_reference_frame(f, device)
+
+    q2, stats2 = m.predict_video_source(Wrap())
+    assert abs(float(q2) - float(q)) < 1e-4

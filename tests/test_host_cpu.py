@@ -34,7 +34,7 @@ def test_library_exports_every_declared_symbol():
     nat.build()                                    # hipcc cross-compiles for gfx950 without a GPU
     L = ctypes.CDLL(nat.LIB_PATH)
     declared = header_functions()
-    assert len(declared) == 15
+    assert len(declared) == 16
     for name in declared:
         assert hasattr(L, name), "libfvvdp_hip.so does not export " + name
     assert sorted(nat.SYMBOLS) == declared         # the ctypes binding covers exactly the header
@@ -248,3 +248,23 @@ def test_visualize_diff_map_colouring():
         visualize_diff_map(dm, colormap_type="nope")
     t = vis_tonemap(torch.log(ctx), 0.6)
     assert float(t.min()) >= 0.19 and float(t.max()) <= 0.81
+
+
+def test_yuv_source_class_matches_reference_unpack():
+    """fvvdp_video_source_yuv_frames: torch-side unpack/get_frame against the reference's RGB and luminance frames."""
+    from fovvideovdp_amd.synth import synth_yuv_pair
+    z = load("g7_yuv_ingest")
+    for tag, (N, H, W, bd, css, cs, disp, fps) in {"420_8_709": (8, 68, 120, 8, "420", "bt709", "standard_fhd", 30),
+                                                   "444_10_2020pq": (6, 54, 96, 10, "444", "bt2020nc", "standard_hdr_pq", 60)}.items():
+        ty, ry = synth_yuv_pair(N, H, W, bit_depth=bd, chroma_ss=css)
+        vs = fv.fvvdp_video_source_yuv_frames(ty, ry, fps, W, H, bit_depth=bd, chroma_ss=css, color_space=cs, display_photometry=disp)
+        assert vs.get_video_size() == (H, W, N) and vs.get_frames_per_second() == fps
+        rgb = vs.unpack(vs.test_yuv[1], torch.device("cpu")).numpy()
+        assert np.max(np.abs(rgb - z[f"{tag}_rgb_f1"])) < 2e-6
+        L = vs.get_test_frame(1)[0, 0, 0].numpy()
+        g = z[f"{tag}_lum_f1"]
+        assert np.max(np.abs(L - g) / g) < (2e-4 if "pq" in tag else 5e-6)
+    with pytest.raises(RuntimeError):
+        fv.fvvdp_video_source_yuv_frames(ty, ry, 30, 97, 54, bit_depth=10, chroma_ss="420", display_photometry="standard_fhd")
+    with pytest.raises(RuntimeError):
+        fv.fvvdp_video_source_yuv_frames(ty[:, :-1], ry[:, :-1], 30, W, H, bit_depth=10, chroma_ss="444", display_photometry="standard_fhd")

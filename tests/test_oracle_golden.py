@@ -223,3 +223,32 @@ def test_foveated_pq_g4_small():
             # amplified where the CSF is steep (finest band): a few 1e-3 per pixel, zero-mean
             rel = np.abs(s - gs) / gs
             assert np.max(rel) < 3e-2 and np.mean(rel) < 1e-3, (ff, i, float(np.max(rel)), float(np.mean(rel)))
+
+
+YUV_CASES = {"420_8_709": (8, 68, 120, 8, "420", "bt709", "standard_fhd", 30),
+             "444_10_2020pq": (6, 54, 96, 10, "444", "bt2020nc", "standard_hdr_pq", 60)}
+
+
+def yuv_arrays(N, H, W, bd, css):
+    from fovvideovdp_amd.synth import synth_yuv_pair
+    ty, ry = synth_yuv_pair(N, H, W, bit_depth=bd, chroma_ss=css)
+    if bd == 8:
+        return ty.numpy(), ry.numpy()
+    return ty.numpy().astype(np.uint16), ry.numpy().astype(np.uint16)
+
+
+@pytest.mark.parametrize("tag", list(YUV_CASES))
+def test_yuv_ingest_g7(tag):
+    """Raw planar YUV -> RGB (fixed->float, 4:2:0 bilinear chroma, colour matrix) -> photometry -> metric, against the
+    reference's own unpack (video_source_file.py:219-276) run without ffmpeg (tools/gen_golden.py g7)."""
+    z = load("g7_yuv_ingest")
+    N, H, W, bd, css, cs, disp, fps = YUV_CASES[tag]
+    t, r = yuv_arrays(N, H, W, bd, css)
+    rgb = orc.yuv_unpack(t[1], W, H, bd, css, cs)
+    assert np.max(np.abs(rgb - z[f"{tag}_rgb_f1"])) < 2e-6
+    o = orc.Oracle(disp, color_space="BT.2020" if cs == "bt2020nc" else "sRGB")
+    jod, st = o.predict_yuv(t, r, fps, W, H, bd, css, cs)
+    assert abs(float(jod) - float(z[f"{tag}_jod"])) < 2e-5
+    check_q(st["Q_per_ch"][:2], z[f"{tag}_Q"][:2])
+    q, gq = st["Q_per_ch"].astype(np.float64), z[f"{tag}_Q"].astype(np.float64)
+    assert np.all(np.abs(q - gq) <= 4e-3 * np.abs(gq) + 1e-6 * np.max(gq))     # tiny frames: coarse bands are a few pixels

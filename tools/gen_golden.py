@@ -342,6 +342,61 @@ def g6(pyfvvdp):
     save("g6_heatmaps", out)
 
 
+def g7(pyfvvdp):
+    """Raw planar YUV ingest: the reference's video_reader_yuv_pytorch.unpack (video_source_file.py:219-276) is run on
+    synthetic YUV frames through a reader object built without ffmpeg, wrapped in a video source and scored."""
+    from fovvideovdp_amd.synth import synth_yuv_pair
+    import pyfvvdp.video_source_file as vsf
+    from pyfvvdp.video_source import fvvdp_video_source_dm, reshuffle_dims
+    out = {}
+    for tag, (N, H, W, bd, css, cs, disp, fps) in {"420_8_709": (8, 68, 120, 8, "420", "bt709", "standard_fhd", 30),
+                                                   "444_10_2020pq": (6, 54, 96, 10, "444", "bt2020nc", "standard_hdr_pq", 60)}.items():
+        ty, ry = synth_yuv_pair(N, H, W, bit_depth=bd, chroma_ss=css)
+        tnp = ty.numpy() if bd == 8 else ty.numpy().astype(np.uint16)
+        rnp = ry.numpy() if bd == 8 else ry.numpy().astype(np.uint16)
+
+        def reader():
+            r = object.__new__(vsf.video_reader_yuv_pytorch)
+            r.width, r.height, r.bit_depth, r.chroma_ss, r.color_space = W, H, bd, css, cs
+            r.y_pixels, r.y_shape = W * H, (H, W)
+            r.uv_shape = (H // 2, W // 2) if css == "420" else (H, W)
+            r.uv_pixels = r.uv_shape[0] * r.uv_shape[1]
+            return r
+        rd = reader()
+
+        class Src(fvvdp_video_source_dm):
+            def __init__(self):
+                super().__init__(display_photometry=disp, color_space_name="BT.2020" if cs == "bt2020nc" else "sRGB")
+
+            def get_video_size(self):
+                return (H, W, N)
+
+            def get_frames_per_second(self):
+                return fps
+
+            def _fr(self, arr, f, device):
+                t = reshuffle_dims(rd.unpack(arr[f], device), in_dims='HWC', out_dims="BCFHW")
+                L = self.dm_photometry.forward(t)
+                c = self.color_to_luminance
+                return L[:, 0:1] * c[0] + L[:, 1:2] * c[1] + L[:, 2:3] * c[2]
+
+            def get_test_frame(self, f, device):
+                return self._fr(tnp, f, device)
+
+            def get_reference_frame(self, f, device):
+                return self._fr(rnp, f, device)
+
+        fv = pyfvvdp.fvvdp(display_name=disp, heatmap=None, device=torch.device("cpu"), quiet=True)
+        with torch.no_grad():
+            q, st = fv.predict_video_source(Src())
+        out[f"{tag}_jod"] = np.float32(q.item())
+        out[f"{tag}_Q"] = st["Q_per_ch"]
+        out[f"{tag}_rgb_f1"] = rd.unpack(tnp[1], torch.device("cpu")).numpy()
+        out[f"{tag}_lum_f1"] = Src().get_test_frame(1, torch.device("cpu"))[0, 0, 0].numpy()
+        print("g7", tag, "JOD", out[f"{tag}_jod"])
+    save("g7_yuv_ingest", out)
+
+
 def main():
     which = sys.argv[1:] or ["g0", "g1", "g2", "g5"]
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
@@ -366,6 +421,8 @@ def main():
             g5(pyfvvdp)
         elif w == "g6":
             g6(pyfvvdp)
+        elif w == "g7":
+            g7(pyfvvdp)
         else:
             raise SystemExit("unknown case " + w)
         print(w, "done in %.1f s" % (time.time() - t0), flush=True)
