@@ -1037,21 +1037,43 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
         }
         const float vm = valid ? 1.0f : 0.0f;
         const float lcn = lg_bm - llb;                                   // log2(m / lb)
-#pragma unroll
-        for (int cc = 0; cc < HP; ++cc) {
-            const float dT = d[cc].x, dR = d[cc].y;
-            const float q = cc == 0 ? a.q0 : a.q1;
-            const float ls = slog[cc] + lcn;                             // log2(S/gain * m / lb)
-            // D = |T'-R'|^p / (1 + (k*min(|T'|,|R'|))^q), T' = T*S   (fvvdp.py:585-595), in the log2 domain
+        // D = |T'-R'|^p / (1 + (k*min(|T'|,|R'|))^q), T' = T*S   (fvvdp.py:585-595), in the log2 domain.
+        // Video: the two temporal channels are carried as one (sustained, transient) pair through packed fp32 ops;
+        // only the transcendentals are per component.
+        float ldd_dbg[2] = {0.0f, 0.0f};
+        if constexpr (HP == 2) {
+            const v2f sl = v2f{slog[0], slog[1]};
+            const v2f lsb = sl + splat(lcn + lg_base);                   // log2(S * m / lb)
+            const v2f lsm = sl + splat(lcn + lg_mask);                   // log2(k * S * m / lb)
+            const v2f ldiff = v2f{fast_log2(fabsf(d[0].x - d[0].y)), fast_log2(fabsf(d[1].x - d[1].y))};
+            const v2f lmin = v2f{fast_log2(fminf(fabsf(d[0].x), fabsf(d[0].y))), fast_log2(fminf(fabsf(d[1].x), fabsf(d[1].y)))};
+            const v2f ld = (ldiff + lsb) * splat(a.p);
+            const v2f lm = (lmin + lsm) * v2f{a.q0, a.q1};
+            const v2f one_mq = v2f{fast_exp2(lm.x), fast_exp2(lm.y)} + splat(1.0f);
+            const v2f t = ld - v2f{fast_log2(one_mq.x), fast_log2(one_mq.y)};
+            const v2f ldd = v2f{fminf(t.x, a.lg_dmax), fminf(t.y, a.lg_dmax)};
+            const v2f bl = ldd * splat(a.beta);
+            const v2f term = v2f{fast_exp2(bl.x), fast_exp2(bl.y)};      // D^beta for the spatial pooling (fvvdp.py:467,607)
+            const v2f av = __builtin_elementwise_fma(term, splat(vm), v2f{acc[0], acc[1]});
+            acc[0] = av.x;
+            acc[1] = av.y;
+            ldd_dbg[0] = ldd.x;
+            ldd_dbg[1] = ldd.y;
+        } else {
+            const float dT = d[0].x, dR = d[0].y;
+            const float ls = slog[0] + lcn;
             const float ld = a.p * (fast_log2(fabsf(dT - dR)) + (ls + lg_base));
-            const float mq = fast_exp2(q * (fast_log2(fminf(fabsf(dT), fabsf(dR))) + (ls + lg_mask)));
+            const float mq = fast_exp2(a.q0 * (fast_log2(fminf(fabsf(dT), fabsf(dR))) + (ls + lg_mask)));
             const float ldd = fminf(ld - fast_log2(1.0f + mq), a.lg_dmax);
-            const float term = fast_exp2(a.beta * ldd);                  // D^beta for the spatial pooling (fvvdp.py:467,607)
-            acc[cc] = fmaf(term, vm, acc[cc]);
-            if constexpr (DBG) {
-                if (valid) {
+            acc[0] = fmaf(fast_exp2(a.beta * ldd), vm, acc[0]);
+            ldd_dbg[0] = ldd;
+        }
+        if constexpr (DBG) {
+            if (valid) {
+#pragma unroll
+                for (int cc = 0; cc < HP; ++cc) {
                     const size_t o = (((size_t)frame * 2 + cc) * h + y) * w + x;
-                    if (a.dD) a.dD[o] = fast_exp2(ldd);
+                    if (a.dD) a.dD[o] = fast_exp2(ldd_dbg[cc]);
                     if (a.dS) a.dS[o] = fast_exp2(slog[cc]);
                 }
             }
