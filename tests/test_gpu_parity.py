@@ -531,3 +531,27 @@ def test_yuv_ingest_golden(fv, tag):
 
     q2, stats2 = m.predict_video_source(Wrap())
     assert abs(float(q2) - float(q)) < 1e-4
+
+
+def test_frame_range_and_sharded_predict(fv):
+    """Frame sharding building blocks on the GPU: evaluating output-frame ranges separately (each range reads its own
+    temporal halo) reproduces the full run; predict_frame_sharded with a single rank equals predict."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from fovvideovdp_amd.sharding import predict_frame_sharded, shard_range
+    N, H, W, fps = 11, 72, 128, 30
+    test, ref = synth_video_pair(N, H, W)
+    for pad in ("replicate", "circular"):
+        m = fv.fvvdp(display_name="standard_fhd", temp_padding=pad)
+        q, st = m.predict(test, ref, frames_per_second=fps)
+        vs = fv.fvvdp_video_source_array(test, ref, fps, display_photometry=m.display_photometry)
+        parts = []
+        for k in range(3):
+            f0, f1 = shard_range(N, k, 3)
+            qk, sk = m.predict_video_source(vs, frame_range=(f0, f1), pool=False)
+            assert qk is None and sk["Q_per_ch"].shape[2] == f1 - f0
+            parts.append(sk["Q_per_ch"])
+        Q = np.concatenate(parts, axis=2)
+        assert np.allclose(Q, st["Q_per_ch"], rtol=2e-6, atol=0)
+        q1, s1 = predict_frame_sharded(m, vs, 0, 1)
+        assert abs(float(q1) - float(q)) < 2e-6
+        assert np.allclose(s1["Q_per_ch"], st["Q_per_ch"], rtol=2e-6, atol=0)
