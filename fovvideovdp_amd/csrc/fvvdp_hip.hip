@@ -773,6 +773,8 @@ struct BandArgs {
     float* Gc;              // coarse level [n][hc][wc][P]
     int w, h, wc, hc;
     int n_strips, n_chunks, cr;
+    int n_items;            // work items (waves) of this launch
+    int lut_lds;            // foveated: 1 = the band's LUT slice fits the dynamic LDS and is copied there
     float band_mul;
     const float4* csf;      // [32] records {S_log0[i], S_log1[i], S_log0[i+1]-S_log0[i], S_log1[i+1]-S_log1[i]}
     const float4* csf_y;    // [32] records {Y_log[i], ...} (foveated path: knots of the Y axis)
@@ -800,16 +802,17 @@ struct BandArgs {
     int frame_w, frame_h;
 };
 
-#ifndef BAND_MIN_WAVES
-#define BAND_MIN_WAVES 1
-#endif
+
+#define FOV_WPB 4            // foveated mode: 4 independent waves per workgroup share the band's LUT slice in LDS
+extern __shared__ __attribute__((aligned(16))) float4 s_lut_dyn[];
 
 template <int P, bool DBG, bool FOV>
-__global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs a) {
+__global__ __launch_bounds__(FOV ? 64 * FOV_WPB : 64, (FOV || DBG) ? 2 : 4) void band_kernel(const BandArgs a) {
     constexpr int HP = P / 2;   // (test, ref) pairs = temporal channels
+    constexpr int WPB = FOV ? FOV_WPB : 1;
     __shared__ float4 s_csf[FVVDP_LUT_N];
 
-    const int lane = threadIdx.x;
+    const int lane = FOV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
     // XCD-aware work order: hardware places workgroup b on XCD b % 8 (speed only, never correctness).  Give each
     // XCD a contiguous range of work items (strip fastest, then chunk, then frame) so that neighbouring strips,
     // which share their 4+4 halo columns, run on the same XCD at about the same time and hit in its L2.
@@ -817,7 +820,9 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
     {
         const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
         bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
+        if constexpr (FOV) bid = bid * WPB + (threadIdx.x >> 6);
     }
+    const bool wave_has_work = !FOV || bid < a.n_items;
     const int strip = bid % a.n_strips;
     bid /= a.n_strips;
     const int chunk = bid % a.n_chunks;
@@ -836,13 +841,25 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
     const int xc0 = min(max(X0, 0), w - 1), xc1 = min(max(X1, 0), w - 1);
     const bool col1_ok = X1 < w;
 
-    __shared__ float s_ax[FOV ? 3 * FVVDP_LUT_N : 1];
+    __shared__ float2 s_ax[FOV ? 3 * FVVDP_LUT_N : 1];     // {knot k, 1/(knot k+1 - knot k + 1e-6)} of the three axes
     if constexpr (!FOV) {
         if (lane < FVVDP_LUT_N) s_csf[lane] = a.csf[lane];
     } else {
-        for (int i = lane; i < 3 * FVVDP_LUT_N; i += 64) s_ax[i] = a.axes[i];
+        for (int i = threadIdx.x; i < 3 * FVVDP_LUT_N; i += 64 * WPB) {
+            const int k = i % FVVDP_LUT_N;
+            const float x0 = a.axes[i];
+            const float x1 = a.axes[k + 1 < FVVDP_LUT_N ? i + 1 : i];
+            s_ax[i] = make_float2(x0, 1.0f / (x1 - x0 + 0.000001f));
+        }
+        if (a.lut_lds) {
+            const int nl = FVVDP_LUT_N * FVVDP_LUT_N * a.rw;
+            for (int i = threadIdx.x; i < nl; i += 64 * WPB) s_lut_dyn[i] = a.sublut[i];
+        }
     }
     __syncthreads();
+    if constexpr (FOV) {
+        if (!wave_has_work) return;
+    }
 
     // horizontal 5-tap weights of this lane's coarse column incl. the reference's edge fix-ups
     // (gausspyr_reduce, fvvdp_lpyr_dec.py:198-205; the right-edge branch is selected by the parity of the ROW
@@ -971,8 +988,8 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
     const float lg_mask = a.lg_gain + a.lg_k;      // log2(k*S)
 
     // per-pixel tail: contrast, CSF, masking, pooling  (fvvdp_lpyr_dec.py:259-269, fvvdp.py:395-467)
-    auto band_px = [&](const Px<P>& g, const Px<P>& e, bool valid, int y, int x, float vx, float vy) {
-        (void)x;
+    auto band_px = [&](const Px<P>& g, const Px<P>& e, bool valid, int y, int x, float vx, float vy, float res_mag) {
+        (void)x; (void)res_mag;
         const float lb = fmaxf(e.h[0].y, a.lbkg_min);                  // plane 1 = reference (sustained)
         // contrast = min((g-e)/lb, cmax) * m.  Dividing by lb>0 commutes with |.|, min and the clamp, so the
         // division is carried as -log2(lb) in the log domain below: no reciprocal, no per-plane multiply.
@@ -998,17 +1015,6 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
             // eccentricity and resolution magnification (fvvdp.py:424-437, fvvdp_display_model.py:475-526).
             // (tan(a+d)-tan(a))/tan(d) == cos(d)/(cos(a)cos(a+d)): evaluated in this form it needs no slow tan and
             // does not lose digits to the reference's fp32 finite difference (whose noise, ~5e-4, bounds parity).
-            float res_mag;
-            if (a.mvx) {                          // user geometry: maps evaluated by the caller
-                const int yc = min(y, h - 1), xc = min(x, w - 1);
-                const size_t o = (size_t)yc * w + xc;
-                vx = a.mvx[o];
-                vy = a.mvy[o];
-                res_mag = a.mrm[o];
-            } else {
-                const float va = fminf(__builtin_amdgcn_sqrtf(vx * vx + vy * vy), 89.9f) * 0.017453292519943295f;
-                res_mag = a.cos_delta * fast_rcp(__cosf(va) * __cosf(va + a.delta_rad));
-            }
             const float dx = vx - gx, dy = vy - gy;
             const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
             const float rho = a.rho_band * res_mag;
@@ -1017,17 +1023,23 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
             // interval on each (uniform) axis from the grid, fraction from the stored knots incl. interp.py:16's +1e-6
             auto axis = [&](int ax, float q, int lo, int hi, int& k, float& f) {
                 k = min(max((int)floorf((q - a.first[ax]) * a.inv_step[ax]), lo), hi);
-                const float x0 = s_ax[ax * FVVDP_LUT_N + k], x1 = s_ax[ax * FVVDP_LUT_N + k + 1];
-                f = fmaxf((q - x0) / (x1 - x0 + 0.000001f), 0.0f);
+                const float2 kn = s_ax[ax * FVVDP_LUT_N + k];
+                f = fmaxf((q - kn.x) * kn.y, 0.0f);
             };
             int kY, kR, kE;
             float fY, fR, fE;
             axis(0, yq, 0, FVVDP_LUT_N - 2, kY, fY);
             axis(1, rq, a.i_lo, a.i_lo + a.rw - 1, kR, fR);
             axis(2, eq, 0, FVVDP_LUT_N - 2, kE, fE);
-            const float4* sb = a.sublut + ((size_t)(kE * FVVDP_LUT_N + kY) * a.rw + (kR - a.i_lo));
-            const size_t sj = a.rw, sk = (size_t)FVVDP_LUT_N * a.rw;
-            const float4 v00 = sb[0], v10 = sb[sj], v01 = sb[sk], v11 = sb[sk + sj];      // v[dj][dk]
+            const int so = (kE * FVVDP_LUT_N + kY) * a.rw + (kR - a.i_lo);
+            const int sj = a.rw, sk = FVVDP_LUT_N * a.rw;
+            float4 v00, v10, v01, v11;                                                      // v[dj][dk]
+            if (a.lut_lds) {
+                v00 = s_lut_dyn[so]; v10 = s_lut_dyn[so + sj]; v01 = s_lut_dyn[so + sk]; v11 = s_lut_dyn[so + sk + sj];
+            } else {
+                const float4* sb = a.sublut + so;
+                v00 = sb[0]; v10 = sb[sj]; v01 = sb[sk]; v11 = sb[sk + sj];
+            }
             const float gR = 1.0f - fR, gY = 1.0f - fY, gE = 1.0f - fE;
             // interp3 (interp.py:53-57), same association: rho blend, then Y, then ecc
             slog[0] = ((v00.x * gR + v00.z * fR) * gY + (v10.x * gR + v10.z * fR) * fY) * gE +
@@ -1137,10 +1149,34 @@ __global__ __launch_bounds__(64, BAND_MIN_WAVES) void band_kernel(const BandArgs
             vy0 = atanf(-yp0 * a.size_m1 / (float)h / a.dist_m) * 57.29577951308232f;
             vy1 = atanf(-yp1 * a.size_m1 / (float)h / a.dist_m) * 57.29577951308232f;
         }
-        band_px(W[0][0], x00, active, 2 * c, X0, vxa, vy0);
-        band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vxb, vy0);
-        band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vxa, vy1);
-        band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vxb, vy1);
+        if constexpr (FOV) {
+            float vx4[4] = {vxa, vxb, vxa, vxb}, vy4[4] = {vy0, vy0, vy1, vy1}, rm4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (a.mvx) {                          // user geometry: maps evaluated by the caller
+                const int ya = min(2 * c, h - 1), yb = min(2 * c + 1, h - 1);
+                const size_t o[4] = {(size_t)ya * w + xc0, (size_t)ya * w + xc1, (size_t)yb * w + xc0, (size_t)yb * w + xc1};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vx4[i] = a.mvx[o[i]];
+                    vy4[i] = a.mvy[o[i]];
+                    rm4[i] = a.mrm[o[i]];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float va = fminf(__builtin_amdgcn_sqrtf(vx4[i] * vx4[i] + vy4[i] * vy4[i]), 89.9f) * 0.017453292519943295f;
+                    rm4[i] = a.cos_delta * fast_rcp(__cosf(va) * __cosf(va + a.delta_rad));
+                }
+            }
+            band_px(W[0][0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0]);
+            band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1]);
+            band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vx4[2], vy4[2], rm4[2]);
+            band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vx4[3], vy4[3], rm4[3]);
+        } else {
+            band_px(W[0][0], x00, active, 2 * c, X0, 0.0f, 0.0f, 1.0f);
+            band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, 0.0f, 0.0f, 1.0f);
+            band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, 0.0f, 0.0f, 1.0f);
+            band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, 0.0f, 0.0f, 1.0f);
+        }
         }
         Gm1 = G0;
         G0 = Gp1;
@@ -1757,8 +1793,10 @@ template <int P>
 static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, hipStream_t st) {
     dim3 grid(nblocks), block(64);
     if (fov) {
-        if (dbg) hipLaunchKernelGGL((band_kernel<P, true, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((band_kernel<P, false, true>), grid, block, 0, st, a);
+        const dim3 gridf((nblocks + FOV_WPB - 1) / FOV_WPB), blockf(64 * FOV_WPB);
+        const size_t lds = a.lut_lds ? (size_t)FVVDP_LUT_N * FVVDP_LUT_N * a.rw * sizeof(float4) : 0;
+        if (dbg) hipLaunchKernelGGL((band_kernel<P, true, true>), gridf, blockf, lds, st, a);
+        else hipLaunchKernelGGL((band_kernel<P, false, true>), gridf, blockf, lds, st, a);
     } else {
         if (dbg) hipLaunchKernelGGL((band_kernel<P, true, false>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((band_kernel<P, false, false>), grid, block, 0, st, a);
@@ -1854,6 +1892,8 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
         }
         const int nblk = a.n_strips * a.n_chunks;
         if (nblk > c->max_blk[b]) return fail(FVVDP_ESTATE, "internal: partial buffer too small");
+        a.n_items = nblk * n;
+        a.lut_lds = (fov && (size_t)FVVDP_LUT_N * FVVDP_LUT_N * c->sub_rw[b] * sizeof(float4) <= 48 * 1024) ? 1 : 0;
         {
             Timed tm(c, 1 + b, st);
             if (c->P == 4) launch_band<4>(a, nblk * n, dbg, fov, st);

@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void copy_f4(const float4* __restrict__ p, flo
 
 // the band kernel's read pattern: single-wave workgroups, each walks down `rows` rows of a [H][W] float4 image,
 // reading 2 x float4 per lane per row (lane l: pixels 2l, 2l+1 of a 128-pixel strip), 2 rows per step, prefetch 1.
+__device__ size_t g_skew = 0;
 template <int ACTIVE, int HALO_L, int NT>
 __global__ __launch_bounds__(64) void read_strips(const float4* __restrict__ img, int W, int H, int n_strips, int chunk_rows,
                                                   int n_chunks, float4* __restrict__ coarse, float* out) {
@@ -47,7 +48,7 @@ __global__ __launch_bounds__(64) void read_strips(const float4* __restrict__ img
     const int frame = bid / (n_strips * n_chunks);
     const int lane = threadIdx.x;
     const int x0 = min(max(strip * 2 * ACTIVE + 2 * (lane - HALO_L), 0), W - 2);
-    const float4* base = img + (size_t)frame * W * H;
+    const float4* base = img + (size_t)frame * ((size_t)W * H + g_skew);
     const int r0 = chunk * chunk_rows, r1 = min(r0 + chunk_rows, H);
     float acc = 0.f;
     auto LD = [&](size_t i) -> float4 {
@@ -114,16 +115,15 @@ int main() {
         double t = timeit([&] { hipLaunchKernelGGL(copy_f4<4>, dim3(blocks), dim3(256), 0, 0, p, q, n4); });
         printf("copy_f4<4>  blocks %6d: %.2f TB/s (r+w)\n", blocks, 2 * gb / t / 1e3);
     }
-    for (int chunk_rows : {270, 1080}) {
-        const int n_chunks = (H + chunk_rows - 1) / chunk_rows;
-        const int n_strips = 32, grid = n_strips * n_chunks * N;
-        double t;
-        t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 2>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
-        printf("rows/chunk %4d: row-major coarse, nt stores        : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
-        t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 6>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
-        printf("rows/chunk %4d: strip-contiguous coarse, nt stores : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
-        t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 4>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
-        printf("rows/chunk %4d: strip-contiguous coarse, plain     : %.2f TB/s alg\n", chunk_rows, 1.25 * gb / t / 1e3);
+    for (size_t skew : {(size_t)0, (size_t)16, (size_t)1040, (size_t)65552}) {     // float4 units
+        CK(hipMemcpyToSymbol(HIP_SYMBOL(g_skew), &skew, sizeof(skew)));
+        const int chunk_rows = 1080, n_chunks = 2, n_strips = 32, grid = n_strips * n_chunks * 59;
+        double best = 1e9;
+        for (int rep = 0; rep < 3; ++rep) {
+            double t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 2>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+            best = t < best ? t : best;
+        }
+        printf("frame skew %6zu float4: read_strips + nt coarse write: %.2f TB/s alg (59 frames)\n", skew, 1.25 * gb * 59 / 60 / best / 1e3);
     }
     return 0;
 }
