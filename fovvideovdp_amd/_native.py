@@ -74,14 +74,15 @@ _lib = None
 
 def build(force=False, verbose=False):
     """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
-    if not force and os.path.isfile(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(
-            os.path.getmtime(SRC_PATH), os.path.getmtime(os.path.join(INCLUDE_DIR, "fvvdp_hip.h"))):
+    csrc = os.path.dirname(SRC_PATH)
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(INCLUDE_DIR, "fvvdp_hip.h")]
+    if not force and os.path.isfile(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(f) for f in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -pragma-unroll-threshold: the temporal kernels keep their filter window in registers and rely on FULL unrolling
     # of the tap loops (static ring slots); the default size cap silently falls back to scratch-memory indexing
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
-           "-pragma-unroll-threshold=1000000", "-I" + INCLUDE_DIR, SRC_PATH, "-o", LIB_PATH]
+           "-pragma-unroll-threshold=1000000", "-I" + INCLUDE_DIR, "-I" + os.path.dirname(SRC_PATH), SRC_PATH, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

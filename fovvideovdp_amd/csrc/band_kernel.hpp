@@ -1,0 +1,494 @@
+// Stage 2 kernel: one fused pass per pyramid level (reduce, expand, contrast, CSF, masking, pooling).
+// Included by fvvdp_hip.hip (one translation unit).
+#pragma once
+// ------------------------------------------------------------------------------------------------------------
+// stage 2: fused pyramid level
+//   read Gaussian level i once, write level i+1 once, and in the same pass expand level i+1, form the contrast
+//   band, weight by the CSF, apply mutual masking and accumulate sum(D^beta)  (nothing else touches HBM).
+//
+//   One single-wave workgroup streams down a strip of 120 fine (60 coarse) columns: lane l owns coarse column
+//   J = 60*strip+l and the two fine columns 2J, 2J+1 (4 fine pixels per step).  Vertical 5-tap reduce and the vertical
+//   half of the expand are thread-local on a register window of 5 fine rows; the horizontal halves take the
+//   neighbour lanes' values through DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1) -- no LDS, no
+//   barriers, so the waves of a CU run completely decoupled and hide each other's HBM latency.  Plane pairs
+//   (test, ref) live in adjacent registers and go through packed fp32 math (v_pk_fma_f32), which also makes the
+//   test and reference planes bit-symmetric (identical inputs give exactly D = 0).
+// ------------------------------------------------------------------------------------------------------------
+#define STRIP_J 60          // coarse columns produced per wave (64 lanes - 2 halo lanes each side)
+
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int P>
+struct Px {                 // one pixel: P/2 (test, ref) pairs
+    v2f h[P / 2];
+};
+
+template <int P>
+__device__ __forceinline__ Px<P> ld_px(const float* p);
+template <>
+__device__ __forceinline__ Px<4> ld_px<4>(const float* p) {
+    const float4 t = *reinterpret_cast<const float4*>(p);
+    Px<4> r;
+    r.h[0] = v2f{t.x, t.y};
+    r.h[1] = v2f{t.z, t.w};
+    return r;
+}
+template <>
+__device__ __forceinline__ Px<2> ld_px<2>(const float* p) {
+    const float2 t = *reinterpret_cast<const float2*>(p);
+    Px<2> r;
+    r.h[0] = v2f{t.x, t.y};
+    return r;
+}
+// the coarse level is written once and only read by the next launch: non-temporal stores (measured +2-3 % on the
+// read+write mix of this kernel, tools/microbench/membw.hip)
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_px(float* p, const Px<4>& a) {
+    __builtin_nontemporal_store(v4f{a.h[0].x, a.h[0].y, a.h[1].x, a.h[1].y}, reinterpret_cast<v4f*>(p));
+}
+__device__ __forceinline__ void st_px(float* p, const Px<2>& a) {
+    __builtin_nontemporal_store(a.h[0], reinterpret_cast<v2f*>(p));
+}
+
+__device__ __forceinline__ v2f splat(float s) { return v2f{s, s}; }
+// a*s + c on both halves (v_pk_fma_f32)
+__device__ __forceinline__ v2f pfma(v2f a, float s, v2f c) { return __builtin_elementwise_fma(a, splat(s), c); }
+
+// value held by the lane to the left / right (0 at the wave's ends)
+__device__ __forceinline__ float from_left(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_right(float x) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
+}
+// acc + w * neighbour(x), per component (v_fmac_f32 with a DPP source)
+__device__ __forceinline__ v2f fma_left(v2f x, float w, v2f acc) {
+    return v2f{fmaf(from_left(x.x), w, acc.x), fmaf(from_left(x.y), w, acc.y)};
+}
+__device__ __forceinline__ v2f fma_right(v2f x, float w, v2f acc) {
+    return v2f{fmaf(from_right(x.x), w, acc.x), fmaf(from_right(x.y), w, acc.y)};
+}
+
+struct BandArgs {
+    const float* Gf;        // fine level   [n][h][w][P]
+    float* Gc;              // coarse level [n][hc][wc][P]
+    int w, h, wc, hc;
+    int n_strips, n_chunks, cr;
+    int n_items;            // work items (waves) of this launch
+    int lut_lds;            // foveated: 1 = the band's LUT slice fits the dynamic LDS and is copied there
+    float band_mul;
+    const float4* csf;      // [32] records {S_log0[i], S_log1[i], S_log0[i+1]-S_log0[i], S_log1[i+1]-S_log1[i]}
+    const float4* csf_y;    // [32] records {Y_log[i], ...} (foveated path: knots of the Y axis)
+    float y_first, y_inv_step;
+    float y_lo, y_hi;       // clamp range of L_bkg (lut Y[0], Y[-1])
+    float ly_lo, ly_hi;     // the same in log2
+    float lg_gain, lg_k;    // log2(sens_gain), log2(mask_k)
+    float p, q0, q1, beta, lbkg_min, cmax, lg_dmax;
+    float* partial;         // [n][n_strips*n_chunks][2]
+    float* dD;
+    float* dC;
+    float* dL;
+    float* dS;
+    // foveated (FOV == true)
+    const float4* sublut;   // per band: [32 ecc][32 Y][rw] of {S_log0[i], S_log1[i], S_log0[i+1], S_log1[i+1]} (i = rho knot)
+    const float* axes;      // [3][32] knots: Y_log, rho_log, ecc_sqrt
+    int rw, i_lo;           // rho knots covered by the band's sub-LUT: [i_lo, i_lo+rw]
+    const float* fix;       // device [n][2]: gaze in frame pixels, or gaze view direction in degrees (map mode)
+    const float* mvx;       // map mode (user geometry): view direction x,y [h][w] in degrees and resolution
+    const float* mvy;       //   magnification [h][w] of this band, evaluated by the caller with the user's
+    const float* mrm;       //   geometry object; nullptr = stock geometry computed in-kernel
+    float size_m0, size_m1, dist_m, cos_delta, delta_rad;
+    float rho_band, rho_lo, rho_hi, ecc_lo, ecc_hi;
+    float inv_step[3], first[3];   // uniform-grid estimates of the three axes
+    int frame_w, frame_h;
+};
+
+
+#define FOV_WPB 4            // foveated mode: 4 independent waves per workgroup share the band's LUT slice in LDS
+extern __shared__ __attribute__((aligned(16))) float4 s_lut_dyn[];
+
+template <int P, bool DBG, bool FOV>
+__global__ __launch_bounds__(FOV ? 64 * FOV_WPB : 64, (FOV || DBG) ? 2 : 4) void band_kernel(const BandArgs a) {
+    constexpr int HP = P / 2;   // (test, ref) pairs = temporal channels
+    constexpr int WPB = FOV ? FOV_WPB : 1;
+    __shared__ float4 s_csf[FVVDP_LUT_N];
+
+    const int lane = FOV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    // XCD-aware work order: hardware places workgroup b on XCD b % 8 (speed only, never correctness).  Give each
+    // XCD a contiguous range of work items (strip fastest, then chunk, then frame) so that neighbouring strips,
+    // which share their 4+4 halo columns, run on the same XCD at about the same time and hit in its L2.
+    int bid;
+    {
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
+        bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
+        if constexpr (FOV) bid = bid * WPB + (threadIdx.x >> 6);
+    }
+    const bool wave_has_work = !FOV || bid < a.n_items;
+    const int strip = bid % a.n_strips;
+    bid /= a.n_strips;
+    const int chunk = bid % a.n_chunks;
+    const int frame = bid / a.n_chunks;
+    const int blk = chunk * a.n_strips + strip;
+
+    const int w = a.w, h = a.h, wc = a.wc, hc = a.hc;
+    // lane l of strip s owns coarse column J = 60*s + l, i.e. fine columns 120*s + 2l (+1): the 128 fine pixels a
+    // wave reads per row start at byte 1920*s of the row -> aligned to the 128-byte lines.  Lanes 2..61 produce
+    // output; lanes 0,1 and 62,63 only feed their neighbours (in strip 0 the image border makes lanes 0,1 complete).
+    const int J = strip * STRIP_J + lane;
+    const int ca = chunk * a.cr;
+    const int cb = min(ca + a.cr, hc);
+    const bool active = (lane >= 2 || strip == 0) && (lane < 62) && (J < wc);
+    const int X0 = 2 * J, X1 = 2 * J + 1;
+    const int xc0 = min(max(X0, 0), w - 1), xc1 = min(max(X1, 0), w - 1);
+    const bool col1_ok = X1 < w;
+
+    __shared__ float2 s_ax[FOV ? 3 * FVVDP_LUT_N : 1];     // {knot k, 1/(knot k+1 - knot k + 1e-6)} of the three axes
+    if constexpr (!FOV) {
+        if (lane < FVVDP_LUT_N) s_csf[lane] = a.csf[lane];
+    } else {
+        for (int i = threadIdx.x; i < 3 * FVVDP_LUT_N; i += 64 * WPB) {
+            const int k = i % FVVDP_LUT_N;
+            const float x0 = a.axes[i];
+            const float x1 = a.axes[k + 1 < FVVDP_LUT_N ? i + 1 : i];
+            s_ax[i] = make_float2(x0, 1.0f / (x1 - x0 + 0.000001f));
+        }
+        if (a.lut_lds) {
+            const int nl = FVVDP_LUT_N * FVVDP_LUT_N * a.rw;
+            for (int i = threadIdx.x; i < nl; i += 64 * WPB) s_lut_dyn[i] = a.sublut[i];
+        }
+    }
+    __syncthreads();
+    if constexpr (FOV) {
+        if (!wave_has_work) return;
+    }
+
+    // horizontal 5-tap weights of this lane's coarse column incl. the reference's edge fix-ups
+    // (gausspyr_reduce, fvvdp_lpyr_dec.py:198-205; the right-edge branch is selected by the parity of the ROW
+    // count, :202, reproduced here on purpose).  Taps: E[l-1], O[l-1], E[l], O[l], E[l+1]  (E/O = even/odd fine
+    // column of a lane); taps falling outside the image get weight 0 and their fix-up is folded into the
+    // in-range taps.
+    const float K0 = 0.05f, K1 = 0.25f, K2 = 0.4f, K3 = 0.25f, K4 = 0.05f;
+    float wq0 = K0, wq1 = K1, wq2 = K2, wq3 = K3, wq4 = K4;
+    if (J == 0) {
+        wq2 += K1;
+        wq3 += K0;
+        wq0 = 0.0f;
+        wq1 = 0.0f;
+    }
+    if (J == wc - 1) {
+        const bool hodd = (h & 1) != 0;
+        if (w & 1) {   // own columns: X0 = w-1 (tap 2), X1 = w (outside)
+            wq3 = 0.0f;
+            wq4 = 0.0f;
+            if (hodd) { wq2 += K3; wq1 += K4; } else { wq2 += K4; }
+        } else {       // own columns: w-2 (tap 2), w-1 (tap 3); tap 4 = column w is outside
+            wq4 = 0.0f;
+            if (hodd) { wq3 += K3; wq2 += K4; } else { wq3 += K4; }
+        }
+    }
+    // horizontal expand weights (2K = .1 .8 .1 / .5 .5, gausspyr_expand fvvdp_lpyr_dec.py:126-142,233); a
+    // neighbour outside the coarse row is the clamped (own) column, so its weight moves to the centre tap
+    const bool at_l = (J <= 0), at_r = (J >= wc - 1);
+    const float el = at_l ? 0.0f : 0.1f, er = at_r ? 0.0f : 0.1f;
+    const float ec = 0.8f + (at_l ? 0.1f : 0.0f) + (at_r ? 0.1f : 0.0f);
+    const float orr = at_r ? 0.0f : 0.5f;
+    const float oc = at_r ? 1.0f : 0.5f;
+
+    const float* Gf = a.Gf + (size_t)frame * h * w * P;
+    float* Gc = a.Gc + (size_t)frame * hc * wc * P;
+
+    auto load_row = [&](int r, Px<P>& p0, Px<P>& p1) {
+        int rr = r < 0 ? -1 - r : (r >= h ? 2 * h - 1 - r : r);   // symmetric padding (fvvdp_lpyr_dec.py:190-195)
+        rr = min(max(rr, 0), h - 1);
+        const float* row = Gf + (size_t)rr * w * P;
+        p0 = ld_px<P>(row + (size_t)xc0 * P);
+        p1 = ld_px<P>(row + (size_t)xc1 * P);
+    };
+
+    Px<P> W[5][2];
+
+    // one coarse row from the current window: vertical 5-tap in registers, horizontal 5-tap across lanes
+    auto coarse_step = [&]() -> Px<P> {
+        Px<P> c, va, vb;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            v2f a0 = W[0][0].h[k] * K0;
+            a0 = pfma(W[1][0].h[k], K1, a0);
+            a0 = pfma(W[2][0].h[k], K2, a0);
+            a0 = pfma(W[3][0].h[k], K3, a0);
+            va.h[k] = pfma(W[4][0].h[k], K4, a0);
+            v2f b0 = W[0][1].h[k] * K0;
+            b0 = pfma(W[1][1].h[k], K1, b0);
+            b0 = pfma(W[2][1].h[k], K2, b0);
+            b0 = pfma(W[3][1].h[k], K3, b0);
+            vb.h[k] = pfma(W[4][1].h[k], K4, b0);
+        }
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            v2f acc = va.h[k] * wq2;
+            acc = pfma(vb.h[k], wq3, acc);
+            acc = fma_left(va.h[k], wq0, acc);
+            acc = fma_left(vb.h[k], wq1, acc);
+            c.h[k] = fma_right(va.h[k], wq4, acc);
+        }
+        return c;
+    };
+    auto shift_window = [&](const Px<P> (&n0)[2], const Px<P> (&n1)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            W[0][j] = W[2][j];
+            W[1][j] = W[3][j];
+            W[2][j] = W[4][j];
+            W[3][j] = n0[j];
+            W[4][j] = n1[j];
+        }
+    };
+
+    // ---- prologue: coarse rows ca-1 and ca --------------------------------------------------------------
+    {
+        const int r0 = 2 * (ca - 1) - 2;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) load_row(r0 + k, W[k][0], W[k][1]);
+    }
+    const Px<P> cA = coarse_step();
+    Px<P> nx0[2], nx1[2];
+    load_row(2 * ca + 1, nx0[0], nx0[1]);
+    load_row(2 * ca + 2, nx1[0], nx1[1]);
+    shift_window(nx0, nx1);
+    const Px<P> cB = coarse_step();
+    if (active) st_px(Gc + ((size_t)ca * wc + J) * P, cB);
+    Px<P> Gm1 = (ca > 0) ? cA : cB;
+    Px<P> G0 = cB;
+    load_row(2 * ca + 3, nx0[0], nx0[1]);
+    load_row(2 * ca + 4, nx1[0], nx1[1]);
+
+    float acc[2] = {0.0f, 0.0f};
+
+    // foveated constants of this lane's two fine columns
+    float vxa = 0.0f, vxb = 0.0f, gx = 0.0f, gy = 0.0f;
+    if constexpr (FOV) {
+        // pix2view_direction (fvvdp_display_model.py:498-510) on the band grid, pixel centres at +0.5
+        const float xa = ((float)X0 + 0.5f) + (-(float)w / 2.0f);
+        const float xb = ((float)X1 + 0.5f) + (-(float)w / 2.0f);
+        vxa = atanf(xa * a.size_m0 / (float)w / a.dist_m) * 57.29577951308232f;
+        vxb = atanf(xb * a.size_m0 / (float)w / a.dist_m) * 57.29577951308232f;
+        if (a.mvx) {
+            gx = a.fix[2 * frame + 0];
+            gy = a.fix[2 * frame + 1];
+        } else {
+            const float fxp = a.fix[2 * frame + 0] + 0.5f, fyp = a.fix[2 * frame + 1] + 0.5f;
+            const float gxm = (fxp + (-(float)a.frame_w / 2.0f)) * a.size_m0 / (float)a.frame_w;
+            const float gym = -(fyp + (-(float)a.frame_h / 2.0f)) * a.size_m1 / (float)a.frame_h;
+            gx = atanf(gxm / a.dist_m) * 57.29577951308232f;
+            gy = atanf(gym / a.dist_m) * 57.29577951308232f;
+        }
+    }
+
+    const float lg_bm = __log2f(a.band_mul);
+    const float lg_base = a.lg_gain;              // log2(S) = interp + log2(gain)      (fvvdp.py:447)
+    const float lg_mask = a.lg_gain + a.lg_k;      // log2(k*S)
+
+    // per-pixel tail: contrast, CSF, masking, pooling  (fvvdp_lpyr_dec.py:259-269, fvvdp.py:395-467)
+    auto band_px = [&](const Px<P>& g, const Px<P>& e, bool valid, int y, int x, float vx, float vy, float res_mag) {
+        (void)x; (void)res_mag;
+        const float lb = fmaxf(e.h[0].y, a.lbkg_min);                  // plane 1 = reference (sustained)
+        // contrast = min((g-e)/lb, cmax) * m.  Dividing by lb>0 commutes with |.|, min and the clamp, so the
+        // division is carried as -log2(lb) in the log domain below: no reciprocal, no per-plane multiply.
+        const float dcap = a.cmax * lb;                                // (g-e)/lb <= cmax  <=>  g-e <= cmax*lb
+        v2f d[HP];
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            const v2f t = g.h[k] - e.h[k];
+            d[k] = v2f{fminf(t.x, dcap), fminf(t.y, dcap)};            // upper clamp only (fvvdp_lpyr_dec.py:266)
+        }
+        const float llb = fast_log2(lb);
+        const float yq = fminf(fmaxf(llb, a.ly_lo), a.ly_hi);          // = log2(clamp(lb, Y[0], Y[-1]))  (fvvdp.py:530)
+        float slog[2] = {0.0f, 0.0f};
+        if constexpr (!FOV) {
+            // 1-D table over log2(L_bkg) (uniform knots): interval from the grid, value = v[i] + f*(v[i+1]-v[i])
+            const float t = (yq - a.y_first) * a.y_inv_step;
+            const float fi = fminf(fmaxf(floorf(t), 0.0f), (float)(FVVDP_LUT_N - 2));
+            const float4 r = s_csf[(int)fi];                           // {v0[i], v1[i], v0[i+1]-v0[i], v1[i+1]-v1[i]}
+            const float f = t - fi;
+            slog[0] = fmaf(f, r.z, r.x);
+            slog[1] = fmaf(f, r.w, r.y);
+        } else {
+            // eccentricity and resolution magnification (fvvdp.py:424-437, fvvdp_display_model.py:475-526).
+            // (tan(a+d)-tan(a))/tan(d) == cos(d)/(cos(a)cos(a+d)): evaluated in this form it needs no slow tan and
+            // does not lose digits to the reference's fp32 finite difference (whose noise, ~5e-4, bounds parity).
+            const float dx = vx - gx, dy = vy - gy;
+            const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
+            const float rho = a.rho_band * res_mag;
+            const float rq = fast_log2(fminf(fmaxf(rho, a.rho_lo), a.rho_hi));
+            const float eq = __builtin_amdgcn_sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
+            // interval on each (uniform) axis from the grid, fraction from the stored knots incl. interp.py:16's +1e-6
+            auto axis = [&](int ax, float q, int lo, int hi, int& k, float& f) {
+                k = min(max((int)floorf((q - a.first[ax]) * a.inv_step[ax]), lo), hi);
+                const float2 kn = s_ax[ax * FVVDP_LUT_N + k];
+                f = fmaxf((q - kn.x) * kn.y, 0.0f);
+            };
+            int kY, kR, kE;
+            float fY, fR, fE;
+            axis(0, yq, 0, FVVDP_LUT_N - 2, kY, fY);
+            axis(1, rq, a.i_lo, a.i_lo + a.rw - 1, kR, fR);
+            axis(2, eq, 0, FVVDP_LUT_N - 2, kE, fE);
+            const int so = (kE * FVVDP_LUT_N + kY) * a.rw + (kR - a.i_lo);
+            const int sj = a.rw, sk = FVVDP_LUT_N * a.rw;
+            float4 v00, v10, v01, v11;                                                      // v[dj][dk]
+            if (a.lut_lds) {
+                v00 = s_lut_dyn[so]; v10 = s_lut_dyn[so + sj]; v01 = s_lut_dyn[so + sk]; v11 = s_lut_dyn[so + sk + sj];
+            } else {
+                const float4* sb = a.sublut + so;
+                v00 = sb[0]; v10 = sb[sj]; v01 = sb[sk]; v11 = sb[sk + sj];
+            }
+            const float gR = 1.0f - fR, gY = 1.0f - fY, gE = 1.0f - fE;
+            // interp3 (interp.py:53-57), same association: rho blend, then Y, then ecc
+            slog[0] = ((v00.x * gR + v00.z * fR) * gY + (v10.x * gR + v10.z * fR) * fY) * gE +
+                      ((v01.x * gR + v01.z * fR) * gY + (v11.x * gR + v11.z * fR) * fY) * fE;
+            slog[1] = ((v00.y * gR + v00.w * fR) * gY + (v10.y * gR + v10.w * fR) * fY) * gE +
+                      ((v01.y * gR + v01.w * fR) * gY + (v11.y * gR + v11.w * fR) * fY) * fE;
+        }
+        const float vm = valid ? 1.0f : 0.0f;
+        const float lcn = lg_bm - llb;                                   // log2(m / lb)
+        // D = |T'-R'|^p / (1 + (k*min(|T'|,|R'|))^q), T' = T*S   (fvvdp.py:585-595), in the log2 domain.
+        // Video: the two temporal channels are carried as one (sustained, transient) pair through packed fp32 ops;
+        // only the transcendentals are per component.
+        float ldd_dbg[2] = {0.0f, 0.0f};
+        if constexpr (HP == 2) {
+            const v2f sl = v2f{slog[0], slog[1]};
+            const v2f lsb = sl + splat(lcn + lg_base);                   // log2(S * m / lb)
+            const v2f lsm = sl + splat(lcn + lg_mask);                   // log2(k * S * m / lb)
+            const v2f ldiff = v2f{fast_log2(fabsf(d[0].x - d[0].y)), fast_log2(fabsf(d[1].x - d[1].y))};
+            const v2f lmin = v2f{fast_log2(fminf(fabsf(d[0].x), fabsf(d[0].y))), fast_log2(fminf(fabsf(d[1].x), fabsf(d[1].y)))};
+            const v2f ld = (ldiff + lsb) * splat(a.p);
+            const v2f lm = (lmin + lsm) * v2f{a.q0, a.q1};
+            const v2f one_mq = v2f{fast_exp2(lm.x), fast_exp2(lm.y)} + splat(1.0f);
+            const v2f t = ld - v2f{fast_log2(one_mq.x), fast_log2(one_mq.y)};
+            const v2f ldd = v2f{fminf(t.x, a.lg_dmax), fminf(t.y, a.lg_dmax)};
+            const v2f bl = ldd * splat(a.beta);
+            const v2f term = v2f{fast_exp2(bl.x), fast_exp2(bl.y)};      // D^beta for the spatial pooling (fvvdp.py:467,607)
+            const v2f av = __builtin_elementwise_fma(term, splat(vm), v2f{acc[0], acc[1]});
+            acc[0] = av.x;
+            acc[1] = av.y;
+            ldd_dbg[0] = ldd.x;
+            ldd_dbg[1] = ldd.y;
+        } else {
+            const float dT = d[0].x, dR = d[0].y;
+            const float ls = slog[0] + lcn;
+            const float ld = a.p * (fast_log2(fabsf(dT - dR)) + (ls + lg_base));
+            const float mq = fast_exp2(a.q0 * (fast_log2(fminf(fabsf(dT), fabsf(dR))) + (ls + lg_mask)));
+            const float ldd = fminf(ld - fast_log2(1.0f + mq), a.lg_dmax);
+            acc[0] = fmaf(fast_exp2(a.beta * ldd), vm, acc[0]);
+            ldd_dbg[0] = ldd;
+        }
+        if constexpr (DBG) {
+            if (valid) {
+#pragma unroll
+                for (int cc = 0; cc < HP; ++cc) {
+                    const size_t o = (((size_t)frame * 2 + cc) * h + y) * w + x;
+                    if (a.dD) a.dD[o] = fast_exp2(ldd_dbg[cc]);
+                    if (a.dS) a.dS[o] = fast_exp2(slog[cc]);
+                }
+            }
+        }
+        if constexpr (DBG) {
+            if (valid) {
+                if (a.dC) {
+                    const float sc = a.band_mul / lb;
+#pragma unroll
+                    for (int k = 0; k < HP; ++k) {
+                        a.dC[(((size_t)frame * P + 2 * k) * h + y) * w + x] = d[k].x * sc;
+                        a.dC[(((size_t)frame * P + 2 * k + 1) * h + y) * w + x] = d[k].y * sc;
+                    }
+                }
+                if (a.dL) a.dL[((size_t)frame * h + y) * w + x] = lb;
+            }
+        }
+    };
+
+    // ---- main loop: band rows 2c, 2c+1 for c in [ca, cb) ------------------------------------------------
+    for (int c = ca; c < cb; ++c) {
+        shift_window(nx0, nx1);               // window = fine rows 2c .. 2c+4
+        if (c + 1 < cb) {                     // prefetch the two rows of the next step
+            load_row(2 * c + 5, nx0[0], nx0[1]);
+            load_row(2 * c + 6, nx1[0], nx1[1]);
+        }
+        const Px<P> cN = coarse_step();       // coarse row c+1
+        const bool has_next = (c + 1) <= (hc - 1);
+        Px<P> Gp1 = has_next ? cN : G0;       // index clamp of the expand (fvvdp_lpyr_dec.py:134,138)
+        if (has_next && (c + 1) < cb && active) st_px(Gc + ((size_t)(c + 1) * wc + J) * P, cN);
+        Px<P> x00, x01, x10, x11;             // expanded level at (row 2c|2c+1, col X0|X1)
+        Px<P> evE, evO;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            // vertical expand on the coarse column: even fine row 2c (.1 .8 .1), odd fine row 2c+1 (.5 .5)
+            v2f t = Gm1.h[k] * 0.1f;
+            t = pfma(G0.h[k], 0.8f, t);
+            evE.h[k] = pfma(Gp1.h[k], 0.1f, t);
+            evO.h[k] = pfma(Gp1.h[k], 0.5f, G0.h[k] * 0.5f);
+        }
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            v2f t = evE.h[k] * ec;
+            t = fma_left(evE.h[k], el, t);
+            x00.h[k] = fma_right(evE.h[k], er, t);
+            x01.h[k] = fma_right(evE.h[k], orr, evE.h[k] * oc);
+            t = evO.h[k] * ec;
+            t = fma_left(evO.h[k], el, t);
+            x10.h[k] = fma_right(evO.h[k], er, t);
+            x11.h[k] = fma_right(evO.h[k], orr, evO.h[k] * oc);
+        }
+        const bool row1_ok = (2 * c + 1) < h;
+#if defined(BAND_ABLATE) && BAND_ABLATE >= 1      // profiling ablation: no per-pixel tail, keep the data flow alive
+        acc[0] += x00.h[0].x + x01.h[0].x + x10.h[0].x + x11.h[0].x + W[0][0].h[0].x + W[0][1].h[0].x + W[1][0].h[0].x + W[1][1].h[0].x;
+        if (false)
+#endif
+        {
+        float vy0 = 0.0f, vy1 = 0.0f;        // vertical view angle of the two fine rows (foveated)
+        if constexpr (FOV) {
+            const float yp0 = ((float)(2 * c) + 0.5f) + (-(float)h / 2.0f), yp1 = yp0 + 1.0f;
+            vy0 = atanf(-yp0 * a.size_m1 / (float)h / a.dist_m) * 57.29577951308232f;
+            vy1 = atanf(-yp1 * a.size_m1 / (float)h / a.dist_m) * 57.29577951308232f;
+        }
+        if constexpr (FOV) {
+            float vx4[4] = {vxa, vxb, vxa, vxb}, vy4[4] = {vy0, vy0, vy1, vy1}, rm4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+            if (a.mvx) {                          // user geometry: maps evaluated by the caller
+                const int ya = min(2 * c, h - 1), yb = min(2 * c + 1, h - 1);
+                const size_t o[4] = {(size_t)ya * w + xc0, (size_t)ya * w + xc1, (size_t)yb * w + xc0, (size_t)yb * w + xc1};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    vx4[i] = a.mvx[o[i]];
+                    vy4[i] = a.mvy[o[i]];
+                    rm4[i] = a.mrm[o[i]];
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float va = fminf(__builtin_amdgcn_sqrtf(vx4[i] * vx4[i] + vy4[i] * vy4[i]), 89.9f) * 0.017453292519943295f;
+                    rm4[i] = a.cos_delta * fast_rcp(__cosf(va) * __cosf(va + a.delta_rad));
+                }
+            }
+            band_px(W[0][0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0]);
+            band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1]);
+            band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vx4[2], vy4[2], rm4[2]);
+            band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vx4[3], vy4[3], rm4[3]);
+        } else {
+            band_px(W[0][0], x00, active, 2 * c, X0, 0.0f, 0.0f, 1.0f);
+            band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, 0.0f, 0.0f, 1.0f);
+            band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, 0.0f, 0.0f, 1.0f);
+            band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, 0.0f, 0.0f, 1.0f);
+        }
+        }
+        Gm1 = G0;
+        G0 = Gp1;
+    }
+
+    const float s0 = wave_sum(acc[0]);
+    const float s1 = wave_sum(acc[1]);
+    if (lane == 0) {
+        float* o = a.partial + ((size_t)frame * (a.n_strips * a.n_chunks) + blk) * 2;
+        o[0] = s0;
+        o[1] = s1;
+    }
+}
+

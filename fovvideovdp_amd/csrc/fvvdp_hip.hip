@@ -39,1226 +39,10 @@ static int fail(int code, const char* fmt, ...) {
 
 extern "C" const char* fvvdp_last_error(void) { return g_err; }
 
-// ------------------------------------------------------------------------------------------------------------
-// small device helpers
-// ------------------------------------------------------------------------------------------------------------
-template <int P>
-struct Pix {
-    float v[P];
-};
-
-template <int P>
-__device__ __forceinline__ Pix<P> ld_pix(const float* p);
-template <>
-__device__ __forceinline__ Pix<4> ld_pix<4>(const float* p) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    return Pix<4>{{t.x, t.y, t.z, t.w}};
-}
-template <>
-__device__ __forceinline__ Pix<2> ld_pix<2>(const float* p) {
-    const float2 t = *reinterpret_cast<const float2*>(p);
-    return Pix<2>{{t.x, t.y}};
-}
-__device__ __forceinline__ void st_pix(float* p, const Pix<4>& a) {
-    *reinterpret_cast<float4*>(p) = make_float4(a.v[0], a.v[1], a.v[2], a.v[3]);
-}
-__device__ __forceinline__ void st_pix(float* p, const Pix<2>& a) {
-    *reinterpret_cast<float2*>(p) = make_float2(a.v[0], a.v[1]);
-}
-
-__device__ __forceinline__ float fast_log2(float x) { return __builtin_amdgcn_logf(x); }   // v_log_f32
-__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }  // v_exp_f32
-__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }    // v_rcp_f32
-
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// stage 1: unpack + display photometry + luminance + temporal FIR  ->  pyramid level 0 (interleaved planes)
-// ------------------------------------------------------------------------------------------------------------
-enum { SRC_U8 = 0, SRC_U16 = 1, SRC_F32 = 2 };
-
-struct EotfDev {
-    int kind;
-    float scale;    // Y_peak - Y_black
-    float y_black;
-    float y_peak;
-    float gamma;
-    float l_min, l_max;
-    const float* lut;
-};
-
-// Per-channel display model on a float sample V (fvvdp_display_model.py:147-165).  `bad` is set when V was
-// outside [0,1] for an EOTF that clamps.
-__device__ __forceinline__ float eotf_f32(float V, const EotfDev& e, bool& bad) {
-    switch (e.kind) {
-        case FVVDP_EOTF_SRGB: {
-            bad = bad || (V > 1.0f) || (V < 0.0f);
-            V = fminf(fmaxf(V, 0.0f), 1.0f);
-            const float hi = fast_exp2(2.4f * fast_log2((V + 0.055f) / 1.055f));
-            const float lin = V > 0.04045f ? hi : V / 12.92f;
-            return __fadd_rn(__fmul_rn(e.scale, lin), e.y_black);
-        }
-        case FVVDP_EOTF_GAMMA: {
-            bad = bad || (V > 1.0f) || (V < 0.0f);
-            V = fminf(fmaxf(V, 0.0f), 1.0f);
-            const float lin = V > 0.0f ? fast_exp2(e.gamma * fast_log2(V)) : 0.0f;
-            return __fadd_rn(__fmul_rn(e.scale, lin), e.y_black);
-        }
-        case FVVDP_EOTF_PQ: {
-            bad = bad || (V > 1.0f) || (V < 0.0f);
-            V = fminf(fmaxf(V, 0.0f), 1.0f);
-            const float m = 78.843750000000000f, n = 0.15930175781250000f;
-            const float c1 = 0.83593750000000000f, c2 = 18.851562500000000f, c3 = 18.687500000000000f;
-            const float im_t = V > 0.0f ? fast_exp2(fast_log2(V) * (1.0f / m)) : 0.0f;
-            const float r = fmaxf(im_t - c1, 0.0f) / (c2 - c3 * im_t);
-            const float L = r > 0.0f ? 10000.0f * fast_exp2(fast_log2(r) * (1.0f / n)) : 0.0f;
-            return fminf(fmaxf(L, 0.005f), e.y_peak) + e.y_black;
-        }
-        case FVVDP_EOTF_LINEAR:
-            return fminf(fmaxf(V, 0.005f), e.y_peak) + e.y_black;
-        case FVVDP_EOTF_ABSOLUTE:
-            return fminf(fmaxf(V, e.l_min), e.l_max);
-        default:
-            return V;
-    }
-}
-
-// Luminance of PX consecutive pixels of one frame of one stream.
-//   U8 : LDS table lutw[c][code] = lut[code]*w[c] (same products and same summation order as the reference:
-//        (Lr*w0 + Lg*w1) + Lb*w2, video_source.py:206)
-template <int SRC, int PX>
-struct Sampler {
-    const void* base;
-    size_t chan_stride;
-    int C;
-    const float* lutw;     // LDS, [3][256], SRC_U8 only
-    const float* lut16;    // global, SRC_U16 only
-    float w0, w1, w2;
-    EotfDev e;
-
-    __device__ __forceinline__ void chan(const void* p, size_t off, float (&o)[PX], int c, bool& bad) const {
-        if constexpr (SRC == SRC_U8) {
-            const unsigned char* q = reinterpret_cast<const unsigned char*>(p) + off;
-            unsigned char code[PX];
-            if constexpr (PX == 4) {
-                const uchar4 t = *reinterpret_cast<const uchar4*>(q);
-                code[0] = t.x; code[1] = t.y; code[2] = t.z; code[3] = t.w;
-            } else if constexpr (PX == 2) {
-                const uchar2 t = *reinterpret_cast<const uchar2*>(q);
-                code[0] = t.x; code[1] = t.y;
-            } else {
-                code[0] = *q;
-            }
-#pragma unroll
-            for (int i = 0; i < PX; ++i) o[i] = lutw[c * 256 + code[i]];
-        } else if constexpr (SRC == SRC_U16) {
-            const unsigned short* q = reinterpret_cast<const unsigned short*>(p) + off;
-            unsigned short code[PX];
-            if constexpr (PX == 4) {
-                const ushort4 t = *reinterpret_cast<const ushort4*>(q);
-                code[0] = t.x; code[1] = t.y; code[2] = t.z; code[3] = t.w;
-            } else if constexpr (PX == 2) {
-                const ushort2 t = *reinterpret_cast<const ushort2*>(q);
-                code[0] = t.x; code[1] = t.y;
-            } else {
-                code[0] = *q;
-            }
-            const float wc = (c == 0) ? w0 : ((c == 1) ? w1 : w2);
-#pragma unroll
-            for (int i = 0; i < PX; ++i) o[i] = __fmul_rn(lut16[code[i]], wc);
-        } else {
-            const float* q = reinterpret_cast<const float*>(p) + off;
-            float V[PX];
-            if constexpr (PX == 4) {
-                const float4 t = *reinterpret_cast<const float4*>(q);
-                V[0] = t.x; V[1] = t.y; V[2] = t.z; V[3] = t.w;
-            } else if constexpr (PX == 2) {
-                const float2 t = *reinterpret_cast<const float2*>(q);
-                V[0] = t.x; V[1] = t.y;
-            } else {
-                V[0] = *q;
-            }
-            const float wc = (c == 0) ? w0 : ((c == 1) ? w1 : w2);
-#pragma unroll
-            for (int i = 0; i < PX; ++i) o[i] = __fmul_rn(eotf_f32(V[i], e, bad), wc);
-        }
-    }
-
-    // frame offset `foff` (elements) already includes f*frame_stride + pixel index
-    __device__ __forceinline__ void lum(size_t foff, float (&L)[PX], bool& bad) const {
-        if (C == 3) {
-            float a[PX], b[PX], c[PX];
-            chan(base, foff, a, 0, bad);
-            chan(base, foff + chan_stride, b, 1, bad);
-            chan(base, foff + 2 * chan_stride, c, 2, bad);
-#pragma unroll
-            for (int i = 0; i < PX; ++i) L[i] = __fadd_rn(__fadd_rn(a[i], b[i]), c[i]);
-        } else {
-            chan(base, foff, L, 0, bad);
-        }
-    }
-};
-
-#define T_MAX_IDX 320   // history + outputs of one launch
-struct TemporalArgs {
-    const void* src[2];
-    size_t chan_stride, frame_stride;
-    int C, HW;
-    EotfDev e;
-    float w[3];
-    int n_out;
-    int fl;                // true filter length (<= FL)
-    float* out;            // level 0 of the first output slot: [n_out][HW][4]
-    int* oob;
-    float taps[2][32];
-    int idx[T_MAX_IDX];    // [FL-1+n_out], entries before the true history are padded with a valid frame
-};
-
-__device__ __forceinline__ void build_lutw(float* lutw, const float* lut, int C, const float* w, int tid, int nthreads) {
-    for (int i = tid; i < 256; i += nthreads) {
-        const float l = lut[i];
-        if (C == 3) {
-            lutw[i] = __fmul_rn(l, w[0]);
-            lutw[256 + i] = __fmul_rn(l, w[1]);
-            lutw[512 + i] = __fmul_rn(l, w[2]);
-        } else {
-            lutw[i] = l;
-        }
-    }
-}
-
-// Temporally tiled FIR: one thread owns PX pixels for the whole launch and keeps the last FL luminance values of
-// both streams in registers (ring with compile-time slot indices), so every source frame is read exactly once and
-// every output pixel is written once as one float4 (test-sust, ref-sust, test-trans, ref-trans).
-// Reference: fvvdp.py:294-300 (R[:,2cc+s] = sum_k window[s][k] * F[cc].flip(0)[k]).
-// PX raw samples of one channel.  A thread's PX pixels are 256 apart (pixel i of thread t in block b is
-// b*256*PX + i*256 + t): every load and every store instruction of a wave then covers one contiguous run of
-// memory (64 x 1/2/4 B loads, 64 x 16 B = 1 KiB stores of finished float4 pixels).
-template <int SRC, int PX>
-struct RawPx {
-    unsigned int wd[PX];
-    __device__ __forceinline__ unsigned int code(int i) const { return wd[i]; }              // integer sources
-    __device__ __forceinline__ float value(int i) const { return __uint_as_float(wd[i]); }   // float source
-};
-
-template <int SRC, int PX>
-__device__ __forceinline__ RawPx<SRC, PX> load_raw(const void* base, size_t off, const int (&px)[PX]) {
-    RawPx<SRC, PX> r;
-#pragma unroll
-    for (int i = 0; i < PX; ++i) {
-        if constexpr (SRC == SRC_U8) r.wd[i] = reinterpret_cast<const unsigned char*>(base)[off + px[i]];
-        else if constexpr (SRC == SRC_U16) r.wd[i] = reinterpret_cast<const unsigned short*>(base)[off + px[i]];
-        else r.wd[i] = reinterpret_cast<const unsigned int*>(base)[off + px[i]];
-    }
-    return r;
-}
-
-// raw samples of all channels of one frame of one stream -> luminance of PX pixels
-template <int SRC, int PX>
-struct RawFrame {
-    RawPx<SRC, PX> ch[3];
-};
-
-template <int SRC, int PX>
-__device__ __forceinline__ RawFrame<SRC, PX> fetch_frame(const void* base, size_t off, size_t chan_stride, int C,
-                                                         const int (&px)[PX]) {
-    RawFrame<SRC, PX> f;
-    f.ch[0] = load_raw<SRC, PX>(base, off, px);
-    if (C == 3) {
-        f.ch[1] = load_raw<SRC, PX>(base, off + chan_stride, px);
-        f.ch[2] = load_raw<SRC, PX>(base, off + 2 * chan_stride, px);
-    } else {
-        f.ch[1] = f.ch[0];
-        f.ch[2] = f.ch[0];
-    }
-    return f;
-}
-
-template <int SRC, int PX, typename FRAME>
-__device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lutw, const float* lut16,
-                                          const float (&w)[3], const EotfDev& e, float (&L)[PX], bool& bad) {
-    float v[3][PX];
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (c > 0 && C != 3) break;
-#pragma unroll
-        for (int i = 0; i < PX; ++i) {
-            if constexpr (SRC == SRC_U8) v[c][i] = lutw[c * 256 + f.ch[c].code(i)];
-            else if constexpr (SRC == SRC_U16) v[c][i] = __fmul_rn(lut16[f.ch[c].code(i)], w[c]);
-            else v[c][i] = __fmul_rn(eotf_f32(f.ch[c].value(i), e, bad), w[c]);
-        }
-    }
-#pragma unroll
-    for (int i = 0; i < PX; ++i) L[i] = (C == 3) ? __fadd_rn(__fadd_rn(v[0][i], v[1][i]), v[2][i]) : v[0][i];
-}
-
-// Temporally tiled FIR: one thread owns PX pixels for the whole launch and keeps the last FL luminance values of
-// both streams in registers (ring with compile-time slot indices), so every source frame is read exactly once and
-// every output pixel is written once as one float4 (test-sust, ref-sust, test-trans, ref-trans).  The raw samples
-// of the next frame are fetched while the current one is filtered (software prefetch, one frame ahead).
-// Reference: fvvdp.py:294-300 (R[:,2cc+s] = sum_k window[s][k] * F[cc].flip(0)[k]).
-#ifndef TDIST
-#define TDIST 1          // frames of raw samples in flight per thread; 2 and 4 measured slower (VGPRs -> occupancy)
-#endif
-template <int FL, int PX, int SRC>
-__global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a) {
-    __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
-    if constexpr (SRC == SRC_U8) {
-        build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 256);
-        __syncthreads();
-    }
-    int px[PX];          // this thread's pixels (clamped for the loads; stores are predicated on `ok`)
-    bool ok[PX];
-#pragma unroll
-    for (int i = 0; i < PX; ++i) {
-        const int q = blockIdx.x * (256 * PX) + i * 256 + threadIdx.x;
-        ok[i] = q < a.HW;
-        px[i] = ok[i] ? q : a.HW - 1;
-    }
-    const float w[3] = {a.C == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};
-    bool bad = false;
-    float ring[2][FL][PX];
-#pragma unroll
-    for (int u = 0; u < FL; ++u)
-#pragma unroll
-        for (int i = 0; i < PX; ++i) ring[0][u][i] = ring[1][u][i] = 0.0f;
-    // virtual time v = 0 .. FL-2 is the history, v = FL-1+t the newest frame of output t; ring slot = v % FL.
-    // The same pipelined loop fills the history and produces the outputs, so at most one frame is in flight.
-    const int total = FL - 1 + a.n_out;
-    RawFrame<SRC, PX> nx[TDIST][2];           // raw samples of the next TDIST frames, in flight
-#pragma unroll
-    for (int d = 0; d < TDIST; ++d) {
-        const size_t off = (size_t)a.idx[d < total ? d : total - 1] * a.frame_stride;
-        nx[d][0] = fetch_frame<SRC, PX>(a.src[0], off, a.chan_stride, a.C, px);
-        nx[d][1] = fetch_frame<SRC, PX>(a.src[1], off, a.chan_stride, a.C, px);
-    }
-    for (int v0 = 0; v0 < total; v0 += FL) {
-#pragma unroll
-        for (int u = 0; u < FL; ++u) {
-            const int v = v0 + u;
-            if (v < total) {
-                const RawFrame<SRC, PX> cur0 = nx[u % TDIST][0], cur1 = nx[u % TDIST][1];
-                if (v + TDIST < total) {
-                    const size_t off = (size_t)a.idx[v + TDIST] * a.frame_stride;
-                    nx[u % TDIST][0] = fetch_frame<SRC, PX>(a.src[0], off, a.chan_stride, a.C, px);
-                    nx[u % TDIST][1] = fetch_frame<SRC, PX>(a.src[1], off, a.chan_stride, a.C, px);
-                }
-                frame_lum<SRC, PX, RawFrame<SRC, PX>>(cur0, a.C, lutw, a.e.lut, w, a.e, ring[0][u], bad);
-                frame_lum<SRC, PX, RawFrame<SRC, PX>>(cur1, a.C, lutw, a.e.lut, w, a.e, ring[1][u], bad);
-                if (v >= FL - 1) {
-                    float acc[4][PX];
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
-                    // oldest tap first, like the reference's sum over the window dimension
-#pragma unroll
-                    for (int k = FL - 1; k >= 0; --k) {
-                        const int sl = (u - k + 2 * FL) % FL;
-                        const float f0 = a.taps[0][k], f1 = a.taps[1][k];
-#pragma unroll
-                        for (int i = 0; i < PX; ++i) {
-                            acc[0][i] = fmaf(ring[0][sl][i], f0, acc[0][i]);
-                            acc[1][i] = fmaf(ring[1][sl][i], f0, acc[1][i]);
-                            acc[2][i] = fmaf(ring[0][sl][i], f1, acc[2][i]);
-                            acc[3][i] = fmaf(ring[1][sl][i], f1, acc[3][i]);
-                        }
-                    }
-                    float* o = a.out + (size_t)(v - (FL - 1)) * a.HW * 4;
-#pragma unroll
-                    for (int i = 0; i < PX; ++i)
-                        if (ok[i])
-                            *reinterpret_cast<float4*>(o + (size_t)px[i] * 4) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
-                }
-            }
-        }
-    }
-    if (bad && a.oob) atomicOr(a.oob, 1);
-}
-
-// ---- vector variant of the temporally tiled FIR (the fast path) -------------------------------------------------
-// Single-wave workgroups; a lane owns PX CONSECUTIVE pixels, so one load per channel fetches all of them
-// (4 uint8 = one dword, 4 uint16 = 8 B, 4 fp32 = 16 B: 4x fewer memory instructions than the per-pixel loads of
-// temporal_ring_kernel).  The finished float4 pixels are transposed through LDS (padded rows, conflict-free) so that
-// every store instruction of the wave still writes one contiguous 1 KiB run.  Needs HW % PX == 0 and PX-sample
-// aligned strides; other sizes take temporal_ring_kernel.
-template <int SRC, int PX>
-struct RawVec {
-    static constexpr int ES = (SRC == SRC_U8 ? 1 : (SRC == SRC_U16 ? 2 : 4));
-    static constexpr int WORDS = (ES * PX + 3) / 4;
-    unsigned int wd[WORDS];
-    __device__ __forceinline__ unsigned int code(int i) const {
-        if constexpr (SRC == SRC_U8) return (wd[i / 4] >> (8 * (i % 4))) & 0xFFu;
-        else return (wd[i / 2] >> (16 * (i % 2))) & 0xFFFFu;
-    }
-    __device__ __forceinline__ float value(int i) const { return __uint_as_float(wd[i]); }
-};
-template <int SRC, int PX>
-struct RawVecFrame {
-    RawVec<SRC, PX> ch[3];
-};
-
-template <int SRC, int PX>
-__device__ __forceinline__ RawVec<SRC, PX> load_vec(const void* base, size_t off) {
-    RawVec<SRC, PX> r;
-    constexpr int ES = RawVec<SRC, PX>::ES;
-    constexpr int BYTES = ES * PX;
-    const char* q = reinterpret_cast<const char*>(base) + off * ES;
-    if constexpr (BYTES == 16) {
-        const uint4 t = *reinterpret_cast<const uint4*>(q);
-        r.wd[0] = t.x; r.wd[1] = t.y; r.wd[2] = t.z; r.wd[3] = t.w;
-    } else if constexpr (BYTES == 8) {
-        const uint2 t = *reinterpret_cast<const uint2*>(q);
-        r.wd[0] = t.x; r.wd[1] = t.y;
-    } else if constexpr (BYTES == 4) {
-        r.wd[0] = *reinterpret_cast<const unsigned int*>(q);
-    } else {
-        r.wd[0] = *reinterpret_cast<const unsigned short*>(q);
-    }
-    return r;
-}
-
-template <int SRC, int PX>
-__device__ __forceinline__ RawVecFrame<SRC, PX> fetch_vec(const void* base, size_t off, size_t chan_stride, int C) {
-    RawVecFrame<SRC, PX> f;
-    f.ch[0] = load_vec<SRC, PX>(base, off);
-    if (C == 3) {
-        f.ch[1] = load_vec<SRC, PX>(base, off + chan_stride);
-        f.ch[2] = load_vec<SRC, PX>(base, off + 2 * chan_stride);
-    } else {
-        f.ch[1] = f.ch[0];
-        f.ch[2] = f.ch[0];
-    }
-    return f;
-}
-
-template <int FL, int PX, int SRC>
-__global__ __launch_bounds__(64) void temporal_vec_kernel(const TemporalArgs a) {
-    __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
-    __shared__ float4 s_t[64 * (PX + 1)];          // one padded row of PX float4 per lane
-    const int lane = threadIdx.x;
-    if constexpr (SRC == SRC_U8) build_lutw(lutw, a.e.lut, a.C, a.w, lane, 64);
-    __syncthreads();
-    const int p0 = blockIdx.x * (64 * PX);          // first pixel of this wave
-    const int pl = min(p0 + lane * PX, a.HW - PX);  // this lane's PX consecutive pixels (clamped: loads stay in range)
-    const float w[3] = {a.C == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};
-    bool bad = false;
-    float ring[2][FL][PX];
-#pragma unroll
-    for (int u = 0; u < FL; ++u)
-#pragma unroll
-        for (int i = 0; i < PX; ++i) ring[0][u][i] = ring[1][u][i] = 0.0f;
-    const int total = FL - 1 + a.n_out;
-    RawVecFrame<SRC, PX> nx[2];
-    {
-        const size_t off = (size_t)a.idx[0] * a.frame_stride + pl;
-        nx[0] = fetch_vec<SRC, PX>(a.src[0], off, a.chan_stride, a.C);
-        nx[1] = fetch_vec<SRC, PX>(a.src[1], off, a.chan_stride, a.C);
-    }
-    for (int v0 = 0; v0 < total; v0 += FL) {
-#pragma unroll
-        for (int u = 0; u < FL; ++u) {
-            const int v = v0 + u;
-            if (v < total) {
-                const RawVecFrame<SRC, PX> cur0 = nx[0], cur1 = nx[1];
-                if (v + 1 < total) {
-                    const size_t off = (size_t)a.idx[v + 1] * a.frame_stride + pl;
-                    nx[0] = fetch_vec<SRC, PX>(a.src[0], off, a.chan_stride, a.C);
-                    nx[1] = fetch_vec<SRC, PX>(a.src[1], off, a.chan_stride, a.C);
-                }
-                frame_lum<SRC, PX, RawVecFrame<SRC, PX>>(cur0, a.C, lutw, a.e.lut, w, a.e, ring[0][u], bad);
-                frame_lum<SRC, PX, RawVecFrame<SRC, PX>>(cur1, a.C, lutw, a.e.lut, w, a.e, ring[1][u], bad);
-                if (v >= FL - 1) {
-                    float acc[4][PX];
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
-#pragma unroll
-                    for (int k = FL - 1; k >= 0; --k) {      // oldest tap first, like the reference's sum over the window
-                        const int sl = (u - k + 2 * FL) % FL;
-                        const float f0 = a.taps[0][k], f1 = a.taps[1][k];
-#pragma unroll
-                        for (int i = 0; i < PX; ++i) {
-                            acc[0][i] = fmaf(ring[0][sl][i], f0, acc[0][i]);
-                            acc[1][i] = fmaf(ring[1][sl][i], f0, acc[1][i]);
-                            acc[2][i] = fmaf(ring[0][sl][i], f1, acc[2][i]);
-                            acc[3][i] = fmaf(ring[1][sl][i], f1, acc[3][i]);
-                        }
-                    }
-                    // transpose through LDS: lane l holds pixels l*PX..l*PX+PX-1, store i writes pixels i*64+l
-                    __syncthreads();                         // single wave: orders the LDS accesses only
-#pragma unroll
-                    for (int i = 0; i < PX; ++i)
-                        s_t[lane * (PX + 1) + i] = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
-                    __syncthreads();
-                    float4* o = reinterpret_cast<float4*>(a.out) + (size_t)(v - (FL - 1)) * a.HW + p0;
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) {
-                        const int q = i * 64 + lane;
-                        const float4 val = s_t[(q / PX) * (PX + 1) + (q % PX)];
-                        if (p0 + q < a.HW) o[q] = val;
-                    }
-                }
-            }
-        }
-    }
-    if (bad && a.oob) atomicOr(a.oob, 1);
-}
-
-// ---- planar YUV ingest fused with the temporal filter ---------------------------------------------------------
-// Replaces video_reader_yuv_pytorch.unpack / _fixed2float_upscale (video_source_file.py:219-276) + _prepare_frame
-// (:355-363): limited-range fixed->float (Y: w*Y-16/219 clipped to [0,1]; Cb,Cr: w*c-128/224 clipped to +-0.5),
-// 4:2:0 chroma bilinear x2 (torch interpolate, align_corners=False: source = (dst+0.5)/2-0.5 clamped at 0),
-// YCbCr->RGB matrix, clip to [0,1], display model per channel, RGB->luminance, then the same register-ring FIR
-// as the other temporal kernels.  One thread owns PX pixels 256 apart (coalesced Y loads and float4 stores).
-struct YuvArgs {
-    const void* src[2];
-    size_t frame_stride;     // elements between frames
-    int W, H, uvw, uvh;
-    int chroma420;
-    float wy, wc;            // 1/(2^(b-8)*219), 1/(2^(b-8)*224)
-    float m[9];              // ycbcr2rgb, row-major: R = m0*Y + m1*Cb + m2*Cr ...
-    EotfDev e;
-    float w[3];
-    int n_out, fl;
-    float* out;
-    int* oob;
-    float taps[2][32];
-    int idx[T_MAX_IDX];
-};
-
-template <typename T>
-__device__ __forceinline__ float yuv_lum(const T* __restrict__ f, const YuvArgs& a, int p, bool& bad) {
-    const int HW = a.W * a.H;
-    const int y = p / a.W, x = p - y * a.W;
-    const float Yf = fminf(fmaxf(a.wy * (float)f[p] - (16.0f / 219.0f), 0.0f), 1.0f);
-    const T* U = f + HW;
-    const T* V = U + a.uvw * a.uvh;
-    auto cf = [&](const T* pl, int yy, int xx) {
-        return fminf(fmaxf(a.wc * (float)pl[yy * a.uvw + xx] - (128.0f / 224.0f), -0.5f), 0.5f);
-    };
-    float u, v;
-    if (a.chroma420) {
-        const float sy = fmaxf(((float)y + 0.5f) * 0.5f - 0.5f, 0.0f), sx = fmaxf(((float)x + 0.5f) * 0.5f - 0.5f, 0.0f);
-        const int y0 = (int)sy, x0 = (int)sx;
-        const int y1 = min(y0 + 1, a.uvh - 1), x1 = min(x0 + 1, a.uvw - 1);
-        const float fy = sy - (float)y0, fx = sx - (float)x0;
-        const float gy = 1.0f - fy, gx = 1.0f - fx;
-        u = gy * (gx * cf(U, y0, x0) + fx * cf(U, y0, x1)) + fy * (gx * cf(U, y1, x0) + fx * cf(U, y1, x1));
-        v = gy * (gx * cf(V, y0, x0) + fx * cf(V, y0, x1)) + fy * (gx * cf(V, y1, x0) + fx * cf(V, y1, x1));
-    } else {
-        u = cf(U, y, x);
-        v = cf(V, y, x);
-    }
-    float L = 0.0f;
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        float rgb = a.m[3 * c] * Yf + a.m[3 * c + 1] * u + a.m[3 * c + 2] * v;
-        rgb = fminf(fmaxf(rgb, 0.0f), 1.0f);
-        const float l = __fmul_rn(eotf_f32(rgb, a.e, bad), a.w[c]);
-        L = (c == 0) ? l : __fadd_rn(L, l);
-    }
-    return L;
-}
-
-template <int FL, int PX, typename T>
-__global__ __launch_bounds__(256) void temporal_yuv_kernel(const YuvArgs a) {
-    const int HW = a.W * a.H;
-    int px[PX];
-    bool ok[PX];
-#pragma unroll
-    for (int i = 0; i < PX; ++i) {
-        const int q = blockIdx.x * (256 * PX) + i * 256 + threadIdx.x;
-        ok[i] = q < HW;
-        px[i] = ok[i] ? q : HW - 1;
-    }
-    bool bad = false;
-    float ring[2][FL][PX];
-#pragma unroll
-    for (int u = 0; u < FL; ++u)
-#pragma unroll
-        for (int i = 0; i < PX; ++i) ring[0][u][i] = ring[1][u][i] = 0.0f;
-    const int total = FL - 1 + a.n_out;
-    for (int v0 = 0; v0 < total; v0 += FL) {
-#pragma unroll
-        for (int u = 0; u < FL; ++u) {
-            const int v = v0 + u;
-            if (v < total) {
-                const size_t off = (size_t)a.idx[v] * a.frame_stride;
-                const T* f0 = reinterpret_cast<const T*>(a.src[0]) + off;
-                const T* f1 = reinterpret_cast<const T*>(a.src[1]) + off;
-#pragma unroll
-                for (int i = 0; i < PX; ++i) {
-                    ring[0][u][i] = yuv_lum<T>(f0, a, px[i], bad);
-                    ring[1][u][i] = yuv_lum<T>(f1, a, px[i], bad);
-                }
-                if (v >= FL - 1) {
-                    float acc[4][PX];
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
-#pragma unroll
-                    for (int k = FL - 1; k >= 0; --k) {
-                        const int sl = (u - k + 2 * FL) % FL;
-                        const float t0 = a.taps[0][k], t1 = a.taps[1][k];
-#pragma unroll
-                        for (int i = 0; i < PX; ++i) {
-                            acc[0][i] = fmaf(ring[0][sl][i], t0, acc[0][i]);
-                            acc[1][i] = fmaf(ring[1][sl][i], t0, acc[1][i]);
-                            acc[2][i] = fmaf(ring[0][sl][i], t1, acc[2][i]);
-                            acc[3][i] = fmaf(ring[1][sl][i], t1, acc[3][i]);
-                        }
-                    }
-                    float* o = a.out + (size_t)(v - (FL - 1)) * HW * 4;
-#pragma unroll
-                    for (int i = 0; i < PX; ++i)
-                        if (ok[i])
-                            *reinterpret_cast<float4*>(o + (size_t)px[i] * 4) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
-                }
-            }
-        }
-    }
-    if (bad && a.oob) atomicOr(a.oob, 1);
-}
-
-// Generic (any fl, any frame size) version: one thread per pixel per output frame, the window is re-read from
-// the source (L2-served).  Used for fl > 32, for frame sizes that are not a multiple of 4 pixels and for still
-// images (P == 2: out = (L_test, L_ref), fvvdp.py:251-253).
-struct GenericArgs {
-    const void* src[2];
-    size_t chan_stride, frame_stride;
-    int C, HW;
-    EotfDev e;
-    float w[3];
-    int n_out, fl;
-    float* out;
-    int* oob;
-    const float* taps;   // device [2][fl]
-    const int* idx;      // device [fl-1+n_out]
-};
-
-template <int SRC, int P>
-__global__ __launch_bounds__(256) void temporal_generic_kernel(const GenericArgs a) {
-    __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
-    if constexpr (SRC == SRC_U8) {
-        build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 256);
-        __syncthreads();
-    }
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const int t = blockIdx.y;
-    if (p >= a.HW) return;
-    Sampler<SRC, 1> S[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        S[s].base = a.src[s];
-        S[s].chan_stride = a.chan_stride;
-        S[s].C = a.C;
-        S[s].lutw = lutw;
-        S[s].lut16 = a.e.lut;
-        S[s].w0 = a.C == 3 ? a.w[0] : 1.0f;
-        S[s].w1 = a.w[1];
-        S[s].w2 = a.w[2];
-        S[s].e = a.e;
-    }
-    bool bad = false;
-    if constexpr (P == 2) {
-        float lt[1], lr[1];
-        const size_t off = (size_t)a.idx[t] * a.frame_stride + p;
-        S[0].lum(off, lt, bad);
-        S[1].lum(off, lr, bad);
-        *reinterpret_cast<float2*>(a.out + ((size_t)t * a.HW + p) * 2) = make_float2(lt[0], lr[0]);
-    } else {
-        float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
-        for (int k = a.fl - 1; k >= 0; --k) {
-            const size_t off = (size_t)a.idx[a.fl - 1 + t - k] * a.frame_stride + p;
-            float lt[1], lr[1];
-            S[0].lum(off, lt, bad);
-            S[1].lum(off, lr, bad);
-            const float f0 = a.taps[k], f1 = a.taps[a.fl + k];
-            acc[0] = fmaf(lt[0], f0, acc[0]);
-            acc[1] = fmaf(lr[0], f0, acc[1]);
-            acc[2] = fmaf(lt[0], f1, acc[2]);
-            acc[3] = fmaf(lr[0], f1, acc[3]);
-        }
-        *reinterpret_cast<float4*>(a.out + ((size_t)t * a.HW + p) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
-    }
-    if (bad && a.oob) atomicOr(a.oob, 1);
-}
-
-// planar [n][P][HW] <-> interleaved [n][HW][P]
-template <int P>
-__global__ void interleave_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int to_interleaved) {
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    const int f = blockIdx.y;
-    if (p >= HW) return;
-#pragma unroll
-    for (int k = 0; k < P; ++k) {
-        if (to_interleaved)
-            out[((size_t)f * HW + p) * P + k] = in[((size_t)f * P + k) * HW + p];
-        else
-            out[((size_t)f * P + k) * HW + p] = in[((size_t)f * HW + p) * P + k];
-    }
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// stage 2: fused pyramid level
-//   read Gaussian level i once, write level i+1 once, and in the same pass expand level i+1, form the contrast
-//   band, weight by the CSF, apply mutual masking and accumulate sum(D^beta)  (nothing else touches HBM).
-//
-//   One single-wave workgroup streams down a strip of 120 fine (60 coarse) columns: lane l owns coarse column
-//   J = 60*strip+l and the two fine columns 2J, 2J+1 (4 fine pixels per step).  Vertical 5-tap reduce and the vertical
-//   half of the expand are thread-local on a register window of 5 fine rows; the horizontal halves take the
-//   neighbour lanes' values through DPP wave shifts (v_mov_b32_dpp wave_shr:1 / wave_shl:1) -- no LDS, no
-//   barriers, so the waves of a CU run completely decoupled and hide each other's HBM latency.  Plane pairs
-//   (test, ref) live in adjacent registers and go through packed fp32 math (v_pk_fma_f32), which also makes the
-//   test and reference planes bit-symmetric (identical inputs give exactly D = 0).
-// ------------------------------------------------------------------------------------------------------------
-#define STRIP_J 60          // coarse columns produced per wave (64 lanes - 2 halo lanes each side)
-
-typedef float v2f __attribute__((ext_vector_type(2)));
-
-template <int P>
-struct Px {                 // one pixel: P/2 (test, ref) pairs
-    v2f h[P / 2];
-};
-
-template <int P>
-__device__ __forceinline__ Px<P> ld_px(const float* p);
-template <>
-__device__ __forceinline__ Px<4> ld_px<4>(const float* p) {
-    const float4 t = *reinterpret_cast<const float4*>(p);
-    Px<4> r;
-    r.h[0] = v2f{t.x, t.y};
-    r.h[1] = v2f{t.z, t.w};
-    return r;
-}
-template <>
-__device__ __forceinline__ Px<2> ld_px<2>(const float* p) {
-    const float2 t = *reinterpret_cast<const float2*>(p);
-    Px<2> r;
-    r.h[0] = v2f{t.x, t.y};
-    return r;
-}
-// the coarse level is written once and only read by the next launch: non-temporal stores (measured +2-3 % on the
-// read+write mix of this kernel, tools/microbench/membw.hip)
-typedef float v4f __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_px(float* p, const Px<4>& a) {
-    __builtin_nontemporal_store(v4f{a.h[0].x, a.h[0].y, a.h[1].x, a.h[1].y}, reinterpret_cast<v4f*>(p));
-}
-__device__ __forceinline__ void st_px(float* p, const Px<2>& a) {
-    __builtin_nontemporal_store(a.h[0], reinterpret_cast<v2f*>(p));
-}
-
-__device__ __forceinline__ v2f splat(float s) { return v2f{s, s}; }
-// a*s + c on both halves (v_pk_fma_f32)
-__device__ __forceinline__ v2f pfma(v2f a, float s, v2f c) { return __builtin_elementwise_fma(a, splat(s), c); }
-
-// value held by the lane to the left / right (0 at the wave's ends)
-__device__ __forceinline__ float from_left(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float from_right(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
-}
-// acc + w * neighbour(x), per component (v_fmac_f32 with a DPP source)
-__device__ __forceinline__ v2f fma_left(v2f x, float w, v2f acc) {
-    return v2f{fmaf(from_left(x.x), w, acc.x), fmaf(from_left(x.y), w, acc.y)};
-}
-__device__ __forceinline__ v2f fma_right(v2f x, float w, v2f acc) {
-    return v2f{fmaf(from_right(x.x), w, acc.x), fmaf(from_right(x.y), w, acc.y)};
-}
-
-struct BandArgs {
-    const float* Gf;        // fine level   [n][h][w][P]
-    float* Gc;              // coarse level [n][hc][wc][P]
-    int w, h, wc, hc;
-    int n_strips, n_chunks, cr;
-    int n_items;            // work items (waves) of this launch
-    int lut_lds;            // foveated: 1 = the band's LUT slice fits the dynamic LDS and is copied there
-    float band_mul;
-    const float4* csf;      // [32] records {S_log0[i], S_log1[i], S_log0[i+1]-S_log0[i], S_log1[i+1]-S_log1[i]}
-    const float4* csf_y;    // [32] records {Y_log[i], ...} (foveated path: knots of the Y axis)
-    float y_first, y_inv_step;
-    float y_lo, y_hi;       // clamp range of L_bkg (lut Y[0], Y[-1])
-    float ly_lo, ly_hi;     // the same in log2
-    float lg_gain, lg_k;    // log2(sens_gain), log2(mask_k)
-    float p, q0, q1, beta, lbkg_min, cmax, lg_dmax;
-    float* partial;         // [n][n_strips*n_chunks][2]
-    float* dD;
-    float* dC;
-    float* dL;
-    float* dS;
-    // foveated (FOV == true)
-    const float4* sublut;   // per band: [32 ecc][32 Y][rw] of {S_log0[i], S_log1[i], S_log0[i+1], S_log1[i+1]} (i = rho knot)
-    const float* axes;      // [3][32] knots: Y_log, rho_log, ecc_sqrt
-    int rw, i_lo;           // rho knots covered by the band's sub-LUT: [i_lo, i_lo+rw]
-    const float* fix;       // device [n][2]: gaze in frame pixels, or gaze view direction in degrees (map mode)
-    const float* mvx;       // map mode (user geometry): view direction x,y [h][w] in degrees and resolution
-    const float* mvy;       //   magnification [h][w] of this band, evaluated by the caller with the user's
-    const float* mrm;       //   geometry object; nullptr = stock geometry computed in-kernel
-    float size_m0, size_m1, dist_m, cos_delta, delta_rad;
-    float rho_band, rho_lo, rho_hi, ecc_lo, ecc_hi;
-    float inv_step[3], first[3];   // uniform-grid estimates of the three axes
-    int frame_w, frame_h;
-};
-
-
-#define FOV_WPB 4            // foveated mode: 4 independent waves per workgroup share the band's LUT slice in LDS
-extern __shared__ __attribute__((aligned(16))) float4 s_lut_dyn[];
-
-template <int P, bool DBG, bool FOV>
-__global__ __launch_bounds__(FOV ? 64 * FOV_WPB : 64, (FOV || DBG) ? 2 : 4) void band_kernel(const BandArgs a) {
-    constexpr int HP = P / 2;   // (test, ref) pairs = temporal channels
-    constexpr int WPB = FOV ? FOV_WPB : 1;
-    __shared__ float4 s_csf[FVVDP_LUT_N];
-
-    const int lane = FOV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
-    // XCD-aware work order: hardware places workgroup b on XCD b % 8 (speed only, never correctness).  Give each
-    // XCD a contiguous range of work items (strip fastest, then chunk, then frame) so that neighbouring strips,
-    // which share their 4+4 halo columns, run on the same XCD at about the same time and hit in its L2.
-    int bid;
-    {
-        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
-        bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
-        if constexpr (FOV) bid = bid * WPB + (threadIdx.x >> 6);
-    }
-    const bool wave_has_work = !FOV || bid < a.n_items;
-    const int strip = bid % a.n_strips;
-    bid /= a.n_strips;
-    const int chunk = bid % a.n_chunks;
-    const int frame = bid / a.n_chunks;
-    const int blk = chunk * a.n_strips + strip;
-
-    const int w = a.w, h = a.h, wc = a.wc, hc = a.hc;
-    // lane l of strip s owns coarse column J = 60*s + l, i.e. fine columns 120*s + 2l (+1): the 128 fine pixels a
-    // wave reads per row start at byte 1920*s of the row -> aligned to the 128-byte lines.  Lanes 2..61 produce
-    // output; lanes 0,1 and 62,63 only feed their neighbours (in strip 0 the image border makes lanes 0,1 complete).
-    const int J = strip * STRIP_J + lane;
-    const int ca = chunk * a.cr;
-    const int cb = min(ca + a.cr, hc);
-    const bool active = (lane >= 2 || strip == 0) && (lane < 62) && (J < wc);
-    const int X0 = 2 * J, X1 = 2 * J + 1;
-    const int xc0 = min(max(X0, 0), w - 1), xc1 = min(max(X1, 0), w - 1);
-    const bool col1_ok = X1 < w;
-
-    __shared__ float2 s_ax[FOV ? 3 * FVVDP_LUT_N : 1];     // {knot k, 1/(knot k+1 - knot k + 1e-6)} of the three axes
-    if constexpr (!FOV) {
-        if (lane < FVVDP_LUT_N) s_csf[lane] = a.csf[lane];
-    } else {
-        for (int i = threadIdx.x; i < 3 * FVVDP_LUT_N; i += 64 * WPB) {
-            const int k = i % FVVDP_LUT_N;
-            const float x0 = a.axes[i];
-            const float x1 = a.axes[k + 1 < FVVDP_LUT_N ? i + 1 : i];
-            s_ax[i] = make_float2(x0, 1.0f / (x1 - x0 + 0.000001f));
-        }
-        if (a.lut_lds) {
-            const int nl = FVVDP_LUT_N * FVVDP_LUT_N * a.rw;
-            for (int i = threadIdx.x; i < nl; i += 64 * WPB) s_lut_dyn[i] = a.sublut[i];
-        }
-    }
-    __syncthreads();
-    if constexpr (FOV) {
-        if (!wave_has_work) return;
-    }
-
-    // horizontal 5-tap weights of this lane's coarse column incl. the reference's edge fix-ups
-    // (gausspyr_reduce, fvvdp_lpyr_dec.py:198-205; the right-edge branch is selected by the parity of the ROW
-    // count, :202, reproduced here on purpose).  Taps: E[l-1], O[l-1], E[l], O[l], E[l+1]  (E/O = even/odd fine
-    // column of a lane); taps falling outside the image get weight 0 and their fix-up is folded into the
-    // in-range taps.
-    const float K0 = 0.05f, K1 = 0.25f, K2 = 0.4f, K3 = 0.25f, K4 = 0.05f;
-    float wq0 = K0, wq1 = K1, wq2 = K2, wq3 = K3, wq4 = K4;
-    if (J == 0) {
-        wq2 += K1;
-        wq3 += K0;
-        wq0 = 0.0f;
-        wq1 = 0.0f;
-    }
-    if (J == wc - 1) {
-        const bool hodd = (h & 1) != 0;
-        if (w & 1) {   // own columns: X0 = w-1 (tap 2), X1 = w (outside)
-            wq3 = 0.0f;
-            wq4 = 0.0f;
-            if (hodd) { wq2 += K3; wq1 += K4; } else { wq2 += K4; }
-        } else {       // own columns: w-2 (tap 2), w-1 (tap 3); tap 4 = column w is outside
-            wq4 = 0.0f;
-            if (hodd) { wq3 += K3; wq2 += K4; } else { wq3 += K4; }
-        }
-    }
-    // horizontal expand weights (2K = .1 .8 .1 / .5 .5, gausspyr_expand fvvdp_lpyr_dec.py:126-142,233); a
-    // neighbour outside the coarse row is the clamped (own) column, so its weight moves to the centre tap
-    const bool at_l = (J <= 0), at_r = (J >= wc - 1);
-    const float el = at_l ? 0.0f : 0.1f, er = at_r ? 0.0f : 0.1f;
-    const float ec = 0.8f + (at_l ? 0.1f : 0.0f) + (at_r ? 0.1f : 0.0f);
-    const float orr = at_r ? 0.0f : 0.5f;
-    const float oc = at_r ? 1.0f : 0.5f;
-
-    const float* Gf = a.Gf + (size_t)frame * h * w * P;
-    float* Gc = a.Gc + (size_t)frame * hc * wc * P;
-
-    auto load_row = [&](int r, Px<P>& p0, Px<P>& p1) {
-        int rr = r < 0 ? -1 - r : (r >= h ? 2 * h - 1 - r : r);   // symmetric padding (fvvdp_lpyr_dec.py:190-195)
-        rr = min(max(rr, 0), h - 1);
-        const float* row = Gf + (size_t)rr * w * P;
-        p0 = ld_px<P>(row + (size_t)xc0 * P);
-        p1 = ld_px<P>(row + (size_t)xc1 * P);
-    };
-
-    Px<P> W[5][2];
-
-    // one coarse row from the current window: vertical 5-tap in registers, horizontal 5-tap across lanes
-    auto coarse_step = [&]() -> Px<P> {
-        Px<P> c, va, vb;
-#pragma unroll
-        for (int k = 0; k < HP; ++k) {
-            v2f a0 = W[0][0].h[k] * K0;
-            a0 = pfma(W[1][0].h[k], K1, a0);
-            a0 = pfma(W[2][0].h[k], K2, a0);
-            a0 = pfma(W[3][0].h[k], K3, a0);
-            va.h[k] = pfma(W[4][0].h[k], K4, a0);
-            v2f b0 = W[0][1].h[k] * K0;
-            b0 = pfma(W[1][1].h[k], K1, b0);
-            b0 = pfma(W[2][1].h[k], K2, b0);
-            b0 = pfma(W[3][1].h[k], K3, b0);
-            vb.h[k] = pfma(W[4][1].h[k], K4, b0);
-        }
-#pragma unroll
-        for (int k = 0; k < HP; ++k) {
-            v2f acc = va.h[k] * wq2;
-            acc = pfma(vb.h[k], wq3, acc);
-            acc = fma_left(va.h[k], wq0, acc);
-            acc = fma_left(vb.h[k], wq1, acc);
-            c.h[k] = fma_right(va.h[k], wq4, acc);
-        }
-        return c;
-    };
-    auto shift_window = [&](const Px<P> (&n0)[2], const Px<P> (&n1)[2]) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            W[0][j] = W[2][j];
-            W[1][j] = W[3][j];
-            W[2][j] = W[4][j];
-            W[3][j] = n0[j];
-            W[4][j] = n1[j];
-        }
-    };
-
-    // ---- prologue: coarse rows ca-1 and ca --------------------------------------------------------------
-    {
-        const int r0 = 2 * (ca - 1) - 2;
-#pragma unroll
-        for (int k = 0; k < 5; ++k) load_row(r0 + k, W[k][0], W[k][1]);
-    }
-    const Px<P> cA = coarse_step();
-    Px<P> nx0[2], nx1[2];
-    load_row(2 * ca + 1, nx0[0], nx0[1]);
-    load_row(2 * ca + 2, nx1[0], nx1[1]);
-    shift_window(nx0, nx1);
-    const Px<P> cB = coarse_step();
-    if (active) st_px(Gc + ((size_t)ca * wc + J) * P, cB);
-    Px<P> Gm1 = (ca > 0) ? cA : cB;
-    Px<P> G0 = cB;
-    load_row(2 * ca + 3, nx0[0], nx0[1]);
-    load_row(2 * ca + 4, nx1[0], nx1[1]);
-
-    float acc[2] = {0.0f, 0.0f};
-
-    // foveated constants of this lane's two fine columns
-    float vxa = 0.0f, vxb = 0.0f, gx = 0.0f, gy = 0.0f;
-    if constexpr (FOV) {
-        // pix2view_direction (fvvdp_display_model.py:498-510) on the band grid, pixel centres at +0.5
-        const float xa = ((float)X0 + 0.5f) + (-(float)w / 2.0f);
-        const float xb = ((float)X1 + 0.5f) + (-(float)w / 2.0f);
-        vxa = atanf(xa * a.size_m0 / (float)w / a.dist_m) * 57.29577951308232f;
-        vxb = atanf(xb * a.size_m0 / (float)w / a.dist_m) * 57.29577951308232f;
-        if (a.mvx) {
-            gx = a.fix[2 * frame + 0];
-            gy = a.fix[2 * frame + 1];
-        } else {
-            const float fxp = a.fix[2 * frame + 0] + 0.5f, fyp = a.fix[2 * frame + 1] + 0.5f;
-            const float gxm = (fxp + (-(float)a.frame_w / 2.0f)) * a.size_m0 / (float)a.frame_w;
-            const float gym = -(fyp + (-(float)a.frame_h / 2.0f)) * a.size_m1 / (float)a.frame_h;
-            gx = atanf(gxm / a.dist_m) * 57.29577951308232f;
-            gy = atanf(gym / a.dist_m) * 57.29577951308232f;
-        }
-    }
-
-    const float lg_bm = __log2f(a.band_mul);
-    const float lg_base = a.lg_gain;              // log2(S) = interp + log2(gain)      (fvvdp.py:447)
-    const float lg_mask = a.lg_gain + a.lg_k;      // log2(k*S)
-
-    // per-pixel tail: contrast, CSF, masking, pooling  (fvvdp_lpyr_dec.py:259-269, fvvdp.py:395-467)
-    auto band_px = [&](const Px<P>& g, const Px<P>& e, bool valid, int y, int x, float vx, float vy, float res_mag) {
-        (void)x; (void)res_mag;
-        const float lb = fmaxf(e.h[0].y, a.lbkg_min);                  // plane 1 = reference (sustained)
-        // contrast = min((g-e)/lb, cmax) * m.  Dividing by lb>0 commutes with |.|, min and the clamp, so the
-        // division is carried as -log2(lb) in the log domain below: no reciprocal, no per-plane multiply.
-        const float dcap = a.cmax * lb;                                // (g-e)/lb <= cmax  <=>  g-e <= cmax*lb
-        v2f d[HP];
-#pragma unroll
-        for (int k = 0; k < HP; ++k) {
-            const v2f t = g.h[k] - e.h[k];
-            d[k] = v2f{fminf(t.x, dcap), fminf(t.y, dcap)};            // upper clamp only (fvvdp_lpyr_dec.py:266)
-        }
-        const float llb = fast_log2(lb);
-        const float yq = fminf(fmaxf(llb, a.ly_lo), a.ly_hi);          // = log2(clamp(lb, Y[0], Y[-1]))  (fvvdp.py:530)
-        float slog[2] = {0.0f, 0.0f};
-        if constexpr (!FOV) {
-            // 1-D table over log2(L_bkg) (uniform knots): interval from the grid, value = v[i] + f*(v[i+1]-v[i])
-            const float t = (yq - a.y_first) * a.y_inv_step;
-            const float fi = fminf(fmaxf(floorf(t), 0.0f), (float)(FVVDP_LUT_N - 2));
-            const float4 r = s_csf[(int)fi];                           // {v0[i], v1[i], v0[i+1]-v0[i], v1[i+1]-v1[i]}
-            const float f = t - fi;
-            slog[0] = fmaf(f, r.z, r.x);
-            slog[1] = fmaf(f, r.w, r.y);
-        } else {
-            // eccentricity and resolution magnification (fvvdp.py:424-437, fvvdp_display_model.py:475-526).
-            // (tan(a+d)-tan(a))/tan(d) == cos(d)/(cos(a)cos(a+d)): evaluated in this form it needs no slow tan and
-            // does not lose digits to the reference's fp32 finite difference (whose noise, ~5e-4, bounds parity).
-            const float dx = vx - gx, dy = vy - gy;
-            const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
-            const float rho = a.rho_band * res_mag;
-            const float rq = fast_log2(fminf(fmaxf(rho, a.rho_lo), a.rho_hi));
-            const float eq = __builtin_amdgcn_sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
-            // interval on each (uniform) axis from the grid, fraction from the stored knots incl. interp.py:16's +1e-6
-            auto axis = [&](int ax, float q, int lo, int hi, int& k, float& f) {
-                k = min(max((int)floorf((q - a.first[ax]) * a.inv_step[ax]), lo), hi);
-                const float2 kn = s_ax[ax * FVVDP_LUT_N + k];
-                f = fmaxf((q - kn.x) * kn.y, 0.0f);
-            };
-            int kY, kR, kE;
-            float fY, fR, fE;
-            axis(0, yq, 0, FVVDP_LUT_N - 2, kY, fY);
-            axis(1, rq, a.i_lo, a.i_lo + a.rw - 1, kR, fR);
-            axis(2, eq, 0, FVVDP_LUT_N - 2, kE, fE);
-            const int so = (kE * FVVDP_LUT_N + kY) * a.rw + (kR - a.i_lo);
-            const int sj = a.rw, sk = FVVDP_LUT_N * a.rw;
-            float4 v00, v10, v01, v11;                                                      // v[dj][dk]
-            if (a.lut_lds) {
-                v00 = s_lut_dyn[so]; v10 = s_lut_dyn[so + sj]; v01 = s_lut_dyn[so + sk]; v11 = s_lut_dyn[so + sk + sj];
-            } else {
-                const float4* sb = a.sublut + so;
-                v00 = sb[0]; v10 = sb[sj]; v01 = sb[sk]; v11 = sb[sk + sj];
-            }
-            const float gR = 1.0f - fR, gY = 1.0f - fY, gE = 1.0f - fE;
-            // interp3 (interp.py:53-57), same association: rho blend, then Y, then ecc
-            slog[0] = ((v00.x * gR + v00.z * fR) * gY + (v10.x * gR + v10.z * fR) * fY) * gE +
-                      ((v01.x * gR + v01.z * fR) * gY + (v11.x * gR + v11.z * fR) * fY) * fE;
-            slog[1] = ((v00.y * gR + v00.w * fR) * gY + (v10.y * gR + v10.w * fR) * fY) * gE +
-                      ((v01.y * gR + v01.w * fR) * gY + (v11.y * gR + v11.w * fR) * fY) * fE;
-        }
-        const float vm = valid ? 1.0f : 0.0f;
-        const float lcn = lg_bm - llb;                                   // log2(m / lb)
-        // D = |T'-R'|^p / (1 + (k*min(|T'|,|R'|))^q), T' = T*S   (fvvdp.py:585-595), in the log2 domain.
-        // Video: the two temporal channels are carried as one (sustained, transient) pair through packed fp32 ops;
-        // only the transcendentals are per component.
-        float ldd_dbg[2] = {0.0f, 0.0f};
-        if constexpr (HP == 2) {
-            const v2f sl = v2f{slog[0], slog[1]};
-            const v2f lsb = sl + splat(lcn + lg_base);                   // log2(S * m / lb)
-            const v2f lsm = sl + splat(lcn + lg_mask);                   // log2(k * S * m / lb)
-            const v2f ldiff = v2f{fast_log2(fabsf(d[0].x - d[0].y)), fast_log2(fabsf(d[1].x - d[1].y))};
-            const v2f lmin = v2f{fast_log2(fminf(fabsf(d[0].x), fabsf(d[0].y))), fast_log2(fminf(fabsf(d[1].x), fabsf(d[1].y)))};
-            const v2f ld = (ldiff + lsb) * splat(a.p);
-            const v2f lm = (lmin + lsm) * v2f{a.q0, a.q1};
-            const v2f one_mq = v2f{fast_exp2(lm.x), fast_exp2(lm.y)} + splat(1.0f);
-            const v2f t = ld - v2f{fast_log2(one_mq.x), fast_log2(one_mq.y)};
-            const v2f ldd = v2f{fminf(t.x, a.lg_dmax), fminf(t.y, a.lg_dmax)};
-            const v2f bl = ldd * splat(a.beta);
-            const v2f term = v2f{fast_exp2(bl.x), fast_exp2(bl.y)};      // D^beta for the spatial pooling (fvvdp.py:467,607)
-            const v2f av = __builtin_elementwise_fma(term, splat(vm), v2f{acc[0], acc[1]});
-            acc[0] = av.x;
-            acc[1] = av.y;
-            ldd_dbg[0] = ldd.x;
-            ldd_dbg[1] = ldd.y;
-        } else {
-            const float dT = d[0].x, dR = d[0].y;
-            const float ls = slog[0] + lcn;
-            const float ld = a.p * (fast_log2(fabsf(dT - dR)) + (ls + lg_base));
-            const float mq = fast_exp2(a.q0 * (fast_log2(fminf(fabsf(dT), fabsf(dR))) + (ls + lg_mask)));
-            const float ldd = fminf(ld - fast_log2(1.0f + mq), a.lg_dmax);
-            acc[0] = fmaf(fast_exp2(a.beta * ldd), vm, acc[0]);
-            ldd_dbg[0] = ldd;
-        }
-        if constexpr (DBG) {
-            if (valid) {
-#pragma unroll
-                for (int cc = 0; cc < HP; ++cc) {
-                    const size_t o = (((size_t)frame * 2 + cc) * h + y) * w + x;
-                    if (a.dD) a.dD[o] = fast_exp2(ldd_dbg[cc]);
-                    if (a.dS) a.dS[o] = fast_exp2(slog[cc]);
-                }
-            }
-        }
-        if constexpr (DBG) {
-            if (valid) {
-                if (a.dC) {
-                    const float sc = a.band_mul / lb;
-#pragma unroll
-                    for (int k = 0; k < HP; ++k) {
-                        a.dC[(((size_t)frame * P + 2 * k) * h + y) * w + x] = d[k].x * sc;
-                        a.dC[(((size_t)frame * P + 2 * k + 1) * h + y) * w + x] = d[k].y * sc;
-                    }
-                }
-                if (a.dL) a.dL[((size_t)frame * h + y) * w + x] = lb;
-            }
-        }
-    };
-
-    // ---- main loop: band rows 2c, 2c+1 for c in [ca, cb) ------------------------------------------------
-    for (int c = ca; c < cb; ++c) {
-        shift_window(nx0, nx1);               // window = fine rows 2c .. 2c+4
-        if (c + 1 < cb) {                     // prefetch the two rows of the next step
-            load_row(2 * c + 5, nx0[0], nx0[1]);
-            load_row(2 * c + 6, nx1[0], nx1[1]);
-        }
-        const Px<P> cN = coarse_step();       // coarse row c+1
-        const bool has_next = (c + 1) <= (hc - 1);
-        Px<P> Gp1 = has_next ? cN : G0;       // index clamp of the expand (fvvdp_lpyr_dec.py:134,138)
-        if (has_next && (c + 1) < cb && active) st_px(Gc + ((size_t)(c + 1) * wc + J) * P, cN);
-        Px<P> x00, x01, x10, x11;             // expanded level at (row 2c|2c+1, col X0|X1)
-        Px<P> evE, evO;
-#pragma unroll
-        for (int k = 0; k < HP; ++k) {
-            // vertical expand on the coarse column: even fine row 2c (.1 .8 .1), odd fine row 2c+1 (.5 .5)
-            v2f t = Gm1.h[k] * 0.1f;
-            t = pfma(G0.h[k], 0.8f, t);
-            evE.h[k] = pfma(Gp1.h[k], 0.1f, t);
-            evO.h[k] = pfma(Gp1.h[k], 0.5f, G0.h[k] * 0.5f);
-        }
-#pragma unroll
-        for (int k = 0; k < HP; ++k) {
-            v2f t = evE.h[k] * ec;
-            t = fma_left(evE.h[k], el, t);
-            x00.h[k] = fma_right(evE.h[k], er, t);
-            x01.h[k] = fma_right(evE.h[k], orr, evE.h[k] * oc);
-            t = evO.h[k] * ec;
-            t = fma_left(evO.h[k], el, t);
-            x10.h[k] = fma_right(evO.h[k], er, t);
-            x11.h[k] = fma_right(evO.h[k], orr, evO.h[k] * oc);
-        }
-        const bool row1_ok = (2 * c + 1) < h;
-#if defined(BAND_ABLATE) && BAND_ABLATE >= 1      // profiling ablation: no per-pixel tail, keep the data flow alive
-        acc[0] += x00.h[0].x + x01.h[0].x + x10.h[0].x + x11.h[0].x + W[0][0].h[0].x + W[0][1].h[0].x + W[1][0].h[0].x + W[1][1].h[0].x;
-        if (false)
-#endif
-        {
-        float vy0 = 0.0f, vy1 = 0.0f;        // vertical view angle of the two fine rows (foveated)
-        if constexpr (FOV) {
-            const float yp0 = ((float)(2 * c) + 0.5f) + (-(float)h / 2.0f), yp1 = yp0 + 1.0f;
-            vy0 = atanf(-yp0 * a.size_m1 / (float)h / a.dist_m) * 57.29577951308232f;
-            vy1 = atanf(-yp1 * a.size_m1 / (float)h / a.dist_m) * 57.29577951308232f;
-        }
-        if constexpr (FOV) {
-            float vx4[4] = {vxa, vxb, vxa, vxb}, vy4[4] = {vy0, vy0, vy1, vy1}, rm4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-            if (a.mvx) {                          // user geometry: maps evaluated by the caller
-                const int ya = min(2 * c, h - 1), yb = min(2 * c + 1, h - 1);
-                const size_t o[4] = {(size_t)ya * w + xc0, (size_t)ya * w + xc1, (size_t)yb * w + xc0, (size_t)yb * w + xc1};
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    vx4[i] = a.mvx[o[i]];
-                    vy4[i] = a.mvy[o[i]];
-                    rm4[i] = a.mrm[o[i]];
-                }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float va = fminf(__builtin_amdgcn_sqrtf(vx4[i] * vx4[i] + vy4[i] * vy4[i]), 89.9f) * 0.017453292519943295f;
-                    rm4[i] = a.cos_delta * fast_rcp(__cosf(va) * __cosf(va + a.delta_rad));
-                }
-            }
-            band_px(W[0][0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0]);
-            band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1]);
-            band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vx4[2], vy4[2], rm4[2]);
-            band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vx4[3], vy4[3], rm4[3]);
-        } else {
-            band_px(W[0][0], x00, active, 2 * c, X0, 0.0f, 0.0f, 1.0f);
-            band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, 0.0f, 0.0f, 1.0f);
-            band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, 0.0f, 0.0f, 1.0f);
-            band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, 0.0f, 0.0f, 1.0f);
-        }
-        }
-        Gm1 = G0;
-        G0 = Gp1;
-    }
-
-    const float s0 = wave_sum(acc[0]);
-    const float s1 = wave_sum(acc[1]);
-    if (lane == 0) {
-        float* o = a.partial + ((size_t)frame * (a.n_strips * a.n_chunks) + blk) * 2;
-        o[0] = s0;
-        o[1] = s1;
-    }
-}
-
-// Q[band][cc][slot] = (sum D^beta / n_px)^(1/beta)   (lp_norm, fvvdp.py:598-607); fixed summation order.
-struct FinalizeArgs {
-    const float* partial;
-    float* Q;
-    int n_bands, n, q_stride, q_col0, tc;
-    float inv_beta;
-    int nblk[FVVDP_MAX_BANDS];
-    long long off[FVVDP_MAX_BANDS];
-    float npx[FVVDP_MAX_BANDS];
-};
-
-__global__ __launch_bounds__(64) void finalize_kernel(const FinalizeArgs a) {
-    // one wave per (band, cc, slot); lane l adds partials l, l+64, ... in fp64, then a fixed shuffle tree
-    const int i = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int s = i % a.n;
-    const int cc = (i / a.n) % 2;
-    const int b = i / (2 * a.n);
-    float q = 0.0f;
-    if (cc < a.tc) {
-        const float* p = a.partial + a.off[b] + (size_t)s * a.nblk[b] * 2 + cc;
-        double sum = 0.0;
-        for (int k = lane; k < a.nblk[b]; k += 64) sum += (double)p[2 * k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
-        q = (float)pow(sum / (double)a.npx[b], (double)a.inv_beta);
-    }
-    if (lane == 0) a.Q[((size_t)b * 2 + cc) * a.q_stride + a.q_col0 + s] = q;
-}
-
-// Heat-map reconstruction, one level: out = expand(coarse) + (D0 + w*D1)/m   [then ^beta_jod * |jod_a| on level 0]
-// (heatmap_pyr.set_band / reconstruct, fvvdp_lpyr_dec.py:65-71,94-101; expand closed form as in band_kernel).
-struct HeatArgs {
-    const float* D;        // [n][2][h][w]
-    const float* coarse;   // [n][hc][wc] or nullptr for the coarsest band
-    float* out;            // [n][h][w]
-    int w, h, wc, hc, tc;
-    float w_trans, inv_m, beta_jod, scale;
-    int final_level;
-};
-
-__global__ __launch_bounds__(256) void heat_level_kernel(const HeatArgs a) {
-    const int x = blockIdx.x * 256 + threadIdx.x;
-    const int y = blockIdx.y;
-    const int f = blockIdx.z;
-    if (x >= a.w) return;
-    const size_t plane = (size_t)a.h * a.w;
-    const size_t o = (size_t)y * a.w + x;
-    float v = a.D[((size_t)f * 2) * plane + o];
-    if (a.tc == 2) v = v + a.w_trans * a.D[((size_t)f * 2 + 1) * plane + o];
-    v = v * a.inv_m;
-    if (a.coarse) {
-        const float* c = a.coarse + (size_t)f * a.hc * a.wc;
-        const int cy = y >> 1, cx = x >> 1;
-        const int r0 = max(cy - 1, 0), r1 = cy, r2 = min(cy + 1, a.hc - 1);
-        const int c0 = max(cx - 1, 0), c1 = cx, c2 = min(cx + 1, a.wc - 1);
-        auto col = [&](int cc) -> float {     // vertical pass first (gausspyr_expand, fvvdp_lpyr_dec.py:225-228)
-            if (y & 1) return 0.5f * c[(size_t)r1 * a.wc + cc] + 0.5f * c[(size_t)r2 * a.wc + cc];
-            return (0.1f * c[(size_t)r0 * a.wc + cc] + 0.8f * c[(size_t)r1 * a.wc + cc]) + 0.1f * c[(size_t)r2 * a.wc + cc];
-        };
-        float e;
-        if (x & 1) e = 0.5f * col(c1) + 0.5f * col(c2);
-        else e = (0.1f * col(c0) + 0.8f * col(c1)) + 0.1f * col(c2);
-        v = e + v;
-    }
-    if (a.final_level) v = powf(v, a.beta_jod) * a.scale;
-    a.out[(size_t)f * plane + o] = v;
-}
+#include "device_common.hpp"
+#include "temporal_kernels.hpp"
+#include "band_kernel.hpp"
+#include "aux_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------------------
 // context
