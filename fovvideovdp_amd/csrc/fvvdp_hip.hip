@@ -432,6 +432,19 @@ static void launch_yuv(int bytes, const YuvArgs& a, hipStream_t st) {
     else hipLaunchKernelGGL((temporal_yuv_kernel<FL, PX, unsigned short>), grid, block, 0, st, a);
 }
 
+template <int FL>
+static void launch_yuv_vec(int bytes, bool c420, const YuvArgs& a, hipStream_t st) {
+    const int HW = a.W * a.H;
+    dim3 grid((HW + 255) / 256), block(64);
+    if (bytes == 1) {
+        if (c420) hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned char, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned char, false>), grid, block, 0, st, a);
+    } else {
+        if (c420) hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned short, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned short, false>), grid, block, 0, st, a);
+    }
+}
+
 extern "C" int fvvdp_temporal_channels_yuv(fvvdp_ctx* c, const void* d_test, const void* d_ref, const fvvdp_yuv_format* fmt,
                                            size_t frame_stride, const fvvdp_eotf* eotf, const float* h_rgb2y,
                                            const int32_t* h_frame_idx, const float* h_taps, int fl, int n_out, int slot0,
@@ -476,7 +489,14 @@ extern "C" int fvvdp_temporal_channels_yuv(fvvdp_ctx* c, const void* d_test, con
             a.idx[u] = h_frame_idx[src < 0 ? 0 : src];
         }
         const int bytes = fmt->bit_depth > 8 ? 2 : 1;
-        if (FL == 8) launch_yuv<8, 2>(bytes, a, st);
+        // vector kernel: 4 consecutive pixels per lane -> rows, planes and frames must keep 4-sample alignment
+        const size_t al = (size_t)bytes * 4;
+        const bool vec_ok = !getenv("FVVDP_TEMPORAL_SCALAR") && FL <= 16 && (c->W % 4 == 0) && (frame_stride % 4 == 0) &&
+                            (reinterpret_cast<uintptr_t>(d_test) % al == 0) && (reinterpret_cast<uintptr_t>(d_ref) % al == 0);
+        if (vec_ok) {
+            if (FL == 8) launch_yuv_vec<8>(bytes, a.chroma420 != 0, a, st);
+            else launch_yuv_vec<16>(bytes, a.chroma420 != 0, a, st);
+        } else if (FL == 8) launch_yuv<8, 2>(bytes, a, st);
         else if (FL == 16) launch_yuv<16, 2>(bytes, a, st);
         else launch_yuv<32, 1>(bytes, a, st);
     }

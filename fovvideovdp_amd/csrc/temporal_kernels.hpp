@@ -18,38 +18,68 @@ struct EotfDev {
 
 // Per-channel display model on a float sample V (fvvdp_display_model.py:147-165).  `bad` is set when V was
 // outside [0,1] for an EOTF that clamps.
+template <int KIND>
+__device__ __forceinline__ float eotf_one(float V, const EotfDev& e, bool& bad) {
+    if constexpr (KIND == FVVDP_EOTF_SRGB) {
+        bad = bad || (V > 1.0f) || (V < 0.0f);
+        V = fminf(fmaxf(V, 0.0f), 1.0f);
+        // constant divisions as reciprocal multiplies (<= 1 ulp, below the error of the fast log2/exp2 pair)
+        const float hi = fast_exp2(2.4f * fast_log2((V + 0.055f) * (1.0f / 1.055f)));
+        const float lin = V > 0.04045f ? hi : V * (1.0f / 12.92f);
+        return __fadd_rn(__fmul_rn(e.scale, lin), e.y_black);
+    } else if constexpr (KIND == FVVDP_EOTF_GAMMA) {
+        bad = bad || (V > 1.0f) || (V < 0.0f);
+        V = fminf(fmaxf(V, 0.0f), 1.0f);
+        const float lin = V > 0.0f ? fast_exp2(e.gamma * fast_log2(V)) : 0.0f;
+        return __fadd_rn(__fmul_rn(e.scale, lin), e.y_black);
+    } else if constexpr (KIND == FVVDP_EOTF_PQ) {
+        bad = bad || (V > 1.0f) || (V < 0.0f);
+        V = fminf(fmaxf(V, 0.0f), 1.0f);
+        const float m = 78.843750000000000f, n = 0.15930175781250000f;
+        const float c1 = 0.83593750000000000f, c2 = 18.851562500000000f, c3 = 18.687500000000000f;
+        const float im_t = V > 0.0f ? fast_exp2(fast_log2(V) * (1.0f / m)) : 0.0f;
+        const float r = fmaxf(im_t - c1, 0.0f) * __builtin_amdgcn_rcpf(c2 - c3 * im_t);
+        const float L = r > 0.0f ? 10000.0f * fast_exp2(fast_log2(r) * (1.0f / n)) : 0.0f;
+        return fminf(fmaxf(L, 0.005f), e.y_peak) + e.y_black;
+    } else if constexpr (KIND == FVVDP_EOTF_LINEAR) {
+        return fminf(fmaxf(V, 0.005f), e.y_peak) + e.y_black;
+    } else if constexpr (KIND == FVVDP_EOTF_ABSOLUTE) {
+        return fminf(fmaxf(V, e.l_min), e.l_max);
+    } else {
+        return V;
+    }
+}
+
 __device__ __forceinline__ float eotf_f32(float V, const EotfDev& e, bool& bad) {
     switch (e.kind) {
-        case FVVDP_EOTF_SRGB: {
-            bad = bad || (V > 1.0f) || (V < 0.0f);
-            V = fminf(fmaxf(V, 0.0f), 1.0f);
-            const float hi = fast_exp2(2.4f * fast_log2((V + 0.055f) / 1.055f));
-            const float lin = V > 0.04045f ? hi : V / 12.92f;
-            return __fadd_rn(__fmul_rn(e.scale, lin), e.y_black);
-        }
-        case FVVDP_EOTF_GAMMA: {
-            bad = bad || (V > 1.0f) || (V < 0.0f);
-            V = fminf(fmaxf(V, 0.0f), 1.0f);
-            const float lin = V > 0.0f ? fast_exp2(e.gamma * fast_log2(V)) : 0.0f;
-            return __fadd_rn(__fmul_rn(e.scale, lin), e.y_black);
-        }
-        case FVVDP_EOTF_PQ: {
-            bad = bad || (V > 1.0f) || (V < 0.0f);
-            V = fminf(fmaxf(V, 0.0f), 1.0f);
-            const float m = 78.843750000000000f, n = 0.15930175781250000f;
-            const float c1 = 0.83593750000000000f, c2 = 18.851562500000000f, c3 = 18.687500000000000f;
-            const float im_t = V > 0.0f ? fast_exp2(fast_log2(V) * (1.0f / m)) : 0.0f;
-            const float r = fmaxf(im_t - c1, 0.0f) / (c2 - c3 * im_t);
-            const float L = r > 0.0f ? 10000.0f * fast_exp2(fast_log2(r) * (1.0f / n)) : 0.0f;
-            return fminf(fmaxf(L, 0.005f), e.y_peak) + e.y_black;
-        }
-        case FVVDP_EOTF_LINEAR:
-            return fminf(fmaxf(V, 0.005f), e.y_peak) + e.y_black;
-        case FVVDP_EOTF_ABSOLUTE:
-            return fminf(fmaxf(V, e.l_min), e.l_max);
-        default:
-            return V;
+        case FVVDP_EOTF_SRGB: return eotf_one<FVVDP_EOTF_SRGB>(V, e, bad);
+        case FVVDP_EOTF_GAMMA: return eotf_one<FVVDP_EOTF_GAMMA>(V, e, bad);
+        case FVVDP_EOTF_PQ: return eotf_one<FVVDP_EOTF_PQ>(V, e, bad);
+        case FVVDP_EOTF_LINEAR: return eotf_one<FVVDP_EOTF_LINEAR>(V, e, bad);
+        case FVVDP_EOTF_ABSOLUTE: return eotf_one<FVVDP_EOTF_ABSOLUTE>(V, e, bad);
+        default: return V;
     }
+}
+
+// N samples at once with ONE (wave-uniform) branch on the display model: in the register-ring kernels the per-sample
+// switch of eotf_f32 is replicated FL x PX x 3 x 2 times, which made their code several times larger than the
+// instruction cache although only one case ever runs.
+template <int N>
+__device__ __forceinline__ void eotf_apply(float (&V)[N], const EotfDev& e, bool& bad) {
+#define FVVDP_EOTF_CASE(K)                                             \
+    case K: {                                                          \
+        _Pragma("unroll") for (int i = 0; i < N; ++i) V[i] = eotf_one<K>(V[i], e, bad); \
+        break;                                                         \
+    }
+    switch (e.kind) {
+        FVVDP_EOTF_CASE(FVVDP_EOTF_SRGB)
+        FVVDP_EOTF_CASE(FVVDP_EOTF_GAMMA)
+        FVVDP_EOTF_CASE(FVVDP_EOTF_PQ)
+        FVVDP_EOTF_CASE(FVVDP_EOTF_LINEAR)
+        FVVDP_EOTF_CASE(FVVDP_EOTF_ABSOLUTE)
+        default: break;
+    }
+#undef FVVDP_EOTF_CASE
 }
 
 // Luminance of PX consecutive pixels of one frame of one stream.
@@ -207,14 +237,35 @@ template <int SRC, int PX, typename FRAME>
 __device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lutw, const float* lut16,
                                           const float (&w)[3], const EotfDev& e, float (&L)[PX], bool& bad) {
     float v[3][PX];
+    if constexpr (SRC == SRC_F32) {
+        if (C == 3) {
+            float t[3 * PX];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        if (c > 0 && C != 3) break;
+            for (int c = 0; c < 3; ++c)
 #pragma unroll
-        for (int i = 0; i < PX; ++i) {
-            if constexpr (SRC == SRC_U8) v[c][i] = lutw[c * 256 + f.ch[c].code(i)];
-            else if constexpr (SRC == SRC_U16) v[c][i] = __fmul_rn(lut16[f.ch[c].code(i)], w[c]);
-            else v[c][i] = __fmul_rn(eotf_f32(f.ch[c].value(i), e, bad), w[c]);
+                for (int i = 0; i < PX; ++i) t[c * PX + i] = f.ch[c].value(i);
+            eotf_apply<3 * PX>(t, e, bad);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < PX; ++i) v[c][i] = __fmul_rn(t[c * PX + i], w[c]);
+        } else {
+            float t[PX];
+#pragma unroll
+            for (int i = 0; i < PX; ++i) t[i] = f.ch[0].value(i);
+            eotf_apply<PX>(t, e, bad);
+#pragma unroll
+            for (int i = 0; i < PX; ++i) v[0][i] = __fmul_rn(t[i], w[0]);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            if (c > 0 && C != 3) break;
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                if constexpr (SRC == SRC_U8) v[c][i] = lutw[c * 256 + f.ch[c].code(i)];
+                else v[c][i] = __fmul_rn(lut16[f.ch[c].code(i)], w[c]);
+            }
         }
     }
 #pragma unroll
@@ -539,6 +590,219 @@ __global__ __launch_bounds__(256) void temporal_yuv_kernel(const YuvArgs a) {
                     for (int i = 0; i < PX; ++i)
                         if (ok[i])
                             *reinterpret_cast<float4*>(o + (size_t)px[i] * 4) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+                }
+            }
+        }
+    }
+    if (bad && a.oob) atomicOr(a.oob, 1);
+}
+
+// ---- vector variant of the YUV ingest (the fast path for W % 4 == 0) -----------------------------------------------
+// Single-wave workgroups, a lane owns 4 CONSECUTIVE pixels of one image row (x0 = 4j).  Everything that depends only
+// on the pixel position (plane offsets, the bilinear weights of the 4:2:0 chroma upsampling) is computed once per
+// lane; per frame a lane issues one Y load (4 samples) and, per chroma plane and source row, one aligned pair load
+// (columns 2j, 2j+1) plus the two neighbour columns (2j-1, 2j+2, clamped) -- 13 loads for 4 pixels instead of 36.
+// The arithmetic (order of the products and sums) is the one of yuv_lum above, so both kernels agree bit for bit;
+// raw samples of the next frame are prefetched while the current one is converted, and the finished float4 pixels
+// go through the same LDS transpose as temporal_vec_kernel.
+template <typename T, bool C420>
+struct YuvRaw {
+    static constexpr int YW = (int)sizeof(T);          // dwords holding 4 samples: 1 (8 bit) or 2 (10..16 bit)
+    unsigned int y[YW];
+    // 4:2:0: [plane][row] pair = columns 2j,2j+1 packed; lft / rgt = neighbour columns.  4:4:4: cp[plane][0..YW-1].
+    unsigned int cp[2][2], lft[2][2], rgt[2][2];
+    __device__ __forceinline__ float ysample(int i) const {
+        if constexpr (sizeof(T) == 1) return (float)((y[0] >> (8 * i)) & 0xFFu);
+        else return (float)((y[i / 2] >> (16 * (i % 2))) & 0xFFFFu);
+    }
+    __device__ __forceinline__ float c444(int pl, int i) const {
+        if constexpr (sizeof(T) == 1) return (float)((cp[pl][0] >> (8 * i)) & 0xFFu);
+        else return (float)((cp[pl][i / 2] >> (16 * (i % 2))) & 0xFFFFu);
+    }
+    __device__ __forceinline__ float pair(int pl, int r, int k) const {
+        if constexpr (sizeof(T) == 1) return (float)((cp[pl][r] >> (8 * k)) & 0xFFu);
+        else return (float)((cp[pl][r] >> (16 * k)) & 0xFFFFu);
+    }
+};
+
+struct YuvGeom {           // per-lane constants
+    int oy;                // element offset of the 4 luma samples inside a frame
+    int opair[2];          // offsets (from the start of a chroma plane) of the pair in the two source rows
+    int oleft[2], oright[2];
+    float fy, gy;          // vertical weights
+    float fx0, gx0;        // horizontal weights of pixel 0 (0/1 at the left image edge, else .75/.25)
+};
+
+template <typename T, bool C420>
+__device__ __forceinline__ YuvRaw<T, C420> yuv_fetch(const T* __restrict__ f, const YuvGeom& g, int HW, int uvplane) {
+    YuvRaw<T, C420> r;
+    if constexpr (sizeof(T) == 1) {
+        r.y[0] = *reinterpret_cast<const unsigned int*>(f + g.oy);
+    } else {
+        const uint2 t = *reinterpret_cast<const uint2*>(f + g.oy);
+        r.y[0] = t.x; r.y[1] = t.y;
+    }
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        const T* P = f + HW + pl * uvplane;
+        if constexpr (C420) {
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                if constexpr (sizeof(T) == 1) r.cp[pl][rr] = *reinterpret_cast<const unsigned short*>(P + g.opair[rr]);
+                else r.cp[pl][rr] = *reinterpret_cast<const unsigned int*>(P + g.opair[rr]);
+                r.lft[pl][rr] = P[g.oleft[rr]];
+                r.rgt[pl][rr] = P[g.oright[rr]];
+            }
+        } else {
+            if constexpr (sizeof(T) == 1) {
+                r.cp[pl][0] = *reinterpret_cast<const unsigned int*>(P + g.oy);
+            } else {
+                const uint2 t = *reinterpret_cast<const uint2*>(P + g.oy);
+                r.cp[pl][0] = t.x; r.cp[pl][1] = t.y;
+            }
+        }
+    }
+    return r;
+}
+
+template <typename T, bool C420>
+__device__ __forceinline__ void yuv_vec_rgb(const YuvRaw<T, C420>& r, const YuvArgs& a, const YuvGeom& g, float (&rgb)[12]) {
+    auto cf = [&](float code) { return fminf(fmaxf(a.wc * code - (128.0f / 224.0f), -0.5f), 0.5f); };
+    float uv[2][4];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) {
+        if constexpr (C420) {
+            float hrow[2][4];
+#pragma unroll
+            for (int rr = 0; rr < 2; ++rr) {
+                const float cl = cf((float)r.lft[pl][rr]), c0 = cf(r.pair(pl, rr, 0)), c1 = cf(r.pair(pl, rr, 1)), cr = cf((float)r.rgt[pl][rr]);
+                hrow[rr][0] = g.gx0 * cl + g.fx0 * c0;
+                hrow[rr][1] = 0.75f * c0 + 0.25f * c1;
+                hrow[rr][2] = 0.25f * c0 + 0.75f * c1;
+                hrow[rr][3] = 0.75f * c1 + 0.25f * cr;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) uv[pl][i] = g.gy * hrow[0][i] + g.fy * hrow[1][i];
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) uv[pl][i] = cf(r.c444(pl, i));
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float Yf = fminf(fmaxf(a.wy * r.ysample(i) - (16.0f / 219.0f), 0.0f), 1.0f);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = a.m[3 * c] * Yf + a.m[3 * c + 1] * uv[0][i] + a.m[3 * c + 2] * uv[1][i];
+            rgb[3 * i + c] = fminf(fmaxf(v, 0.0f), 1.0f);
+        }
+    }
+}
+
+// display model + luminance of the 4 pixels of both streams (rgb[s][3*i+c])
+__device__ __forceinline__ void yuv_vec_lum2(float (&rgb)[24], const YuvArgs& a, float (&L0)[4], float (&L1)[4], bool& bad) {
+    eotf_apply<24>(rgb, a.e, bad);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        L0[i] = __fadd_rn(__fadd_rn(__fmul_rn(rgb[3 * i], a.w[0]), __fmul_rn(rgb[3 * i + 1], a.w[1])), __fmul_rn(rgb[3 * i + 2], a.w[2]));
+        L1[i] = __fadd_rn(__fadd_rn(__fmul_rn(rgb[12 + 3 * i], a.w[0]), __fmul_rn(rgb[12 + 3 * i + 1], a.w[1])),
+                          __fmul_rn(rgb[12 + 3 * i + 2], a.w[2]));
+    }
+}
+
+template <int FL, typename T, bool C420>
+__global__ __launch_bounds__(64) void temporal_yuv_vec_kernel(const YuvArgs a) {
+    constexpr int PX = 4;
+    __shared__ float4 s_t[64 * (PX + 1)];
+    const int lane = threadIdx.x;
+    const int HW = a.W * a.H;
+    const int uvplane = a.uvw * a.uvh;
+    const int p0 = blockIdx.x * (64 * PX);
+    const int pl = min(p0 + lane * PX, HW - PX);
+    YuvGeom g;
+    {
+        const int y = pl / a.W, x = pl - y * a.W;
+        g.oy = pl;
+        if constexpr (C420) {
+            // torch bilinear, align_corners=False: source = (dst + 0.5)/2 - 0.5 clamped at 0 (video_source_file.py:262-266)
+            const float sy = fmaxf(((float)y + 0.5f) * 0.5f - 0.5f, 0.0f);
+            const int y0 = (int)sy, y1 = min(y0 + 1, a.uvh - 1);
+            g.fy = sy - (float)y0;
+            g.gy = 1.0f - g.fy;
+            const int j2 = x >> 1;                       // column of the aligned pair
+            const int cl = max(j2 - 1, 0), cr = min(j2 + 2, a.uvw - 1);
+            g.opair[0] = y0 * a.uvw + j2;  g.opair[1] = y1 * a.uvw + j2;
+            g.oleft[0] = y0 * a.uvw + cl;  g.oleft[1] = y1 * a.uvw + cl;
+            g.oright[0] = y0 * a.uvw + cr; g.oright[1] = y1 * a.uvw + cr;
+            const float sx = fmaxf(((float)x + 0.5f) * 0.5f - 0.5f, 0.0f);
+            g.fx0 = sx - (float)(int)sx;                 // 0 at x == 0 (then the "left" column is column 0 itself), else .75
+            g.gx0 = 1.0f - g.fx0;
+        } else {
+            g.fy = g.gy = g.fx0 = g.gx0 = 0.0f;
+            g.opair[0] = g.opair[1] = g.oleft[0] = g.oleft[1] = g.oright[0] = g.oright[1] = 0;
+        }
+    }
+    bool bad = false;
+    float ring[2][FL][PX];
+#pragma unroll
+    for (int u = 0; u < FL; ++u)
+#pragma unroll
+        for (int i = 0; i < PX; ++i) ring[0][u][i] = ring[1][u][i] = 0.0f;
+    const int total = FL - 1 + a.n_out;
+    YuvRaw<T, C420> nx[2];
+    {
+        const size_t off = (size_t)a.idx[0] * a.frame_stride;
+        nx[0] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[0]) + off, g, HW, uvplane);
+        nx[1] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[1]) + off, g, HW, uvplane);
+    }
+    for (int v0 = 0; v0 < total; v0 += FL) {
+#pragma unroll
+        for (int u = 0; u < FL; ++u) {
+            const int v = v0 + u;
+            if (v < total) {
+                const YuvRaw<T, C420> cur0 = nx[0], cur1 = nx[1];
+                if (v + 1 < total) {
+                    const size_t off = (size_t)a.idx[v + 1] * a.frame_stride;
+                    nx[0] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[0]) + off, g, HW, uvplane);
+                    nx[1] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[1]) + off, g, HW, uvplane);
+                }
+                float rgb[24];
+                {
+                    float t0[12], t1[12];
+                    yuv_vec_rgb<T, C420>(cur0, a, g, t0);
+                    yuv_vec_rgb<T, C420>(cur1, a, g, t1);
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) { rgb[i] = t0[i]; rgb[12 + i] = t1[i]; }
+                }
+                yuv_vec_lum2(rgb, a, ring[0][u], ring[1][u], bad);
+                if (v >= FL - 1) {
+                    float acc[4][PX];
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
+#pragma unroll
+                    for (int k = FL - 1; k >= 0; --k) {
+                        const int sl = (u - k + 2 * FL) % FL;
+                        const float t0 = a.taps[0][k], t1 = a.taps[1][k];
+#pragma unroll
+                        for (int i = 0; i < PX; ++i) {
+                            acc[0][i] = fmaf(ring[0][sl][i], t0, acc[0][i]);
+                            acc[1][i] = fmaf(ring[1][sl][i], t0, acc[1][i]);
+                            acc[2][i] = fmaf(ring[0][sl][i], t1, acc[2][i]);
+                            acc[3][i] = fmaf(ring[1][sl][i], t1, acc[3][i]);
+                        }
+                    }
+                    __syncthreads();
+#pragma unroll
+                    for (int i = 0; i < PX; ++i)
+                        s_t[lane * (PX + 1) + i] = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+                    __syncthreads();
+                    float4* o = reinterpret_cast<float4*>(a.out) + (size_t)(v - (FL - 1)) * HW + p0;
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) {
+                        const int q = i * 64 + lane;
+                        const float4 val = s_t[(q / PX) * (PX + 1) + (q % PX)];
+                        if (p0 + q < HW) o[q] = val;
+                    }
                 }
             }
         }

@@ -56,3 +56,44 @@ def test_video_sizes_vs_oracle(H, W):
     assert abs(float(q) - float(oq)) < 2e-4
     a, b = st["Q_per_ch"].astype(np.float64), ost["Q_per_ch"].astype(np.float64)
     assert np.all(np.abs(a - b) <= 5e-3 * np.abs(b) + 1e-5 * np.max(b)), (H, W)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,bd,css,fps", [(36, 64, 8, "420", 30), (70, 260, 8, "420", 30), (38, 132, 10, "420", 30),
+                                            (34, 68, 8, "444", 30), (50, 96, 10, "444", 60), (46, 520, 8, "420", 60),
+                                            (8, 8, 8, "420", 30), (10, 12, 10, "420", 30)])
+def test_yuv_vector_kernel_equals_scalar_kernel(H, W, bd, css, fps, monkeypatch):
+    """The vectorised YUV ingest (4 consecutive pixels per lane, shared chroma taps) and the per-pixel kernel it
+    replaces do the same arithmetic in the same order: their pooled band differences must agree to fp32 rounding;
+    rows that are not a multiple of the 256-pixel wave tile, odd chroma heights and the image edges are covered.
+    (test_yuv_ingest_golden pins the vector kernel against the reference's unpack pipeline; the per-pixel kernel stays
+    the path for widths that are not a multiple of 4 and for fl > 16.)"""
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_yuv_pair
+    N = 7
+    ty, ry = synth_yuv_pair(N, H, W, bit_depth=bd, chroma_ss=css)
+    m = fv.fvvdp(display_name="standard_fhd")
+    vs = fv.fvvdp_video_source_yuv_frames(ty, ry, fps, W, H, bit_depth=bd, chroma_ss=css, color_space="bt709",
+                                          display_photometry=m.display_photometry)
+    import ctypes as C
+    from fovvideovdp_amd import _native as nat
+
+    def channels():           # level 0 of the context = the temporal channels of the batch just processed
+        out = torch.empty((N, 4, H, W), dtype=torch.float32, device="cuda")
+        nat.check(nat.lib().fvvdp_export_level(m._ctx.handle, 0, N, C.c_void_p(out.data_ptr()),
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out.cpu().numpy()
+
+    q_vec, s_vec = m.predict_video_source(vs)
+    r_vec = channels()
+    monkeypatch.setenv("FVVDP_TEMPORAL_SCALAR", "1")
+    q_sca, s_sca = m.predict_video_source(vs)
+    r_sca = channels()
+    monkeypatch.delenv("FVVDP_TEMPORAL_SCALAR")
+    assert np.isfinite(r_vec).all() and r_sca[:, :2].min() > 0
+    # per pixel: a few ulp of the sustained luminance (fused-multiply-add contraction may differ between the kernels)
+    scale = np.maximum(np.abs(r_sca[:, :2]), 1e-3)
+    assert np.max(np.abs(r_vec[:, :2] - r_sca[:, :2]) / scale) < 2e-6
+    assert np.max(np.abs(r_vec[:, 2:] - r_sca[:, 2:]) / scale) < 2e-6
+    assert np.allclose(s_vec["Q_per_ch"], s_sca["Q_per_ch"], rtol=2e-4, atol=1e-6 * float(np.max(s_sca["Q_per_ch"])))
+    assert abs(float(q_vec) - float(q_sca)) < 1e-5
