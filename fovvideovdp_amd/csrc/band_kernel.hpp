@@ -16,7 +16,6 @@
 // ------------------------------------------------------------------------------------------------------------
 #define STRIP_J 60          // coarse columns produced per wave (64 lanes - 2 halo lanes each side)
 
-typedef float v2f __attribute__((ext_vector_type(2)));
 
 template <int P>
 struct Px {                 // one pixel: P/2 (test, ref) pairs
@@ -49,10 +48,6 @@ __device__ __forceinline__ void st_px(float* p, const Px<4>& a) {
 __device__ __forceinline__ void st_px(float* p, const Px<2>& a) {
     __builtin_nontemporal_store(a.h[0], reinterpret_cast<v2f*>(p));
 }
-
-__device__ __forceinline__ v2f splat(float s) { return v2f{s, s}; }
-// a*s + c on both halves (v_pk_fma_f32)
-__device__ __forceinline__ v2f pfma(v2f a, float s, v2f c) { return __builtin_elementwise_fma(a, splat(s), c); }
 
 // value held by the lane to the left / right (0 at the wave's ends)
 __device__ __forceinline__ float from_left(float x) {

@@ -37,3 +37,19 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// Packed fp32 pair: the two video streams (test, reference) or two temporal channels go through the same arithmetic,
+// so they are kept as a 2-vector and the compiler emits v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 for them.
+typedef float v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ v2f splat(float s) { return v2f{s, s}; }
+__device__ __forceinline__ v2f pfma(v2f a, float s, v2f c) { return __builtin_elementwise_fma(a, splat(s), c); }
+// clamp to [lo, hi] as one v_med3_f32 per component (fminf(fmaxf()) costs three: IEEE max first canonicalises its input)
+__device__ __forceinline__ v2f clamp2(v2f x, float lo, float hi) {
+    return v2f{__builtin_amdgcn_fmed3f(x.x, lo, hi), __builtin_amdgcn_fmed3f(x.y, lo, hi)};
+}
+// raw 32-bit value held by the lane to the left / right (0 at the wave's ends): v_mov_b32 with a DPP wave shift
+__device__ __forceinline__ unsigned int lane_left_u32(unsigned int x) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x138 /*wave_shr:1*/, 0xf, 0xf, true);
+}
+__device__ __forceinline__ unsigned int lane_right_u32(unsigned int x) {
+    return (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x130 /*wave_shl:1*/, 0xf, 0xf, true);
+}

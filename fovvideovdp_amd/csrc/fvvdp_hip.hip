@@ -435,7 +435,7 @@ static void launch_yuv(int bytes, const YuvArgs& a, hipStream_t st) {
 template <int FL>
 static void launch_yuv_vec(int bytes, bool c420, const YuvArgs& a, hipStream_t st) {
     const int HW = a.W * a.H;
-    dim3 grid((HW + 255) / 256), block(64);
+    dim3 grid((HW / 4 + YUV_QUADS - 1) / YUV_QUADS), block(64);
     if (bytes == 1) {
         if (c420) hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned char, true>), grid, block, 0, st, a);
         else hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned char, false>), grid, block, 0, st, a);

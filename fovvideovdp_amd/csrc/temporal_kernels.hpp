@@ -601,16 +601,19 @@ __global__ __launch_bounds__(256) void temporal_yuv_kernel(const YuvArgs a) {
 // Single-wave workgroups, a lane owns 4 CONSECUTIVE pixels of one image row (x0 = 4j).  Everything that depends only
 // on the pixel position (plane offsets, the bilinear weights of the 4:2:0 chroma upsampling) is computed once per
 // lane; per frame a lane issues one Y load (4 samples) and, per chroma plane and source row, one aligned pair load
-// (columns 2j, 2j+1) plus the two neighbour columns (2j-1, 2j+2, clamped) -- 13 loads for 4 pixels instead of 36.
-// The arithmetic (order of the products and sums) is the one of yuv_lum above, so both kernels agree bit for bit;
-// raw samples of the next frame are prefetched while the current one is converted, and the finished float4 pixels
-// go through the same LDS transpose as temporal_vec_kernel.
+// (columns 2j, 2j+1); the two neighbour columns (2j-1, 2j+2, clamped) come from the adjacent lanes through DPP
+// (sub-dword loads are address-rate limited: with 12 of them per lane the kernel ran at the speed of the per-pixel one).
+// Test and reference stream are converted together as packed (test, reference) pairs (v_pk_* instructions); the
+// result agrees with yuv_lum above to rounding order.  Raw samples of the next frame are prefetched while the
+// current one is converted, and the finished float4 pixels go through the same LDS transpose as temporal_vec_kernel.
 template <typename T, bool C420>
 struct YuvRaw {
     static constexpr int YW = (int)sizeof(T);          // dwords holding 4 samples: 1 (8 bit) or 2 (10..16 bit)
     unsigned int y[YW];
-    // 4:2:0: [plane][row] pair = columns 2j,2j+1 packed; lft / rgt = neighbour columns.  4:4:4: cp[plane][0..YW-1].
-    unsigned int cp[2][2], lft[2][2], rgt[2][2];
+    // 4:2:0: cp[plane][row] = chroma columns 2j, 2j+1 packed; the neighbour columns 2j-1 / 2j+2 are the pair words of
+    // the adjacent lanes (DPP; lanes 0 and 63 of a wave are halo lanes that only supply them).
+    // 4:4:4: cp[plane][0..YW-1] = 4 samples.
+    unsigned int cp[2][2];
     __device__ __forceinline__ float ysample(int i) const {
         if constexpr (sizeof(T) == 1) return (float)((y[0] >> (8 * i)) & 0xFFu);
         else return (float)((y[i / 2] >> (16 * (i % 2))) & 0xFFFFu);
@@ -619,18 +622,16 @@ struct YuvRaw {
         if constexpr (sizeof(T) == 1) return (float)((cp[pl][0] >> (8 * i)) & 0xFFu);
         else return (float)((cp[pl][i / 2] >> (16 * (i % 2))) & 0xFFFFu);
     }
-    __device__ __forceinline__ float pair(int pl, int r, int k) const {
-        if constexpr (sizeof(T) == 1) return (float)((cp[pl][r] >> (8 * k)) & 0xFFu);
-        else return (float)((cp[pl][r] >> (16 * k)) & 0xFFFFu);
+    static __device__ __forceinline__ float lo(unsigned int w) { return (float)(w & (sizeof(T) == 1 ? 0xFFu : 0xFFFFu)); }
+    static __device__ __forceinline__ float hi(unsigned int w) {
+        return (float)((w >> (8 * (int)sizeof(T))) & (sizeof(T) == 1 ? 0xFFu : 0xFFFFu));
     }
 };
 
 struct YuvGeom {           // per-lane constants
     int oy;                // element offset of the 4 luma samples inside a frame
     int opair[2];          // offsets (from the start of a chroma plane) of the pair in the two source rows
-    int oleft[2], oright[2];
-    float fy, gy;          // vertical weights
-    float fx0, gx0;        // horizontal weights of pixel 0 (0/1 at the left image edge, else .75/.25)
+    bool left_own, right_own;   // the clamped neighbour column is one of the lane's own pair (image edges)
 };
 
 template <typename T, bool C420>
@@ -650,8 +651,6 @@ __device__ __forceinline__ YuvRaw<T, C420> yuv_fetch(const T* __restrict__ f, co
             for (int rr = 0; rr < 2; ++rr) {
                 if constexpr (sizeof(T) == 1) r.cp[pl][rr] = *reinterpret_cast<const unsigned short*>(P + g.opair[rr]);
                 else r.cp[pl][rr] = *reinterpret_cast<const unsigned int*>(P + g.opair[rr]);
-                r.lft[pl][rr] = P[g.oleft[rr]];
-                r.rgt[pl][rr] = P[g.oright[rr]];
             }
         } else {
             if constexpr (sizeof(T) == 1) {
@@ -665,51 +664,112 @@ __device__ __forceinline__ YuvRaw<T, C420> yuv_fetch(const T* __restrict__ f, co
     return r;
 }
 
+// RGB (clipped to [0,1]) of the lane's 4 pixels for both streams at once: rgb[3*i+c] = (test, reference).
+// 4:2:0 chroma: the four source columns are blended vertically first, then horizontally (2 x fewer products than the
+// per-pixel form; the result differs from it by rounding order only).
 template <typename T, bool C420>
-__device__ __forceinline__ void yuv_vec_rgb(const YuvRaw<T, C420>& r, const YuvArgs& a, const YuvGeom& g, float (&rgb)[12]) {
-    auto cf = [&](float code) { return fminf(fmaxf(a.wc * code - (128.0f / 224.0f), -0.5f), 0.5f); };
-    float uv[2][4];
+__device__ __forceinline__ void yuv_pair_rgb(const YuvRaw<T, C420>& r0, const YuvRaw<T, C420>& r1, const YuvArgs& a,
+                                             const YuvGeom& g, float fy, float gy, float fx0, float gx0, v2f (&rgb)[12]) {
+    auto cf = [&](float c0, float c1) { return clamp2(pfma(v2f{c0, c1}, a.wc, splat(-(128.0f / 224.0f))), -0.5f, 0.5f); };
+    v2f uv[2][4];
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
         if constexpr (C420) {
-            float hrow[2][4];
+            using R = YuvRaw<T, C420>;
+            v2f rowv[4][2];
 #pragma unroll
             for (int rr = 0; rr < 2; ++rr) {
-                const float cl = cf((float)r.lft[pl][rr]), c0 = cf(r.pair(pl, rr, 0)), c1 = cf(r.pair(pl, rr, 1)), cr = cf((float)r.rgt[pl][rr]);
-                hrow[rr][0] = g.gx0 * cl + g.fx0 * c0;
-                hrow[rr][1] = 0.75f * c0 + 0.25f * c1;
-                hrow[rr][2] = 0.25f * c0 + 0.75f * c1;
-                hrow[rr][3] = 0.75f * c1 + 0.25f * cr;
+                const unsigned int w0 = r0.cp[pl][rr], w1 = r1.cp[pl][rr];
+                // neighbour columns: the adjacent lane's pair word or (image edge) an own column
+                const unsigned int l0 = lane_left_u32(w0), l1 = lane_left_u32(w1);
+                const unsigned int n0 = lane_right_u32(w0), n1 = lane_right_u32(w1);
+                const float lf0 = g.left_own ? R::lo(w0) : R::hi(l0);
+                const float lf1 = g.left_own ? R::lo(w1) : R::hi(l1);
+                const float rt0 = g.right_own ? R::hi(w0) : R::lo(n0);
+                const float rt1 = g.right_own ? R::hi(w1) : R::lo(n1);
+                rowv[0][rr] = cf(lf0, lf1);
+                rowv[1][rr] = cf(R::lo(w0), R::lo(w1));
+                rowv[2][rr] = cf(R::hi(w0), R::hi(w1));
+                rowv[3][rr] = cf(rt0, rt1);
             }
+            v2f col[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) uv[pl][i] = g.gy * hrow[0][i] + g.fy * hrow[1][i];
+            for (int k = 0; k < 4; ++k) col[k] = pfma(rowv[k][1], fy, rowv[k][0] * gy);
+            uv[pl][0] = pfma(col[1], fx0, col[0] * gx0);
+            uv[pl][1] = pfma(col[2], 0.25f, col[1] * 0.75f);
+            uv[pl][2] = pfma(col[2], 0.75f, col[1] * 0.25f);
+            uv[pl][3] = pfma(col[3], 0.25f, col[2] * 0.75f);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) uv[pl][i] = cf(r.c444(pl, i));
+            for (int i = 0; i < 4; ++i) uv[pl][i] = cf(r0.c444(pl, i), r1.c444(pl, i));
         }
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const float Yf = fminf(fmaxf(a.wy * r.ysample(i) - (16.0f / 219.0f), 0.0f), 1.0f);
+        const v2f Yf = clamp2(pfma(v2f{r0.ysample(i), r1.ysample(i)}, a.wy, splat(-(16.0f / 219.0f))), 0.0f, 1.0f);
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float v = a.m[3 * c] * Yf + a.m[3 * c + 1] * uv[0][i] + a.m[3 * c + 2] * uv[1][i];
-            rgb[3 * i + c] = fminf(fmaxf(v, 0.0f), 1.0f);
+            v2f v = Yf * a.m[3 * c];
+            v = pfma(uv[0][i], a.m[3 * c + 1], v);
+            v = pfma(uv[1][i], a.m[3 * c + 2], v);
+            rgb[3 * i + c] = clamp2(v, 0.0f, 1.0f);
         }
     }
 }
 
-// display model + luminance of the 4 pixels of both streams (rgb[s][3*i+c])
-__device__ __forceinline__ void yuv_vec_lum2(float (&rgb)[24], const YuvArgs& a, float (&L0)[4], float (&L1)[4], bool& bad) {
-    eotf_apply<24>(rgb, a.e, bad);
+// Display model on N (test, reference) pairs whose values are already inside [0,1]; one wave-uniform branch.
+// The affine parts run packed; scale*lin and +y_black keep their separate roundings (fvvdp_display_model.py:160-165).
+template <int N>
+__device__ __forceinline__ void eotf_apply_pairs(v2f (&V)[N], const EotfDev& e) {
+#pragma clang fp contract(off)
+    bool bad = false;
+    switch (e.kind) {
+        case FVVDP_EOTF_SRGB: {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        L0[i] = __fadd_rn(__fadd_rn(__fmul_rn(rgb[3 * i], a.w[0]), __fmul_rn(rgb[3 * i + 1], a.w[1])), __fmul_rn(rgb[3 * i + 2], a.w[2]));
-        L1[i] = __fadd_rn(__fadd_rn(__fmul_rn(rgb[12 + 3 * i], a.w[0]), __fmul_rn(rgb[12 + 3 * i + 1], a.w[1])),
-                          __fmul_rn(rgb[12 + 3 * i + 2], a.w[2]));
+            for (int i = 0; i < N; ++i) {
+                const v2f t = (V[i] + 0.055f) * (1.0f / 1.055f);
+                const v2f ex = v2f{fast_log2(t.x), fast_log2(t.y)} * 2.4f;
+                const v2f lo = V[i] * (1.0f / 12.92f);
+                const v2f lin = v2f{V[i].x > 0.04045f ? fast_exp2(ex.x) : lo.x, V[i].y > 0.04045f ? fast_exp2(ex.y) : lo.y};
+                V[i] = lin * e.scale + e.y_black;
+            }
+            break;
+        }
+        case FVVDP_EOTF_GAMMA: {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const v2f ex = v2f{fast_log2(V[i].x), fast_log2(V[i].y)} * e.gamma;
+                const v2f lin = v2f{V[i].x > 0.0f ? fast_exp2(ex.x) : 0.0f, V[i].y > 0.0f ? fast_exp2(ex.y) : 0.0f};
+                V[i] = lin * e.scale + e.y_black;
+            }
+            break;
+        }
+        case FVVDP_EOTF_PQ: {
+#pragma unroll
+            for (int i = 0; i < N; ++i) V[i] = v2f{eotf_one<FVVDP_EOTF_PQ>(V[i].x, e, bad), eotf_one<FVVDP_EOTF_PQ>(V[i].y, e, bad)};
+            break;
+        }
+        case FVVDP_EOTF_LINEAR: {
+#pragma unroll
+            for (int i = 0; i < N; ++i) V[i] = clamp2(V[i], 0.005f, e.y_peak) + e.y_black;
+            break;
+        }
+        case FVVDP_EOTF_ABSOLUTE: {
+#pragma unroll
+            for (int i = 0; i < N; ++i) V[i] = clamp2(V[i], e.l_min, e.l_max);
+            break;
+        }
+        default: break;
     }
 }
 
+// luminance (R*w0 + G*w1) + B*w2 with the reference's separate roundings (video_source.py:206)
+__device__ __forceinline__ v2f lum_pair(v2f r, v2f g, v2f b, float w0, float w1, float w2) {
+#pragma clang fp contract(off)
+    return (r * w0 + g * w1) + b * w2;
+}
+
+#define YUV_QUADS 62     // pixel quads (4 consecutive pixels) written per wave
 template <int FL, typename T, bool C420>
 __global__ __launch_bounds__(64) void temporal_yuv_vec_kernel(const YuvArgs a) {
     constexpr int PX = 4;
@@ -717,9 +777,15 @@ __global__ __launch_bounds__(64) void temporal_yuv_vec_kernel(const YuvArgs a) {
     const int lane = threadIdx.x;
     const int HW = a.W * a.H;
     const int uvplane = a.uvw * a.uvh;
-    const int p0 = blockIdx.x * (64 * PX);
-    const int pl = min(p0 + lane * PX, HW - PX);
+    // lanes 1..62 own the wave's 62 pixel quads; lanes 0 and 63 convert the quads next to them, only to hand their
+    // chroma columns to lanes 1 and 62 (quads are clamped to the frame: a clamped lane duplicates its neighbour,
+    // which then sits at a row start / end and does not look at it)
+    const int p0 = blockIdx.x * (YUV_QUADS * PX);
+    const int quad = min(max(blockIdx.x * YUV_QUADS - 1 + lane, 0), HW / PX - 1);
+    const int pl = quad * PX;
     YuvGeom g;
+    float g_fy = 0.0f, g_gy = 0.0f;      // vertical bilinear weights
+    float g_fx0 = 0.0f, g_gx0 = 0.0f;    // horizontal weights of pixel 0 (0/1 at the left image edge, else .75/.25)
     {
         const int y = pl / a.W, x = pl - y * a.W;
         g.oy = pl;
@@ -727,27 +793,27 @@ __global__ __launch_bounds__(64) void temporal_yuv_vec_kernel(const YuvArgs a) {
             // torch bilinear, align_corners=False: source = (dst + 0.5)/2 - 0.5 clamped at 0 (video_source_file.py:262-266)
             const float sy = fmaxf(((float)y + 0.5f) * 0.5f - 0.5f, 0.0f);
             const int y0 = (int)sy, y1 = min(y0 + 1, a.uvh - 1);
-            g.fy = sy - (float)y0;
-            g.gy = 1.0f - g.fy;
+            g_fy = sy - (float)y0;
+            g_gy = 1.0f - g_fy;
             const int j2 = x >> 1;                       // column of the aligned pair
-            const int cl = max(j2 - 1, 0), cr = min(j2 + 2, a.uvw - 1);
             g.opair[0] = y0 * a.uvw + j2;  g.opair[1] = y1 * a.uvw + j2;
-            g.oleft[0] = y0 * a.uvw + cl;  g.oleft[1] = y1 * a.uvw + cl;
-            g.oright[0] = y0 * a.uvw + cr; g.oright[1] = y1 * a.uvw + cr;
+            // lanes to the left / right hold the adjacent quad of the same row unless this lane starts / ends the row
+            // (lanes clamped to the last quad of the frame sit at a row end as well)
+            g.left_own = (j2 == 0);
+            g.right_own = (j2 + 2 > a.uvw - 1);
             const float sx = fmaxf(((float)x + 0.5f) * 0.5f - 0.5f, 0.0f);
-            g.fx0 = sx - (float)(int)sx;                 // 0 at x == 0 (then the "left" column is column 0 itself), else .75
-            g.gx0 = 1.0f - g.fx0;
+            g_fx0 = sx - (float)(int)sx;                 // 0 at x == 0 (then the "left" column is column 0 itself), else .75
+            g_gx0 = 1.0f - g_fx0;
         } else {
-            g.fy = g.gy = g.fx0 = g.gx0 = 0.0f;
-            g.opair[0] = g.opair[1] = g.oleft[0] = g.oleft[1] = g.oright[0] = g.oright[1] = 0;
+            g.opair[0] = g.opair[1] = 0;
+            g.left_own = g.right_own = false;
         }
     }
-    bool bad = false;
-    float ring[2][FL][PX];
+    v2f ring[FL][PX];                                     // (test, reference) luminance of the last FL frames
 #pragma unroll
     for (int u = 0; u < FL; ++u)
 #pragma unroll
-        for (int i = 0; i < PX; ++i) ring[0][u][i] = ring[1][u][i] = 0.0f;
+        for (int i = 0; i < PX; ++i) ring[u][i] = splat(0.0f);
     const int total = FL - 1 + a.n_out;
     YuvRaw<T, C420> nx[2];
     {
@@ -755,59 +821,62 @@ __global__ __launch_bounds__(64) void temporal_yuv_vec_kernel(const YuvArgs a) {
         nx[0] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[0]) + off, g, HW, uvplane);
         nx[1] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[1]) + off, g, HW, uvplane);
     }
-    for (int v0 = 0; v0 < total; v0 += FL) {
+    // The conversion of a frame (the expensive part) exists once in the code; only the ring update + FIR, whose
+    // register slots must be compile-time constants, is replicated FL times and selected by a wave-uniform branch.
+    // (Unrolling the whole body FL times, as the RGB kernels do with their tiny LUT conversion, makes this kernel
+    // larger than the instruction cache.)
+    int u = 0;                                            // ring slot of frame v (= v % FL)
+    for (int v = 0; v < total; ++v) {
+        const YuvRaw<T, C420> cur0 = nx[0], cur1 = nx[1];
+        if (v + 1 < total) {
+            const size_t off = (size_t)a.idx[v + 1] * a.frame_stride;
+            nx[0] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[0]) + off, g, HW, uvplane);
+            nx[1] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[1]) + off, g, HW, uvplane);
+        }
+        v2f rgb[12];
+        yuv_pair_rgb<T, C420>(cur0, cur1, a, g, g_fy, g_gy, g_fx0, g_gx0, rgb);
+        eotf_apply_pairs<12>(rgb, a.e);
+        v2f L[PX];
 #pragma unroll
-        for (int u = 0; u < FL; ++u) {
-            const int v = v0 + u;
-            if (v < total) {
-                const YuvRaw<T, C420> cur0 = nx[0], cur1 = nx[1];
-                if (v + 1 < total) {
-                    const size_t off = (size_t)a.idx[v + 1] * a.frame_stride;
-                    nx[0] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[0]) + off, g, HW, uvplane);
-                    nx[1] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[1]) + off, g, HW, uvplane);
+        for (int i = 0; i < PX; ++i) L[i] = lum_pair(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], a.w[0], a.w[1], a.w[2]);
+        v2f acc_s[PX], acc_t[PX];                         // sustained / transient channel of (test, reference)
+#pragma unroll
+        for (int uu = 0; uu < FL; ++uu) {
+            if (uu == u) {
+#pragma unroll
+                for (int i = 0; i < PX; ++i) {
+                    ring[uu][i] = L[i];
+                    acc_s[i] = acc_t[i] = splat(0.0f);
                 }
-                float rgb[24];
-                {
-                    float t0[12], t1[12];
-                    yuv_vec_rgb<T, C420>(cur0, a, g, t0);
-                    yuv_vec_rgb<T, C420>(cur1, a, g, t1);
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) { rgb[i] = t0[i]; rgb[12 + i] = t1[i]; }
-                }
-                yuv_vec_lum2(rgb, a, ring[0][u], ring[1][u], bad);
-                if (v >= FL - 1) {
-                    float acc[4][PX];
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
-#pragma unroll
-                    for (int k = FL - 1; k >= 0; --k) {
-                        const int sl = (u - k + 2 * FL) % FL;
-                        const float t0 = a.taps[0][k], t1 = a.taps[1][k];
-#pragma unroll
-                        for (int i = 0; i < PX; ++i) {
-                            acc[0][i] = fmaf(ring[0][sl][i], t0, acc[0][i]);
-                            acc[1][i] = fmaf(ring[1][sl][i], t0, acc[1][i]);
-                            acc[2][i] = fmaf(ring[0][sl][i], t1, acc[2][i]);
-                            acc[3][i] = fmaf(ring[1][sl][i], t1, acc[3][i]);
-                        }
-                    }
-                    __syncthreads();
-#pragma unroll
-                    for (int i = 0; i < PX; ++i)
-                        s_t[lane * (PX + 1) + i] = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
-                    __syncthreads();
-                    float4* o = reinterpret_cast<float4*>(a.out) + (size_t)(v - (FL - 1)) * HW + p0;
+                for (int k = FL - 1; k >= 0; --k) {      // oldest tap first, like the reference's sum over the window
+                    const int sl = (uu - k + 2 * FL) % FL;
+                    const float t0 = a.taps[0][k], t1 = a.taps[1][k];
 #pragma unroll
                     for (int i = 0; i < PX; ++i) {
-                        const int q = i * 64 + lane;
-                        const float4 val = s_t[(q / PX) * (PX + 1) + (q % PX)];
-                        if (p0 + q < HW) o[q] = val;
+                        acc_s[i] = pfma(ring[sl][i], t0, acc_s[i]);
+                        acc_t[i] = pfma(ring[sl][i], t1, acc_t[i]);
                     }
                 }
             }
         }
+        u = (u + 1 == FL) ? 0 : u + 1;
+        if (v >= FL - 1) {
+            __syncthreads();                              // single wave: orders the LDS accesses only
+#pragma unroll
+            for (int i = 0; i < PX; ++i)
+                s_t[lane * (PX + 1) + i] = make_float4(acc_s[i].x, acc_s[i].y, acc_t[i].x, acc_t[i].y);   // row `lane` = quad lane-1
+            __syncthreads();
+            float4* o = reinterpret_cast<float4*>(a.out) + (size_t)(v - (FL - 1)) * HW + p0;
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                const int q = i * 64 + lane;              // pixel of the wave's 248-pixel run
+                const int qq = min(q, YUV_QUADS * PX - 1);
+                const float4 val = s_t[(qq / PX + 1) * (PX + 1) + (qq % PX)];
+                if (q < YUV_QUADS * PX && p0 + q < HW) o[q] = val;
+            }
+        }
     }
-    if (bad && a.oob) atomicOr(a.oob, 1);
 }
 
 // Generic (any fl, any frame size) version: one thread per pixel per output frame, the window is re-read from
