@@ -189,7 +189,9 @@ class fvvdp:
         if self.do_heatmap:
             batch = max(1, min(batch, int(2e9 // (width * height * 4 * 12))))     # D maps + context image per frame
             dmap_channels = 1 if self.heatmap == "raw" else 3
-            heatmap = torch.zeros([1, dmap_channels, n_out, height, width], dtype=torch.float16, device=torch.device('cpu'))
+            # fp16 on the host like the reference (fvvdp.py:216-221); every element is written below, and page-locked
+            # memory lets the batches stream back at link speed while the next batch is computed
+            heatmap = self._host_buffer([1, dmap_channels, n_out, height, width])
         ctx = self._context(width, height, n_bands, planes, batch, rho_band)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         Q = torch.zeros((n_bands, 2, n_out), dtype=torch.float32, device=self.device)
@@ -222,7 +224,7 @@ class fvvdp:
             nat.check(nat.lib().fvvdp_bands_forward(ctx.handle, nb, C.c_void_p(Q.data_ptr()), n_out, b0 - f0,
                                                     fx, g, maps_arr, stream))
             if self.do_heatmap:
-                heatmap[:, :, b0 - f0:b0 - f0 + nb] = self._heatmap_batch(ctx, nb, dmaps, planes, width, height, stream)
+                self._heatmap_batch(ctx, nb, dmaps, planes, width, height, stream, heatmap, b0 - f0)
 
         Q_jod = self.do_pooling_and_jods(Q, rho_band[0:-1]) if pool else None
         stats = {}
@@ -238,8 +240,16 @@ class fvvdp:
             logging.warning("Pixel outside the valid range 0-1")
         return (Q_jod.squeeze() if pool else None, stats)
 
-    def _heatmap_batch(self, ctx, nb, dmaps, planes, width, height, stream):
-        """Difference maps of `nb` frames -> fp16 CPU tensor [1, 1|3, nb, H, W] (fvvdp.py:469-476)."""
+    @staticmethod
+    def _host_buffer(shape):
+        try:
+            return torch.empty(shape, dtype=torch.float16, pin_memory=True)
+        except RuntimeError:                      # page-locking refused (ulimit): plain pageable memory
+            return torch.empty(shape, dtype=torch.float16)
+
+    def _heatmap_batch(self, ctx, nb, dmaps, planes, width, height, stream, heatmap, k0):
+        """Difference maps of `nb` frames -> heatmap[0, :, k0:k0+nb] (fp16, host) (fvvdp.py:469-476).  The maps are
+        finished on the device in the output layout and copied back asynchronously, one contiguous run per channel."""
         from .visualize_diff_map import visualize_diff_map
         ptrs = (C.c_void_p * len(dmaps))(*[d.data_ptr() for d in dmaps])
         dmap = torch.empty((nb, height, width), dtype=torch.float32, device=self.device)
@@ -247,15 +257,17 @@ class fvvdp:
         nat.check(nat.lib().fvvdp_heatmap_reconstruct(ctx.handle, nb, ptrs, float(self.w_transient), beta_jod,
                                                       abs(float(self.jod_a)), C.c_void_p(dmap.data_ptr()), stream))
         if self.heatmap == "raw":
-            return dmap.to(torch.float16).cpu().view(1, 1, nb, height, width)
+            heatmap[0, 0, k0:k0 + nb].copy_(dmap.to(torch.float16), non_blocking=True)
+            return
         lvl0 = torch.empty((nb, planes, height, width), dtype=torch.float32, device=self.device)
         nat.check(nat.lib().fvvdp_export_level(ctx.handle, 0, nb, C.c_void_p(lvl0.data_ptr()), stream))
-        out = torch.empty((1, 3, nb, height, width), dtype=torch.float16)
+        out = torch.empty((3, nb, height, width), dtype=torch.float16, device=self.device)
         for k in range(nb):      # tone mapping is per frame (global histogram of the frame)
             col = visualize_diff_map(dmap[k].view(1, 1, height, width), context_image=lvl0[k:k + 1, 0:1],
                                      colormap_type=self.heatmap)
-            out[0, :, k] = col[0].to(torch.float16).cpu()
-        return out
+            out[:, k] = col[0]
+        for ch in range(3):
+            heatmap[0, ch, k0:k0 + nb].copy_(out[ch], non_blocking=True)
 
     # ---- pooling and JOD regression (Python, as in the reference) ------------------------------------------
     def do_pooling_and_jods(self, Q_per_ch, rho_band):
