@@ -14,6 +14,7 @@ INCLUDE_DIR = os.path.join(ROOT, "include")
 
 FVVDP_U8, FVVDP_U16, FVVDP_F32 = 0, 1, 2
 EOTF_LUT, EOTF_SRGB, EOTF_GAMMA, EOTF_PQ, EOTF_LINEAR, EOTF_ABSOLUTE, EOTF_NONE = range(7)
+PSNR_SLICES = 256            # FVVDP_PSNR_SLICES
 MAX_BANDS = 16
 MAX_TAPS = 256
 LUT_N = 32
@@ -35,6 +36,10 @@ class YuvFormat(C.Structure):
 
 class Geom(C.Structure):
     _fields_ = [("display_size_m", C.c_float * 2), ("distance_m", C.c_float), ("ppd_centre", C.c_float)]
+
+
+class Pu21(C.Structure):
+    _fields_ = [("p", C.c_float * 7), ("L_min", C.c_float), ("L_max", C.c_float)]
 
 
 class BandMaps(C.Structure):
@@ -65,6 +70,9 @@ SYMBOLS = {
     "fvvdp_heatmap_reconstruct": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_float, C.c_float, C.c_float,
                                             C.c_void_p, C.c_void_p]),
     "fvvdp_export_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "fvvdp_pu21_sse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
+                                 C.POINTER(Eotf), C.POINTER(C.c_float), C.POINTER(Pu21), C.c_int, C.c_void_p, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
     "fvvdp_ctx_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "fvvdp_ctx_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int, C.c_int]),
 }

@@ -43,6 +43,7 @@ extern "C" const char* fvvdp_last_error(void) { return g_err; }
 #include "temporal_kernels.hpp"
 #include "band_kernel.hpp"
 #include "aux_kernels.hpp"
+#include "psnr_kernel.hpp"
 
 // ------------------------------------------------------------------------------------------------------------
 // context
@@ -513,6 +514,56 @@ extern "C" int fvvdp_load_channels_planar(fvvdp_ctx* c, const float* d_R, int n,
     float* out = c->level[0] + (size_t)slot0 * HW * c->P;
     if (c->P == 4) hipLaunchKernelGGL((interleave_kernel<4>), grid, block, 0, st, d_R, out, HW, 1);
     else hipLaunchKernelGGL((interleave_kernel<2>), grid, block, 0, st, d_R, out, HW, 1);
+    HIP_TRY(hipGetLastError());
+    return FVVDP_OK;
+}
+
+template <int PX>
+static void launch_pu21(int dtype, const Pu21Args& a, int n_frames, hipStream_t st) {
+    dim3 grid(FVVDP_PSNR_SLICES, n_frames), block(256);
+    if (dtype == FVVDP_U8) hipLaunchKernelGGL((pu21_sse_kernel<SRC_U8, PX>), grid, block, 0, st, a);
+    else if (dtype == FVVDP_U16) hipLaunchKernelGGL((pu21_sse_kernel<SRC_U16, PX>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pu21_sse_kernel<SRC_F32, PX>), grid, block, 0, st, a);
+}
+
+extern "C" int fvvdp_pu21_sse(const void* d_test, const void* d_ref, int dtype, int C, size_t chan_stride,
+                              size_t frame_stride, size_t n_pixels, const fvvdp_eotf* eotf, const float* h_rgb2y,
+                              const fvvdp_pu21* pu, int n_frames, double* d_partial, double* d_sse, int32_t* d_oob_flag,
+                              void* stream) {
+    if (!d_test || !d_ref || !eotf || !pu || !d_partial || !d_sse) return fail(FVVDP_EINVAL, "null argument");
+    if (dtype < FVVDP_U8 || dtype > FVVDP_F32) return fail(FVVDP_EINVAL, "Only uint8, uint16 and float32 is currently supported");
+    if (C != 1 && C != 3) return fail(FVVDP_EINVAL, "The content must have either 1 or 3 colour channels.");
+    if (C == 3 && !h_rgb2y) return fail(FVVDP_EINVAL, "rgb2y weights required for C == 3");
+    if (n_frames < 1 || n_frames > 65535) return fail(FVVDP_EINVAL, "n_frames %d out of range (1..65535 per call)", n_frames);
+    if (n_pixels < 1 || n_pixels > 0x7FFFFFFFu) return fail(FVVDP_EINVAL, "n_pixels out of range");
+    if (eotf->kind == FVVDP_EOTF_LUT && (dtype == FVVDP_F32 || !eotf->d_lut)) return fail(FVVDP_EINVAL, "FVVDP_EOTF_LUT needs an integer source and a table");
+    if (eotf->kind != FVVDP_EOTF_LUT && dtype != FVVDP_F32) return fail(FVVDP_EINVAL, "integer sources need FVVDP_EOTF_LUT");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    Pu21Args a;
+    memset(&a, 0, sizeof(a));
+    a.src[0] = d_test;
+    a.src[1] = d_ref;
+    a.chan_stride = chan_stride;
+    a.frame_stride = frame_stride;
+    a.C = C;
+    a.HW = (unsigned int)n_pixels;
+    const unsigned int per = (unsigned int)((n_pixels + FVVDP_PSNR_SLICES - 1) / FVVDP_PSNR_SLICES);
+    a.chunk = (per + 3u) & ~3u;
+    a.e = make_eotf(eotf);
+    if (C == 3) { a.w[0] = h_rgb2y[0]; a.w[1] = h_rgb2y[1]; a.w[2] = h_rgb2y[2]; } else { a.w[0] = 1.0f; }
+    for (int i = 0; i < 7; ++i) a.p[i] = pu->p[i];
+    a.l_min = pu->L_min;
+    a.l_max = pu->L_max;
+    a.partial = d_partial;
+    a.oob = d_oob_flag;
+    // 4 consecutive samples per load where every plane and frame keeps 4-sample alignment
+    const int es = dtype == FVVDP_U8 ? 1 : (dtype == FVVDP_U16 ? 2 : 4);
+    const bool vec_ok = (n_pixels % 4 == 0) && (chan_stride % 4 == 0) && (frame_stride % 4 == 0) &&
+                        (reinterpret_cast<uintptr_t>(d_test) % (size_t)(es * 4) == 0) &&
+                        (reinterpret_cast<uintptr_t>(d_ref) % (size_t)(es * 4) == 0);
+    if (vec_ok) launch_pu21<4>(dtype, a, n_frames, st);
+    else launch_pu21<1>(dtype, a, n_frames, st);
+    hipLaunchKernelGGL(pu21_finalize_kernel, dim3(n_frames), dim3(64), 0, st, d_partial, d_sse);
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;
 }

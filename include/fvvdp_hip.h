@@ -216,6 +216,23 @@ int fvvdp_export_level(fvvdp_ctx* ctx, int level, int n, float* d_out, void* str
 int fvvdp_ctx_timing_enable(fvvdp_ctx* ctx, int on);
 int fvvdp_ctx_timing_read(fvvdp_ctx* ctx, float* h_ms, int32_t* h_count, int capacity, int reset);
 
+/* ---- PU21-PSNR side metric ---------------------------------------------------
+ * Replaces the per-frame body of pu_psnr.predict_video_source (pyfvvdp/pupsnr.py:64-76): luminance of both streams
+ * through the same ingest as fvvdp_temporal_channels (video_source.py:180-208), PU.encode (pyfvvdp/utils.py:183-193,
+ * clip to [L_min, L_max], V = p6*(((p0 + p1*Y^p3)/(1 + p2*Y^p3))^p4 - p5)) and the sum of squared differences of
+ * each frame.  Stateless (no context): d_sse[f] = sum over the n_pixels pixels of frame f of (V_test - V_ref)^2 in
+ * fp64, summed in a fixed order; d_partial is workspace of n_frames * FVVDP_PSNR_SLICES doubles.  The caller turns
+ * it into dB: mean over frames of 20*log10(peak / sqrt(sse / n_pixels))  (psnr_fn, pupsnr.py:78-79).          */
+#define FVVDP_PSNR_SLICES 256
+typedef struct {
+    float p[7];              /* PU21 parameters (utils.py:171-178, 'banding_glare' by default) */
+    float L_min, L_max;      /* 0.005, 10000 */
+} fvvdp_pu21;
+int fvvdp_pu21_sse(const void* d_test, const void* d_ref, int dtype, int channels, size_t chan_stride,
+                   size_t frame_stride, size_t n_pixels, const fvvdp_eotf* eotf, const float* h_rgb2y,
+                   const fvvdp_pu21* pu, int n_frames, double* d_partial, double* d_sse, int32_t* d_oob_flag,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif

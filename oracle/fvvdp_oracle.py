@@ -519,6 +519,44 @@ def do_pooling_and_jods(Q_per_ch, prm):
 # --------------------------------------------------------------------------------------------------------
 # per-frame core and the frame loop  (pyfvvdp/fvvdp.py:190-334, 359-478)
 # --------------------------------------------------------------------------------------------------------
+# --------------------------------------------------------------------------------------------------------
+# PU21-PSNR side metric  (pyfvvdp/pupsnr.py:52-79, pyfvvdp/utils.py:157-202)
+# --------------------------------------------------------------------------------------------------------
+PU21_BANDING_GLARE = (234.0235618, 216.9339286, 0.0001091864237, 0.893206924, 0.06733984121, 1.444718567, 567.6315065)
+PU21_L_MIN, PU21_L_MAX = 0.005, 10000.0
+
+
+def pu21_peak(p=PU21_BANDING_GLARE, L_max=PU21_L_MAX):
+    """utils.py:181 (python floats = fp64, like the reference)"""
+    return p[6] * (((p[0] + p[1] * L_max ** p[3]) / (1 + p[2] * L_max ** p[3])) ** p[4] - p[5])
+
+
+def pu21_encode(Y, p=PU21_BANDING_GLARE):
+    """PU.encode, utils.py:183-193: clip to [0.005, 10000], rational power function; fp32 like torch."""
+    Y = np.clip(Y.astype(_F), _F(PU21_L_MIN), _F(PU21_L_MAX))
+    Yp = np.power(Y, _F(p[3]))
+    return (_F(p[6]) * (np.power((_F(p[0]) + _F(p[1]) * Yp) / (_F(1) + _F(p[2]) * Yp), _F(p[4])) - _F(p[5]))).astype(_F)
+
+
+def pu_psnr(test, ref, dim_order="BCFHW", display_name="standard_4k", photometry=None, color_space="sRGB"):
+    """pu_psnr.predict_video_source, pupsnr.py:52-79: per frame 20*log10(peak / sqrt(mean((PU(T)-PU(R))^2))),
+    averaged over the frames (fp32 per frame like torch, accumulated in python float)."""
+    test = reshuffle_dims(np.asarray(test), dim_order)
+    ref = reshuffle_dims(np.asarray(ref), dim_order)
+    phot = photometry if photometry is not None else Photometry.load(display_name)
+    rgb2y = load_defaults()["color_spaces.json"][color_space]["RGB2Y"]
+    N = test.shape[2]
+    peak = pu21_peak()
+    acc = 0.0
+    for f in range(N):
+        T, _ = frame_luminance(test, f, phot, rgb2y)
+        R, _ = frame_luminance(ref, f, phot, rgb2y)
+        d = pu21_encode(T) - pu21_encode(R)
+        mse = np.mean((d * d).astype(_F), dtype=_F)
+        acc = acc + float(_F(20.0) * np.log10(_F(peak) / np.sqrt(mse))) / N
+    return acc
+
+
 class Oracle:
     """Mirror of `class fvvdp` restricted to the live branch (local_adapt=gpyr, contrast=weber, pu_dilate=0)."""
 

@@ -555,3 +555,54 @@ def test_frame_range_and_sharded_predict(fv):
         q1, s1 = predict_frame_sharded(m, vs, 0, 1)
         assert abs(float(q1) - float(q)) < 2e-6
         assert np.allclose(s1["Q_per_ch"], st["Q_per_ch"], rtol=2e-6, atol=0)
+
+
+def test_pu21_psnr_golden_and_oracle(fv):
+    """PU21-PSNR through fvvdp_pu21_sse against the reference's pu_psnr (golden g8) and the
+    oracle, for integer and float sources, colour and gray, video and image, and a user-defined source."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    z = load("g8_pu_psnr")
+    test, ref = synth_video_pair(5, 54, 96)
+    f32 = lambda v: v.to(torch.float32)
+    cases = {"u8_srgb_4k": (test, ref, "standard_4k", 30),
+             "u8_gray_fhd": (test[:, 1:2], ref[:, 1:2], "standard_fhd", 30),
+             "f32_pq": (f32(test) / 255.0, f32(ref) / 255.0, "standard_hdr_pq", 60),
+             "f32_linear": (f32(test) * 3.0 + 0.01, f32(ref) * 3.0 + 0.01, "standard_hdr_linear", 24),
+             "image_u8": (test[:, :, 0:1], ref[:, :, 0:1], "standard_4k", 0)}
+    for tag, (t, r, disp, fps) in cases.items():
+        m = fv.pu_psnr(display_name=disp)
+        q, extra = m.predict(t, r, dim_order="BCFHW", frames_per_second=fps)
+        assert extra is None and q.dim() == 0
+        assert abs(float(q) - float(z[f"{tag}_psnr"])) < 2e-3, (tag, float(q), float(z[f"{tag}_psnr"]))
+        assert abs(float(q) - orc.pu_psnr(t.numpy(), r.numpy(), display_name=disp)) < 2e-3
+    # odd frame size (scalar loads), uint16, and the source-object entry point with a user subclass
+    H, W = 37, 53
+    rng = np.random.default_rng(5)
+    t16 = rng.integers(0, 65536, size=(3, H, W), dtype=np.uint16)
+    r16 = np.clip(t16.astype(np.int32) + rng.integers(-900, 900, size=t16.shape), 0, 65535).astype(np.uint16)
+    m = fv.pu_psnr(display_name="standard_fhd")
+    q, _ = m.predict(t16, r16, dim_order="FHW", frames_per_second=30)
+    oq = orc.pu_psnr(t16, r16, dim_order="FHW", display_name="standard_fhd")
+    assert abs(float(q) - oq) < 2e-3
+
+    vs = fv.fvvdp_video_source_array(t16, r16, 30, dim_order="FHW", display_photometry="standard_fhd")
+
+    class Wrap(fv.fvvdp_video_source):
+        def get_video_size(self):
+            return vs.get_video_size()
+
+        def get_frames_per_second(self):
+            return 30
+
+        def get_test_frame(self, f, device):
+            return vs.get_test_frame(f, device)
+
+        def get_reference_frame(self, f, device):
+            return vs.get_reference_frame(f, device)
+
+    q2, _ = m.predict_video_source(Wrap())
+    assert abs(float(q2) - float(q)) < 1e-4
+    # identical inputs: infinite PSNR like the reference (mse == 0)
+    qi, _ = m.predict(t16, t16, dim_order="FHW", frames_per_second=30)
+    assert np.isinf(float(qi))

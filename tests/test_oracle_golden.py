@@ -252,3 +252,26 @@ def test_yuv_ingest_g7(tag):
     check_q(st["Q_per_ch"][:2], z[f"{tag}_Q"][:2])
     q, gq = st["Q_per_ch"].astype(np.float64), z[f"{tag}_Q"].astype(np.float64)
     assert np.all(np.abs(q - gq) <= 4e-3 * np.abs(gq) + 1e-6 * np.max(gq))     # tiny frames: coarse bands are a few pixels
+
+
+def test_pu21_psnr_oracle_vs_reference():
+    """the PU21-PSNR side metric of the oracle against values produced by the reference's
+    pu_psnr.predict_video_source and PU.encode (golden g8)."""
+    import torch
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    z = load("g8_pu_psnr")
+    assert abs(orc.pu21_peak() - float(z["pu_peak"])) < 1e-9
+    enc = orc.pu21_encode(z["pu_in"])
+    assert np.max(np.abs(enc - z["pu_out"])) < 2e-4          # fp32 pow of numpy vs torch, values up to 600
+    test, ref = synth_video_pair(5, 54, 96)
+    t, r = test.numpy(), ref.numpy()
+    cases = {"u8_srgb_4k": (t, r, "standard_4k"),
+             "u8_gray_fhd": (t[:, 1:2], r[:, 1:2], "standard_fhd"),
+             "f32_pq": (t.astype(np.float32) / np.float32(255.0), r.astype(np.float32) / np.float32(255.0), "standard_hdr_pq"),
+             "f32_linear": (t.astype(np.float32) * np.float32(3.0) + np.float32(0.01),
+                            r.astype(np.float32) * np.float32(3.0) + np.float32(0.01), "standard_hdr_linear"),
+             "image_u8": (t[:, :, 0:1], r[:, :, 0:1], "standard_4k")}
+    for tag, (a, b, disp) in cases.items():
+        q = orc.pu_psnr(a, b, display_name=disp)
+        assert abs(q - float(z[f"{tag}_psnr"])) < 2e-3, (tag, q, float(z[f"{tag}_psnr"]))

@@ -397,6 +397,35 @@ def g7(pyfvvdp):
     save("g7_yuv_ingest", out)
 
 
+def g8(pyfvvdp):
+    """PU21-PSNR side metric (pupsnr.py:52-79, utils.py:157-202): the reference's pu_psnr.predict_video_source on
+    array sources built by hand (its own predict() cannot run: it reads attributes that are never set, pupsnr.py:45),
+    plus PU.encode on a luminance ramp."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from pyfvvdp.pupsnr import pu_psnr
+    from pyfvvdp.utils import PU
+    from pyfvvdp.video_source import fvvdp_video_source_array
+    out = {}
+    m = pu_psnr(device=torch.device("cpu"))
+    test, ref = synth_video_pair(5, 54, 96)
+    cases = {"u8_srgb_4k": (test, ref, "standard_4k", 30),
+             "u8_gray_fhd": (test[:, 1:2], ref[:, 1:2], "standard_fhd", 30),
+             "f32_pq": (test.to(torch.float32) / 255.0, ref.to(torch.float32) / 255.0, "standard_hdr_pq", 60),
+             "f32_linear": (test.to(torch.float32) * 3.0 + 0.01, ref.to(torch.float32) * 3.0 + 0.01, "standard_hdr_linear", 24),
+             "image_u8": (test[:, :, 0:1], ref[:, :, 0:1], "standard_4k", 0)}
+    with torch.no_grad():
+        for tag, (t, r, disp, fps) in cases.items():
+            vs = fvvdp_video_source_array(t, r, fps, dim_order="BCFHW", display_photometry=disp)
+            q, _ = m.predict_video_source(vs)
+            out[f"{tag}_psnr"] = np.float64(q.item())
+            print("g8", tag, "PU21-PSNR", out[f"{tag}_psnr"])
+        Y = torch.logspace(-3, 4.2, 200, dtype=torch.float32)
+        out["pu_in"] = Y.numpy()
+        out["pu_out"] = PU().encode(Y).numpy()
+        out["pu_peak"] = np.float64(PU().peak)
+    save("g8_pu_psnr", out)
+
+
 def main():
     which = sys.argv[1:] or ["g0", "g1", "g2", "g5"]
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
@@ -423,6 +452,8 @@ def main():
             g6(pyfvvdp)
         elif w == "g7":
             g7(pyfvvdp)
+        elif w == "g8":
+            g8(pyfvvdp)
         else:
             raise SystemExit("unknown case " + w)
         print(w, "done in %.1f s" % (time.time() - t0), flush=True)
