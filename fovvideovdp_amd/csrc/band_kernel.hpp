@@ -41,7 +41,6 @@ __device__ __forceinline__ Px<2> ld_px<2>(const float* p) {
 }
 // the coarse level is written once and only read by the next launch: non-temporal stores (measured +2-3 % on the
 // read+write mix of this kernel, tools/microbench/membw.hip)
-typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_px(float* p, const Px<4>& a) {
     __builtin_nontemporal_store(v4f{a.h[0].x, a.h[0].y, a.h[1].x, a.h[1].y}, reinterpret_cast<v4f*>(p));
 }

@@ -40,6 +40,7 @@ __device__ __forceinline__ float wave_sum(float v) {
 // Packed fp32 pair: the two video streams (test, reference) or two temporal channels go through the same arithmetic,
 // so they are kept as a 2-vector and the compiler emits v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 for them.
 typedef float v2f __attribute__((ext_vector_type(2)));
+typedef float v4f __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ v2f splat(float s) { return v2f{s, s}; }
 __device__ __forceinline__ v2f pfma(v2f a, float s, v2f c) { return __builtin_elementwise_fma(a, splat(s), c); }
 // clamp to [lo, hi] as one v_med3_f32 per component (fminf(fmaxf()) costs three: IEEE max first canonicalises its input)

@@ -473,7 +473,7 @@ __global__ __launch_bounds__(64) void temporal_vec_kernel(const TemporalArgs a) 
                     for (int i = 0; i < PX; ++i) {
                         const int q = i * 64 + lane;
                         const float4 val = s_t[(q / PX) * (PX + 1) + (q % PX)];
-                        if (p0 + q < a.HW) o[q] = val;
+                        if (p0 + q < a.HW) __builtin_nontemporal_store(v4f{val.x, val.y, val.z, val.w}, reinterpret_cast<v4f*>(o + q));
                     }
                 }
             }
@@ -873,7 +873,8 @@ __global__ __launch_bounds__(64) void temporal_yuv_vec_kernel(const YuvArgs a) {
                 const int q = i * 64 + lane;              // pixel of the wave's 248-pixel run
                 const int qq = min(q, YUV_QUADS * PX - 1);
                 const float4 val = s_t[(qq / PX + 1) * (PX + 1) + (qq % PX)];
-                if (q < YUV_QUADS * PX && p0 + q < HW) o[q] = val;
+                if (q < YUV_QUADS * PX && p0 + q < HW)
+                    __builtin_nontemporal_store(v4f{val.x, val.y, val.z, val.w}, reinterpret_cast<v4f*>(o + q));
             }
         }
     }
