@@ -263,7 +263,11 @@ __device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lu
             if (c > 0 && C != 3) break;
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
+    #ifdef K1_ABLATE_LUT
+                if constexpr (SRC == SRC_U8) v[c][i] = (float)f.ch[c].code(i);
+#else
                 if constexpr (SRC == SRC_U8) v[c][i] = lutw[c * 256 + f.ch[c].code(i)];
+#endif
                 else v[c][i] = __fmul_rn(lut16[f.ch[c].code(i)], w[c]);
             }
         }
@@ -450,8 +454,13 @@ __global__ __launch_bounds__(64) void temporal_vec_kernel(const TemporalArgs a) 
                     float acc[4][PX];
 #pragma unroll
                     for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
+#ifdef K1_ABLATE_FIR
+#pragma unroll
+                    for (int k = 1; k >= 0; --k) {
+#else
 #pragma unroll
                     for (int k = FL - 1; k >= 0; --k) {      // oldest tap first, like the reference's sum over the window
+#endif
                         const int sl = (u - k + 2 * FL) % FL;
                         const float f0 = a.taps[0][k], f1 = a.taps[1][k];
 #pragma unroll
