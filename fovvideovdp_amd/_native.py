@@ -70,6 +70,8 @@ SYMBOLS = {
     "fvvdp_heatmap_reconstruct": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_float, C.c_float, C.c_float,
                                             C.c_void_p, C.c_void_p]),
     "fvvdp_export_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "fvvdp_heatmap_colorize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
+                                         C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p]),
     "fvvdp_pu21_sse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
                                  C.POINTER(Eotf), C.POINTER(C.c_float), C.POINTER(Pu21), C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),

@@ -69,3 +69,160 @@ __global__ __launch_bounds__(256) void heat_level_kernel(const HeatArgs a) {
     a.out[(size_t)f * plane + o] = v;
 }
 
+// ---- colouring of difference maps ---------------------------------------------------------------------------
+// Replaces visualize_diff_map / vis_tonemap / log_luminance of the reference (pyfvvdp/visualize_diff_map.py) for the
+// heat-map outputs "threshold" and "supra-threshold": the difference map indexes a colour map, which modulates a
+// tone-mapped copy of the frame.  The tone curve is per frame: histogram (1024 bins) of the log-luminance of the
+// context image (pyramid level 0, plane 0), cube root, cumulative sum.  Four small passes per batch:
+//   colour_range_kernel  smallest positive and largest luminance of every frame
+//   colour_hist_kernel   histogram of b = log(max(y, floor))
+//   colour_curve_kernel  tone curve v[1024] of every frame
+//   colour_map_kernel    per pixel: tone curve look-up x colour-map look-up -> fp16, planar [3][n][H][W]
+#define COLOUR_BINS 1024
+struct ColourArgs {
+    const float* ctx;        // level 0: [n][HW][P]
+    int P;
+    unsigned int HW;
+    unsigned int* range;     // [n][2]: bit patterns of min positive y, max y
+    unsigned int* hist;      // [n][COLOUR_BINS]
+    float* curve;            // [n][COLOUR_BINS]
+    const float* lin01;      // [COLOUR_BINS] = torch.linspace(0, 1, 1024)
+    const float* dmap;       // [n][HW]
+    __half* out;             // element (c, f, p) at c*chan_stride + f*HW + p
+    size_t chan_stride;
+    int n_knots;
+    float knots[8];
+    float rgb[8][3];
+    float dr;                // dynamic range of the tone-mapped image (0.6)
+};
+
+__global__ __launch_bounds__(256) void colour_range_kernel(const ColourArgs a) {
+    const int f = blockIdx.y;
+    const float* y = a.ctx + (size_t)f * a.HW * a.P;
+    unsigned int mn = 0x7F800000u, mx = 0u;          // +inf, 0: positive floats order like their bit patterns
+    for (unsigned int p = blockIdx.x * 256 + threadIdx.x; p < a.HW; p += gridDim.x * 256) {
+        const float v = y[(size_t)p * a.P];
+        if (v > 0.0f) {
+            mn = min(mn, __float_as_uint(v));
+            mx = max(mx, __float_as_uint(v));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) {
+        mn = min(mn, (unsigned int)__shfl_xor((int)mn, o, 64));
+        mx = max(mx, (unsigned int)__shfl_xor((int)mx, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMin(&a.range[2 * f], mn);
+        atomicMax(&a.range[2 * f + 1], mx);
+    }
+}
+
+// log-luminance of a context pixel and the frame's range (log_luminance: clamp to the smallest positive value)
+struct ColourFrame {
+    float floor_y, b_min, b_max, span;
+};
+__device__ __forceinline__ ColourFrame colour_frame(const ColourArgs& a, int f) {
+    ColourFrame c;
+    c.floor_y = __uint_as_float(a.range[2 * f]);
+    const float top = fmaxf(__uint_as_float(a.range[2 * f + 1]), c.floor_y);
+    c.b_min = logf(c.floor_y);
+    c.b_max = logf(top);
+    c.span = c.b_max - c.b_min;
+    return c;
+}
+
+__global__ __launch_bounds__(256) void colour_hist_kernel(const ColourArgs a) {
+    __shared__ unsigned int h[COLOUR_BINS];
+    const int f = blockIdx.y;
+    for (int i = threadIdx.x; i < COLOUR_BINS; i += 256) h[i] = 0;
+    __syncthreads();
+    const ColourFrame c = colour_frame(a, f);
+    const float scale = (float)COLOUR_BINS / fmaxf(c.span, 1e-30f);
+    const float* y = a.ctx + (size_t)f * a.HW * a.P;
+    for (unsigned int p = blockIdx.x * 256 + threadIdx.x; p < a.HW; p += gridDim.x * 256) {
+        const float b = logf(fmaxf(y[(size_t)p * a.P], c.floor_y));
+        int bin = (int)((b - c.b_min) * scale);       // torch.histc: last bin closed
+        bin = min(max(bin, 0), COLOUR_BINS - 1);
+        atomicAdd(&h[bin], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < COLOUR_BINS; i += 256)
+        if (h[i]) atomicAdd(&a.hist[(size_t)f * COLOUR_BINS + i], h[i]);
+}
+
+// vis_tonemap (visualize_diff_map.py:34-55): v = cumsum(p^(1/3) / sum(p^(1/3))) * dr + (1-dr)/2; one block per frame
+__global__ __launch_bounds__(COLOUR_BINS) void colour_curve_kernel(const ColourArgs a) {
+    __shared__ float s[COLOUR_BINS];
+    __shared__ float s_tot;
+    const int f = blockIdx.x, i = threadIdx.x;
+    const float p = (float)a.hist[(size_t)f * COLOUR_BINS + i] / (float)a.HW;
+    const float dy = powf(p, 1.0f / 3.0f);
+    s[i] = dy;
+    __syncthreads();
+    // inclusive scan (Hillis-Steele): 10 steps over 1024 values
+    for (int o = 1; o < COLOUR_BINS; o <<= 1) {
+        const float t = (i >= o) ? s[i - o] : 0.0f;
+        __syncthreads();
+        s[i] += t;
+        __syncthreads();
+    }
+    if (i == COLOUR_BINS - 1) s_tot = s[i];
+    __syncthreads();
+    a.curve[(size_t)f * COLOUR_BINS + i] = s[i] / s_tot * a.dr + (1.0f - a.dr) * 0.5f;
+}
+
+__global__ __launch_bounds__(256) void colour_map_kernel(const ColourArgs a) {
+    __shared__ float s_v[COLOUR_BINS];
+    __shared__ float s_x[COLOUR_BINS];
+    __shared__ float s_knot[8];
+    __shared__ float s_rgb[8][3];
+    const int f = blockIdx.y;
+    const ColourFrame c = colour_frame(a, f);
+    for (int i = threadIdx.x; i < COLOUR_BINS; i += 256) {
+        s_v[i] = a.curve[(size_t)f * COLOUR_BINS + i];
+        s_x[i] = c.b_min + c.span * a.lin01[i];
+    }
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            s_knot[k] = a.knots[k];
+            s_rgb[k][0] = a.rgb[k][0];
+            s_rgb[k][1] = a.rgb[k][1];
+            s_rgb[k][2] = a.rgb[k][2];
+        }
+    }
+    __syncthreads();
+    const bool flat = c.span < a.dr;                  // low dynamic range: linear mapping (vis_tonemap :38-39)
+    const float inv_step = (float)(COLOUR_BINS - 1) / fmaxf(c.span, 1e-30f);
+    const float* y = a.ctx + (size_t)f * a.HW * a.P;
+    const float* dm = a.dmap + (size_t)f * a.HW;
+    for (unsigned int p = blockIdx.x * 256 + threadIdx.x; p < a.HW; p += gridDim.x * 256) {
+        const float b = logf(fmaxf(y[(size_t)p * a.P], c.floor_y));
+        float tmo;
+        if (flat) {
+            tmo = (b - c.b_min) / (c.span + 1e-3f) * a.dr + (1.0f - a.dr) * 0.5f;
+        } else {
+            // interp1 with the reference's knot search: imax = first knot >= b (clamped), imin = imax - 1
+            int imax = min(max((int)ceilf((b - c.b_min) * inv_step), 0), COLOUR_BINS - 1);
+            while (imax > 0 && s_x[imax - 1] >= b) --imax;
+            while (imax < COLOUR_BINS - 1 && s_x[imax] < b) ++imax;
+            const int imin = max(imax - 1, 0);
+            float frc = (b - s_x[imin]) / (s_x[imax] - s_x[imin] + 0.000001f);
+            frc = (imax == imin) ? 0.0f : fmaxf(frc, 0.0f);
+            tmo = s_v[imin] * (1.0f - frc) + s_v[imax] * frc;
+        }
+        const float d = fminf(fmaxf(dm[p], 0.0f), 1.0f);
+        int kmax = 0;
+        while (kmax < a.n_knots - 1 && s_knot[kmax] < d) ++kmax;
+        const int kmin = max(kmax - 1, 0);
+        float fk = (d - s_knot[kmin]) / (s_knot[kmax] - s_knot[kmin] + 0.000001f);
+        fk = (kmax == kmin) ? 0.0f : fmaxf(fk, 0.0f);
+#pragma unroll
+        for (int ch = 0; ch < 3; ++ch) {
+            const float col = s_rgb[kmin][ch] * (1.0f - fk) + s_rgb[kmax][ch] * fk;
+            const float v = fminf(fmaxf(col * tmo, 0.0f), 1.0f);
+            a.out[(size_t)ch * a.chan_stride + (size_t)f * a.HW + p] = __float2half_rn(v);
+        }
+    }
+}

@@ -8,6 +8,7 @@
 // the P temporal-channel planes of one pixel are adjacent (one aligned float4 for video, float2 for images), so
 // one lane = one pixel, every load/store is 16 B (8 B) wide and all per-pixel math is thread-local.
 #include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
 
 #include <cmath>
 #include <cstdarg>
@@ -80,6 +81,7 @@ struct fvvdp_ctx {
     float* d_taps = nullptr;      // [2][FVVDP_MAX_TAPS]
     int* d_idx = nullptr;         // [max_frames + FVVDP_MAX_TAPS]
     float* heat[FVVDP_MAX_BANDS + 1]{};   // heat-map accumulation images of levels >= 1, allocated on first use
+    unsigned int* colour_ws = nullptr;    // colouring workspace per frame: range[2] + hist[1024] + curve[1024], then lin01[1024]
     size_t scratch = 0;
     long long wave_capacity = 4096;   // resident single-wave workgroups of the band kernel on the whole chip
     // timing
@@ -217,6 +219,7 @@ extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     if (c->csf_y) (void)hipFree(c->csf_y);
     for (int i = 0; i <= FVVDP_MAX_BANDS; ++i)
         if (c->heat[i]) (void)hipFree(c->heat[i]);
+    if (c->colour_ws) (void)hipFree(c->colour_ws);
     if (c->d_fix) (void)hipFree(c->d_fix);
     if (c->d_taps) (void)hipFree(c->d_taps);
     if (c->d_idx) (void)hipFree(c->d_idx);
@@ -828,6 +831,57 @@ extern "C" int fvvdp_heatmap_reconstruct(fvvdp_ctx* c, int n, const float* const
         dim3 grid((a.w + 255) / 256, a.h, n), block(256);
         hipLaunchKernelGGL(heat_level_kernel, grid, block, 0, st, a);
     }
+    HIP_TRY(hipGetLastError());
+    return FVVDP_OK;
+}
+
+extern "C" int fvvdp_heatmap_colorize(fvvdp_ctx* c, int n, const float* d_dmap, const float* h_knots, const float* h_rgb,
+                                      int n_knots, const float* h_lin01, void* d_out_f16, size_t chan_stride, void* stream) {
+    if (!c || !d_dmap || !h_knots || !h_rgb || !h_lin01 || !d_out_f16) return fail(FVVDP_EINVAL, "null argument");
+    if (n < 1 || n > c->max_frames) return fail(FVVDP_EINVAL, "n=%d exceeds max_frames=%d", n, c->max_frames);
+    if (n_knots < 2 || n_knots > 8) return fail(FVVDP_EINVAL, "colour map needs 2..8 knots, got %d", n_knots);
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    const size_t per_frame = 2 + 2 * COLOUR_BINS;                    // 32-bit words
+    if (!c->colour_ws) {
+        int rc = dev_alloc(c, &c->colour_ws, (size_t)c->max_frames * per_frame + COLOUR_BINS);
+        if (rc != FVVDP_OK) return rc;
+    }
+    unsigned int* range = c->colour_ws;
+    unsigned int* hist = range + 2 * (size_t)c->max_frames;
+    float* curve = reinterpret_cast<float*>(hist + (size_t)c->max_frames * COLOUR_BINS);
+    float* lin01 = curve + (size_t)c->max_frames * COLOUR_BINS;
+    // range starts at (+inf, 0), the histograms at 0; the linspace table comes from the caller (torch.linspace)
+    std::vector<unsigned int> init(2 * (size_t)n);
+    for (int f = 0; f < n; ++f) { init[2 * f] = 0x7F800000u; init[2 * f + 1] = 0u; }
+    HIP_TRY(hipMemcpyAsync(range, init.data(), init.size() * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetAsync(hist, 0, (size_t)n * COLOUR_BINS * sizeof(unsigned int), st));
+    HIP_TRY(hipMemcpyAsync(lin01, h_lin01, COLOUR_BINS * sizeof(float), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));                               // `init` and h_lin01 are pageable host memory
+    ColourArgs a;
+    memset(&a, 0, sizeof(a));
+    a.ctx = c->level[0];
+    a.P = c->P;
+    a.HW = (unsigned int)(c->W * c->H);
+    a.range = range;
+    a.hist = hist;
+    a.curve = curve;
+    a.lin01 = lin01;
+    a.dmap = d_dmap;
+    a.out = reinterpret_cast<__half*>(d_out_f16);
+    a.chan_stride = chan_stride;
+    a.n_knots = n_knots;
+    for (int k = 0; k < 8; ++k) {
+        const int kk = k < n_knots ? k : n_knots - 1;
+        a.knots[k] = h_knots[kk];
+        for (int ch = 0; ch < 3; ++ch) a.rgb[k][ch] = h_rgb[3 * kk + ch];
+    }
+    a.dr = 0.6f;
+    const unsigned int blocks = (a.HW + 256 * 16 - 1) / (256 * 16);  // 16 pixels per thread
+    dim3 grid(blocks < 1 ? 1 : blocks, n);
+    hipLaunchKernelGGL(colour_range_kernel, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(colour_hist_kernel, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(colour_curve_kernel, dim3(n), dim3(COLOUR_BINS), 0, st, a);
+    hipLaunchKernelGGL(colour_map_kernel, grid, dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;
 }

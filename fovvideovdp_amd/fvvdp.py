@@ -250,7 +250,6 @@ class fvvdp:
     def _heatmap_batch(self, ctx, nb, dmaps, planes, width, height, stream, heatmap, k0):
         """Difference maps of `nb` frames -> heatmap[0, :, k0:k0+nb] (fp16, host) (fvvdp.py:469-476).  The maps are
         finished on the device in the output layout and copied back asynchronously, one contiguous run per channel."""
-        from .visualize_diff_map import visualize_diff_map
         ptrs = (C.c_void_p * len(dmaps))(*[d.data_ptr() for d in dmaps])
         dmap = torch.empty((nb, height, width), dtype=torch.float32, device=self.device)
         beta_jod = float(np.power(10.0, self.log_jod_exp))
@@ -259,13 +258,14 @@ class fvvdp:
         if self.heatmap == "raw":
             heatmap[0, 0, k0:k0 + nb].copy_(dmap.to(torch.float16), non_blocking=True)
             return
-        lvl0 = torch.empty((nb, planes, height, width), dtype=torch.float32, device=self.device)
-        nat.check(nat.lib().fvvdp_export_level(ctx.handle, 0, nb, C.c_void_p(lvl0.data_ptr()), stream))
+        # colouring on the device (fvvdp_heatmap_colorize): tone-mapped context frame x colour map, fp16, output layout
+        from .visualize_diff_map import color_tables_host
+        knots, rgb = color_tables_host(self.heatmap)
+        lin01 = torch.linspace(0.0, 1.0, 1024).numpy()
         out = torch.empty((3, nb, height, width), dtype=torch.float16, device=self.device)
-        for k in range(nb):      # tone mapping is per frame (global histogram of the frame)
-            col = visualize_diff_map(dmap[k].view(1, 1, height, width), context_image=lvl0[k:k + 1, 0:1],
-                                     colormap_type=self.heatmap)
-            out[:, k] = col[0]
+        nat.check(nat.lib().fvvdp_heatmap_colorize(ctx.handle, nb, C.c_void_p(dmap.data_ptr()), nat.fptr(knots), nat.fptr(rgb),
+                                                   len(knots), nat.fptr(lin01), C.c_void_p(out.data_ptr()),
+                                                   nb * height * width, stream))
         for ch in range(3):
             heatmap[0, ch, k0:k0 + nb].copy_(out[ch], non_blocking=True)
 

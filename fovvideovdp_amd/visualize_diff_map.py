@@ -1,6 +1,6 @@
 """Colouring of difference maps (heat maps): the map modulates a tone-mapped, desaturated copy of the frame.
-Host-side torch code (visualisation, not on the hot path); same results as the reference's
-pyfvvdp/visualize_diff_map.py, which it replaces for `heatmap in {"threshold", "supra-threshold"}`."""
+Torch version of the reference's pyfvvdp/visualize_diff_map.py (same results), kept as the public helper and as the
+checker of the HIP colouring (`fvvdp_heatmap_colorize`) that `fvvdp.predict(..., heatmap=...)` uses."""
 import torch
 
 _LUMA = (0.212656, 0.715158, 0.072186)
@@ -79,6 +79,13 @@ def _color_tables(colormap_type, device):
         color_map_l = color_map[:, 0:1] * _LUMA[0] + color_map[:, 1:2] * _LUMA[1] + color_map[:, 2:3] * _LUMA[2]
         _TABLE_CACHE[key] = (color_map_in, color_map / (torch.cat([color_map_l] * 3, 1) + 0.0001))
     return _TABLE_CACHE[key]
+
+
+def color_tables_host(colormap_type):
+    """(knots[K], colours[K,3]) of a colour map as fp32 numpy arrays for fvvdp_heatmap_colorize: the colours are divided
+    by their luminance (+1e-4) with the same fp32 torch ops as visualize_diff_map."""
+    color_map_in, color_map_ch = _color_tables(colormap_type, torch.device("cpu"))
+    return color_map_in.numpy().astype("float32"), color_map_ch.numpy().astype("float32")
 
 
 def visualize_diff_map(diff_map, context_image=None, type="pmap", colormap_type="supra-threshold"):

@@ -606,3 +606,37 @@ def test_pu21_psnr_golden_and_oracle(fv):
     # identical inputs: infinite PSNR like the reference (mse == 0)
     qi, _ = m.predict(t16, t16, dim_order="FHW", frames_per_second=30)
     assert np.isinf(float(qi))
+
+
+@pytest.mark.parametrize("cmap", ["threshold", "supra-threshold"])
+def test_heatmap_colouring_kernel_vs_torch(fv, cmap):
+    """fvvdp_heatmap_colorize (histogram tone curve of the context frame x colour map, fp16) against the torch
+    restatement of the reference's visualize_diff_map on the same difference map and context frames, for a normal
+    clip and for a low-dynamic-range one (linear branch of vis_tonemap)."""
+    import ctypes as C
+    from fovvideovdp_amd import _native as nat
+    from fovvideovdp_amd.synth import synth_video_pair
+    from fovvideovdp_amd.visualize_diff_map import visualize_diff_map, color_tables_host
+    N, H, W = 3, 70, 124
+    test, ref = synth_video_pair(N, H, W)
+    for scale in (1.0, 0.08):                       # 0.08: code values 0..20 -> luminance range below 0.6 log units
+        t = (test.float() * scale).to(torch.uint8)
+        r = (ref.float() * scale).to(torch.uint8)
+        m = fv.fvvdp(display_name="standard_fhd")
+        m.predict(t, r, frames_per_second=30)                  # leaves the temporal channels in level 0 of the context
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        lvl0 = torch.empty((N, 4, H, W), dtype=torch.float32, device="cuda")
+        nat.check(nat.lib().fvvdp_export_level(m._ctx.handle, 0, N, C.c_void_p(lvl0.data_ptr()), stream))
+        g = torch.Generator(device="cpu").manual_seed(3)
+        dmap = (torch.rand((N, H, W), generator=g) * 1.2 - 0.1).to("cuda")          # also outside [0,1]
+        out = torch.empty((3, N, H, W), dtype=torch.float16, device="cuda")
+        knots, rgb = color_tables_host(cmap)
+        lin01 = torch.linspace(0.0, 1.0, 1024).numpy()
+        nat.check(nat.lib().fvvdp_heatmap_colorize(m._ctx.handle, N, C.c_void_p(dmap.data_ptr()), nat.fptr(knots), nat.fptr(rgb),
+                                                   len(knots), nat.fptr(lin01), C.c_void_p(out.data_ptr()), N * H * W, stream))
+        for k in range(N):
+            want = visualize_diff_map(dmap[k].view(1, 1, H, W), context_image=lvl0[k:k + 1, 0:1], colormap_type=cmap)[0]
+            got = out[:, k].float()
+            # fp16 output (5e-4) + one histogram bin of slack on the tone curve
+            assert float((got - want).abs().max()) < 3e-3, (cmap, scale, k)
+            assert float((got - want).abs().mean()) < 3e-4
