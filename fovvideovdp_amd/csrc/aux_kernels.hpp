@@ -83,7 +83,8 @@ struct ColourArgs {
     const float* ctx;        // level 0: [n][HW][P]
     int P;
     unsigned int HW;
-    unsigned int* range;     // [n][2]: bit patterns of min positive y, max y
+    unsigned int* range;     // [2][range_stride]: bit patterns of the smallest positive y / the largest y of a frame
+    int range_stride;
     unsigned int* hist;      // [n][COLOUR_BINS]
     float* curve;            // [n][COLOUR_BINS]
     const float* lin01;      // [COLOUR_BINS] = torch.linspace(0, 1, 1024)
@@ -113,8 +114,8 @@ __global__ __launch_bounds__(256) void colour_range_kernel(const ColourArgs a) {
         mx = max(mx, (unsigned int)__shfl_xor((int)mx, o, 64));
     }
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&a.range[2 * f], mn);
-        atomicMax(&a.range[2 * f + 1], mx);
+        atomicMin(&a.range[f], mn);
+        atomicMax(&a.range[a.range_stride + f], mx);
     }
 }
 
@@ -124,8 +125,8 @@ struct ColourFrame {
 };
 __device__ __forceinline__ ColourFrame colour_frame(const ColourArgs& a, int f) {
     ColourFrame c;
-    c.floor_y = __uint_as_float(a.range[2 * f]);
-    const float top = fmaxf(__uint_as_float(a.range[2 * f + 1]), c.floor_y);
+    c.floor_y = __uint_as_float(a.range[f]);
+    const float top = fmaxf(__uint_as_float(a.range[a.range_stride + f]), c.floor_y);
     c.b_min = logf(c.floor_y);
     c.b_max = logf(top);
     c.span = c.b_max - c.b_min;

@@ -842,27 +842,29 @@ extern "C" int fvvdp_heatmap_colorize(fvvdp_ctx* c, int n, const float* d_dmap, 
     if (n_knots < 2 || n_knots > 8) return fail(FVVDP_EINVAL, "colour map needs 2..8 knots, got %d", n_knots);
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const size_t per_frame = 2 + 2 * COLOUR_BINS;                    // 32-bit words
+    unsigned int* range;
     if (!c->colour_ws) {
         int rc = dev_alloc(c, &c->colour_ws, (size_t)c->max_frames * per_frame + COLOUR_BINS);
         if (rc != FVVDP_OK) return rc;
+        // the knot table of the tone curve (torch.linspace from the caller) is uploaded once per context
+        float* l = reinterpret_cast<float*>(c->colour_ws + (size_t)c->max_frames * per_frame);
+        HIP_TRY(hipMemcpyAsync(l, h_lin01, COLOUR_BINS * sizeof(float), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
     }
-    unsigned int* range = c->colour_ws;
+    range = c->colour_ws;                                            // [2][max_frames]: min positive, max
     unsigned int* hist = range + 2 * (size_t)c->max_frames;
     float* curve = reinterpret_cast<float*>(hist + (size_t)c->max_frames * COLOUR_BINS);
     float* lin01 = curve + (size_t)c->max_frames * COLOUR_BINS;
-    // range starts at (+inf, 0), the histograms at 0; the linspace table comes from the caller (torch.linspace)
-    std::vector<unsigned int> init(2 * (size_t)n);
-    for (int f = 0; f < n; ++f) { init[2 * f] = 0x7F800000u; init[2 * f + 1] = 0u; }
-    HIP_TRY(hipMemcpyAsync(range, init.data(), init.size() * sizeof(unsigned int), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(range), 0x7F800000, (size_t)n, st));           // +inf
+    HIP_TRY(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(range + c->max_frames), 0, (size_t)n, st));
     HIP_TRY(hipMemsetAsync(hist, 0, (size_t)n * COLOUR_BINS * sizeof(unsigned int), st));
-    HIP_TRY(hipMemcpyAsync(lin01, h_lin01, COLOUR_BINS * sizeof(float), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));                               // `init` and h_lin01 are pageable host memory
     ColourArgs a;
     memset(&a, 0, sizeof(a));
     a.ctx = c->level[0];
     a.P = c->P;
     a.HW = (unsigned int)(c->W * c->H);
     a.range = range;
+    a.range_stride = c->max_frames;
     a.hist = hist;
     a.curve = curve;
     a.lin01 = lin01;

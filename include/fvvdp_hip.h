@@ -210,7 +210,7 @@ int fvvdp_heatmap_reconstruct(fvvdp_ctx* ctx, int n, const float* const* h_dD, f
  * (clamped to [0,1]) indexes a colour map (n_knots <= 8 knots h_knots, luminance-normalised colours h_rgb[n_knots][3])
  * and modulates a tone-mapped copy of the context frame = plane 0 of pyramid level 0 of slots [0,n) (histogram tone
  * curve per frame, 1024 bins; h_lin01 = torch.linspace(0,1,1024), the knot positions of the curve).  Output fp16,
- * element (c,f,y,x) at c*chan_stride + (f*H + y)*W + x.  Synchronises the stream once (small host tables).   */
+ * element (c,f,y,x) at c*chan_stride + (f*H + y)*W + x.  Asynchronous except for the first call on a context.  */
 int fvvdp_heatmap_colorize(fvvdp_ctx* ctx, int n, const float* d_dmap, const float* h_knots, const float* h_rgb,
                            int n_knots, const float* h_lin01, void* d_out_f16, size_t chan_stride, void* stream);
 
