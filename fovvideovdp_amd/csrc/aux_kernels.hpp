@@ -113,9 +113,15 @@ __global__ __launch_bounds__(256) void colour_range_kernel(const ColourArgs a) {
         mn = min(mn, (unsigned int)__shfl_xor((int)mn, o, 64));
         mx = max(mx, (unsigned int)__shfl_xor((int)mx, o, 64));
     }
+    __shared__ unsigned int s_mn[4], s_mx[4];
     if ((threadIdx.x & 63) == 0) {
-        atomicMin(&a.range[f], mn);
-        atomicMax(&a.range[a.range_stride + f], mx);
+        s_mn[threadIdx.x >> 6] = mn;
+        s_mx[threadIdx.x >> 6] = mx;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicMin(&a.range[f], min(min(s_mn[0], s_mn[1]), min(s_mn[2], s_mn[3])));
+        atomicMax(&a.range[a.range_stride + f], max(max(s_mx[0], s_mx[1]), max(s_mx[2], s_mx[3])));
     }
 }
 

@@ -878,10 +878,12 @@ extern "C" int fvvdp_heatmap_colorize(fvvdp_ctx* c, int n, const float* d_dmap, 
         for (int ch = 0; ch < 3; ++ch) a.rgb[k][ch] = h_rgb[3 * kk + ch];
     }
     a.dr = 0.6f;
-    const unsigned int blocks = (a.HW + 256 * 16 - 1) / (256 * 16);  // 16 pixels per thread
+    const unsigned int blocks = (a.HW + 256 * 16 - 1) / (256 * 16);  // >= 16 pixels per thread
     dim3 grid(blocks < 1 ? 1 : blocks, n);
-    hipLaunchKernelGGL(colour_range_kernel, grid, dim3(256), 0, st, a);
-    hipLaunchKernelGGL(colour_hist_kernel, grid, dim3(256), 0, st, a);
+    // the two reductions end in atomics on a few addresses per frame: bound the number of blocks that flush
+    dim3 grid_red(grid.x > 96 ? 96 : grid.x, n);
+    hipLaunchKernelGGL(colour_range_kernel, grid_red, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(colour_hist_kernel, grid_red, dim3(256), 0, st, a);
     hipLaunchKernelGGL(colour_curve_kernel, dim3(n), dim3(COLOUR_BINS), 0, st, a);
     hipLaunchKernelGGL(colour_map_kernel, grid, dim3(256), 0, st, a);
     HIP_TRY(hipGetLastError());

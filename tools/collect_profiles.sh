@@ -1,0 +1,25 @@
+#!/bin/bash
+# Produce the profile bundle kept under profiles/ (run on the GPU box through gpurun; writes gpurun_out/prof_bundle/).
+#   1. bench.py unprofiled                       2. rocprofv3 --kernel-trace of bench.py (summary table)
+#   3. two separate --pmc passes (FETCH_SIZE, WRITE_SIZE) of the band kernels -> level-0 HBM traffic per launch
+#   4. kernel traces of the YUV ingest, PU21-PSNR and heat-map probes
+set -u
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_bundle
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+python $R/bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o bench -- python $R/bench.py --no-cpu-baseline > $OUT/bench_profiled.json 2> /tmp/kt.err
+python $R/tools/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) --band-levels 7 > $OUT/kernel_trace_bench.md
+rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf -o f -- python $R/tools/gpu_bandonly.py > /tmp/pf.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw -o w -- python $R/tools/gpu_bandonly.py > /tmp/pw.log 2>&1
+python $R/tools/pmc_level0.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) $OUT/pmc_level0.json > /dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/ky -o yuv -- python $R/tools/gpu_yuv.py 2160x3840x60:8:420 2160x3840x60:10:420:60 2160x3840x60:8:444 > $OUT/yuv_probe.txt 2> /tmp/ky.err
+python $R/tools/rocpd_summary.py $(find /tmp/ky -name "*.db" | head -1) --only temporal_yuv > $OUT/kernel_trace_yuv.md
+rocprofv3 --kernel-trace --stats -d /tmp/kp -o psnr -- python $R/tools/gpu_psnr.py > $OUT/psnr_probe.txt 2> /tmp/kp.err
+python $R/tools/rocpd_summary.py $(find /tmp/kp -name "*.db" | head -1) --only pu21 > $OUT/kernel_trace_psnr.md
+rocprofv3 --kernel-trace --stats -d /tmp/kh -o heat -- python $R/tools/gpu_heatprof.py 12 threshold > /tmp/kh.out 2> /tmp/kh.err
+grep "^total" /tmp/kh.out > $OUT/heat_probe.txt
+python $R/tools/rocpd_summary.py $(find /tmp/kh -name "*.db" | head -1) --band-levels 7 > /tmp/kh.md
+grep -E "kernel \||---|colour_|heat_level|band_kernel<4, true" /tmp/kh.md > $OUT/kernel_trace_heat.md
+ls -la $OUT
