@@ -169,6 +169,13 @@ def main():
                "kind": "port", "sample": "%d output frames (frames %d..%d, incl. their %d-frame temporal window) of the same "
                "%dx%d pair, numpy fp32 oracle, single thread; host has %d cores" % (nf, frames[0], frames[-1], fl_guard(fps) + 1, W, H, os.cpu_count())}
 
+    # second half of the metric: |JOD - JOD of the reference| for rank 0's pair, from the committed golden
+    # (tests/golden/g3_synth_uhd_60f.npz = the reference's own torch-CPU run on this synthetic pair, tools/gen_golden.py g3)
+    jod_delta = None
+    gpath = os.path.join(ROOT, "tests", "golden", "g3_synth_uhd_60f.npz")
+    if rank == 0 and (W, H, N, fps, args.display) == (3840, 2160, 60, 30, "standard_4k") and os.path.exists(gpath):
+        jod_delta = abs(float(jods[0]) - float(np.load(gpath)["jod"]))
+
     if rank == 0:
         out = {"metric": "Mpixels/s (test+ref) at 4Kx60f; JOD delta vs reference", "value": round(mpix, 1),
                "unit": "Mpixels/s (test+ref)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -177,7 +184,8 @@ def main():
                "config": {"workload": "%dx%d x%d-frame synthetic uint8 RGB video pair per GPU, %s, %d fps, foveated=off "
                                       "(BASELINE.json configs[2]); pairs sharded one per GPU" % (W, H, N, args.display, fps),
                           "parallelism": "pair-sharded x%d, one all-reduce of Q_per_ch" % world},
-               "jod": [round(j, 6) for j in jods], "roofline": roof, "cpu_baseline": cpu}
+               "jod": [round(j, 6) for j in jods],
+               "jod_delta_vs_reference": None if jod_delta is None else float("%.3g" % jod_delta), "roofline": roof, "cpu_baseline": cpu}
         out.update(extra)
         print(json.dumps(out), flush=True)
     if dist is not None:
