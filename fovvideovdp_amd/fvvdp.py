@@ -113,6 +113,7 @@ class fvvdp:
         self.csf_lut = [utils.load_csf_lut(om, self.csf_sigma, self.k_cm, self.csf_cache_dirs) for om in self.omega]
         self._ctx = None
         self._lut_dev = {}
+        self._chan_w = {}
         self.timing = None
 
     # ---- configuration ------------------------------------------------------------------------------------
@@ -194,8 +195,11 @@ class fvvdp:
             heatmap = self._host_buffer([1, dmap_channels, n_out, height, width])
         ctx = self._context(width, height, n_bands, planes, batch, rho_band)
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
-        Q = torch.zeros((n_bands, 2, n_out), dtype=torch.float32, device=self.device)
-        oob = torch.zeros(1, dtype=torch.int32, device=self.device)
+        # results + the out-of-range flag share one buffer: a single device->host copy (and sync) per call
+        nq = n_bands * 2 * n_out
+        res = torch.zeros(nq + 1, dtype=torch.float32, device=self.device)
+        Q = res[:nq].view(n_bands, 2, n_out)
+        oob = res[nq:].view(torch.int32)
         widx = window_frame_indices(N_frames, fl, self.temp_padding) if not is_image else np.zeros(1, np.int32)
         feeder = self._make_feeder(vid_source, width, height)
 
@@ -228,7 +232,8 @@ class fvvdp:
 
         Q_jod = self.do_pooling_and_jods(Q, rho_band[0:-1]) if pool else None
         stats = {}
-        stats['Q_per_ch'] = Q.detach().cpu().numpy()        # the one host synchronisation of the call
+        res_h = res.detach().cpu()                           # the one host synchronisation of the call
+        stats['Q_per_ch'] = res_h[:nq].view(n_bands, 2, n_out).numpy()
         stats['rho_band'] = rho_band
         stats['frames_per_second'] = vid_source.get_frames_per_second()
         stats['width'] = width
@@ -236,7 +241,7 @@ class fvvdp:
         stats['N_frames'] = N_frames
         if self.do_heatmap:
             stats['heatmap'] = heatmap
-        if int(oob.item()) != 0:
+        if int(res_h[nq:].view(torch.int32)[0]) != 0:
             logging.warning("Pixel outside the valid range 0-1")
         return (Q_jod.squeeze() if pool else None, stats)
 
@@ -277,8 +282,10 @@ class fvvdp:
         Q = Q_per_ch
         d = Q.dim() - 3                        # 0, or 1 with a leading batch of videos
         if Q.shape[d + 1] == 2:
-            w = torch.tensor([1.0, self.w_transient], dtype=Q.dtype, device=Q.device).view(1, 2, 1)
-            Q = Q * w
+            key = (str(Q.device), Q.dtype)             # cached: a host->device upload per call costs a stream sync
+            if key not in self._chan_w:
+                self._chan_w[key] = torch.tensor([1.0, self.w_transient], dtype=Q.dtype, device=Q.device).view(1, 2, 1)
+            Q = Q * self._chan_w[key]
         Q_sc = self.lp_norm(Q, self.beta_sch, d + 0, False)
         Q_tc = self.lp_norm(Q_sc, self.beta_tch, d + 1, False)
         Q_all = self.lp_norm(Q_tc, self.beta_t, d + 2, True)
