@@ -164,6 +164,10 @@ class fvvdp:
         """
         if self.device.type != "cuda":
             raise RuntimeError("fovvideovdp_amd needs an AMD GPU (torch device 'cuda'); there is no CPU fallback")
+        with torch.cuda.device(self.device):       # the library launches on the calling thread's current device
+            return self._predict_on_device(vid_source, fixation_point, frame_range, pool)
+
+    def _predict_on_device(self, vid_source, fixation_point, frame_range, pool):
         height, width, N_frames = vid_source.get_video_size()
         f0, f1 = (0, N_frames) if frame_range is None else frame_range
         if not (0 <= f0 < f1 <= N_frames):
