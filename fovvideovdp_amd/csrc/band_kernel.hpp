@@ -101,8 +101,13 @@ struct BandArgs {
 #define FOV_WPB 4            // foveated mode: 4 independent waves per workgroup share the band's LUT slice in LDS
 extern __shared__ __attribute__((aligned(16))) float4 s_lut_dyn[];
 
-template <int P, bool DBG, bool FOV>
-__global__ __launch_bounds__(FOV ? 64 * FOV_WPB : 64, (FOV || DBG) ? 2 : 4) void band_kernel(const BandArgs a) {
+// FOVM: 0 = non-foveated, 1 = foveated with the band's LUT slice in (dynamic) LDS, 2 = foveated, LUT slice in global
+// memory (slice too large, or the map-writing variant).  A compile-time choice: with a run-time flag the compiler
+// merges the two look-ups into one flat load, which is slower than ds_read_b128.
+template <int P, bool DBG, int FOVM>
+__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, (FOVM || DBG) ? 2 : 4) void band_kernel(const BandArgs a) {
+    constexpr bool FOV = FOVM != 0;
+    constexpr bool LUT_LDS = FOVM == 1;
     constexpr int HP = P / 2;   // (test, ref) pairs = temporal channels
     constexpr int WPB = FOV ? FOV_WPB : 1;
     __shared__ float4 s_csf[FVVDP_LUT_N];
@@ -146,9 +151,17 @@ __global__ __launch_bounds__(FOV ? 64 * FOV_WPB : 64, (FOV || DBG) ? 2 : 4) void
             const float x1 = a.axes[k + 1 < FVVDP_LUT_N ? i + 1 : i];
             s_ax[i] = make_float2(x0, 1.0f / (x1 - x0 + 0.000001f));
         }
-        if (a.lut_lds) {
+        if constexpr (LUT_LDS) {
             const int nl = FVVDP_LUT_N * FVVDP_LUT_N * a.rw;
             for (int i = threadIdx.x; i < nl; i += 64 * WPB) s_lut_dyn[i] = a.sublut[i];
+        }
+        // vertical view angle of every band row (pix2view_direction, fvvdp_display_model.py:498-510): one atan per
+        // row and workgroup instead of two per wave and step
+        float* s_vy = reinterpret_cast<float*>(s_lut_dyn + (LUT_LDS ? FVVDP_LUT_N * FVVDP_LUT_N * a.rw : 0));
+        const float kyb = a.size_m1 / (float)a.h / a.dist_m;
+        for (int i = threadIdx.x; i < a.h; i += 64 * WPB) {
+            const float yp = ((float)i + 0.5f) + (-(float)a.h / 2.0f);
+            s_vy[i] = atanf(-yp * kyb) * 57.29577951308232f;
         }
     }
     __syncthreads();
@@ -264,8 +277,9 @@ __global__ __launch_bounds__(FOV ? 64 * FOV_WPB : 64, (FOV || DBG) ? 2 : 4) void
         // pix2view_direction (fvvdp_display_model.py:498-510) on the band grid, pixel centres at +0.5
         const float xa = ((float)X0 + 0.5f) + (-(float)w / 2.0f);
         const float xb = ((float)X1 + 0.5f) + (-(float)w / 2.0f);
-        vxa = atanf(xa * a.size_m0 / (float)w / a.dist_m) * 57.29577951308232f;
-        vxb = atanf(xb * a.size_m0 / (float)w / a.dist_m) * 57.29577951308232f;
+        const float kx = a.size_m0 / (float)w / a.dist_m;
+        vxa = atanf(xa * kx) * 57.29577951308232f;
+        vxb = atanf(xb * kx) * 57.29577951308232f;
         if (a.mvx) {
             gx = a.fix[2 * frame + 0];
             gy = a.fix[2 * frame + 1];
@@ -329,7 +343,7 @@ __global__ __launch_bounds__(FOV ? 64 * FOV_WPB : 64, (FOV || DBG) ? 2 : 4) void
             const int so = (kE * FVVDP_LUT_N + kY) * a.rw + (kR - a.i_lo);
             const int sj = a.rw, sk = FVVDP_LUT_N * a.rw;
             float4 v00, v10, v01, v11;                                                      // v[dj][dk]
-            if (a.lut_lds) {
+            if constexpr (LUT_LDS) {
                 v00 = s_lut_dyn[so]; v10 = s_lut_dyn[so + sj]; v01 = s_lut_dyn[so + sk]; v11 = s_lut_dyn[so + sk + sj];
             } else {
                 const float4* sb = a.sublut + so;
@@ -440,9 +454,9 @@ __global__ __launch_bounds__(FOV ? 64 * FOV_WPB : 64, (FOV || DBG) ? 2 : 4) void
         {
         float vy0 = 0.0f, vy1 = 0.0f;        // vertical view angle of the two fine rows (foveated)
         if constexpr (FOV) {
-            const float yp0 = ((float)(2 * c) + 0.5f) + (-(float)h / 2.0f), yp1 = yp0 + 1.0f;
-            vy0 = atanf(-yp0 * a.size_m1 / (float)h / a.dist_m) * 57.29577951308232f;
-            vy1 = atanf(-yp1 * a.size_m1 / (float)h / a.dist_m) * 57.29577951308232f;
+            const float* s_vy = reinterpret_cast<const float*>(s_lut_dyn + (LUT_LDS ? FVVDP_LUT_N * FVVDP_LUT_N * a.rw : 0));
+            vy0 = s_vy[2 * c];
+            vy1 = s_vy[min(2 * c + 1, h - 1)];
         }
         if constexpr (FOV) {
             float vx4[4] = {vxa, vxb, vxa, vxb}, vy4[4] = {vy0, vy0, vy1, vy1}, rm4[4] = {1.0f, 1.0f, 1.0f, 1.0f};

@@ -201,8 +201,8 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
             if (hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
         }
         hipError_t e = (planes == 4)
-            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, band_kernel<4, false, false>, 64, 0)
-            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, band_kernel<2, false, false>, 64, 0);
+            ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, band_kernel<4, false, 0>, 64, 0)
+            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, band_kernel<2, false, 0>, 64, 0);
         if (e != hipSuccess || per_cu < 1) per_cu = 16;
         c->wave_capacity = (long long)per_cu * cus;
     }
@@ -652,12 +652,15 @@ static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, hipS
     dim3 grid(nblocks), block(64);
     if (fov) {
         const dim3 gridf((nblocks + FOV_WPB - 1) / FOV_WPB), blockf(64 * FOV_WPB);
-        const size_t lds = a.lut_lds ? (size_t)FVVDP_LUT_N * FVVDP_LUT_N * a.rw * sizeof(float4) : 0;
-        if (dbg) hipLaunchKernelGGL((band_kernel<P, true, true>), gridf, blockf, lds, st, a);
-        else hipLaunchKernelGGL((band_kernel<P, false, true>), gridf, blockf, lds, st, a);
+        // dynamic LDS: [LUT slice of the band (mode 1)] + vertical view angle of every band row
+        const size_t lds_vy = (size_t)a.h * sizeof(float);
+        const size_t lds_lut = (size_t)FVVDP_LUT_N * FVVDP_LUT_N * a.rw * sizeof(float4);
+        if (dbg) hipLaunchKernelGGL((band_kernel<P, true, 2>), gridf, blockf, lds_vy, st, a);
+        else if (a.lut_lds) hipLaunchKernelGGL((band_kernel<P, false, 1>), gridf, blockf, lds_lut + lds_vy, st, a);
+        else hipLaunchKernelGGL((band_kernel<P, false, 2>), gridf, blockf, lds_vy, st, a);
     } else {
-        if (dbg) hipLaunchKernelGGL((band_kernel<P, true, false>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((band_kernel<P, false, false>), grid, block, 0, st, a);
+        if (dbg) hipLaunchKernelGGL((band_kernel<P, true, 0>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((band_kernel<P, false, 0>), grid, block, 0, st, a);
     }
 }
 
@@ -751,7 +754,10 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
         const int nblk = a.n_strips * a.n_chunks;
         if (nblk > c->max_blk[b]) return fail(FVVDP_ESTATE, "internal: partial buffer too small");
         a.n_items = nblk * n;
-        a.lut_lds = (fov && (size_t)FVVDP_LUT_N * FVVDP_LUT_N * c->sub_rw[b] * sizeof(float4) <= 48 * 1024) ? 1 : 0;
+        {   // LUT slice in LDS if it fits next to the row table (64 KB of dynamic LDS without opting in to more)
+            const size_t lut_b = (size_t)FVVDP_LUT_N * FVVDP_LUT_N * c->sub_rw[b] * sizeof(float4);
+            a.lut_lds = (fov && lut_b <= 48 * 1024 && lut_b + (size_t)c->lh[b] * sizeof(float) <= 64 * 1024) ? 1 : 0;
+        }
         {
             Timed tm(c, 1 + b, st);
             if (c->P == 4) launch_band<4>(a, nblk * n, dbg, fov, st);
