@@ -21,5 +21,9 @@ python $R/tools/rocpd_summary.py $(find /tmp/kp -name "*.db" | head -1) --only p
 rocprofv3 --kernel-trace --stats -d /tmp/kh -o heat -- python $R/tools/gpu_heatprof.py 12 threshold > /tmp/kh.out 2> /tmp/kh.err
 grep "^total" /tmp/kh.out > $OUT/heat_probe.txt
 python $R/tools/rocpd_summary.py $(find /tmp/kh -name "*.db" | head -1) --band-levels 7 > /tmp/kh.md
-grep -E "kernel \||---|colour_|heat_level|band_kernel<4, true" /tmp/kh.md > $OUT/kernel_trace_heat.md
+grep -E "kernel \||---|colour_|heat_level|band_kernel<4, true, 0>" /tmp/kh.md > $OUT/kernel_trace_heat.md
+rocprofv3 --kernel-trace --stats -d /tmp/kf -o fov -- python $R/tools/gpu_config4.py > /tmp/kf.out 2> /tmp/kf.err
+grep -E "^config4|^Q_per_ch|^kernel us" /tmp/kf.out > $OUT/fov_probe.txt
+python $R/tools/rocpd_summary.py $(find /tmp/kf -name "*.db" | head -1) --band-levels 7 > /tmp/kf.md
+grep -E "kernel \||---|band_kernel<4, false, 1>|temporal_vec" /tmp/kf.md > $OUT/kernel_trace_fov.md
 ls -la $OUT
