@@ -97,3 +97,24 @@ def test_yuv_vector_kernel_equals_scalar_kernel(H, W, bd, css, fps, monkeypatch)
     assert np.max(np.abs(r_vec[:, 2:] - r_sca[:, 2:]) / scale) < 2e-6
     assert np.allclose(s_vec["Q_per_ch"], s_sca["Q_per_ch"], rtol=2e-4, atol=1e-6 * float(np.max(s_sca["Q_per_ch"])))
     assert abs(float(q_vec) - float(q_sca)) < 1e-5
+
+
+@pytest.mark.parametrize("H,W,bd,css,fps,N", [(40, 72, 8, "420", 120, 34), (36, 66, 10, "420", 25, 9), (30, 50, 8, "444", 50, 14)])
+def test_yuv_other_frame_rates_and_widths_vs_oracle(H, W, bd, css, fps, N):
+    """YUV sources outside the vector kernel's domain -- 120 fps (30 taps: per-pixel kernel with the 32-slot ring),
+    widths that are not a multiple of 4 -- and a zero-padded filter (25 fps: 7 taps in the 8-slot ring), against the
+    oracle's restatement of the reference's unpack + metric."""
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_yuv_pair
+    from oracle import fvvdp_oracle as orc
+    ty, ry = synth_yuv_pair(N, H, W, bit_depth=bd, chroma_ss=css)
+    m = fv.fvvdp(display_name="standard_fhd")
+    vs = fv.fvvdp_video_source_yuv_frames(ty, ry, fps, W, H, bit_depth=bd, chroma_ss=css, color_space="bt709",
+                                          display_photometry=m.display_photometry)
+    q, st = m.predict_video_source(vs)
+    tn = ty.numpy() if bd == 8 else ty.numpy().astype(np.uint16)
+    rn = ry.numpy() if bd == 8 else ry.numpy().astype(np.uint16)
+    oq, ost = orc.Oracle("standard_fhd").predict_yuv(tn, rn, fps, W, H, bit_depth=bd, chroma_ss=css, color_space="bt709")
+    assert abs(float(q) - float(oq)) < 2e-4, (float(q), float(oq))
+    a, b = st["Q_per_ch"].astype(np.float64), ost["Q_per_ch"].astype(np.float64)
+    assert np.all(np.abs(a - b) <= 5e-3 * np.abs(b) + 1e-5 * np.max(b))
