@@ -114,6 +114,7 @@ class fvvdp:
         self._ctx = None
         self._lut_dev = {}
         self._chan_w = {}
+        self._filters = {}
         self.timing = None
 
     # ---- configuration ------------------------------------------------------------------------------------
@@ -182,8 +183,12 @@ class fvvdp:
         else:
             fps = vid_source.get_frames_per_second()
             self.filter_len = int(np.ceil(250.0 / (1000.0 / fps)))
-            self.F, _ = self.get_temporal_filters(fps)
-            fl, taps = self.filter_len, np.ascontiguousarray(self.F.numpy(), dtype=np.float32)
+            fkey = (float(fps), self.filter_len, float(self.sustained_sigma), float(self.sustained_beta))
+            if fkey not in self._filters:            # taps depend on the frame rate only: evaluated once per rate
+                F, _ = self.get_temporal_filters(fps)
+                self._filters[fkey] = (F, np.ascontiguousarray(F.numpy(), dtype=np.float32))
+            self.F, taps = self._filters[fkey]
+            fl = self.filter_len
             if fl > nat.MAX_TAPS:
                 raise RuntimeError("frame rate too high: temporal filter longer than %d taps" % nat.MAX_TAPS)
         fix = self._fixation(fixation_point, width, height, N_frames) if self.foveated else None
