@@ -38,6 +38,11 @@ class Geom(C.Structure):
     _fields_ = [("display_size_m", C.c_float * 2), ("distance_m", C.c_float), ("ppd_centre", C.c_float)]
 
 
+class PoolParams(C.Structure):
+    _fields_ = [("beta_sch", C.c_float), ("beta_tch", C.c_float), ("beta_t", C.c_float), ("w_transient", C.c_float),
+                ("jod_a", C.c_float), ("beta_jod", C.c_float)]
+
+
 class Pu21(C.Structure):
     _fields_ = [("p", C.c_float * 7), ("L_min", C.c_float), ("L_max", C.c_float)]
 
@@ -70,6 +75,7 @@ SYMBOLS = {
     "fvvdp_heatmap_reconstruct": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_float, C.c_float, C.c_float,
                                             C.c_void_p, C.c_void_p]),
     "fvvdp_export_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "fvvdp_pool_jod": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(PoolParams), C.c_void_p, C.c_void_p]),
     "fvvdp_heatmap_colorize": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_int,
                                          C.POINTER(C.c_float), C.c_void_p, C.c_size_t, C.c_void_p]),
     "fvvdp_pu21_sse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,

@@ -30,6 +30,49 @@ __global__ __launch_bounds__(64) void finalize_kernel(const FinalizeArgs a) {
     if (lane == 0) a.Q[((size_t)b * 2 + cc) * a.q_stride + a.q_col0 + s] = q;
 }
 
+// Pooling of the per-band, per-channel, per-frame differences into one JOD value (do_pooling_and_jods,
+// fvvdp.py:337-357): Minkowski sums over bands (beta_sch), temporal channels (beta_tch, transient weighted by
+// w_transient) and frames (beta_t, normalised), then the JOD regression.  One workgroup; frames are spread over the
+// threads and combined in a fixed order, so the value is run-to-run identical.
+struct PoolArgs {
+    const float* Q;          // [n_bands][2][q_stride]
+    int n_bands, n_ch, n_frames, q_stride;
+    float beta_sch, beta_tch, beta_t, w_transient, jod_a, beta_jod;
+    float* out;
+};
+
+__device__ __forceinline__ float pool_pow(float x, float p) { return p == 1.0f ? x : powf(x, p); }
+
+__global__ __launch_bounds__(256) void pool_jod_kernel(const PoolArgs a) {
+    __shared__ double s_part[256];
+    double acc = 0.0;
+    for (int f = threadIdx.x; f < a.n_frames; f += 256) {
+        float qt = 0.0f;
+        for (int c = 0; c < a.n_ch; ++c) {
+            const float wc = (a.n_ch == 2 && c == 1) ? a.w_transient : 1.0f;
+            float qs = 0.0f;
+            for (int b = 0; b < a.n_bands; ++b)
+                qs += pool_pow(fabsf(a.Q[((size_t)b * 2 + c) * a.q_stride + f] * wc), a.beta_sch);
+            qs = pool_pow(qs, 1.0f / a.beta_sch);
+            qt += pool_pow(qs, a.beta_tch);
+        }
+        qt = pool_pow(qt, 1.0f / a.beta_tch);
+        acc += (double)pool_pow(qt, a.beta_t);
+    }
+    s_part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o >= 1; o >>= 1) {
+        if ((int)threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // lp_norm(..., normalize=True): norm / N^(1/p)   (fvvdp.py:598-607)
+        const float q_all = pool_pow((float)(s_part[0] / (double)a.n_frames), 1.0f / a.beta_t);
+        const float sgn = a.jod_a < 0.0f ? -1.0f : 1.0f;
+        a.out[0] = sgn * powf(powf(fabsf(a.jod_a), 1.0f / a.beta_jod) * q_all, a.beta_jod) + 10.0f;
+    }
+}
+
 // Heat-map reconstruction, one level: out = expand(coarse) + (D0 + w*D1)/m   [then ^beta_jod * |jod_a| on level 0]
 // (heatmap_pyr.set_band / reconstruct, fvvdp_lpyr_dec.py:65-71,94-101; expand closed form as in band_kernel).
 struct HeatArgs {

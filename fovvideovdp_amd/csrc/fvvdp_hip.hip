@@ -806,6 +806,32 @@ extern "C" int fvvdp_ctx_set_view_maps(fvvdp_ctx* c, int band, const float* d_vi
     return FVVDP_OK;
 }
 
+extern "C" int fvvdp_pool_jod(const float* d_Q, int n_bands, int n_channels, int n_frames, int q_stride,
+                              const fvvdp_pool_params* prm, float* d_jod, void* stream) {
+    if (!d_Q || !prm || !d_jod) return fail(FVVDP_EINVAL, "null argument");
+    if (n_bands < 1 || n_frames < 1 || q_stride < n_frames) return fail(FVVDP_EINVAL, "bad Q_per_ch shape");
+    if (n_channels != 1 && n_channels != 2) return fail(FVVDP_EINVAL, "n_channels must be 1 (image) or 2 (video)");
+    if (!(prm->beta_sch > 0.0f) || !(prm->beta_tch > 0.0f) || !(prm->beta_t > 0.0f) || !(prm->beta_jod > 0.0f))
+        return fail(FVVDP_EINVAL, "pooling exponents must be positive");
+    PoolArgs a;
+    memset(&a, 0, sizeof(a));
+    a.Q = d_Q;
+    a.n_bands = n_bands;
+    a.n_ch = n_channels;
+    a.n_frames = n_frames;
+    a.q_stride = q_stride;
+    a.beta_sch = prm->beta_sch;
+    a.beta_tch = prm->beta_tch;
+    a.beta_t = prm->beta_t;
+    a.w_transient = prm->w_transient;
+    a.jod_a = prm->jod_a;
+    a.beta_jod = prm->beta_jod;
+    a.out = d_jod;
+    hipLaunchKernelGGL(pool_jod_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
+    HIP_TRY(hipGetLastError());
+    return FVVDP_OK;
+}
+
 extern "C" int fvvdp_heatmap_reconstruct(fvvdp_ctx* c, int n, const float* const* h_dD, float w_transient, float beta_jod,
                                          float jod_a_abs, float* d_out, void* stream) {
     if (!c || !h_dD || !d_out) return fail(FVVDP_EINVAL, "null argument");

@@ -206,9 +206,9 @@ class fvvdp:
         stream = C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
         # results + the out-of-range flag share one buffer: a single device->host copy (and sync) per call
         nq = n_bands * 2 * n_out
-        res = torch.zeros(nq + 1, dtype=torch.float32, device=self.device)
+        res = torch.zeros(nq + 2, dtype=torch.float32, device=self.device)      # Q_per_ch | range flag | JOD
         Q = res[:nq].view(n_bands, 2, n_out)
-        oob = res[nq:].view(torch.int32)
+        oob = res[nq:nq + 1].view(torch.int32)
         widx = window_frame_indices(N_frames, fl, self.temp_padding) if not is_image else np.zeros(1, np.int32)
         feeder = self._make_feeder(vid_source, width, height)
 
@@ -239,7 +239,13 @@ class fvvdp:
             if self.do_heatmap:
                 self._heatmap_batch(ctx, nb, dmaps, planes, width, height, stream, heatmap, b0 - f0)
 
-        Q_jod = self.do_pooling_and_jods(Q, rho_band[0:-1]) if pool else None
+        Q_jod = None
+        if pool:                                             # pooling + JOD regression in one small kernel
+            pp = nat.PoolParams(self.beta_sch, self.beta_tch, self.beta_t, self.w_transient, self.jod_a,
+                                float(10.0 ** self.log_jod_exp))
+            nat.check(nat.lib().fvvdp_pool_jod(C.c_void_p(Q.data_ptr()), n_bands, 2, n_out, n_out, C.byref(pp),
+                                               C.c_void_p(res[nq + 1:].data_ptr()), stream))
+            Q_jod = res[nq + 1]
         stats = {}
         res_h = res.detach().cpu()                           # the one host synchronisation of the call
         stats['Q_per_ch'] = res_h[:nq].view(n_bands, 2, n_out).numpy()
@@ -250,9 +256,9 @@ class fvvdp:
         stats['N_frames'] = N_frames
         if self.do_heatmap:
             stats['heatmap'] = heatmap
-        if int(res_h[nq:].view(torch.int32)[0]) != 0:
+        if int(res_h[nq:nq + 1].view(torch.int32)[0]) != 0:
             logging.warning("Pixel outside the valid range 0-1")
-        return (Q_jod.squeeze() if pool else None, stats)
+        return (Q_jod, stats)
 
     @staticmethod
     def _host_buffer(shape):

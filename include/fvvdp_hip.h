@@ -205,6 +205,21 @@ int fvvdp_heatmap_reconstruct(fvvdp_ctx* ctx, int n, const float* const* h_dD, f
 
 /* ---- introspection (tests, profiling) --------------------------------------------------------------------- */
 
+/* Pooling + JOD regression on the device (reference: do_pooling_and_jods, fvvdp.py:337-357, lp_norm :598-607):
+ *   Q_sc[c,f] = (sum_b |Q[b,c,f]*w_c|^beta_sch)^(1/beta_sch), w = (1, w_transient) for video
+ *   Q_tc[f]   = (sum_c Q_sc^beta_tch)^(1/beta_tch);  Q = (mean_f Q_tc^beta_t)^(1/beta_t)
+ *   JOD       = sign(jod_a) * (|jod_a|^(1/beta_jod) * Q)^beta_jod + 10
+ * d_Q is the [n_bands][2][q_stride] array written by fvvdp_bands_forward (n_channels = 1 for images: plane 1 unused).
+ * Saves the dozen tiny framework kernels of the Python version at the end of every call; the Python method stays for
+ * callers that pool their own Q_per_ch (frame / pair sharding).                                                   */
+typedef struct {
+    float beta_sch, beta_tch, beta_t;   /* fvvdp_parameters.json: 1, 0.666092, 1 */
+    float w_transient;                  /* 0.25 */
+    float jod_a, beta_jod;              /* -0.0161713, 10^log_jod_exp */
+} fvvdp_pool_params;
+int fvvdp_pool_jod(const float* d_Q, int n_bands, int n_channels, int n_frames, int q_stride,
+                   const fvvdp_pool_params* prm, float* d_jod, void* stream);
+
 /* Colouring of difference maps for heatmap = "threshold" / "supra-threshold" (reference: visualize_diff_map,
  * vis_tonemap, log_luminance in pyfvvdp/visualize_diff_map.py, called at fvvdp.py:474-476): the map d_dmap[n][H][W]
  * (clamped to [0,1]) indexes a colour map (n_knots <= 8 knots h_knots, luminance-normalised colours h_rgb[n_knots][3])

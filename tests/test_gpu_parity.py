@@ -640,3 +640,19 @@ def test_heatmap_colouring_kernel_vs_torch(fv, cmap):
             # fp16 output (5e-4) + one histogram bin of slack on the tone curve
             assert float((got - want).abs().max()) < 3e-3, (cmap, scale, k)
             assert float((got - want).abs().mean()) < 3e-4
+
+
+def test_pooling_kernel_equals_python_pooling(fv):
+    """fvvdp_pool_jod (used by predict) against the Python do_pooling_and_jods (the reference's formulation in torch ops)
+    on the same Q_per_ch: default calibration, a video and an image, and non-default exponents that take the pow paths."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    test, ref = synth_video_pair(300, 36, 64)                     # more frames than threads of the pooling workgroup
+    for over in ({}, {"beta_sch": 2.0, "beta_t": 3.0, "beta_tch": 0.9, "jod_a": 0.02}):
+        m = fv.fvvdp(display_name="standard_fhd")
+        for k, v in over.items():
+            setattr(m, k, v)
+        for (t, r, fps) in ((test, ref, 30), (test[:, :, 0:1], ref[:, :, 0:1], 0)):
+            q, st = m.predict(t, r, frames_per_second=fps)
+            want = m.do_pooling_and_jods(torch.from_numpy(st["Q_per_ch"]).cuda(), None)
+            assert q.dim() == 0 and q.device.type == "cuda"
+            assert abs(float(q) - float(want)) < 5e-6, (over, fps, float(q), float(want))
