@@ -4,7 +4,7 @@
 A "step" is one full pass of the hot path over one synthetic 3840x2160 x 60-frame video pair per GPU
 (BASELINE.json configs[2]: uint8 RGB, standard_4k, 30 fps -> 8-tap temporal filter, foveated off), inputs already
 resident in HBM: unpack + sRGB display model + luminance + temporal filtering + pyramid + CSF + masking + pooling
-+ the Python JOD regression.  value = Mpixels/s (test+ref) = 2*W*H*N*steps*n_gpus / wall seconds.
++ pooling and JOD regression.  value = Mpixels/s (test+ref) = 2*W*H*N*steps*n_gpus / wall seconds.
 
   python bench.py [--gpus N --steps K --warmup W]           (N>1: launched by torch.distributed.run)
 

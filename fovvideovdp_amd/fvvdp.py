@@ -34,9 +34,23 @@ def _interpolants(x_q, x):
     return imin, imax, ifrc
 
 
+_BAND_CACHE = {}
+
+
 def band_frequencies(W, H, ppd):
     """Number of band-pass levels and their centre frequencies [cpd] for a W x H frame at `ppd` pixels/degree
-    (same rule as the reference's pyramid constructor, pyfvvdp/fvvdp_lpyr_dec.py:15-49)."""
+    (same rule as the reference's pyramid constructor, pyfvvdp/fvvdp_lpyr_dec.py:15-49).  Memoised per (W, H, ppd);
+    callers get their own copy of the array."""
+    key = (int(W), int(H), float(ppd))
+    if key not in _BAND_CACHE:
+        if len(_BAND_CACHE) > 256:
+            _BAND_CACHE.clear()
+        _BAND_CACHE[key] = _band_frequencies(W, H, ppd)
+    height, freqs = _BAND_CACHE[key]
+    return height, freqs.copy()
+
+
+def _band_frequencies(W, H, ppd):
     max_levels = int(np.floor(np.log2(min(H, W)))) - 1
     octave = 0.3228 * np.power(2.0, -np.arange(0.0, 14.0))
     bands = np.concatenate([[1.0], octave]) * ppd / 2.0
