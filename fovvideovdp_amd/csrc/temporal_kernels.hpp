@@ -611,7 +611,7 @@ __global__ __launch_bounds__(256) void temporal_yuv_kernel(const YuvArgs a) {
 // on the pixel position (plane offsets, the bilinear weights of the 4:2:0 chroma upsampling) is computed once per
 // lane; per frame a lane issues one Y load (4 samples) and, per chroma plane and source row, one aligned pair load
 // (columns 2j, 2j+1); the two neighbour columns (2j-1, 2j+2, clamped) come from the adjacent lanes through DPP
-// (sub-dword loads are address-rate limited: with 12 of them per lane the kernel ran at the speed of the per-pixel one).
+// (5 loads per lane, frame and stream instead of 13, and no edge-lane branches).
 // Test and reference stream are converted together as packed (test, reference) pairs (v_pk_* instructions); the
 // result agrees with yuv_lum above to rounding order.  Raw samples of the next frame are prefetched while the
 // current one is converted, and the finished float4 pixels go through the same LDS transpose as temporal_vec_kernel.
