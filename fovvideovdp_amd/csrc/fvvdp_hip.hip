@@ -320,12 +320,13 @@ static void launch_ring(int dtype, const TemporalArgs& a, hipStream_t st) {
 template <int FL, int PX>
 static void launch_vec(int dtype, const TemporalArgs& a, hipStream_t st) {
     dim3 grid((a.HW + 64 * PX - 1) / (64 * PX)), block(64);
+    constexpr int TD = 1;
     if (dtype == FVVDP_U8)
-        hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_U8>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_U8, TD>), grid, block, 0, st, a);
     else if (dtype == FVVDP_U16)
-        hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_U16>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_U16, TD>), grid, block, 0, st, a);
     else
-        hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_F32>), grid, block, 0, st, a);
+        hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_F32, TD>), grid, block, 0, st, a);
 }
 
 template <int P>
@@ -383,7 +384,7 @@ extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const v
                 a.idx[u] = h_frame_idx[src < 0 ? 0 : src];
             }
             // vector path needs the lane's PX consecutive samples to be naturally aligned
-            const int PXv = FL == 32 ? 2 : 4;
+            const int PXv = FL == 8 ? 4 : 2;
             const int es = dtype == FVVDP_U8 ? 1 : (dtype == FVVDP_U16 ? 2 : 4);
             const bool vec_ok = !getenv("FVVDP_TEMPORAL_SCALAR") && (HW % PXv == 0) && (HW >= PXv) &&
                                 (chan_stride % PXv == 0) && (frame_stride % PXv == 0) &&
@@ -391,7 +392,7 @@ extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const v
                                 (reinterpret_cast<uintptr_t>(d_ref) % (size_t)(es * PXv) == 0);
             if (vec_ok) {
                 if (FL == 8) launch_vec<8, 4>(dtype, a, st);
-                else if (FL == 16) launch_vec<16, 4>(dtype, a, st);
+                else if (FL == 16) launch_vec<16, 2>(dtype, a, st);
                 else launch_vec<32, 2>(dtype, a, st);
             } else {
                 if (FL == 8) launch_ring<8, 4>(dtype, a, st);
