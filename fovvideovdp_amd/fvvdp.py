@@ -128,6 +128,7 @@ class fvvdp:
         self._ctx = None
         self._lut_dev = {}
         self._chan_w = {}
+        self._copy_stream = None
         self._filters = {}
         self.timing = None
 
@@ -262,6 +263,8 @@ class fvvdp:
             Q_jod = res[nq + 1]
         stats = {}
         res_h = res.detach().cpu()                           # the one host synchronisation of the call
+        if self.do_heatmap and self._copy_stream is not None:
+            self._copy_stream.synchronize()                  # ... plus the side stream that carries the maps
         stats['Q_per_ch'] = res_h[:nq].view(n_bands, 2, n_out).numpy()
         stats['rho_band'] = rho_band
         stats['frames_per_second'] = vid_source.get_frames_per_second()
@@ -290,7 +293,7 @@ class fvvdp:
         nat.check(nat.lib().fvvdp_heatmap_reconstruct(ctx.handle, nb, ptrs, float(self.w_transient), beta_jod,
                                                       abs(float(self.jod_a)), C.c_void_p(dmap.data_ptr()), stream))
         if self.heatmap == "raw":
-            heatmap[0, 0, k0:k0 + nb].copy_(dmap.to(torch.float16), non_blocking=True)
+            self._copy_back(dmap.to(torch.float16).unsqueeze(0), [heatmap[0, 0, k0:k0 + nb]])
             return
         # colouring on the device (fvvdp_heatmap_colorize): tone-mapped context frame x colour map, fp16, output layout
         from .visualize_diff_map import color_tables_host
@@ -300,8 +303,21 @@ class fvvdp:
         nat.check(nat.lib().fvvdp_heatmap_colorize(ctx.handle, nb, C.c_void_p(dmap.data_ptr()), nat.fptr(knots), nat.fptr(rgb),
                                                    len(knots), nat.fptr(lin01), C.c_void_p(out.data_ptr()),
                                                    nb * height * width, stream))
-        for ch in range(3):
-            heatmap[0, ch, k0:k0 + nb].copy_(out[ch], non_blocking=True)
+        self._copy_back(out, [heatmap[0, ch, k0:k0 + nb] for ch in range(3)])
+
+    def _copy_back(self, src, dst_list):
+        """Device -> host copies of finished maps on a side stream, so that the next batch's kernels run meanwhile
+        (page-locked destination; with pageable memory the copy is synchronous anyway)."""
+        main = torch.cuda.current_stream(self.device)
+        if self._copy_stream is None:
+            self._copy_stream = torch.cuda.Stream(device=self.device)
+        done = torch.cuda.Event()
+        done.record(main)
+        with torch.cuda.stream(self._copy_stream):
+            self._copy_stream.wait_event(done)
+            for i, dst in enumerate(dst_list):
+                dst.copy_(src[i], non_blocking=True)
+        src.record_stream(self._copy_stream)      # the caching allocator must not hand `src` out before the copy ran
 
     # ---- pooling and JOD regression (Python, as in the reference) ------------------------------------------
     def do_pooling_and_jods(self, Q_per_ch, rho_band):
