@@ -547,7 +547,8 @@ class fvvdp:
                         N * HW, HW, C.byref(e), nat.fptr(w), idx.ctypes.data_as(C.POINTER(C.c_int32)),
                         nat.fptr(taps), fl, n_out, 0, C.c_void_p(oob.data_ptr()), stream))
                 return feed
-        if isinstance(vs, fvvdp_video_source_yuv_frames) and native_eotf(vs.dm_photometry) is not None:
+        if (isinstance(vs, fvvdp_video_source_yuv_frames) and native_eotf(vs.dm_photometry) is not None
+                and not (hasattr(vs, "_resizing") and vs._resizing())):
             # raw planar YUV: unpacking, chroma upsampling, colour matrix and display model run in the HIP kernel
             test_d = vs.test_yuv.to(self.device).contiguous()
             ref_d = vs.reference_yuv.to(self.device).contiguous()

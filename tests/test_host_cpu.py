@@ -268,3 +268,27 @@ def test_yuv_source_class_matches_reference_unpack():
         fv.fvvdp_video_source_yuv_frames(ty, ry, 30, 97, 54, bit_depth=10, chroma_ss="420", display_photometry="standard_fhd")
     with pytest.raises(RuntimeError):
         fv.fvvdp_video_source_yuv_frames(ty[:, :-1], ry[:, :-1], 30, W, H, bit_depth=10, chroma_ss="444", display_photometry="standard_fhd")
+
+
+def test_yuv_file_name_properties():
+    """decode_video_props / create_yuv_fname against answers obtained from the reference's own functions
+    (pyfvvdp/video_source_yuv.py:6-64, run in the build container)."""
+    import fovvideovdp_amd as fv
+    known = {
+        "clip_120x68_8b_420_709_30fps.yuv": dict(width=120, height=68, fps=30.0, bit_depth=8, color_space="709", chroma_ss="420"),
+        "/x/y/Bosphorus_3840x2160_10b_420_2020_59.94fps.yuv": dict(width=3840, height=2160, fps=59.94, bit_depth=10, color_space="2020", chroma_ss="420"),
+        "noprops.yuv": dict(width=1920, height=1080, fps=24, bit_depth=8, color_space="2020", chroma_ss="420"),
+        "t_64x48_8_bt709_25fps.yuv": dict(width=64, height=48, fps=25.0, bit_depth=8, color_space="709", chroma_ss="420"),
+        "z_1920x1080_50fps_ct2020_10b_444.yuv": dict(width=1920, height=1080, fps=50.0, bit_depth=10, color_space="2020", chroma_ss="444"),
+        "weird_12x_34_8b.yuv": dict(width=1920, height=1080, fps=24, bit_depth=8, color_space="2020", chroma_ss="420"),
+    }
+    for name, want in known.items():
+        assert fv.decode_video_props(name) == want, name
+    # the reference raises ValueError on a 'p' suffix (int('720p')); accepted here
+    assert fv.decode_video_props("a_1280x720p_444_10_pq2020_24fps.yuv")["height"] == 720
+    assert fv.create_yuv_fname("base", dict(width=64, height=48, bit_depth=10, color_space="2020", chroma_ss="420", fps=29.97)) \
+        == "base_64x48_10b_420_2020_29.97fps.yuv"
+    assert fv.create_yuv_fname("base", dict(width=64, height=48, bit_depth=8, color_space="709", chroma_ss="444", fps=30.0)) \
+        == "base_64x48_8b_444_709_30fps.yuv"
+    p = fv.decode_video_props(fv.create_yuv_fname("rt", dict(width=66, height=34, bit_depth=10, color_space="709", chroma_ss="444", fps=50)))
+    assert (p["width"], p["height"], p["bit_depth"], p["color_space"], p["chroma_ss"], p["fps"]) == (66, 34, 10, "709", "444", 50.0)
