@@ -135,8 +135,12 @@ class fvvdp:
     # ---- configuration ------------------------------------------------------------------------------------
     def update_device(self, device):
         self.device = torch.device(device)
+        if self._ctx is not None:
+            self._ctx.close()
         self._ctx = None
         self._lut_dev = {}
+        self._chan_w = {}
+        self._copy_stream = None
 
     def load_config(self):
         parameters = utils.config_files.load("fvvdp_parameters.json")
