@@ -275,3 +275,15 @@ def test_pu21_psnr_oracle_vs_reference():
     for tag, (a, b, disp) in cases.items():
         q = orc.pu_psnr(a, b, display_name=disp)
         assert abs(q - float(z[f"{tag}_psnr"])) < 2e-3, (tag, q, float(z[f"{tag}_psnr"]))
+
+
+def test_cpu_baseline_helper_runs_frames_in_parallel(tmp_path):
+    """oracle/cpu_bench.py (the cpu_baseline leg of bench.py): two worker processes, one output frame each; the helper
+    reports a wall time that covers the per-frame times."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import cpu_bench
+    t, r = synth_video_pair(10, 68, 120)
+    wall, per = cpu_bench.timed_frames(t.numpy(), r.numpy(), 30, "standard_fhd", 8, 2, str(tmp_path), timeout=120)
+    assert len(per) == 2 and all(p > 0 for p in per)
+    assert wall >= max(per) - 1e-3 and wall < max(per) + 1.0
+    assert not list(tmp_path.iterdir())                       # temporary frame files removed
