@@ -14,6 +14,10 @@ python $R/tools/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) --band-l
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf -o f -- python $R/tools/gpu_bandonly.py > /tmp/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw -o w -- python $R/tools/gpu_bandonly.py > /tmp/pw.log 2>&1
 python $R/tools/pmc_level0.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) $OUT/pmc_level0.json > /dev/null
+# K1 (temporal kernel): HBM traffic per 60-frame launch from the same two counters (algorithmic: 67 frames read x 49.8 MB + 60 x 132.7 MB written)
+STAGE=all REPS=2 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf1 -o f -- python $R/tools/gpu_bandonly.py > /tmp/pf1.log 2>&1
+STAGE=all REPS=2 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw1 -o w -- python $R/tools/gpu_bandonly.py > /tmp/pw1.log 2>&1
+( python $R/tools/pmc_query.py $(find /tmp/pf1 -name "*.db" | head -1) temporal_vec_kernel; python $R/tools/pmc_query.py $(find /tmp/pw1 -name "*.db" | head -1) temporal_vec_kernel ) > $OUT/pmc_k1.txt
 rocprofv3 --kernel-trace --stats -d /tmp/ky -o yuv -- python $R/tools/gpu_yuv.py 2160x3840x60:8:420 2160x3840x60:10:420:60 2160x3840x60:8:444 > $OUT/yuv_probe.txt 2> /tmp/ky.err
 python $R/tools/rocpd_summary.py $(find /tmp/ky -name "*.db" | head -1) --only temporal_yuv > $OUT/kernel_trace_yuv.md
 rocprofv3 --kernel-trace --stats -d /tmp/kp -o psnr -- python $R/tools/gpu_psnr.py > $OUT/psnr_probe.txt 2> /tmp/kp.err

@@ -37,6 +37,16 @@ bench.py JSON of the unprofiled run on the same box, right before:
 {rd('pmc_level0.json')}
 ```
 
+K1 (`temporal_vec_kernel<8,4,0>`), same counters over whole `predict` calls (KiB per dispatch).  Algorithmic per 60-frame
+launch: 60 x 132.7 MB = 7.96 GB written -- WRITE_SIZE agrees to 4 digits; 67 source frames x 49.8 MB = 3.33 GB read -- the
+raw FETCH_SIZE is 1.49 GB, i.e. the counter's scale for these 4 B/lane loads is 2.23, not the 2.0 that MI355X_MICROARCH.md
+calibrates for 16 B/lane streaming reads ("other access widths are uncalibrated"); every source byte is read exactly once
+by construction (one lane owns its pixels for the whole launch):
+
+```
+{rd('pmc_k1.txt')}
+```
+
 ## "Next"-row kernels (SURVEY section 8(f)) and the foveated configuration, same call
 
 YUV ingest (`tools/gpu_yuv.py`: 4K x60, 4:2:0 8 bit 30 fps / 4:2:0 10 bit 60 fps / 4:4:4 8 bit 30 fps; one launch = 60 output frames):
