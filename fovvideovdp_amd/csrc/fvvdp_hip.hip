@@ -401,13 +401,20 @@ extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const v
             }
         }
     } else {
-        // rare path: tables go through device buffers, uploaded synchronously
+        // images, fl > 32 and frame sizes without 4-sample alignment: one thread per pixel and output frame
         if (fl - 1 + n_out > c->max_frames + FVVDP_MAX_TAPS) return fail(FVVDP_EINVAL, "too many frames for one call");
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMemcpy(c->d_taps, h_taps, sizeof(float) * 2 * fl, hipMemcpyHostToDevice));
-        HIP_TRY(hipMemcpy(c->d_idx, h_frame_idx, sizeof(int) * (fl - 1 + n_out), hipMemcpyHostToDevice));
         GenericArgs a;
         memset(&a, 0, sizeof(a));
+        if (fl <= 32 && fl - 1 + n_out <= T_MAX_IDX) {
+            // still images and short clips: the tables ride in the kernel arguments
+            a.inline_tables = 1;
+            for (int k = 0; k < 2 * fl; ++k) a.taps_i[k] = h_taps[k];
+            for (int k = 0; k < fl - 1 + n_out; ++k) a.idx_i[k] = h_frame_idx[k];
+        } else {
+            HIP_TRY(hipStreamSynchronize(st));
+            HIP_TRY(hipMemcpy(c->d_taps, h_taps, sizeof(float) * 2 * fl, hipMemcpyHostToDevice));
+            HIP_TRY(hipMemcpy(c->d_idx, h_frame_idx, sizeof(int) * (fl - 1 + n_out), hipMemcpyHostToDevice));
+        }
         a.src[0] = d_test;
         a.src[1] = d_ref;
         a.chan_stride = chan_stride;

@@ -909,8 +909,11 @@ struct GenericArgs {
     int n_out, fl;
     float* out;
     int* oob;
-    const float* taps;   // device [2][fl]
+    const float* taps;   // device [2][fl]                        (used when inline_tables == 0)
     const int* idx;      // device [fl-1+n_out]
+    int inline_tables;   // 1: short tables travel in the kernel arguments (no upload, no stream sync)
+    float taps_i[2 * 32];
+    int idx_i[T_MAX_IDX];
 };
 
 template <int SRC, int P>
@@ -939,18 +942,20 @@ __global__ __launch_bounds__(256) void temporal_generic_kernel(const GenericArgs
     bool bad = false;
     if constexpr (P == 2) {
         float lt[1], lr[1];
-        const size_t off = (size_t)a.idx[t] * a.frame_stride + p;
+        const size_t off = (size_t)(a.inline_tables ? a.idx_i[t] : a.idx[t]) * a.frame_stride + p;
         S[0].lum(off, lt, bad);
         S[1].lum(off, lr, bad);
         *reinterpret_cast<float2*>(a.out + ((size_t)t * a.HW + p) * 2) = make_float2(lt[0], lr[0]);
     } else {
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int k = a.fl - 1; k >= 0; --k) {
-            const size_t off = (size_t)a.idx[a.fl - 1 + t - k] * a.frame_stride + p;
+            const int fi = a.fl - 1 + t - k;
+            const size_t off = (size_t)(a.inline_tables ? a.idx_i[fi] : a.idx[fi]) * a.frame_stride + p;
             float lt[1], lr[1];
             S[0].lum(off, lt, bad);
             S[1].lum(off, lr, bad);
-            const float f0 = a.taps[k], f1 = a.taps[a.fl + k];
+            const float f0 = a.inline_tables ? a.taps_i[k] : a.taps[k];
+            const float f1 = a.inline_tables ? a.taps_i[a.fl + k] : a.taps[a.fl + k];
             acc[0] = fmaf(lt[0], f0, acc[0]);
             acc[1] = fmaf(lr[0], f0, acc[1]);
             acc[2] = fmaf(lt[0], f1, acc[2]);
