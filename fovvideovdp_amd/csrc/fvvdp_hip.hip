@@ -598,11 +598,12 @@ extern "C" int fvvdp_export_level(fvvdp_ctx* c, int level, int n, float* d_out, 
 // [1, res_mag(corner of the screen)], so only a few rho knots are live per band; the slice is stored as
 // [ecc][Y][rho] of float4 {S0[i], S1[i], S0[i+1], S1[i+1]} so that one aligned 16-byte load returns the two rho
 // corners of both temporal channels and neighbouring pixels (similar ecc, Y) share cache lines.
-static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g) {
+static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
     fvvdp_geom key;
     memset(&key, 0, sizeof(key));
     if (g) key = *g;
     if (c->sub_valid && memcmp(&c->sub_geom, &key, sizeof(key)) == 0) return FVVDP_OK;
+    HIP_TRY(hipStreamSynchronize(st));            // geometry changed: kernels of earlier calls may still read the old slices
     double mag_max = 1.0, mag_min = 1.0;
     if (g) {
         const double delta = (1.0 / (double)g->ppd_centre) / 2.0 * M_PI / 180.0;
@@ -683,9 +684,10 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
     if (!fov && !c->csf_set) return fail(FVVDP_ESTATE, "fvvdp_ctx_set_csf_1d not called");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     if (fov) {
-        HIP_TRY(hipStreamSynchronize(st));
-        HIP_TRY(hipMemcpy(c->d_fix, h_fixation, sizeof(float) * 2 * n, hipMemcpyHostToDevice));
-        int rc = build_sublut(c, geom);
+        // stream-ordered after the kernels of the previous call that still read d_fix; the source is pageable host
+        // memory, which the runtime stages before the call returns
+        HIP_TRY(hipMemcpyAsync(c->d_fix, h_fixation, sizeof(float) * 2 * n, hipMemcpyHostToDevice, st));
+        int rc = build_sublut(c, geom, st);
         if (rc != FVVDP_OK) return rc;
     }
     FinalizeArgs fa;
