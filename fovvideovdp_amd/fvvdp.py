@@ -283,10 +283,13 @@ class fvvdp:
 
     @staticmethod
     def _host_buffer(shape):
-        try:
-            return torch.empty(shape, dtype=torch.float16, pin_memory=True)
-        except RuntimeError:                      # page-locking refused (ulimit): plain pageable memory
-            return torch.empty(shape, dtype=torch.float16)
+        nbytes = 2 * int(np.prod(shape))
+        if nbytes <= (4 << 30):                   # long clips: do not page-lock tens of GB of host memory
+            try:
+                return torch.empty(shape, dtype=torch.float16, pin_memory=True)
+            except RuntimeError:                  # page-locking refused (ulimit): plain pageable memory
+                pass
+        return torch.empty(shape, dtype=torch.float16)
 
     def _heatmap_batch(self, ctx, nb, dmaps, planes, width, height, stream, heatmap, k0):
         """Difference maps of `nb` frames -> heatmap[0, :, k0:k0+nb] (fp16, host) (fvvdp.py:469-476).  The maps are
