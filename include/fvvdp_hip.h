@@ -18,7 +18,8 @@
  *   - `stream` is a hipStream_t passed as void* (e.g. torch.cuda.current_stream().cuda_stream); all kernels are
  *     enqueued on it and nothing synchronises except where stated.
  *   - the context owns only its scratch (pyramid levels, tables, partial sums), allocated once in
- *     fvvdp_ctx_create; per-call functions never allocate.  One context per (device, stream); not thread-safe.
+ *     fvvdp_ctx_create (the heat-map functions add theirs on first use); per-call functions do not allocate
+ *     otherwise.  One context per (device, stream); not thread-safe.
  *   - pyramid planes: P = 4 for video (test-sustained, ref-sustained, test-transient, ref-transient;
  *     pyfvvdp/fvvdp.py:293) or P = 2 for a still image (test, ref; pyfvvdp/fvvdp.py:251-253).
  */
@@ -151,7 +152,9 @@ int fvvdp_ctx_set_view_maps(fvvdp_ctx* ctx, int band, const float* d_view_x, con
  *   h_taps          [2][fl] temporal filters (get_temporal_filters, fvvdp.py:609-630); tap k weights the frame
  *                   k steps in the past.  planes == 2 (still image): fl must be 1 and only h_taps[0] is used.
  *   d_oob_flag      optional int: set to 1 if a float sample was outside [0,1] (the caller re-emits the
- *                   reference's warning "Pixel outside the valid range 0-1")                               */
+ *                   reference's warning "Pixel outside the valid range 0-1")
+ * Asynchronous; only fl > 32 or more than 320 window entries (tables too large for the kernel arguments) make the call
+ * synchronise the stream for two small uploads.                                                              */
 int fvvdp_temporal_channels(fvvdp_ctx* ctx, const void* d_test, const void* d_ref, int dtype, int C,
                             size_t chan_stride, size_t frame_stride, const fvvdp_eotf* eotf,
                             const float* h_rgb2y, const int32_t* h_frame_idx, const float* h_taps, int fl,
@@ -203,7 +206,7 @@ int fvvdp_bands_forward(fvvdp_ctx* ctx, int n, float* d_Q, int q_stride, int q_c
 int fvvdp_heatmap_reconstruct(fvvdp_ctx* ctx, int n, const float* const* h_dD, float w_transient, float beta_jod,
                               float jod_a_abs, float* d_out, void* stream);
 
-/* ---- introspection (tests, profiling) --------------------------------------------------------------------- */
+/* ---- stage 3: pooling over bands / channels / frames and the JOD regression ------------------------------------ */
 
 /* Pooling + JOD regression on the device (reference: do_pooling_and_jods, fvvdp.py:337-357, lp_norm :598-607):
  *   Q_sc[c,f] = (sum_b |Q[b,c,f]*w_c|^beta_sch)^(1/beta_sch), w = (1, w_transient) for video
@@ -228,6 +231,8 @@ int fvvdp_pool_jod(const float* d_Q, int n_bands, int n_channels, int n_frames, 
  * element (c,f,y,x) at c*chan_stride + (f*H + y)*W + x.  Asynchronous except for the first call on a context.  */
 int fvvdp_heatmap_colorize(fvvdp_ctx* ctx, int n, const float* d_dmap, const float* h_knots, const float* h_rgb,
                            int n_knots, const float* h_lin01, void* d_out_f16, size_t chan_stride, void* stream);
+
+/* ---- introspection (tests, profiling) --------------------------------------------------------------------- */
 
 /* Copy Gaussian level `level` of slots [0,n) to planar fp32 d_out[n][P][h][w] (gaussian_pyramid_dec,
  * fvvdp_lpyr_dec.py:144-158). */
