@@ -39,13 +39,23 @@ __device__ __forceinline__ Px<2> ld_px<2>(const float* p) {
     r.h[0] = v2f{t.x, t.y};
     return r;
 }
-// the coarse level is written once and only read by the next launch: non-temporal stores (measured +2-3 % on the
-// read+write mix of this kernel, tools/microbench/membw.hip)
-__device__ __forceinline__ void st_px(float* p, const Px<4>& a) {
-    __builtin_nontemporal_store(v4f{a.h[0].x, a.h[0].y, a.h[1].x, a.h[1].y}, reinterpret_cast<v4f*>(p));
+// The coarse level is written once and only read by the next launch: non-temporal stores (measured +2-3 % on the
+// read+write mix of this kernel, tools/microbench/membw.hip).  The store goes through a buffer resource that covers the
+// frame's coarse level: a lane (or a whole wave) that must not write passes an out-of-range offset, which the hardware
+// drops.  This keeps the store in straight-line code: behind a branch, the compiler has to wait for vmcnt(0) at the
+// top of the next step (loads and stores share one in-order counter on gfx9), i.e. every step would wait for the
+// previous step's store to be acknowledged before its own prefetched rows are usable.
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+#define FVVDP_NO_STORE 0xFFFFFFFFu
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t level_rsrc(float* base, unsigned int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
 }
-__device__ __forceinline__ void st_px(float* p, const Px<2>& a) {
-    __builtin_nontemporal_store(a.h[0], reinterpret_cast<v2f*>(p));
+__device__ __forceinline__ void st_px(__amdgpu_buffer_rsrc_t r, unsigned int byte_off, const Px<4>& a) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{a.h[0].x, a.h[0].y, a.h[1].x, a.h[1].y}), r, byte_off, 0, 2 /*nt*/);
+}
+__device__ __forceinline__ void st_px(__amdgpu_buffer_rsrc_t r, unsigned int byte_off, const Px<2>& a) {
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, a.h[0]), r, byte_off, 0, 2 /*nt*/);
 }
 
 // value held by the lane to the left / right (0 at the wave's ends)
@@ -203,6 +213,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, (FOVM || DBG) ? 2 : 4) vo
 
     const float* Gf = a.Gf + (size_t)frame * h * w * P;
     float* Gc = a.Gc + (size_t)frame * hc * wc * P;
+    const __amdgpu_buffer_rsrc_t Gc_rsrc = level_rsrc(Gc, (unsigned int)(hc * wc * P) * 4u);     // <= 33 MB per frame
 
     auto load_row = [&](int r, Px<P>& p0, Px<P>& p1) {
         int rr = r < 0 ? -1 - r : (r >= h ? 2 * h - 1 - r : r);   // symmetric padding (fvvdp_lpyr_dec.py:190-195)
@@ -263,7 +274,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, (FOVM || DBG) ? 2 : 4) vo
     load_row(2 * ca + 2, nx1[0], nx1[1]);
     shift_window(nx0, nx1);
     const Px<P> cB = coarse_step();
-    if (active) st_px(Gc + ((size_t)ca * wc + J) * P, cB);
+    st_px(Gc_rsrc, active ? (unsigned int)(ca * wc + J) * (P * 4u) : FVVDP_NO_STORE, cB);
     Px<P> Gm1 = (ca > 0) ? cA : cB;
     Px<P> G0 = cB;
     load_row(2 * ca + 3, nx0[0], nx0[1]);
@@ -417,14 +428,15 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, (FOVM || DBG) ? 2 : 4) vo
     // ---- main loop: band rows 2c, 2c+1 for c in [ca, cb) ------------------------------------------------
     for (int c = ca; c < cb; ++c) {
         shift_window(nx0, nx1);               // window = fine rows 2c .. 2c+4
-        if (c + 1 < cb) {                     // prefetch the two rows of the next step
-            load_row(2 * c + 5, nx0[0], nx0[1]);
-            load_row(2 * c + 6, nx1[0], nx1[1]);
-        }
+        // prefetch the two rows of the next step.  Unconditional (the last step re-reads two rows it does not use; the row
+        // index is clamped into the image): with the loads and the store in straight-line code the wait at the top of
+        // the next step is vmcnt(1) -- rows landed, store still in flight -- instead of vmcnt(0).
+        load_row(2 * c + 5, nx0[0], nx0[1]);
+        load_row(2 * c + 6, nx1[0], nx1[1]);
         const Px<P> cN = coarse_step();       // coarse row c+1
         const bool has_next = (c + 1) <= (hc - 1);
         Px<P> Gp1 = has_next ? cN : G0;       // index clamp of the expand (fvvdp_lpyr_dec.py:134,138)
-        if (has_next && (c + 1) < cb && active) st_px(Gc + ((size_t)(c + 1) * wc + J) * P, cN);
+        st_px(Gc_rsrc, (has_next && (c + 1) < cb && active) ? (unsigned int)((c + 1) * wc + J) * (P * 4u) : FVVDP_NO_STORE, cN);
         Px<P> x00, x01, x10, x11;             // expanded level at (row 2c|2c+1, col X0|X1)
         Px<P> evE, evO;
 #pragma unroll

@@ -265,3 +265,60 @@ def native_geometry(geometry):
     if type(geometry) is fvvdp_display_geometry and geometry.fixed_ppd is None:
         return dict(display_size_m=geometry.display_size_m, distance_m=geometry.distance_m, ppd_centre=geometry.ppd_centre)
     return None
+
+
+def photometry_state(photometry):
+    """Value key of a STOCK photometry object (every attribute its `forward` reads), or None for user classes whose
+    state cannot be enumerated."""
+    t = type(photometry)
+    if t is fvvdp_display_photo_eotf:
+        return ("eotf", float(photometry.Y_peak), float(photometry.contrast), str(photometry.EOTF), float(photometry.gamma),
+                float(photometry.E_ambient), float(photometry.k_refl))
+    if t is fvvdp_display_photo_gog:
+        return ("gog", float(photometry.Y_peak), float(photometry.contrast), float(photometry.gamma),
+                float(photometry.E_ambient), float(photometry.k_refl))
+    if t is fvvdp_display_photo_absolute:
+        return ("abs", float(photometry.L_min), float(photometry.L_max))
+    return None
+
+
+class code_value_tables:
+    """Device-resident luminance of every integer code value (256 or 65536 entries) through a display model's own
+    `forward` (so user photometry subclasses work).
+
+    Entries are keyed by VALUE, never by object identity (CPython reuses `id()` after garbage collection): stock
+    classes by the attributes their `forward` reads; any other class is re-tabulated on the host on every request
+    and the cached device copy is reused only when the fresh table is bit-identical to it."""
+
+    MAX_ENTRIES = 16
+
+    def __init__(self):
+        self._stock = {}        # (state tuple, nbits) -> device tensor
+        self._user = {}         # nbits -> (host table, device tensor)
+
+    def clear(self):
+        self._stock.clear()
+        self._user.clear()
+
+    @staticmethod
+    def _tabulate(photometry, nbits):
+        n = 1 << nbits
+        codes = torch.arange(n, dtype=torch.int32).to(torch.float32) / float(n - 1)
+        return photometry.forward(codes.view(1, 1, 1, 1, n)).reshape(-1).to(torch.float32).contiguous().cpu()
+
+    def get(self, photometry, nbits, device):
+        state = photometry_state(photometry)
+        if state is not None:
+            key = (state, nbits, str(device))
+            if key not in self._stock:
+                if len(self._stock) >= self.MAX_ENTRIES:
+                    self._stock.clear()
+                self._stock[key] = self._tabulate(photometry, nbits).to(device)
+            return self._stock[key]
+        host = self._tabulate(photometry, nbits)
+        key = (nbits, str(device))
+        hit = self._user.get(key)
+        if hit is None or not torch.equal(hit[0], host):
+            hit = (host, host.to(device))
+            self._user[key] = hit
+        return hit[1]

@@ -18,7 +18,8 @@ import torch
 
 from . import _native as nat
 from . import utils
-from .display_model import (fvvdp_display_geometry, fvvdp_display_photometry, native_eotf, native_geometry)
+from .display_model import (code_value_tables, fvvdp_display_geometry, fvvdp_display_photometry, native_eotf,
+                            native_geometry)
 from .video_source import fvvdp_video_source_array
 from .video_source_yuv import fvvdp_video_source_yuv_frames
 
@@ -120,17 +121,17 @@ class fvvdp:
             device = torch.device('cuda:0') if (torch.cuda.is_available() and torch.cuda.device_count() > 0) else torch.device('cpu')
         self.device = torch.device(device)
         self.batch_frames = batch_frames
+        self._ctx = None
+        self._lut_dev = code_value_tables()
+        self._chan_w = {}
+        self._copy_stream = None
+        self._filters = {}
+        self.timing = None
         self.set_display_model(display_name, display_photometry=display_photometry, display_geometry=display_geometry)
         self.load_config()
         self.csf_cache_dirs = ["csf_cache"]
         self.omega = [0, 5]
         self.csf_lut = [utils.load_csf_lut(om, self.csf_sigma, self.k_cm, self.csf_cache_dirs) for om in self.omega]
-        self._ctx = None
-        self._lut_dev = {}
-        self._chan_w = {}
-        self._copy_stream = None
-        self._filters = {}
-        self.timing = None
 
     # ---- configuration ------------------------------------------------------------------------------------
     def update_device(self, device):
@@ -138,9 +139,16 @@ class fvvdp:
         if self._ctx is not None:
             self._ctx.close()
         self._ctx = None
-        self._lut_dev = {}
+        self._lut_dev.clear()
         self._chan_w = {}
         self._copy_stream = None
+
+    def _drop_context(self):
+        """Everything baked into the native context at creation (band frequencies, CSF tables, model constants,
+        geometry maps) is stale once the display or the parameters change: the next call builds a fresh one."""
+        if self._ctx is not None:
+            self._ctx.close()
+        self._ctx = None
 
     def load_config(self):
         parameters = utils.config_files.load("fvvdp_parameters.json")
@@ -155,6 +163,7 @@ class fvvdp:
             raise RuntimeError("Only the shipped model variant (local_adapt=gpyr, contrast=weber, pu_dilate=0, "
                                "min_mutual_masking_perc_norm2) is implemented by the HIP path")
         self.debug = False
+        self._drop_context()
 
     def set_display_model(self, display_name="standard_4k", display_photometry=None, display_geometry=None):
         if display_photometry is None:
@@ -168,6 +177,8 @@ class fvvdp:
         else:
             self.display_geometry = display_geometry
         self.pix_per_deg = self.display_geometry.get_ppd()
+        self._drop_context()
+        self._lut_dev.clear()
 
     # ---- public prediction API ------------------------------------------------------------------------------
     def predict(self, test_cont, reference_cont, dim_order="BCFHW", frames_per_second=0, fixation_point=None):
@@ -418,14 +429,26 @@ class fvvdp:
                 tab[bb, cc] = t.numpy()
         return np.ascontiguousarray(self.csf_lut[0]["Y_log"], dtype=np.float32), tab
 
+    def _context_key(self, W, H, n_bands, planes, batch, rho_band):
+        """Everything the native context bakes in at creation, by VALUE: size, band frequencies (display resolution /
+        distance), mode, model constants and the identity of the CSF tables.  (The reference re-reads all of these on
+        every call, pyfvvdp/fvvdp.py:147-161,209-213,442-447.)"""
+        prm = self.native_params()
+        pv = (prm.mask_p, prm.mask_q[0], prm.mask_q[1], prm.mask_k, prm.beta, prm.sens_gain, prm.lbkg_min,
+              prm.contrast_max, prm.d_max)
+        lut_id = tuple((id(l["S_log"]), l["S_log"].shape) for l in self.csf_lut)
+        return (W, H, n_bands, planes, batch, tuple(float(r) for r in rho_band), bool(self.foveated), pv, lut_id,
+                str(self.device), self.timing is not None)
+
     def _context(self, W, H, n_bands, planes, batch, rho_band):
-        key = (W, H, n_bands, planes, batch)
+        key = self._context_key(W, H, n_bands, planes, batch, rho_band)
         if self._ctx is not None and self._ctx.key == key:
             return self._ctx
-        if self._ctx is not None:
-            self._ctx.close()
+        self._drop_context()
         with torch.cuda.device(self.device):
             ctx = _Context(W, H, n_bands, planes, batch, rho_band, self.native_params())
+            ctx.key = key
+            ctx.luts = self.csf_lut           # keeps the arrays whose id() is part of the key alive
             if self.foveated:
                 for cc in range(2):
                     l = self.csf_lut[cc]
@@ -449,7 +472,9 @@ class fvvdp:
     def _set_view_maps(self, ctx, n_bands, width, height):
         """User geometry model: evaluate its pix2view_direction / get_resolution_magnification once per band on the
         band's pixel grid (as the reference does per frame, fvvdp.py:424-437) and hand the maps to the kernels."""
-        if getattr(ctx, "view_maps", None) is not None:
+        geom = self.display_geometry
+        gstate = tuple(sorted((k, repr(v)) for k, v in vars(geom).items() if isinstance(v, (int, float, str, tuple, list, type(None)))))
+        if getattr(ctx, "view_maps", None) is not None and ctx.view_geom is geom and ctx.view_gstate == gstate:
             return
         maps = []
         w_b, h_b = width, height
@@ -469,6 +494,7 @@ class fvvdp:
                                                         C.c_void_p(rm.data_ptr()), float(rm.min()), float(rm.max())))
             w_b, h_b = (w_b + 1) // 2, (h_b + 1) // 2
         ctx.view_maps = maps          # keep the tensors alive as long as the context
+        ctx.view_geom, ctx.view_gstate = geom, gstate     # strong reference: the object's id cannot be recycled
 
     def _gaze_view_dirs(self, fix_px, width, height):
         """Gaze positions [n,2] in frame pixels -> view directions in degrees through the user's geometry."""
@@ -500,15 +526,19 @@ class fvvdp:
         return np.ascontiguousarray(fp, dtype=np.float32)
 
     def _code_lut(self, photometry, nbits):
-        """Luminance of every integer code value through the display model, evaluated once per display with the
-        model's own `forward` (so user photometry subclasses work) and kept on the device."""
-        key = (id(photometry), nbits)
-        if key not in self._lut_dev:
-            n = 1 << nbits
-            codes = torch.arange(n, dtype=torch.int32).to(torch.float32) / float(n - 1)
-            lut = photometry.forward(codes.view(1, 1, 1, 1, n)).reshape(-1).to(torch.float32)
-            self._lut_dev[key] = lut.contiguous().to(self.device)
-        return self._lut_dev[key]
+        """Luminance of every integer code value through the display model's own `forward` (user photometry
+        subclasses work), kept on the device; cached by value, see display_model.code_value_tables."""
+        return self._lut_dev.get(photometry, nbits, self.device)
+
+    def _to_unit_float(self, a):
+        a = a.to(self.device)
+        if a.dtype is torch.float32:
+            return a
+        if a.dtype is torch.uint8:
+            return a.to(torch.float32) / 255
+        if a.dtype is torch.int16:
+            return (a.to(torch.int32) & 0xFFFF).to(torch.float32) / 65535
+        raise RuntimeError("Only uint8, uint16 and float32 is currently supported")
 
     def _make_feeder(self, vs, width, height):
         """Returns feed(ctx, idx, taps, fl, n_out, oob, stream): fills pyramid level 0 of slots [0, n_out)."""
@@ -519,6 +549,10 @@ class fvvdp:
             ref = vs.reference_video
             if test.shape[0] != 1:
                 raise RuntimeError("Only batch size 1 is supported (as in the reference's sliding-window code)")
+            if ref.dtype != test.dtype:
+                # the reference unpacks each array by its own dtype (video_source.py:186-200): bring both to
+                # normalised fp32 code values on the device, then the common float path applies
+                test, ref = self._to_unit_float(test), self._to_unit_float(ref)
             dt = test.dtype
             if dt is torch.uint8:
                 dtype, nbits = nat.FVVDP_U8, 8

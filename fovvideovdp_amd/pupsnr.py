@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import _native as nat
-from .display_model import fvvdp_display_photometry, native_eotf
+from .display_model import code_value_tables, fvvdp_display_photometry, native_eotf
 from .video_source import fvvdp_video_source_array
 
 
@@ -57,7 +57,7 @@ class pu_psnr:
         self.display_photometry = (fvvdp_display_photometry.load(display_name) if display_photometry is None
                                    else display_photometry)
         self.color_space = color_space
-        self._lut_dev = {}
+        self._lut_dev = code_value_tables()
 
     def predict(self, test_cont, reference_cont, dim_order="BCFHW", frames_per_second=0, fixation_point=None,
                 frame_padding="replicate"):
@@ -83,13 +83,7 @@ class pu_psnr:
 
     # ---- host side of fvvdp_pu21_sse ----------------------------------------------------------------------
     def _code_lut(self, photometry, nbits):
-        key = (id(photometry), nbits)
-        if key not in self._lut_dev:
-            n = 1 << nbits
-            codes = torch.arange(n, dtype=torch.int32).to(torch.float32) / float(n - 1)
-            lut = photometry.forward(codes.view(1, 1, 1, 1, n)).reshape(-1).to(torch.float32)
-            self._lut_dev[key] = lut.contiguous().to(self.device)
-        return self._lut_dev[key]
+        return self._lut_dev.get(photometry, nbits, self.device)
 
     def _call(self, test_d, ref_d, dtype, C_ch, chan_stride, frame_stride, HW, e, w, n, sse, oob, stream):
         partial = torch.empty(n * nat.PSNR_SLICES, dtype=torch.float64, device=self.device)
@@ -103,6 +97,8 @@ class pu_psnr:
         test, ref = vs.test_video, vs.reference_video
         if test.shape[0] != 1:
             raise RuntimeError("Only batch size 1 is supported")
+        if ref.dtype != test.dtype:              # each array is unpacked by its own dtype (video_source.py:186-200)
+            test, ref = self._to_unit_float(test), self._to_unit_float(ref)
         dt = test.dtype
         if dt is torch.uint8:
             dtype, nbits = nat.FVVDP_U8, 8
@@ -132,6 +128,16 @@ class pu_psnr:
         w = np.asarray(vs.color_to_luminance, dtype=np.float32) if C_ch == 3 else None
         self._call(test_d, ref_d, dtype, C_ch, N * HW, HW, HW, e, w, N, sse, oob, stream)
         return True
+
+    def _to_unit_float(self, a):
+        a = a.to(self.device)
+        if a.dtype is torch.float32:
+            return a
+        if a.dtype is torch.uint8:
+            return a.to(torch.float32) / 255
+        if a.dtype is torch.int16:
+            return (a.to(torch.int32) & 0xFFFF).to(torch.float32) / 65535
+        raise RuntimeError("Only uint8, uint16 and float32 is currently supported")
 
     def _generic_sse(self, vs, HW, N, sse, oob, stream):
         e = nat.Eotf()

@@ -1,0 +1,149 @@
+"""GPU tests of state that must never go stale between calls: the native context and the
+code-value tables are keyed by value, so changing the display, the parameters or the photometry object between calls
+gives the same numbers as a fresh metric object.  The reference re-reads these on every call
+(pyfvvdp/fvvdp.py:147-161,209-213,442-447)."""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fv():
+    import fovvideovdp_amd
+    from fovvideovdp_amd import _native
+    assert torch.cuda.is_available()
+    _native.lib()
+    return fovvideovdp_amd
+
+
+def _pair(N=6, H=96, W=160, seed=3):
+    from fovvideovdp_amd.synth import synth_video_pair
+    return synth_video_pair(N, H, W, pair=seed)
+
+
+def _custom_geometry(fv, ppd_scale):
+    # same resolution as standard_4k (=> same frame size and band count for the test clip) but a different distance
+    g = fv.fvvdp_display_geometry((3840, 2160), distance_m=0.7472 * ppd_scale, diagonal_size_inches=30)
+    return g
+
+
+def test_set_display_model_a_b_a_equals_fresh_objects(fv):
+    test, ref = _pair()
+    ga, gb = _custom_geometry(fv, 1.0), _custom_geometry(fv, 0.93)
+    from fovvideovdp_amd.fvvdp import band_frequencies
+    na, _ = band_frequencies(160, 96, ga.get_ppd())
+    nb, _ = band_frequencies(160, 96, gb.get_ppd())
+    assert na == nb and ga.get_ppd() != gb.get_ppd()       # the case the old (W,H,n_bands,...) key could not tell apart
+
+    def fresh(g):
+        m = fv.fvvdp(display_name="standard_4k", display_geometry=g)
+        q, st = m.predict(test, ref, frames_per_second=30)
+        return float(q), st["Q_per_ch"].copy(), st["rho_band"].copy()
+
+    fa, fb = fresh(ga), fresh(gb)
+    assert fa[0] != fb[0]
+    m = fv.fvvdp(display_name="standard_4k", display_geometry=ga)
+    for g, want in ((ga, fa), (gb, fb), (ga, fa), (gb, fb)):
+        m.set_display_model("standard_4k", display_geometry=g)
+        q, st = m.predict(test, ref, frames_per_second=30)
+        assert float(q) == want[0]
+        assert np.array_equal(st["Q_per_ch"], want[1])
+        assert np.array_equal(st["rho_band"], want[2])
+
+
+def test_named_display_switch_and_parameter_change(fv):
+    test, ref = _pair()
+    m = fv.fvvdp(display_name="standard_4k")
+    q4, _ = m.predict(test, ref, frames_per_second=30)
+    m.set_display_model("standard_fhd")
+    qf, _ = m.predict(test, ref, frames_per_second=30)
+    qf_fresh, _ = fv.fvvdp(display_name="standard_fhd").predict(test, ref, frames_per_second=30)
+    assert float(qf) == float(qf_fresh) and float(qf) != float(q4)
+    # attribute edits (what a calibration loop does) must reach the kernels as well
+    m.mask_c = m.mask_c + 0.1
+    q2, _ = m.predict(test, ref, frames_per_second=30)
+    m2 = fv.fvvdp(display_name="standard_fhd")
+    m2.mask_c = m.mask_c
+    q2_fresh, _ = m2.predict(test, ref, frames_per_second=30)
+    assert float(q2) == float(q2_fresh) and float(q2) != float(qf)
+    # foveated flag flips the CSF table kind inside the context
+    m.foveated = True
+    q3, _ = m.predict(test, ref, frames_per_second=30)
+    m3 = fv.fvvdp(display_name="standard_fhd", foveated=True)
+    m3.mask_c = m.mask_c
+    q3_fresh, _ = m3.predict(test, ref, frames_per_second=30)
+    assert float(q3) == float(q3_fresh)
+
+
+def test_photometry_objects_never_alias(fv):
+    """Sources built from display NAMES create a fresh photometry object each; CPython reuses their id() once they are
+    garbage: a table cached by id() served the previous display's luminances."""
+    test, ref = _pair(N=1)
+    names = ["standard_4k", "standard_hdr_pq", "sdr_4k_30", "iphone_12_pro"]
+    want = {}
+    for n in names:
+        vs = fv.fvvdp_video_source_array(test, ref, 0, display_photometry=n)
+        q, _ = fv.fvvdp(display_name="standard_4k").predict_video_source(vs)
+        want[n] = float(q)
+    assert len(set(want.values())) == len(want)
+    m = fv.fvvdp(display_name="standard_4k")
+    for rep in range(6):
+        for n in want:
+            vs = fv.fvvdp_video_source_array(test, ref, 0, display_photometry=n)
+            q, _ = m.predict_video_source(vs)
+            assert float(q) == want[n], (rep, n)
+            del vs
+            gc.collect()
+    # the PU21-PSNR side metric shares the table cache class
+    p = fv.pu_psnr()
+    vals = []
+    for n in want:
+        vs = fv.fvvdp_video_source_array(test, ref, 0, display_photometry=n)
+        vals.append(float(p.predict_video_source(vs)[0]))
+        del vs
+        gc.collect()
+    assert len(set(vals)) == len(vals)
+
+
+def test_user_photometry_edited_in_place(fv):
+    class Dim(fv.fvvdp_display_photometry):
+        def __init__(self, peak):
+            self.peak = peak
+
+        def forward(self, V):
+            return self.peak * V.clamp(0, 1) ** 2.2 + 0.1
+
+        def get_peak_luminance(self):
+            return self.peak
+
+        def get_black_level(self):
+            return 0.1
+
+    test, ref = _pair(N=1)
+    ph = Dim(100.0)
+    m = fv.fvvdp(display_name="standard_4k", display_photometry=ph)
+    q100, _ = m.predict(test, ref)
+    ph.peak = 400.0
+    q400, _ = m.predict(test, ref)
+    q400_fresh, _ = fv.fvvdp(display_name="standard_4k", display_photometry=Dim(400.0)).predict(test, ref)
+    assert float(q400) == float(q400_fresh) and float(q400) != float(q100)
+
+
+def test_mixed_dtypes_follow_each_arrays_own_dtype(fv):
+    """float32 test against uint8 reference: the reference converts each array by its own dtype
+    (video_source.py:186-200); the kernel must never read one buffer with the other's element size."""
+    test, ref = _pair()
+    m = fv.fvvdp(display_name="standard_4k")
+    q_u8, st_u8 = m.predict(test, ref, frames_per_second=30)
+    q_mix, st_mix = m.predict(test.to(torch.float32) / 255, ref, frames_per_second=30)
+    q_mix2, _ = m.predict(test, ref.to(torch.float32) / 255, frames_per_second=30)
+    assert abs(float(q_mix) - float(q_u8)) < 1e-4 and abs(float(q_mix2) - float(q_u8)) < 1e-4
+    assert np.allclose(st_mix["Q_per_ch"], st_u8["Q_per_ch"], rtol=2e-4, atol=1e-5 * float(st_u8["Q_per_ch"].max()))
+    p = fv.pu_psnr()
+    a = float(p.predict(test, ref, frames_per_second=30)[0])
+    b = float(p.predict(test.to(torch.float32) / 255, ref, frames_per_second=30)[0])
+    assert abs(a - b) < 2e-3

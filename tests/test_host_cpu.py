@@ -314,3 +314,38 @@ def test_load_image_as_array_png(tmp_path):
     assert out.dtype == np.uint16 and out.shape == (37, 53, 1) and np.array_equal(out[:, :, 0], g16)
     with pytest.raises((RuntimeError, OSError)):                    # no imageio: RuntimeError; with it: file not found
         fv.load_image_as_array(str(tmp_path / "missing.jpg"))
+
+
+def test_code_value_tables_are_keyed_by_value_not_identity():
+    """tables cached under id(photometry) were served to a different display once the id was reused."""
+    import gc
+    from fovvideovdp_amd.display_model import code_value_tables, fvvdp_display_photometry, photometry_state
+    cache = code_value_tables()
+    dev = torch.device("cpu")
+    seen = {}
+    for rep in range(4):
+        for name in ("standard_4k", "standard_hdr_pq", "standard_fhd"):
+            ph = fvvdp_display_photometry.load(name)
+            t = cache.get(ph, 8, dev)
+            want = ph.forward((torch.arange(256, dtype=torch.float32) / 255).view(1, 1, 1, 1, 256)).reshape(-1)
+            assert torch.equal(t, want), (rep, name)
+            seen.setdefault(name, t)
+            assert seen[name] is t            # stock displays: one upload per distinct model
+            del ph
+            gc.collect()
+    assert photometry_state(object()) is None
+
+    class User(fvvdp_display_photometry):
+        def __init__(self, k):
+            self.k = k
+
+        def forward(self, V):
+            return self.k * V + 1.0
+
+    u = User(100.0)
+    t1 = cache.get(u, 8, dev)
+    assert cache.get(u, 8, dev) is t1        # unchanged user model: device copy reused
+    u.k = 50.0                               # edited in place: same id, different table
+    t2 = cache.get(u, 8, dev)
+    assert float(t2[255]) == 51.0 and float(t1[255]) == 101.0
+    assert cache.get(User(50.0), 16, dev).numel() == 65536
