@@ -1,0 +1,419 @@
+// Stage 2, two pyramid levels per pass.  Included by fvvdp_hip.hip after band_kernel.hpp.
+#pragma once
+// ------------------------------------------------------------------------------------------------------------
+// band2_kernel: reads Gaussian level A (= level i) once, keeps level B (= i+1) in registers, writes level C (= i+2),
+// and accumulates sum(D^beta) of BOTH contrast bands i and i+1 in the same pass.
+//
+// Why: the one-level kernel (band_kernel) runs at the memory system's ceiling for a 4:1 read:write mix (any mix of
+// reads and writes tops out near 4.9-5.0 TB/s on MI355X, pure reads reach 6.1-6.3: tools/microbench/mix.hip).  The only
+// way to a shorter pass is fewer bytes: level B (1/4 of A) is neither written nor read back -- 4K video, levels
+// 0+1: 207 MB -> 141 MB (+ strip halo) per frame.
+//
+// Work decomposition, as band_kernel: one single-wave workgroup streams down a strip; lane l owns level-B column
+// J = 54*strip - 6 + l, i.e. level-A columns 2J, 2J+1, and (together with its pair lane l^1) level-C column K = J/2.
+// Level A -> B is band_kernel's step (5 A rows in registers, DPP wave shifts for the horizontal taps).  Every second
+// step ("stage k") one level-C row is produced from the last five level-B rows: vertical 5-tap thread-local,
+// horizontal 5-tap over lanes l-2..l+2 (two DPP shifts), result broadcast inside the lane pair; then band B is
+// evaluated for the two level-B rows 2k-2, 2k-1 (vertical expand from C rows k-2..k, horizontal from lanes l-2, l,
+// l+2).  Lanes 6..59 own results (54 of 64: the two-level halo), so strips overlap by 20 level-A columns; rows: a
+// chunk owns level-C rows [ka, kb) and runs 2 extra stages before and 1 after (7 level-A steps of halo).
+//
+// Borders follow the reference exactly as in band_kernel: symmetric rows for the reduce incl. the right-edge fix-up
+// that gausspyr_reduce selects by the ROW-count parity (fvvdp_lpyr_dec.py:198-205), index clamping for the expand
+// (fvvdp_lpyr_dec.py:126-142).  A level-B row past the bottom is the mirrored row (B[hb] = B[hb-1], B[hb+1] = B[hb-2]),
+// which is what both the reduce (symmetric) and the expand (clamp, only B[hb]) ask for.
+// ------------------------------------------------------------------------------------------------------------
+#ifndef F2_PITCH
+#define F2_PITCH 54         // level-B columns owned per wave: lanes 6..59, all the two-level halo leaves valid (the kernel is
+                            // VALU-bound: 54 vs a line-aligned 52 columns measured +3.4 %)
+#define F2_HL 6             // halo lanes on the left (4 on the right); even, so lane parity == column parity
+#endif
+
+struct Band2Args {
+    const float* Ga;        // level A [n][h][w][P]
+    float* Gc;              // level C [n][hc][wc][P]
+    int w, h, wb, hb, wc, hc;
+    int n_strips, n_chunks, kr;       // kr = level-C rows per chunk
+    float mulA, mulB;       // band multipliers (lpyr.get_band, fvvdp_lpyr_dec.py:57-63)
+    const float4* csfA;     // [32] slope-form 1-D CSF records of band A / band B (see BandArgs::csf)
+    const float4* csfB;
+    float y_first, y_inv_step, ly_lo, ly_hi;
+    float lg_gain, lg_k, p, q0, q1, beta, lbkg_min, cmax, lg_dmax;
+    float* partialA;        // [n][n_strips*n_chunks][2]
+    float* partialB;
+};
+
+// ---- horizontal taps with the DPP shift folded into the multiply-add (v_fmac_f32_dpp) ------------------------------
+// The compiler keeps `v_mov_b32_dpp` + `v_pk_fma_f32` for update_dpp() followed by fmaf (its DPP combiner does not fold
+// wave shifts on gfx950), i.e. one extra full-rate VALU instruction per neighbour value; this kernel is VALU-bound, so
+// the taps are written out.  Hazard: a DPP source operand written by a VALU instruction needs 2 wait states, which the
+// compiler cannot see inside an asm statement -> every block opens with `s_nop 1`, and temporaries produced inside a
+// block are read at least 3 instructions later.  Accumulation order = the order of the fma chain it replaces.
+#define DPP_SHR " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define DPP_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+// acc += w0*left(va); acc += w1*left(vb); acc += w4*right(va)            (reduce, taps 0, 1, 4)
+__device__ __forceinline__ v2f dpp_reduce_taps(v2f acc, v2f va, v2f vb, float w0, float w1, float w4) {
+    float x = acc.x, y = acc.y;
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %2, %6" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %1, %3, %6" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %0, %4, %7" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %1, %5, %7" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %0, %2, %8" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %1, %3, %8" DPP_SHL
+                 : "+v"(x), "+v"(y)
+                 : "v"(va.x), "v"(va.y), "v"(vb.x), "v"(vb.y), "v"(w0), "v"(w1), "v"(w4));
+    return v2f{x, y};
+}
+// even += el*left(e); even += er*right(e); odd += orr*right(e)           (expand from columns J-1, J, J+1)
+__device__ __forceinline__ void dpp_expand_taps(v2f e, float el, float er, float orr, v2f& even, v2f& odd) {
+    float ex = even.x, ey = even.y, ox = odd.x, oy = odd.y;
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %4, %6" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %1, %5, %6" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %0, %4, %7" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %1, %5, %7" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %2, %4, %8" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %3, %5, %8" DPP_SHL
+                 : "+v"(ex), "+v"(ey), "+v"(ox), "+v"(oy)
+                 : "v"(e.x), "v"(e.y), "v"(el), "v"(er), "v"(orr));
+    even = v2f{ex, ey};
+    odd = v2f{ox, oy};
+}
+// acc += u3*right(v); acc += u0*left2(v); acc += u1*left(v); acc += u4*right2(v); result of the even lane of each pair
+__device__ __forceinline__ v2f dpp_reduce5_pair(v2f acc, v2f v, float u0, float u1, float u3, float u4) {
+    float x = acc.x, y = acc.y, l1x, l1y, r1x, r1y, ox, oy;
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %2, %8" DPP_SHR "\n\t"
+                 "v_mov_b32_dpp %3, %9" DPP_SHR "\n\t"
+                 "v_mov_b32_dpp %4, %8" DPP_SHL "\n\t"
+                 "v_mov_b32_dpp %5, %9" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %0, %8, %12" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %1, %9, %12" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %0, %2, %10" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %1, %3, %10" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %0, %8, %11" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %1, %9, %11" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %0, %4, %13" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %1, %5, %13" DPP_SHL "\n\t"
+                 "s_nop 1\n\t"
+                 "v_mov_b32_dpp %6, %0 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_mov_b32_dpp %7, %1 quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "+v"(x), "+v"(y), "=&v"(l1x), "=&v"(l1y), "=&v"(r1x), "=&v"(r1y), "=&v"(ox), "=&v"(oy)
+                 : "v"(v.x), "v"(v.y), "v"(u0), "v"(u1), "v"(u3), "v"(u4));
+    return v2f{ox, oy};
+}
+// t += fl*left2(e); t += fr*right2(e)                                     (expand from lanes l-2, l+2)
+__device__ __forceinline__ v2f dpp_expand2_taps(v2f t, v2f e, float fl, float fr) {
+    float x = t.x, y = t.y, l1x, l1y, r1x, r1y;
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %2, %6" DPP_SHR "\n\t"
+                 "v_mov_b32_dpp %3, %7" DPP_SHR "\n\t"
+                 "v_mov_b32_dpp %4, %6" DPP_SHL "\n\t"
+                 "v_mov_b32_dpp %5, %7" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %0, %2, %8" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %1, %3, %8" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %0, %4, %9" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %1, %5, %9" DPP_SHL
+                 : "+v"(x), "+v"(y), "=&v"(l1x), "=&v"(l1y), "=&v"(r1x), "=&v"(r1y)
+                 : "v"(e.x), "v"(e.y), "v"(fl), "v"(fr));
+    return v2f{x, y};
+}
+
+#ifndef BAND2_LB
+#define BAND2_LB 3
+#endif
+template <int P>
+__global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) {
+    constexpr int HP = P / 2;
+    __shared__ float4 s_csf[2][FVVDP_LUT_N];
+    const int lane = threadIdx.x;
+    int bid;
+    {   // XCD-aware work order (see band_kernel)
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
+        bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
+    }
+    const int strip = bid % a.n_strips;
+    bid /= a.n_strips;
+    const int chunk = bid % a.n_chunks;
+    const int frame = bid / a.n_chunks;
+    const int blk = chunk * a.n_strips + strip;
+
+    const int w = a.w, h = a.h, wb = a.wb, hb = a.hb, wc = a.wc, hc = a.hc;
+    const int J = strip * F2_PITCH - F2_HL + lane;          // level-B column (may be < 0 or >= wb in halo lanes)
+    const int K = J >> 1;                                    // level-C column of the lane pair
+    const bool jeven = (lane & 1) == 0;
+    const int ka = chunk * a.kr, kb = min(ka + a.kr, hc);    // owned level-C rows
+    const int ca = 2 * ka, cb = min(2 * kb, hb);             // owned level-B rows = level-A row pairs
+    const bool owned = lane >= F2_HL && lane < F2_HL + F2_PITCH && J < wb;
+    const int X0 = 2 * J, X1 = 2 * J + 1;
+    const int xc0 = min(max(X0, 0), w - 1), xc1 = min(max(X1, 0), w - 1);
+    const bool col1_ok = X1 < w;
+
+    if (lane < FVVDP_LUT_N) {
+        s_csf[0][lane] = a.csfA[lane];
+        s_csf[1][lane] = a.csfB[lane];
+    }
+    __syncthreads();
+
+    const float K0 = 0.05f, K1 = 0.25f, K2 = 0.4f, K3 = 0.25f, K4 = 0.05f;
+    // ---- per-lane horizontal weights, level A -> B (column J) and B -> C (column K); see band_kernel ----------
+    float wq0 = K0, wq1 = K1, wq2 = K2, wq3 = K3, wq4 = K4;
+    if (J == 0) { wq2 += K1; wq3 += K0; wq0 = 0.0f; wq1 = 0.0f; }
+    if (J == wb - 1) {
+        const bool hodd = (h & 1) != 0;
+        if (w & 1) { wq3 = 0.0f; wq4 = 0.0f; if (hodd) { wq2 += K3; wq1 += K4; } else { wq2 += K4; } }
+        else { wq4 = 0.0f; if (hodd) { wq3 += K3; wq2 += K4; } else { wq3 += K4; } }
+    }
+    // taps of C column K at an even lane: B columns 2K-2 .. 2K+2 = lanes l-2, l-1, l, l+1, l+2
+    float uq0 = K0, uq1 = K1, uq2 = K2, uq3 = K3, uq4 = K4;
+    if (K == 0) { uq2 += K1; uq3 += K0; uq0 = 0.0f; uq1 = 0.0f; }
+    if (K == wc - 1) {
+        const bool hodd = (hb & 1) != 0;
+        if (wb & 1) { uq3 = 0.0f; uq4 = 0.0f; if (hodd) { uq2 += K3; uq1 += K4; } else { uq2 += K4; } }
+        else { uq4 = 0.0f; if (hodd) { uq3 += K3; uq2 += K4; } else { uq3 += K4; } }
+    }
+    // expand B -> A at columns X0 (even) / X1 (odd) from B columns J-1, J, J+1
+    const bool at_l = (J <= 0), at_r = (J >= wb - 1);
+    const float el = at_l ? 0.0f : 0.1f, er = at_r ? 0.0f : 0.1f;
+    const float ec = 0.8f + (at_l ? 0.1f : 0.0f) + (at_r ? 0.1f : 0.0f);
+    const float orr = at_r ? 0.0f : 0.5f, oc = at_r ? 1.0f : 0.5f;
+    // expand C -> B at column J from C columns K-1, K, K+1 = lanes l-2, l, l+2 (every lane of a pair holds C[K])
+    const bool k_l = (K <= 0), k_r = (K >= wc - 1);
+    const float fl = (jeven && !k_l) ? 0.1f : 0.0f;
+    const float fr = k_r ? 0.0f : (jeven ? 0.1f : 0.5f);
+    const float fc = jeven ? (0.8f + (k_l ? 0.1f : 0.0f) + (k_r ? 0.1f : 0.0f)) : (k_r ? 1.0f : 0.5f);
+
+    const float* Ga = a.Ga + (size_t)frame * h * w * P;
+    float* Gc = a.Gc + (size_t)frame * hc * wc * P;
+    const __amdgpu_buffer_rsrc_t Gc_rsrc = level_rsrc(Gc, (unsigned int)(hc * wc * P) * 4u);
+
+    auto load_row = [&](int r, Px<P>& p0, Px<P>& p1) {
+        int rr = r < 0 ? -1 - r : (r >= h ? 2 * h - 1 - r : r);   // symmetric padding (fvvdp_lpyr_dec.py:190-195)
+        rr = min(max(rr, 0), h - 1);
+        const float* row = Ga + (size_t)rr * w * P;
+        p0 = ld_px<P>(row + (size_t)xc0 * P);
+        p1 = ld_px<P>(row + (size_t)xc1 * P);
+    };
+
+    Px<P> W[5][2];
+    auto coarse_step = [&]() -> Px<P> {          // level-B row from the current 5-row window of level A
+        Px<P> c, va, vb;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            v2f a0 = W[0][0].h[k] * K0;
+            a0 = pfma(W[1][0].h[k], K1, a0);
+            a0 = pfma(W[2][0].h[k], K2, a0);
+            a0 = pfma(W[3][0].h[k], K3, a0);
+            va.h[k] = pfma(W[4][0].h[k], K4, a0);
+            v2f b0 = W[0][1].h[k] * K0;
+            b0 = pfma(W[1][1].h[k], K1, b0);
+            b0 = pfma(W[2][1].h[k], K2, b0);
+            b0 = pfma(W[3][1].h[k], K3, b0);
+            vb.h[k] = pfma(W[4][1].h[k], K4, b0);
+        }
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            v2f acc = va.h[k] * wq2;
+            acc = pfma(vb.h[k], wq3, acc);
+            c.h[k] = dpp_reduce_taps(acc, va.h[k], vb.h[k], wq0, wq1, wq4);
+        }
+        return c;
+    };
+    auto shift_window = [&](const Px<P> (&n0)[2], const Px<P> (&n1)[2]) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            W[0][j] = W[2][j];
+            W[1][j] = W[3][j];
+            W[2][j] = W[4][j];
+            W[3][j] = n0[j];
+            W[4][j] = n1[j];
+        }
+    };
+
+    float accA[2] = {0.0f, 0.0f}, accB[2] = {0.0f, 0.0f};
+    const float lg_base = a.lg_gain;
+    const float lg_mask = a.lg_gain + a.lg_k;
+    const float lg_bm[2] = {__log2f(a.mulA), __log2f(a.mulB)};
+
+    // per-pixel tail (contrast, CSF, masking, pooling term), see band_kernel::band_px for the derivation
+    auto tail = [&](const Px<P>& g, const Px<P>& e, bool valid, const int band, float (&acc)[2]) {
+#if defined(BAND2_ABLATE) && BAND2_ABLATE >= 1      // profiling ablation: no per-pixel tail, keep the data flow alive
+        acc[0] += g.h[0].x + e.h[0].y + (valid ? 1.0f : 0.0f);
+        (void)band;
+        return;
+#endif
+        const float lb = fmaxf(e.h[0].y, a.lbkg_min);
+        const float dcap = a.cmax * lb;
+        v2f d[HP];
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            const v2f t = g.h[k] - e.h[k];
+            d[k] = v2f{fminf(t.x, dcap), fminf(t.y, dcap)};
+        }
+        const float llb = fast_log2(lb);
+        const float yq = fminf(fmaxf(llb, a.ly_lo), a.ly_hi);
+        const float t = (yq - a.y_first) * a.y_inv_step;
+        const float fi = fminf(fmaxf(floorf(t), 0.0f), (float)(FVVDP_LUT_N - 2));
+        const float4 r = s_csf[band][(int)fi];
+        const float f = t - fi;
+        const float slog0 = fmaf(f, r.z, r.x), slog1 = fmaf(f, r.w, r.y);
+        const float vm = valid ? 1.0f : 0.0f;
+        const float lcn = lg_bm[band] - llb;
+        if constexpr (HP == 2) {
+            const v2f sl = v2f{slog0, slog1};
+            const v2f lsb = sl + splat(lcn + lg_base);
+            const v2f lsm = sl + splat(lcn + lg_mask);
+            const v2f ldiff = v2f{fast_log2(fabsf(d[0].x - d[0].y)), fast_log2(fabsf(d[1].x - d[1].y))};
+            const v2f lmin = v2f{fast_log2(fminf(fabsf(d[0].x), fabsf(d[0].y))), fast_log2(fminf(fabsf(d[1].x), fabsf(d[1].y)))};
+            const v2f ld = (ldiff + lsb) * splat(a.p);
+            const v2f lm = (lmin + lsm) * v2f{a.q0, a.q1};
+            const v2f one_mq = v2f{fast_exp2(lm.x), fast_exp2(lm.y)} + splat(1.0f);
+            const v2f tt = ld - v2f{fast_log2(one_mq.x), fast_log2(one_mq.y)};
+            const v2f ldd = v2f{fminf(tt.x, a.lg_dmax), fminf(tt.y, a.lg_dmax)};
+            const v2f bl = ldd * splat(a.beta);
+            const v2f term = v2f{fast_exp2(bl.x), fast_exp2(bl.y)};
+            const v2f av = __builtin_elementwise_fma(term, splat(vm), v2f{acc[0], acc[1]});
+            acc[0] = av.x;
+            acc[1] = av.y;
+        } else {
+            const float dT = d[0].x, dR = d[0].y;
+            const float ls = slog0 + lcn;
+            const float ld = a.p * (fast_log2(fabsf(dT - dR)) + (ls + lg_base));
+            const float mq = fast_exp2(a.q0 * (fast_log2(fminf(fabsf(dT), fabsf(dR))) + (ls + lg_mask)));
+            const float ldd = fminf(ld - fast_log2(1.0f + mq), a.lg_dmax);
+            acc[0] = fmaf(fast_exp2(a.beta * ldd), vm, acc[0]);
+        }
+    };
+
+    // band A for level-A rows 2c, 2c+1 (window rows 0, 1), expand from level-B rows c-1, c, c+1
+    auto band_a_rows = [&](int c, const Px<P>& Bm1, const Px<P>& B0, const Px<P>& Bp1) {
+        Px<P> x00, x01, x10, x11, evE, evO;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            v2f t = Bm1.h[k] * 0.1f;
+            t = pfma(B0.h[k], 0.8f, t);
+            evE.h[k] = pfma(Bp1.h[k], 0.1f, t);
+            evO.h[k] = pfma(Bp1.h[k], 0.5f, B0.h[k] * 0.5f);
+        }
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            x00.h[k] = evE.h[k] * ec;
+            x01.h[k] = evE.h[k] * oc;
+            dpp_expand_taps(evE.h[k], el, er, orr, x00.h[k], x01.h[k]);
+            x10.h[k] = evO.h[k] * ec;
+            x11.h[k] = evO.h[k] * oc;
+            dpp_expand_taps(evO.h[k], el, er, orr, x10.h[k], x11.h[k]);
+        }
+        const bool row1_ok = (2 * c + 1) < h;
+        tail(W[0][0], x00, owned, 0, accA);
+        tail(W[0][1], x01, owned && col1_ok, 0, accA);
+        tail(W[1][0], x10, owned && row1_ok, 0, accA);
+        tail(W[1][1], x11, owned && row1_ok && col1_ok, 0, accA);
+    };
+
+    // ---- prologue: level-B row 2*ks and the window of the first step ---------------------------------------
+    const int ks = max(ka - 2, 0);
+    const bool last_chunk = kb >= hc;
+    const int kend = last_chunk ? hc - 1 : kb;
+    {
+        const int r0 = 4 * ks - 2;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) load_row(r0 + k, W[k][0], W[k][1]);
+    }
+    Px<P> R[5];                       // level-B rows 2k-2 .. 2k+2 of the running stage (newest last)
+    R[4] = coarse_step();
+    R[0] = R[1] = R[2] = R[3] = R[4];
+    Px<P> CH[3];                      // level-C rows k-2, k-1, k
+    CH[0] = CH[1] = CH[2] = R[4];
+    Px<P> nx0[2], nx1[2];
+    load_row(4 * ks + 3, nx0[0], nx0[1]);
+    load_row(4 * ks + 4, nx1[0], nx1[1]);
+
+    // band B for level-B rows g0 (even), g1 (odd) from the level-C history
+    auto band_b_rows = [&](const Px<P>& g0, const Px<P>& g1, int row0) {
+        Px<P> evE, evO, e0, e1;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            v2f t = CH[0].h[k] * 0.1f;
+            t = pfma(CH[1].h[k], 0.8f, t);
+            evE.h[k] = pfma(CH[2].h[k], 0.1f, t);
+            evO.h[k] = pfma(CH[2].h[k], 0.5f, CH[1].h[k] * 0.5f);
+        }
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            e0.h[k] = dpp_expand2_taps(evE.h[k] * fc, evE.h[k], fl, fr);
+            e1.h[k] = dpp_expand2_taps(evO.h[k] * fc, evO.h[k], fl, fr);
+        }
+        tail(g0, e0, owned && row0 < hb, 1, accB);
+        tail(g1, e1, owned && (row0 + 1) < hb, 1, accB);
+    };
+
+    // ---- main loop: stage k = steps c = 2k, 2k+1, then level-C row k and band B of level-B rows 2k-2, 2k-1 ------
+    for (int k = ks; k <= kend; ++k) {
+        Px<P> Be, Bo;
+        {   // step c = 2k: level-B row 2k+1
+            const int c = 2 * k;
+            shift_window(nx0, nx1);
+            load_row(2 * c + 5, nx0[0], nx0[1]);
+            load_row(2 * c + 6, nx1[0], nx1[1]);
+            Be = coarse_step();
+            if (c + 1 >= hb) Be = R[4];                               // B[hb] = B[hb-1]
+            if (c >= ca && c < cb) band_a_rows(c, R[3], R[4], Be);
+        }
+        {   // step c = 2k+1: level-B row 2k+2
+            const int c = 2 * k + 1;
+            shift_window(nx0, nx1);
+            load_row(2 * c + 5, nx0[0], nx0[1]);
+            load_row(2 * c + 6, nx1[0], nx1[1]);
+            Bo = coarse_step();
+            if (c + 1 >= hb) Bo = (c + 1 == hb) ? Be : R[3];          // B[hb] = B[hb-1];  B[hb+1] = B[hb-2]
+            if (c >= ca && c < cb) band_a_rows(c, R[4], Be, Bo);
+        }
+        // level-B window of this stage: rows 2k-2 .. 2k+2 (top: rows -2, -1 mirror to 1, 0)
+        R[0] = R[2];
+        R[1] = R[3];
+        R[2] = R[4];
+        R[3] = Be;
+        R[4] = Bo;
+        if (k == 0) {
+            R[0] = R[3];
+            R[1] = R[2];
+        }
+        // level-C row k: vertical 5-tap on the lane's own level-B column, horizontal over lanes l-2 .. l+2
+        Px<P> Cn;
+#pragma unroll
+        for (int q = 0; q < HP; ++q) {
+            v2f v = R[0].h[q] * K0;
+            v = pfma(R[1].h[q], K1, v);
+            v = pfma(R[2].h[q], K2, v);
+            v = pfma(R[3].h[q], K3, v);
+            v = pfma(R[4].h[q], K4, v);
+            Cn.h[q] = dpp_reduce5_pair(v * uq2, v, uq0, uq1, uq3, uq4);
+        }
+        st_px(Gc_rsrc, (k >= ka && k < kb && owned && jeven && K < wc) ? (unsigned int)(k * wc + K) * (P * 4u) : FVVDP_NO_STORE, Cn);
+        CH[0] = CH[1];
+        CH[1] = CH[2];
+        CH[2] = Cn;
+        if (k == 0) CH[1] = Cn;                                       // C[-1] = C[0] (index clamp of the expand)
+        const int row0 = 2 * k - 2;
+        if (row0 >= ca && row0 < cb) band_b_rows(R[0], R[1], row0);
+    }
+    // ---- bottom of the image: the last level-B rows against C[hc] = C[hc-1] ---------------------------------
+    if (last_chunk) {
+        const int row0 = 2 * hc - 2;
+        CH[0] = CH[1];
+        CH[1] = CH[2];
+        if (row0 >= ca && row0 < cb) band_b_rows(R[2], R[3], row0);
+    }
+
+    const float a0 = wave_sum(accA[0]), a1 = wave_sum(accA[1]);
+    const float b0 = wave_sum(accB[0]), b1 = wave_sum(accB[1]);
+    if (lane == 0) {
+        const size_t o = ((size_t)frame * (a.n_strips * a.n_chunks) + blk) * 2;
+        a.partialA[o] = a0;
+        a.partialA[o + 1] = a1;
+        a.partialB[o] = b0;
+        a.partialB[o + 1] = b1;
+    }
+}

@@ -43,6 +43,7 @@ extern "C" const char* fvvdp_last_error(void) { return g_err; }
 #include "device_common.hpp"
 #include "temporal_kernels.hpp"
 #include "band_kernel.hpp"
+#include "band2_kernel.hpp"
 #include "aux_kernels.hpp"
 #include "psnr_kernel.hpp"
 
@@ -84,6 +85,7 @@ struct fvvdp_ctx {
     unsigned int* colour_ws = nullptr;    // colouring workspace per frame: range[2] + hist[1024] + curve[1024], then lin01[1024]
     size_t scratch = 0;
     long long wave_capacity = 4096;   // resident single-wave workgroups of the band kernel on the whole chip
+    long long wave_capacity2 = 4096;  // ... of the two-level kernel (band2_kernel)
     // timing
     bool timing = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> ev[FVVDP_MAX_BANDS + 2];
@@ -123,6 +125,26 @@ struct Timed {
 
 // strips cover coarse columns [0,62), [62,122), ... (see band_kernel)
 static int band_strips(int wc) { return wc <= 62 ? 1 : 1 + (wc - 62 + STRIP_J - 1) / STRIP_J; }
+
+static int band2_strips(int wb) { return (wb + F2_PITCH - 1) / F2_PITCH; }
+
+// two-level kernel: a chunk of kr level-C rows costs 2*kr steps of level A plus 7 halo steps and the prologue
+static void chunking2(int hc, int n_strips, int n, long long capacity, int& n_chunks, int& kr) {
+    double best = 1e300;
+    kr = hc;
+    for (int cand = 1; cand <= hc; ++cand) {
+        const long long chunks = (hc + cand - 1) / cand;
+        const long long waves = (long long)n * n_strips * chunks;
+        const long long rounds = (waves + capacity - 1) / capacity;
+        const double cost = (double)rounds * (2.0 * cand + 9.0) * (1.0 + 1e-4 * (double)chunks);
+        if (cost < best) { best = cost; kr = cand; }
+    }
+    if (const char* ov = getenv("FVVDP_BAND2_KR")) {      // tuning override
+        const int v = atoi(ov);
+        if (v >= 1) kr = v > hc ? hc : v;
+    }
+    n_chunks = (hc + kr - 1) / kr;
+}
 
 static void chunking(int hc, int n_strips, int n, long long capacity, int& n_chunks, int& cr) {
     // Every single-wave workgroup does the same amount of work (cr steps + the prologue for the two halo coarse
@@ -180,6 +202,13 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
         const int n_strips = band_strips(c->lw[b + 1]);
         const int max_chunks = (c->lh[b + 1] + 1) / 2;
         c->max_blk[b] = n_strips * max_chunks;
+    }
+    for (int b = 0; b + 1 < n_bands; ++b) {       // two-level launches (bands b, b+1 share one work decomposition)
+        const int blk2 = band2_strips(c->lw[b + 1]) * c->lh[b + 2];
+        if (blk2 > c->max_blk[b]) c->max_blk[b] = blk2;
+        if (blk2 > c->max_blk[b + 1]) c->max_blk[b + 1] = blk2;
+    }
+    for (int b = 0; b < n_bands; ++b) {
         c->partial_off[b] = (long long)off;
         off += (size_t)max_frames * c->max_blk[b] * 2;
     }
@@ -205,6 +234,11 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
             : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, band_kernel<2, false, 0>, 64, 0);
         if (e != hipSuccess || per_cu < 1) per_cu = 16;
         c->wave_capacity = (long long)per_cu * cus;
+        int per_cu2 = 16;
+        e = (planes == 4) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, band2_kernel<4>, 64, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, band2_kernel<2>, 64, 0);
+        if (e != hipSuccess || per_cu2 < 1) per_cu2 = 16;
+        c->wave_capacity2 = (long long)per_cu2 * cus;
     }
     *out = c;
     return FVVDP_OK;
@@ -692,7 +726,67 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
     }
     FinalizeArgs fa;
     memset(&fa, 0, sizeof(fa));
+    // Two pyramid levels per pass where possible (band2_kernel): plain evaluation only -- the map-writing and the
+    // foveated variants, and levels too small for the two-level border logic, take one level per launch.
+    bool any_maps = false;
+    if (maps)
+        for (int b = 0; b < c->n_bands; ++b) any_maps = any_maps || maps[b].d_D || maps[b].d_contrast || maps[b].d_lbkg || maps[b].d_S;
+    // It pays where the one-level kernel is bound by HBM (large levels: 4K levels 0+1 39 vs 46 us per frame); the
+    // two-level kernel is VALU-bound (its strips own 54 of 64 lanes), so small levels stay on the one-level kernel
+    // (960x540 + 480x270: 3.1 vs 2.95 us).  FVVDP_BAND_FUSE=0 / 1 forces never / wherever valid (tests, A/B runs).
+    const char* fuse_env = getenv("FVVDP_BAND_FUSE");
+    const int fuse_mode = fuse_env ? atoi(fuse_env) : -1;
+    const bool fuse_ok = !fov && !any_maps && fuse_mode != 0;
     for (int b = 0; b < c->n_bands; ++b) {
+        const bool big = (long long)c->lw[b] * c->lh[b] >= 1500000;
+        if (fuse_ok && (big || fuse_mode == 1) && b + 1 < c->n_bands && c->lw[b + 1] >= 4 && c->lh[b + 1] >= 4 &&
+            c->lw[b + 2] >= 2 && c->lh[b + 2] >= 2) {
+            Band2Args a;
+            memset(&a, 0, sizeof(a));
+            a.Ga = c->level[b];
+            a.Gc = c->level[b + 2];
+            a.w = c->lw[b];
+            a.h = c->lh[b];
+            a.wb = c->lw[b + 1];
+            a.hb = c->lh[b + 1];
+            a.wc = c->lw[b + 2];
+            a.hc = c->lh[b + 2];
+            a.n_strips = band2_strips(a.wb);
+            chunking2(a.hc, a.n_strips, n, c->wave_capacity2, a.n_chunks, a.kr);
+            a.mulA = (b == 0) ? 1.0f : 2.0f;
+            a.mulB = 2.0f;
+            a.csfA = c->csf + (size_t)b * FVVDP_LUT_N;
+            a.csfB = c->csf + (size_t)(b + 1) * FVVDP_LUT_N;
+            a.y_first = c->y_first;
+            a.y_inv_step = c->y_inv_step;
+            a.ly_lo = log2f(c->y_lo);
+            a.ly_hi = log2f(c->y_hi);
+            a.lg_gain = log2f(c->prm.sens_gain);
+            a.lg_k = log2f(c->prm.mask_k);
+            a.p = c->prm.mask_p;
+            a.q0 = c->prm.mask_q[0];
+            a.q1 = c->prm.mask_q[1];
+            a.beta = c->prm.beta;
+            a.lbkg_min = c->prm.lbkg_min;
+            a.cmax = c->prm.contrast_max;
+            a.lg_dmax = log2f(c->prm.d_max);
+            a.partialA = c->partial + c->partial_off[b];
+            a.partialB = c->partial + c->partial_off[b + 1];
+            const int nblk = a.n_strips * a.n_chunks;
+            if (nblk > c->max_blk[b] || nblk > c->max_blk[b + 1]) return fail(FVVDP_ESTATE, "internal: partial buffer too small");
+            {
+                Timed tm(c, 1 + b, st);
+                if (c->P == 4) hipLaunchKernelGGL((band2_kernel<4>), dim3(nblk * n), dim3(64), 0, st, a);
+                else hipLaunchKernelGGL((band2_kernel<2>), dim3(nblk * n), dim3(64), 0, st, a);
+            }
+            for (int bb = b; bb <= b + 1; ++bb) {
+                fa.nblk[bb] = nblk;
+                fa.off[bb] = c->partial_off[bb];
+                fa.npx[bb] = (float)c->lw[bb] * (float)c->lh[bb];
+            }
+            ++b;                                             // band b+1 is done as well
+            continue;
+        }
         BandArgs a;
         memset(&a, 0, sizeof(a));
         a.Gf = c->level[b];

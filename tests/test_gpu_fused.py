@@ -1,0 +1,86 @@
+"""GPU: the two-levels-per-pass pyramid kernel (band2_kernel) against the one-level kernel and the CPU oracle.
+
+By default the library picks band2_kernel only for large levels (>= 1.5 Mpixel); FVVDP_BAND_FUSE=1 forces it wherever
+its border logic is valid, =0 disables it, FVVDP_BAND2_KR sets the chunk height (level-C rows), so that strip seams,
+chunk seams and all row/column parities of three consecutive levels are exercised at small sizes.  Both kernels
+evaluate the same per-pixel expressions; only the order in which the per-wave partial sums are added differs."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(H, W, seed, N=None):
+    rng = np.random.RandomState(seed)
+    shape = (H, W) if N is None else (N, H, W)
+    base = rng.randint(0, 256, shape).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ref = np.clip(0.6 * base + 50 + 40 * np.sin(xx / 7.0) * np.cos(yy / 5.0), 0, 255).astype(np.uint8)
+    test = np.clip(ref.astype(np.int32) + rng.randint(-6, 7, shape), 0, 255).astype(np.uint8)
+    return test, ref
+
+
+def _run(monkeypatch, test, ref, fuse, kr=None, disp="standard_4k", **kw):
+    import fovvideovdp_amd as fv
+    monkeypatch.setenv("FVVDP_BAND_FUSE", str(fuse))
+    if kr is None:
+        monkeypatch.delenv("FVVDP_BAND2_KR", raising=False)
+    else:
+        monkeypatch.setenv("FVVDP_BAND2_KR", str(kr))
+    q, st = fv.fvvdp(display_name=disp).predict(test, ref, **kw)
+    return float(q), st["Q_per_ch"].astype(np.float64)
+
+
+def _close(a, b, rel=3e-6):
+    # measured: <= 6e-7 relative (different summation order of the partial sums only)
+    assert a.shape == b.shape
+    assert np.all(np.abs(a - b) <= rel * np.abs(b) + 1e-9 * np.max(np.abs(b))), np.max(np.abs(a - b) / (np.abs(b) + 1e-30))
+
+
+# widths around the strip pitch (54 level-B = 108 level-A columns) and its multiples, every row/column parity mod 4
+IMG_SIZES = [(16, 16), (17, 19), (20, 24), (33, 107), (34, 108), (35, 109), (36, 110), (37, 215), (38, 216), (39, 217),
+             (40, 218), (41, 219), (63, 64), (64, 65), (65, 66), (66, 67), (130, 323), (131, 324), (97, 433), (255, 256)]
+
+
+@pytest.mark.parametrize("H,W", IMG_SIZES)
+def test_image_fused_equals_one_level(monkeypatch, H, W):
+    test, ref = _pair(H, W, 31 * H + W)
+    q0, Q0 = _run(monkeypatch, test, ref, 0, dim_order="HW")
+    for kr in (None, 1, 2, 3, 5):
+        q1, Q1 = _run(monkeypatch, test, ref, 1, kr, dim_order="HW")
+        assert abs(q1 - q0) < 2e-6, (H, W, kr)
+        _close(Q1, Q0)
+
+
+@pytest.mark.parametrize("H,W", [(34, 108), (37, 217), (66, 325), (131, 220), (72, 1000)])
+def test_video_fused_equals_one_level_and_oracle(monkeypatch, H, W):
+    from oracle import fvvdp_oracle as orc
+    N = 5
+    test, ref = _pair(H, W, H + 3 * W, N)
+    q0, Q0 = _run(monkeypatch, test, ref, 0, disp="standard_fhd", dim_order="FHW", frames_per_second=30)
+    for kr in (None, 1, 4):
+        q1, Q1 = _run(monkeypatch, test, ref, 1, kr, disp="standard_fhd", dim_order="FHW", frames_per_second=30)
+        assert abs(q1 - q0) < 2e-6
+        _close(Q1, Q0)
+    oq, ost = orc.Oracle("standard_fhd").predict(test, ref, dim_order="FHW", frames_per_second=30)
+    assert abs(q1 - float(oq)) < 1e-4
+    b = ost["Q_per_ch"].astype(np.float64)
+    assert np.all(np.abs(Q1 - b) <= 1e-3 * np.abs(b) + 1e-5 * np.max(b))
+
+
+def test_large_level_takes_the_two_level_kernel_by_default(monkeypatch):
+    """1080p level 0 is above the size threshold: default == forced two-level, bit for bit; and both agree with the
+    one-level kernel."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    test, ref = synth_video_pair(3, 1080, 1920, device="cuda")
+    import fovvideovdp_amd as fv
+    monkeypatch.delenv("FVVDP_BAND_FUSE", raising=False)
+    qd, std = fv.fvvdp(display_name="standard_fhd").predict(test, ref, frames_per_second=30)
+    q1, Q1 = _run(monkeypatch, test, ref, 1, disp="standard_fhd", frames_per_second=30)
+    q0, Q0 = _run(monkeypatch, test, ref, 0, disp="standard_fhd", frames_per_second=30)
+    assert float(qd) == q1 or abs(float(qd) - q1) < 1e-6
+    assert abs(q1 - q0) < 2e-6
+    _close(Q1, Q0)
+    # default takes band2 for level 0+1 only; forced takes it for every pair: the first two bands are bit-identical
+    assert np.array_equal(std["Q_per_ch"][:2], Q1[:2].astype(np.float32))
