@@ -1,17 +1,22 @@
 #!/usr/bin/env python3
 """Benchmark of the FovVideoVDP hot path on MI355X.
 
-A "step" is one full pass of the hot path over one synthetic 3840x2160 x 60-frame video pair per GPU
-(BASELINE.json configs[2]: uint8 RGB, standard_4k, 30 fps -> 8-tap temporal filter, foveated off), inputs already
-resident in HBM: unpack + sRGB display model + luminance + temporal filtering + pyramid + CSF + masking + pooling
-+ pooling and JOD regression.  value = Mpixels/s (test+ref) = 2*W*H*N*steps*n_gpus / wall seconds.
+A "step" is one full pass of the hot path over `--pairs-per-gpu` (default 1) synthetic 3840x2160 x 60-frame video pairs
+per GPU (BASELINE.json configs[2]: uint8 RGB, standard_4k, 30 fps -> 8-tap temporal filter, foveated off; configs[4] is
+`--gpus 8 --pairs-per-gpu 8`), inputs already resident in HBM: unpack + sRGB display model + luminance + temporal
+filtering + pyramid + CSF + masking + pooling + JOD regression.  The pairs of a step are queued back to back without
+host synchronisation; with several ranks the per-frame results are combined by ONE all-reduce of the device buffer.
+value = Mpixels/s (test+ref) = 2*W*H*N*pairs*steps*n_gpus / wall seconds.
 
-  python bench.py [--gpus N --steps K --warmup W]           (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W --pairs-per-gpu P]       (N>1: launched by torch.distributed.run)
 
-One JSON line on rank 0; `roofline` is measured live with HIP events inside the library around the dominant
-kernel (fused pyramid level 0), `cpu_baseline` times the numpy oracle on a bounded sample of the same workload.
+One JSON line on rank 0.  `roofline`: the dominant kernel (two-level pyramid kernel, levels 0+1), timed per launch
+with HIP events inside the library on the kernels' stream (median/min/max over >= 10 launches); `graded_pass`: all
+pyramid levels + finalize against SURVEY 8(d)'s 221.2 MB per 4K frame; `cpu_baseline`: the numpy oracle on a bounded
+sample of the same workload; `value_h2d_inclusive`: the same call on pageable host arrays (never `value`).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -41,12 +46,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--pairs-per-gpu", type=int, default=1, help="independent pairs per rank and step (BASELINE configs[4]: 8)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--frames", type=int, default=60)
     ap.add_argument("--fps", type=int, default=30)
     ap.add_argument("--display", default="standard_4k")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the host-array (PCIe-inclusive) timing")
+    ap.add_argument("--timing-reps", type=int, default=12, help="launches of each kernel timed with HIP events")
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--cpu-procs", type=int, default=8, help="processes of the CPU baseline (1 = time the oracle in-process)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
@@ -72,20 +80,25 @@ def main():
     assert args.gpus == world, "--gpus must equal the number of launched ranks"
 
     import fovvideovdp_amd as fv
+    from fovvideovdp_amd import _native as nat
     from fovvideovdp_amd.synth import synth_video_pair
     from fovvideovdp_amd.sharding import gather_pair_results
 
-    W, H, N, fps = args.width, args.height, args.frames, args.fps
-    test, ref = synth_video_pair(N, H, W, device=dev, pair=rank)     # each rank owns its own pair (pair sharding)
+    W, H, N, fps, K = args.width, args.height, args.frames, args.fps, max(1, args.pairs_per_gpu)
+    # pair sharding: rank r owns pairs r*K .. r*K+K-1, generated on its own GPU (2 x 1.49 GB each at 4K x 60)
+    pairs = [synth_video_pair(N, H, W, device=dev, pair=rank * K + k) for k in range(K)]
     m = fv.fvvdp(display_name=args.display, device=dev)
 
     def step():
-        q, stats = m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
-        if world > 1:
-            # the one collective of the path: every rank's Q_per_ch lands in its own slot of a zero buffer
-            allq = gather_pair_results(torch.from_numpy(stats["Q_per_ch"]).to(dev), rank, world)
-            return m.do_pooling_and_jods(allq, None).tolist()        # all pairs pooled in one batched call
-        return [float(q)]
+        if world == 1 and K == 1:
+            q, _ = m.predict(pairs[0][0], pairs[0][1], dim_order="BCFHW", frames_per_second=fps)
+            return [float(q)]                                        # the reference's call, incl. its host sync
+        # several pairs / ranks: queue every pair without host synchronisation, then the one collective of the path
+        # (all-reduce of a zero buffer in which this rank filled its own slots), pooling of all pairs in one call,
+        # ONE device -> host copy
+        qs = [m.predict(t, r, dim_order="BCFHW", frames_per_second=fps, sync=False)[1]["Q_per_ch"] for (t, r) in pairs]
+        allq = gather_pair_results(torch.stack(qs), rank, world)
+        return m.do_pooling_and_jods(allq, None).tolist()
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -105,56 +118,89 @@ def main():
     if dist is not None:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
-    mpix = 2.0 * W * H * N * args.steps * world / dt / 1e6
+    mpix = 2.0 * W * H * N * K * args.steps * world / dt / 1e6
 
-    # ---- roofline of the dominant kernel (fused pyramid level 0), HIP events on the kernels' own stream ----
+    # ---- per-kernel timing: HIP events inside the library on the kernels' own stream, one reading per launch ----
     roof = None
     extra = {}
+    test, ref = pairs[0]
     if rank == 0:
-        from fovvideovdp_amd import _native as nat
-        import ctypes as C
-        nat.check(nat.lib().fvvdp_ctx_timing_enable(m._ctx.handle, 1))      # same context (same HBM scratch) as the timed steps
+        ctx = m._ctx                                  # same context (same HBM scratch) as the timed steps
+        nat.check(nat.lib().fvvdp_ctx_timing_enable(ctx.handle, 1))
         nk = 16 + 2
         ms = (C.c_float * nk)()
         cnt = (C.c_int32 * nk)()
-        reps = 5
-        nat.check(nat.lib().fvvdp_ctx_timing_read(m._ctx.handle, ms, cnt, nk, 1))
-        for _ in range(reps):
+        nat.check(nat.lib().fvvdp_ctx_timing_read(ctx.handle, ms, cnt, nk, 1))
+        n_bands, batch = ctx.key[2], ctx.key[4]
+        rows = []
+        for _ in range(max(10, args.timing_reps)):
             m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
-        nat.check(nat.lib().fvvdp_ctx_timing_read(m._ctx.handle, ms, cnt, nk, 1))
-        n_bands = m._ctx.key[2]
-        batch = m._ctx.key[4]
+            nat.check(nat.lib().fvvdp_ctx_timing_read(ctx.handle, ms, cnt, nk, 1))
+            rows.append([ms[i] for i in range(n_bands + 2)])          # ms per call: temporal, levels 0.., finalize
+        nat.check(nat.lib().fvvdp_ctx_timing_enable(ctx.handle, 0))
+        t = np.asarray(rows, dtype=np.float64) / N * 1e3              # us per frame
         sizes = level_sizes(W, H, n_bands)
         P = 4
-        # algorithmic bytes of one level-0 launch: read level 0 once, write level 1 once, all P planes fp32
-        launches0 = max(int(cnt[1]), 1)
-        frames_per_launch = N * reps / launches0
-        b0 = 4.0 * P * (sizes[0][0] * sizes[0][1] + sizes[1][0] * sizes[1][1]) * frames_per_launch
-        t0_ms = ms[1] / launches0
-        ach = b0 / (t0_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "band_kernel<4> level 0 (pyramid+CSF+masking+pooling)",
+        alg = [4.0 * P * (sizes[i][0] * sizes[i][1] + sizes[i + 1][0] * sizes[i + 1][1]) for i in range(n_bands)]   # bytes per frame
+        # dominant kernel: the launch recorded at level 0.  A launch that covers two levels (band2_kernel) reports 0 for
+        # the second one; its algorithmic bytes are SURVEY 8(d)'s per-level figure of BOTH levels (what a one-level-per-
+        # pass pyramid streams), although level 1 never leaves the chip -- `traffic` is what it really moves.
+        fused01 = n_bands > 1 and float(np.max(t[:, 2])) == 0.0
+        b0 = alg[0] + (alg[1] if fused01 else 0.0)
+        t0f = t[:, 1]
+        med0 = float(np.median(t0f))
+        ach = b0 / (med0 * 1e-6) / 1e9
+        frames_per_launch = min(N, batch)
+        roof = {"bound": "hbm",
+                "kernel": "band2_kernel<4> pyramid levels 0+1 (reduce x2, expand x2, contrast, CSF, masking, pooling)" if fused01
+                          else "band_kernel<4> level 0 (pyramid+CSF+masking+pooling)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
-                "traffic": None, "avg_launch_ms": round(t0_ms, 4), "bytes_per_launch": int(b0),
-                "frames_per_launch": frames_per_launch}
+                "traffic": None, "avg_launch_ms": round(float(np.mean(t0f)) * frames_per_launch * 1e-3, 4),
+                "median_launch_ms": round(med0 * frames_per_launch * 1e-3, 4),
+                "min_launch_ms": round(float(np.min(t0f)) * frames_per_launch * 1e-3, 4),
+                "max_launch_ms": round(float(np.max(t0f)) * frames_per_launch * 1e-3, 4), "launches_timed": len(rows),
+                "bytes_per_launch": int(b0 * frames_per_launch), "frames_per_launch": frames_per_launch,
+                "frac_at_min": round(b0 / (float(np.min(t0f)) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)}
         # HBM bytes per launch from the PMC counters cannot be collected from inside this process; they come from the
         # committed rocprofv3 --pmc passes of the same kernel and launch shape (tools/pmc_level0.py, profiles/)
-        pmc = sorted(f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("pmc_level0.json")) \
-            if os.path.isdir(os.path.join(ROOT, "profiles")) else []
+        pdir = os.path.join(ROOT, "profiles")
+        pmc = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_level0.json")) if os.path.isdir(pdir) else []
         if pmc and (W, H, int(frames_per_launch)) == (3840, 2160, 60):
-            with open(os.path.join(ROOT, "profiles", pmc[-1])) as f:
+            with open(os.path.join(pdir, pmc[-1])) as f:
                 pj = json.load(f)
-            roof["traffic"] = int(pj["traffic_bytes"])
-            roof["traffic_source"] = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % pmc[-1]
-        # graded pass = all band levels (B_alg of SURVEY section 8(d))
-        b_all = sum(4.0 * P * (sizes[i][0] * sizes[i][1] + sizes[i + 1][0] * sizes[i + 1][1]) for i in range(n_bands)) * N * reps
-        t_all = sum(ms[1 + i] for i in range(n_bands)) + ms[1 + n_bands]
-        extra["graded_pass"] = {"levels_ms_per_frame": [round(ms[1 + i] / (N * reps), 5) for i in range(n_bands)],
-                                "finalize_ms_per_frame": round(ms[1 + n_bands] / (N * reps), 5),
-                                "temporal_ms_per_frame": round(ms[0] / (N * reps), 5),
-                                "hbm_frac_all_levels": round(b_all / (t_all * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                "us_per_frame_all_levels": round(t_all * 1e3 / (N * reps), 2)}
+            if ("band2" in pj.get("kernel", "")) == fused01:
+                roof["traffic"] = int(pj["traffic_bytes"])
+                roof["traffic_source"] = "profiles/%s (FETCH_SIZE x2 + WRITE_SIZE, separate --pmc passes)" % pmc[-1]
+        # graded pass = all band levels + finalize (B_alg of SURVEY section 8(d): 221.2 MB per 4K frame)
+        tot = t[:, 1:].sum(axis=1)
+        b_all = float(sum(alg))
+        extra["graded_pass"] = {"levels_us_per_frame_median": [round(float(x), 2) for x in np.median(t[:, 1:n_bands + 1], axis=0)],
+                                "finalize_us_per_frame": round(float(np.median(t[:, n_bands + 1])), 2),
+                                "temporal_us_per_frame_median": round(float(np.median(t[:, 0])), 2),
+                                "us_per_frame_all_levels": round(float(np.median(tot)), 2),
+                                "us_per_frame_all_levels_min": round(float(np.min(tot)), 2),
+                                "us_per_frame_all_levels_max": round(float(np.max(tot)), 2),
+                                "algorithmic_bytes_per_frame": int(b_all),
+                                "hbm_frac_all_levels": round(b_all / (float(np.median(tot)) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                "hbm_frac_all_levels_at_min": round(b_all / (float(np.min(tot)) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                "calls_timed": len(rows)}
         extra["batch_frames"] = batch
-        nat.check(nat.lib().fvvdp_ctx_timing_enable(m._ctx.handle, 0))
+
+    # ---- the same call on pageable host arrays (PCIe-inclusive; reported beside `value`, never as `value`) ----
+    if rank == 0 and world == 1 and not args.no_h2d:
+        th, rh = test.cpu().numpy(), ref.cpu().numpy()
+        m.predict(th, rh, dim_order="BCFHW", frames_per_second=fps)
+        torch.cuda.synchronize(dev)
+        tb = []
+        for _ in range(2):
+            t1 = time.perf_counter()
+            m.predict(th, rh, dim_order="BCFHW", frames_per_second=fps)
+            torch.cuda.synchronize(dev)
+            tb.append(time.perf_counter() - t1)
+        extra["value_h2d_inclusive"] = round(2.0 * W * H * N / min(tb) / 1e6, 1)
+        extra["h2d_inclusive_note"] = "predict() on pageable numpy arrays (2 x %.2f GB uploaded per call), best of 2: %.1f ms" % (
+            th.nbytes / 1e9, min(tb) * 1e3)
+        del th, rh
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -190,22 +236,31 @@ def main():
                    "kind": "port", "sample": "%d output frames (frames %d..%d, incl. their %d-frame temporal window) of the same "
                    "%dx%d pair, numpy fp32 oracle, single thread; host has %d cores" % (nf, frames[0], frames[-1], fl, W, H, os.cpu_count())}
 
-    # second half of the metric: |JOD - JOD of the reference| for rank 0's pair, from the committed golden
+    # second half of the metric: |JOD - JOD of the reference| for rank 0's first pair, from the committed golden
     # (tests/golden/g3_synth_uhd_60f.npz = the reference's own torch-CPU run on this synthetic pair, tools/gen_golden.py g3)
     jod_delta = None
     gpath = os.path.join(ROOT, "tests", "golden", "g3_synth_uhd_60f.npz")
     if rank == 0 and (W, H, N, fps, args.display) == (3840, 2160, 60, 30, "standard_4k") and os.path.exists(gpath):
-        jod_delta = abs(float(jods[0]) - float(np.load(gpath)["jod"]))
+        g = np.load(gpath)
+        jod_delta = abs(float(jods[0]) - float(g["jod"]))
+        if cpu is not None and "seconds" in g.files:
+            # the real reference (PyTorch CPU, 8 threads) could only be timed in the build container (it cannot travel)
+            cpu["reference_torch_cpu_seconds_build_container"] = round(float(g["seconds"]), 1)
+            cpu["reference_torch_cpu_mpix_s_build_container"] = round(2.0 * W * H * N / float(g["seconds"]) / 1e6, 2)
 
     if rank == 0:
         out = {"metric": "Mpixels/s (test+ref) at 4Kx60f; JOD delta vs reference", "value": round(mpix, 1),
                "unit": "Mpixels/s (test+ref)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": "%dx%d x%d-frame synthetic uint8 RGB video pair per GPU, %s, %d fps, foveated=off "
-                                      "(BASELINE.json configs[2]); pairs sharded one per GPU" % (W, H, N, args.display, fps),
-                          "parallelism": "pair-sharded x%d, one all-reduce of Q_per_ch" % world},
-               "jod": [round(j, 6) for j in jods],
+               "config": {"workload": "%dx%d x%d-frame synthetic uint8 RGB video pair(s), %d per GPU and step, %s, %d fps, "
+                                      "foveated=off (BASELINE.json configs[2]%s)" % (
+                                          W, H, N, K, args.display, fps, "; configs[4]" if (world, K) == (8, 8) else ""),
+                          "pairs_per_gpu": K,
+                          "parallelism": "pair-sharded x%d, %d pair(s) per rank queued without host sync, one all-reduce of "
+                                         "Q_per_ch on the device" % (world, K)},
+               "ms_per_pair": round(dt / args.steps / K * 1e3, 3),
+               "jod": [round(j, 6) for j in jods[:8]],
                "jod_delta_vs_reference": None if jod_delta is None else float("%.3g" % jod_delta), "roofline": roof, "cpu_baseline": cpu}
         out.update(extra)
         print(json.dumps(out), flush=True)

@@ -115,8 +115,8 @@ class fvvdp:
         self.temp_padding = temp_padding
         self.use_checkpoints = use_checkpoints
         self.do_heatmap = (self.heatmap is not None) and (self.heatmap != "none")
-        if use_checkpoints:
-            raise RuntimeError("use_checkpoints (training of the metric) is not supported: the HIP path is forward-only")
+        # use_checkpoints only changes how the reference's autograd graph is stored (fvvdp.py:302-304); the HIP path is
+        # forward-only, so the flag is accepted and ignored; asking for gradients is what is refused (predict*)
         if device is None:
             device = torch.device('cuda:0') if (torch.cuda.is_available() and torch.cuda.device_count() > 0) else torch.device('cpu')
         self.device = torch.device(device)
@@ -181,24 +181,47 @@ class fvvdp:
         self._lut_dev.clear()
 
     # ---- public prediction API ------------------------------------------------------------------------------
-    def predict(self, test_cont, reference_cont, dim_order="BCFHW", frames_per_second=0, fixation_point=None):
+    def predict(self, test_cont, reference_cont, dim_order="BCFHW", frames_per_second=0, fixation_point=None, sync=True):
         vs = fvvdp_video_source_array(test_cont, reference_cont, frames_per_second, dim_order=dim_order,
                                       display_photometry=self.display_photometry, color_space_name=self.color_space)
-        return self.predict_video_source(vs, fixation_point=fixation_point)
+        return self.predict_video_source(vs, fixation_point=fixation_point, sync=sync)
 
-    def predict_video_source(self, vid_source, fixation_point=None, frame_range=None, pool=True):
+    def predict_video_source(self, vid_source, fixation_point=None, frame_range=None, pool=True, sync=True):
         """Returns (Q_JOD 0-d tensor on the compute device, stats dict).
 
-        `frame_range=(f0, f1)` (extension used for frame sharding across GPUs) evaluates only output frames
-        [f0, f1); the temporal window of frame f0 is still filled from the frames before it.  With `pool=False`
-        the JOD regression is skipped and Q_JOD is None (the caller pools after combining shards).
+        Extensions (not in the reference):
+        `frame_range=(f0, f1)` (frame sharding across GPUs) evaluates only output frames [f0, f1); the temporal
+        window of frame f0 is still filled from the frames before it.  With `pool=False` the JOD regression is skipped
+        and Q_JOD is None (the caller pools after combining shards).
+        `sync=False` queues the whole call on the current stream and returns without waiting for the GPU:
+        `stats['Q_per_ch']` is then a DEVICE tensor [bands, 2, frames] (not numpy) and the out-of-range flag is left in
+        `stats['range_flag']` (int32 device tensor; `fvvdp.finish(stats)` converts both and emits the warning).  Many
+        pairs can be queued back to back this way (one per call); the context's scratch is reused in stream order.
         """
         if self.device.type != "cuda":
             raise RuntimeError("fovvideovdp_amd needs an AMD GPU (torch device 'cuda'); there is no CPU fallback")
+        for name in ("test_video", "reference_video"):
+            t = getattr(vid_source, name, None)
+            if isinstance(t, torch.Tensor) and t.requires_grad and torch.is_grad_enabled():
+                raise RuntimeError("Gradients through the metric are not supported on the HIP path (forward-only kernels); "
+                                   "detach the inputs or wrap the call in torch.no_grad()")
         with torch.cuda.device(self.device):       # the library launches on the calling thread's current device
-            return self._predict_on_device(vid_source, fixation_point, frame_range, pool)
+            return self._predict_on_device(vid_source, fixation_point, frame_range, pool, sync)
 
-    def _predict_on_device(self, vid_source, fixation_point, frame_range, pool):
+    @staticmethod
+    def finish(stats):
+        """Completes a `sync=False` result in place: device -> host copy of Q_per_ch (one synchronisation) and the
+        reference's out-of-range warning."""
+        if isinstance(stats.get('Q_per_ch'), torch.Tensor):
+            flag = stats.pop('range_flag', None)
+            q = stats['Q_per_ch']
+            both = torch.cat([q.reshape(-1), flag.view(torch.float32)]).cpu() if flag is not None else q.reshape(-1).cpu()
+            stats['Q_per_ch'] = both[:q.numel()].view(q.shape).numpy()
+            if flag is not None and int(both[q.numel():].view(torch.int32)[0]) != 0:
+                logging.warning("Pixel outside the valid range 0-1")
+        return stats
+
+    def _predict_on_device(self, vid_source, fixation_point, frame_range, pool, sync=True):
         height, width, N_frames = vid_source.get_video_size()
         f0, f1 = (0, N_frames) if frame_range is None else frame_range
         if not (0 <= f0 < f1 <= N_frames):
@@ -277,10 +300,16 @@ class fvvdp:
                                                C.c_void_p(res[nq + 1:].data_ptr()), stream))
             Q_jod = res[nq + 1]
         stats = {}
-        res_h = res.detach().cpu()                           # the one host synchronisation of the call
-        if self.do_heatmap and self._copy_stream is not None:
-            self._copy_stream.synchronize()                  # ... plus the side stream that carries the maps
-        stats['Q_per_ch'] = res_h[:nq].view(n_bands, 2, n_out).numpy()
+        if sync:
+            res_h = res.detach().cpu()                       # the one host synchronisation of the call
+            if self.do_heatmap and self._copy_stream is not None:
+                self._copy_stream.synchronize()              # ... plus the side stream that carries the maps
+            stats['Q_per_ch'] = res_h[:nq].view(n_bands, 2, n_out).numpy()
+        else:
+            if self.do_heatmap:
+                raise RuntimeError("sync=False is not available together with heat-map output")
+            stats['Q_per_ch'] = Q
+            stats['range_flag'] = oob
         stats['rho_band'] = rho_band
         stats['frames_per_second'] = vid_source.get_frames_per_second()
         stats['width'] = width
@@ -288,7 +317,7 @@ class fvvdp:
         stats['N_frames'] = N_frames
         if self.do_heatmap:
             stats['heatmap'] = heatmap
-        if int(res_h[nq:nq + 1].view(torch.int32)[0]) != 0:
+        if sync and int(res_h[nq:nq + 1].view(torch.int32)[0]) != 0:
             logging.warning("Pixel outside the valid range 0-1")
         return (Q_jod, stats)
 

@@ -49,18 +49,34 @@ def frame_sharded_q(compute_range, n_bands, n_frames, rank, world, device, group
 
 
 def predict_frame_sharded(metric, vid_source, rank, world, fixation_point=None, group=None):
-    """Frame-sharded `fvvdp.predict_video_source`: every rank returns the same (Q_JOD, stats)."""
+    """Frame-sharded `fvvdp.predict_video_source`: every rank returns the same (Q_JOD, stats).  This rank's frames
+    are queued without a host synchronisation; their per-frame results go from the kernels' output buffer straight into
+    this rank's slots of the all-reduce buffer on the device."""
     H, W, N = vid_source.get_video_size()
     holder = {}
 
     def compute(f0, f1):
-        _, stats = metric.predict_video_source(vid_source, fixation_point=fixation_point, frame_range=(f0, f1), pool=False)
+        _, stats = metric.predict_video_source(vid_source, fixation_point=fixation_point, frame_range=(f0, f1), pool=False,
+                                               sync=False)
         holder["stats"] = stats
-        return torch.from_numpy(stats["Q_per_ch"])
+        return stats["Q_per_ch"]
 
     from .fvvdp import band_frequencies
-    n_bands, _ = band_frequencies(W, H, metric.pix_per_deg)
+    n_bands, rho_band = band_frequencies(W, H, metric.pix_per_deg)
     Q = frame_sharded_q(compute, n_bands, N, rank, world, metric.device, group)
-    stats = holder.get("stats", {})
+    stats = holder.get("stats")
+    if stats is None:                       # more ranks than frames: this rank computed nothing
+        stats = {"rho_band": rho_band, "frames_per_second": vid_source.get_frames_per_second(), "width": W, "height": H,
+                 "N_frames": N}
+    flag = stats.pop("range_flag", None)
+    if flag is not None:                    # any rank saw an out-of-range pixel -> every rank warns, like the unsharded call
+        flag = flag.clone()
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    jod = metric.do_pooling_and_jods(Q, None)
     stats["Q_per_ch"] = Q.cpu().numpy()
-    return metric.do_pooling_and_jods(Q, None), stats
+    if flag is not None and int(flag.cpu()[0]) != 0:
+        import logging
+        logging.warning("Pixel outside the valid range 0-1")
+    return jod, stats

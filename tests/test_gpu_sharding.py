@@ -1,0 +1,111 @@
+"""GPU: the multi-rank path with the HIP metric.  Two `gloo` ranks share the one GPU of the test box (the same code
+runs with backend nccl = RCCL, one rank per GPU, under bench.py --gpus N): frame sharding through
+`predict_frame_sharded`, pair sharding with several pairs per rank queued without host synchronisation
+(`predict(..., sync=False)` -> device Q_per_ch -> `gather_pair_results`), both bit-equal to the unsharded calls."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N, H, W, FPS = 11, 72, 130, 30
+PAIRS_PER_RANK = 3
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fovvideovdp_amd as fv
+        from fovvideovdp_amd.sharding import gather_pair_results, predict_frame_sharded
+        from fovvideovdp_amd.synth import synth_video_pair
+        dev = torch.device("cuda", 0)
+        m = fv.fvvdp(display_name="standard_fhd", device=dev)
+        test, ref = synth_video_pair(N, H, W, device=dev)
+        vs = fv.fvvdp_video_source_array(test, ref, FPS, display_photometry=m.display_photometry)
+        jod, st = predict_frame_sharded(m, vs, rank, world)
+        # pair sharding, PAIRS_PER_RANK pairs per rank, no host synchronisation between the pairs
+        qs = []
+        for k in range(PAIRS_PER_RANK):
+            tp, rp = synth_video_pair(N, H, W, device=dev, pair=rank * PAIRS_PER_RANK + k)
+            _, s = m.predict(tp, rp, frames_per_second=FPS, sync=False)
+            assert isinstance(s["Q_per_ch"], torch.Tensor) and s["Q_per_ch"].is_cuda
+            qs.append(s["Q_per_ch"])
+        allq = gather_pair_results(torch.stack(qs), rank, world)
+        jods = m.do_pooling_and_jods(allq, None)
+        np.savez(os.path.join(out_dir, f"rank{rank}.npz"), jod=float(jod), Q=st["Q_per_ch"], allq=allq.cpu().numpy(),
+                 jods=jods.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_share_the_gpu(tmp_path):
+    import torch.multiprocessing as mp
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), f"rank{k}.npz")) for k in range(world)]
+    m = fv.fvvdp(display_name="standard_fhd")
+    test, ref = synth_video_pair(N, H, W, device="cuda")
+    q, st = m.predict(test, ref, frames_per_second=FPS)
+    for k in range(world):
+        assert np.array_equal(res[k]["Q"], st["Q_per_ch"])            # frame-sharded == unsharded, bit for bit
+        assert abs(float(res[k]["jod"]) - float(q)) < 2e-6
+    assert np.array_equal(res[0]["allq"], res[1]["allq"]) and np.array_equal(res[0]["jods"], res[1]["jods"])
+    assert res[0]["allq"].shape[0] == world * PAIRS_PER_RANK
+    for p in range(world * PAIRS_PER_RANK):
+        tp, rp = synth_video_pair(N, H, W, device="cuda", pair=p)
+        qp, sp = m.predict(tp, rp, frames_per_second=FPS)
+        assert np.array_equal(res[0]["allq"][p], sp["Q_per_ch"])
+        assert abs(float(res[0]["jods"][p]) - float(qp)) < 2e-6
+
+
+def test_sync_false_and_finish(caplog):
+    import logging
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair
+    m = fv.fvvdp(display_name="standard_fhd")
+    test, ref = synth_video_pair(6, 64, 96, device="cuda")
+    q0, st0 = m.predict(test, ref, frames_per_second=FPS)
+    q1, st1 = m.predict(test, ref, frames_per_second=FPS, sync=False)
+    assert st1["Q_per_ch"].is_cuda and "range_flag" in st1
+    fv.fvvdp.finish(st1)
+    assert isinstance(st1["Q_per_ch"], np.ndarray) and np.array_equal(st1["Q_per_ch"], st0["Q_per_ch"])
+    assert float(q1) == float(q0)
+    # the deferred out-of-range warning
+    t = test.to(torch.float32) / 255 * 1.5
+    with caplog.at_level(logging.WARNING):
+        _, st2 = m.predict(t, ref.to(torch.float32) / 255, frames_per_second=FPS, sync=False)
+        assert not any("outside the valid range" in r.message for r in caplog.records)
+        fv.fvvdp.finish(st2)
+    assert any("outside the valid range" in r.message for r in caplog.records)
+
+
+def test_use_checkpoints_flag_is_accepted_and_gradients_are_refused():
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair
+    m = fv.fvvdp(display_name="standard_fhd", use_checkpoints=True)
+    test, ref = synth_video_pair(3, 40, 64, device="cuda")
+    q, _ = m.predict(test, ref, frames_per_second=FPS)
+    q2, _ = fv.fvvdp(display_name="standard_fhd").predict(test, ref, frames_per_second=FPS)
+    assert float(q) == float(q2)
+    t = (test.to(torch.float32) / 255).requires_grad_(True)
+    with pytest.raises(RuntimeError, match="[Gg]radients"):
+        m.predict(t, ref.to(torch.float32) / 255, frames_per_second=FPS)
+    with torch.no_grad():
+        m.predict(t, ref.to(torch.float32) / 255, frames_per_second=FPS)
