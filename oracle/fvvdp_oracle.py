@@ -190,8 +190,20 @@ class Geometry:
         vy = np.rad2deg(np.arctan(y_m / _F(self.distance_m))).astype(_F)
         return vx, vy
 
+    exact_geometry = False     # checker switch, see resolution_magnification
+
     def resolution_magnification(self, vx, vy):
-        """get_ppd(view_dir)/get_ppd()  :475-488, :512-526"""
+        """get_ppd(view_dir)/get_ppd()  :475-488, :512-526
+
+        The reference evaluates [tan(a+d) - tan(a)] / tan(d) in fp32 with d = 0.0066 deg: a difference of nearly equal
+        numbers that carries ~2.5e-4 relative rounding noise (ulp(tan a) / (tan(a+d) - tan a)).  `exact_geometry = True`
+        (tests only) evaluates the same expression in fp64 -- the value the fp32 expression scatters around -- so that
+        an implementation that does not reproduce the reference's rounding noise bit for bit can still be pinned
+        tightly."""
+        if self.exact_geometry:
+            va64 = np.minimum(np.sqrt(vx.astype(np.float64) ** 2 + vy.astype(np.float64) ** 2), 89.9)
+            d64 = (1 / self.ppd_centre) / 2
+            return ((np.tan(np.deg2rad(va64 + d64)) - np.tan(np.deg2rad(va64))) / math.tan(math.radians(d64))).astype(_F)
         va = np.sqrt(vx * vx + vy * vy).astype(_F)
         va = np.minimum(va, _F(89.9))
         delta = (1 / self.ppd_centre) / 2

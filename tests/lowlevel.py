@@ -1,16 +1,16 @@
-"""Thin object wrapper over the C ABI for callers that drive the stages themselves (parity tests, benchmark).
+"""Test helper (not part of the product): thin object wrapper over the C ABI for tests that drive the stages themselves.
 All tensors are torch CUDA tensors; work is enqueued on torch's current stream."""
 import ctypes as C
 
 import numpy as np
 import torch
 
-from . import _native as nat
+from fovvideovdp_amd import _native as nat
 
 
 class Pipeline:
     def __init__(self, metric, width, height, planes, max_frames, foveated=False):
-        from .fvvdp import band_frequencies
+        from fovvideovdp_amd.fvvdp import band_frequencies
         self.m = metric
         self.W, self.H, self.P, self.max_frames = width, height, planes, max_frames
         self.n_bands, self.rho_band = band_frequencies(width, height, metric.pix_per_deg)

@@ -1,7 +1,10 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI
 (libfvvdp_hip.so) and through the reference-shaped Python API, against (a) golden vectors captured from the real
-reference and (b) the CPU oracle on the same seeded inputs.  Tolerances as in tests/test_oracle_golden.py
-(fp32 rounding noise of this algorithm); JOD within 1e-3 (north-star bound), in practice ~1e-5."""
+reference and (b) the CPU oracle on the same seeded inputs.
+
+Tolerances are <= 3x the errors measured on MI355X (tools/gpu_parity_report.py -> profiles/r02_parity.md, quoted next to
+each bound); they are fp32 rounding noise of this algorithm (the contrast is a difference of nearly equal numbers and
+D ~ contrast^2.4).  JOD: north-star bound 1e-3, measured <= 7e-6 against the reference."""
 import os
 
 import numpy as np
@@ -26,7 +29,10 @@ def fv():
     return fovvideovdp_amd
 
 
-def check_q(q, gq, coarse=1e-3, fine=1e-4):
+def check_q(q, gq, coarse=1e-3, fine=1.5e-4):
+    """Q_per_ch against a golden / the oracle.  End to end from 8-bit input, measured: finest three bands <= 4.9e-5,
+    coarse bands (8x15 pixels at the small golden sizes) <= 8.6e-4.  Stage 2 alone (from the reference's own R) is checked
+    with coarse=4e-4, fine=5e-5 (measured 1.3e-4 / 1.6e-5)."""
     q, gq = np.asarray(q, np.float64), np.asarray(gq, np.float64)
     assert q.shape == gq.shape
     assert np.all(np.abs(q - gq) <= coarse * np.abs(gq) + 1e-6 * np.max(np.abs(gq))), np.max(np.abs(q - gq) / (np.abs(gq) + 1e-6 * np.max(np.abs(gq))))
@@ -51,8 +57,8 @@ def test_readme_known_answer(fv):
     q, stats = m.predict(test, ref, dim_order="HWC")
     assert q.device.type == "cuda" and q.dim() == 0
     assert abs(float(q) - 8.693) < 1e-3
-    assert abs(float(q) - float(z["jod"])) < 1e-4
-    check_q(stats["Q_per_ch"][:, 0:1, :], z["Q_per_ch"][:, 0:1, :])
+    assert abs(float(q) - float(z["jod"])) < 2e-5                                                   # measured 4.8e-6
+    check_q(stats["Q_per_ch"][:, 0:1, :], z["Q_per_ch"][:, 0:1, :], coarse=7e-5, fine=7e-5)         # measured 2.2e-5
     assert np.all(stats["Q_per_ch"][:, 1, :] == 0)
     assert np.allclose(stats["rho_band"], z["rho_band"], rtol=1e-12)
     assert stats["width"] == 1024 and stats["height"] == 683 and stats["N_frames"] == 1
@@ -64,8 +70,8 @@ def test_config1_crop512(fv):
     ref = z0["ref_u16"][85:597, 256:768]
     m = fv.fvvdp(display_name="standard_fhd")
     q, stats = m.predict(z["test_u16"], ref, dim_order="HWC")
-    assert abs(float(q) - float(z["jod"])) < 1e-4
-    check_q(stats["Q_per_ch"][:, 0:1, :], z["Q_per_ch"][:, 0:1, :])
+    assert abs(float(q) - float(z["jod"])) < 2e-5                                                   # measured 7.2e-6
+    check_q(stats["Q_per_ch"][:, 0:1, :], z["Q_per_ch"][:, 0:1, :], coarse=4e-5, fine=4e-5)         # measured 1.1e-5
 
 
 def stage_check(maps, exported, z, frames, n_bands, P):
@@ -77,34 +83,37 @@ def stage_check(maps, exported, z, frames, n_bands, P):
             if key in z.files:
                 gb = z[key] * (1.0 if b == 0 else 2.0)          # kernel output already holds the band multiplier
                 hb = maps[b]["contrast"][fi].cpu().numpy()
-                assert np.max(np.abs(hb - gb)) < 2e-5 * max(float(np.max(np.abs(gb))), 1e-3), key
+                assert np.max(np.abs(hb - gb)) < 4e-6 * max(float(np.max(np.abs(gb))), 1e-3), key      # measured 1.1e-6
             key = f"lbkg_f{ff}_b{b}"
             if key in z.files:
                 gl, hl = z[key], maps[b]["lbkg"][fi].cpu().numpy()
-                assert np.max(np.abs(hl - gl) / gl) < 5e-6, key
+                assert np.max(np.abs(hl - gl) / gl) < 1e-6, key                                    # measured 3.2e-7
             for cc in range(TC):
                 i = cc * n_bands + b
                 key = f"S_f{ff}_i{i}"
                 if key in z.files:
                     gs, hs = z[key], maps[b]["S"][fi, cc].cpu().numpy()
-                    assert np.max(np.abs(hs - gs) / gs) < 2e-5, key
+                    assert np.max(np.abs(hs - gs) / gs) < 3e-6, key                                # measured 7.7e-7
                 key = f"D_f{ff}_i{i}"
                 if key in z.files:
                     gd, hd = z[key].astype(np.float64), maps[b]["D"][fi, cc].cpu().numpy().astype(np.float64)
-                    assert np.max(np.abs(hd - gd) / (np.abs(gd) + 1e-3 * np.max(gd) + 1e-12)) < 2e-2, key
-                    assert abs(hd.sum() / gd.sum() - 1) < (2e-4 if gd.size >= 4096 else 2e-3), key
+                    rel = np.abs(hd - gd) / (np.abs(gd) + 1e-3 * np.max(gd) + 1e-12)
+                    # measured: max 8.7e-3 (single pixels whose contrast is ~1 ulp of the Gaussian levels), mean per map
+                    # <= 1.3e-4 (a 9x16-pixel coarse band; 3.8e-5 on average)
+                    assert np.max(rel) < 2e-2 and np.mean(rel) < 4e-4, key
+                    assert abs(hd.sum() / gd.sum() - 1) < (6e-5 if gd.size >= 4096 else 4e-4), key  # measured 2.0e-5 / 1.3e-4
         # Gaussian base band = last golden 'band'
         key = f"band_f{ff}_b{n_bands}"
         if key in z.files:
             gb, hb = z[key], exported[fi].cpu().numpy()
-            assert np.max(np.abs(hb - gb)) < 3e-6 * np.max(np.abs(gb)), key
+            assert np.max(np.abs(hb - gb)) < 5e-7 * np.max(np.abs(gb)), key                        # measured 1.6e-7
 
 
 @pytest.mark.parametrize("H,W,N,fps", [(135, 240, 10, 30), (68, 121, 12, 60)])
 def test_stages_from_golden_R(fv, H, W, N, fps):
     """C ABI, stage 2 only: feed the reference's own temporal channels R (golden) and compare every stage:
     contrast bands, L_bkg, S, D and the base Gaussian level (both reduce-quirk parities are covered)."""
-    from fovvideovdp_amd.lowlevel import Pipeline
+    from lowlevel import Pipeline
     z = load(f"g2_video_{H}x{W}_replicate")
     frames = (0, 1, N - 1)
     m = fv.fvvdp(display_name="standard_fhd")
@@ -116,12 +125,12 @@ def test_stages_from_golden_R(fv, H, W, N, fps):
     torch.cuda.synchronize()
     assert pipe.n_bands == z["Q_per_ch"].shape[0]
     stage_check(maps, base, z, frames, pipe.n_bands, 4)
-    check_q(Q.cpu().numpy(), z["Q_per_ch"][:, :, list(frames)])
+    check_q(Q.cpu().numpy(), z["Q_per_ch"][:, :, list(frames)], coarse=4e-4, fine=5e-5)
     # run-to-run determinism of the two-stage pooled reduction
     Q2 = pipe.bands_forward(len(frames))
     Q3 = pipe.bands_forward(len(frames))
     assert torch.equal(Q2, Q3)
-    check_q(Q2.cpu().numpy(), z["Q_per_ch"][:, :, list(frames)])
+    check_q(Q2.cpu().numpy(), z["Q_per_ch"][:, :, list(frames)], coarse=4e-4, fine=5e-5)
 
 
 @pytest.mark.parametrize("H,W,N,fps", [(135, 240, 10, 30), (68, 121, 12, 60)])
@@ -133,7 +142,7 @@ def test_video_end_to_end_golden(fv, H, W, N, fps, pad):
     m = fv.fvvdp(display_name="standard_fhd", temp_padding=pad)
     q, stats = m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
     assert np.max(np.abs(m.F.numpy() - z["F"])) < 2e-6 * np.max(np.abs(z["F"]))
-    assert abs(float(q) - float(z["jod"])) < 1e-4, pad
+    assert abs(float(q) - float(z["jod"])) < 5e-6, pad                     # measured 0 (same fp32 value)
     check_q(stats["Q_per_ch"], z["Q_per_ch"])
     # frame batching and device-resident input must not change anything
     m2 = fv.fvvdp(display_name="standard_fhd", temp_padding=pad, batch_frames=3)
@@ -144,7 +153,7 @@ def test_video_end_to_end_golden(fv, H, W, N, fps, pad):
 
 def test_temporal_channels_vs_golden_R(fv):
     """C ABI, stage 1: unpack + sRGB LUT + luminance + FIR against the reference's R, ring and generic kernels."""
-    from fovvideovdp_amd.lowlevel import Pipeline
+    from lowlevel import Pipeline
     from fovvideovdp_amd import _native as nat
     from fovvideovdp_amd.synth import synth_video_pair
     from fovvideovdp_amd.fvvdp import window_frame_indices
@@ -165,7 +174,7 @@ def test_temporal_channels_vs_golden_R(fv):
         R = pipe.export_level(0, N).cpu().numpy()
         for ff in (0, 1, N - 1):
             g = z[f"R_f{ff}"]
-            assert np.max(np.abs(R[ff] - g)) < 2e-6 * np.max(np.abs(g)), (H, W, ff)
+            assert np.max(np.abs(R[ff] - g)) < 2e-6 * np.max(np.abs(g)), (H, W, ff)     # summation order of the 8 / 15 taps
 
 
 def test_f32_gray_and_u16_inputs(fv):
@@ -285,7 +294,7 @@ def test_oracle_random_sizes(fv):
 def test_foveated_pq_golden(fv):
     """Foveated mode with moving gaze on an HDR PQ display (BASELINE config 4 at small size) against the reference:
     end to end through predict(), and per-stage (S, D) through the C ABI from the reference's own R."""
-    from fovvideovdp_amd.lowlevel import Pipeline
+    from lowlevel import Pipeline
     from fovvideovdp_amd.synth import synth_video_pair, synth_gaze
     z = load("g4_foveated_135x240")
     N, H, W = 6, 135, 240
@@ -293,9 +302,22 @@ def test_foveated_pq_golden(fv):
     gaze = synth_gaze(N, H, W)
     m = fv.fvvdp(display_name="standard_hdr_pq", foveated=True)
     q, stats = m.predict(test, ref, frames_per_second=30, fixation_point=gaze.numpy())
-    assert abs(float(q) - float(z["jod"])) < 2e-4
+    assert abs(float(q) - float(z["jod"])) < 1e-4                            # measured 3.6e-5
     qq, gq = stats["Q_per_ch"].astype(np.float64), z["Q_per_ch"].astype(np.float64)
-    assert np.all(np.abs(qq - gq) <= 3e-3 * np.abs(gq) + 1e-6 * np.max(gq)), np.max(np.abs(qq - gq) / (np.abs(gq) + 1e-6 * np.max(gq)))
+    assert np.all(np.abs(qq - gq) <= 3e-3 * np.abs(gq) + 1e-6 * np.max(gq)), np.max(np.abs(qq - gq) / (np.abs(gq) + 1e-6 * np.max(gq)))   # measured 1.75e-3
+    # The spread against the reference is the REFERENCE's rounding noise: its resolution magnification is a finite
+    # difference of fp32 tangents (fvvdp_display_model.py:475-488), ~2.5e-4 relative noise on rho, up to 1e-2 on S where
+    # the CSF is steep.  Evidence, each asserted below: (1) the reference's own S differs from the same formula evaluated
+    # with fp64 geometry by as much as it differs from the kernel (1.08e-2 vs 1.07e-2); (2) the kernel (closed form
+    # cos(d)/(cos(a)cos(a+d)), no cancellation) agrees with the fp64-geometry oracle ~10x better, end to end 1.3e-4 on
+    # Q_per_ch and 2e-6 on JOD.
+    from oracle import fvvdp_oracle as orc
+    oe = orc.Oracle("standard_hdr_pq", foveated=True)
+    oe.geometry.exact_geometry = True
+    oq, ost = oe.predict(test.numpy(), ref.numpy(), frames_per_second=30, fixation_point=gaze.numpy())
+    assert abs(float(q) - float(oq)) < 1e-5                                  # measured 1.9e-6
+    eq = ost["Q_per_ch"].astype(np.float64)
+    assert np.all(np.abs(qq - eq) <= 4e-4 * np.abs(eq) + 1e-6 * np.max(eq)), np.max(np.abs(qq - eq) / (np.abs(eq) + 1e-6 * np.max(eq)))   # measured 1.3e-4
     frames = (0, N - 1)
     pipe = Pipeline(m, W, H, 4, len(frames), foveated=True)
     R = torch.tensor(np.stack([z[f"R_f{ff}"] for ff in frames], 0), device=m.device)
@@ -303,20 +325,29 @@ def test_foveated_pq_golden(fv):
     Q, maps = pipe.bands_forward(len(frames), want_maps=True, fixation=gaze.numpy()[list(frames)])
     torch.cuda.synchronize()
     nb = pipe.n_bands
+    rho_band = orc.band_frequencies(W, H, oe.ppd)[1]
+    worst_ref_vs_exact = 0.0
     for fi, ff in enumerate(frames):
+        oe.capture = {}
+        oe.process_frame(ff, z[f"R_f{ff}"], nb, rho_band, 2, gaze.numpy(), (H, W))
         for b in range(nb):
             gl, hl = z[f"lbkg_f{ff}_b{b}"], maps[b]["lbkg"][fi].cpu().numpy()
-            assert np.max(np.abs(hl - gl) / gl) < 5e-6
+            assert np.max(np.abs(hl - gl) / gl) < 1e-6                       # measured 2.8e-7
             for cc in range(2):
                 i = cc * nb + b
                 gs, hs = z[f"S_f{ff}_i{i}"], maps[b]["S"][fi, cc].cpu().numpy()
-                # rho = rho_band*[tan(a+d)-tan(a)]/tan(d) is a finite difference of fp32 tans in the reference: ~5e-4 noise
-                rel = np.abs(hs - gs) / gs       # amplified where the CSF is steep (finest band), zero-mean
-                assert np.max(rel) < 3e-2 and np.mean(rel) < 1e-3, (ff, b, cc, float(np.max(rel)), float(np.mean(rel)))
+                rel = np.abs(hs - gs) / gs       # vs the reference: its tangent-difference noise, zero-mean
+                assert np.max(rel) < 3e-2 and np.mean(rel) < 1.5e-3, (ff, b, cc, float(np.max(rel)), float(np.mean(rel)))   # measured 1.07e-2 / 9.5e-4 (worst band)
+                es = oe.capture["S"][i]           # same formula, fp64 geometry
+                rex = np.abs(hs - es) / es
+                # max: the one pixel under the gaze, where sqrt(ecc) amplifies a 1e-6 deg rounding difference of ecc
+                assert np.max(rex) < 4e-3 and np.mean(rex) < 3e-5, (ff, b, cc, float(np.max(rex)), float(np.mean(rex)))   # measured 1.3e-3 max
+                worst_ref_vs_exact = max(worst_ref_vs_exact, float(np.max(np.abs(gs - es) / es)))
                 gd, hd = z[f"D_f{ff}_i{i}"].astype(np.float64), maps[b]["D"][fi, cc].cpu().numpy().astype(np.float64)
-                # D ~ S^2.4 and, on this dark HDR content, a band's sum can hang on a few pixels: the rho noise above
-                # shows up as up to ~1e-2 on the finest band's sum
-                assert abs(hd.sum() / gd.sum() - 1) < 3e-2, (ff, b, cc)
+                # D ~ S^2.4 and, on this dark HDR content, a band's sum can hang on a few pixels: the reference's rho noise
+                # shows up as up to 7.5e-3 on the finest band's sum
+                assert abs(hd.sum() / gd.sum() - 1) < 2e-2, (ff, b, cc)
+    assert worst_ref_vs_exact > 3e-3          # (1): the reference itself is this far from its own formula in fp64 (measured 1.08e-2)
     # fixed gaze given as [x, y] and the default (centre) gaze
     q1, _ = m.predict(test, ref, frames_per_second=30, fixation_point=np.array([W // 2, H // 2]))
     q2, _ = m.predict(test, ref, frames_per_second=30)
@@ -393,8 +424,9 @@ def test_full_size_synthetic_video_golden(fv, tag, H, W, disp):
     test, ref = synth_video_pair(60, H, W, device="cuda")
     m = fv.fvvdp(display_name=disp)
     q, stats = m.predict(test, ref, frames_per_second=30)
-    assert abs(float(q) - float(z["jod"])) < 1e-4            # north-star bound: 1e-3
-    check_q(stats["Q_per_ch"], z["Q_per_ch"])
+    assert abs(float(q) - float(z["jod"])) < 5e-6            # north-star bound: 1e-3; measured 9.5e-7
+    tol = 4e-4 if tag == "fhd" else 1.5e-3                   # measured 1.2e-4 / 4.9e-4 (worst element: a transient-channel entry)
+    check_q(stats["Q_per_ch"], z["Q_per_ch"], coarse=tol, fine=tol)
     # frame batching at full size: two batches of 30.  The work split of the pooled sums depends on the number of
     # frames per launch, so the fp32 partial sums are grouped differently: equal to rounding, not bit-equal.
     m2 = fv.fvvdp(display_name=disp, batch_frames=30)
@@ -413,9 +445,9 @@ def test_config4_foveated_uhd_golden(fv):
     assert np.array_equal(gaze.numpy(), z["gaze"])
     m = fv.fvvdp(display_name="standard_hdr_pq", foveated=True)
     q, stats = m.predict(test, ref, frames_per_second=30, fixation_point=gaze.numpy())
-    assert abs(float(q) - float(z["jod"])) < 2e-4
+    assert abs(float(q) - float(z["jod"])) < 4e-5                            # measured 1.2e-5
     qq, gq = stats["Q_per_ch"].astype(np.float64), z["Q_per_ch"].astype(np.float64)
-    assert np.all(np.abs(qq - gq) <= 3e-3 * np.abs(gq) + 1e-6 * np.max(gq))
+    assert np.all(np.abs(qq - gq) <= 2e-3 * np.abs(gq) + 1e-6 * np.max(gq))   # measured 7.1e-4 (the reference's rho noise, see test_foveated_pq_golden)
 
 
 def test_custom_geometry_subclass_foveated(fv):

@@ -36,10 +36,10 @@ def test_image_sizes_vs_oracle(H, W):
             m.predict(test, ref, dim_order="HW")
         return
     q, st = m.predict(test, ref, dim_order="HW")
-    assert abs(float(q) - float(oq)) < 2e-4, (H, W, float(q), float(oq))
+    assert abs(float(q) - float(oq)) < 5e-6, (H, W, float(q), float(oq))            # measured <= 9.5e-7 over the sweep
     a, b = st["Q_per_ch"][:, 0, 0].astype(np.float64), ost["Q_per_ch"][:, 0, 0].astype(np.float64)
     assert a.shape == b.shape
-    assert np.all(np.abs(a - b) <= 5e-3 * np.abs(b) + 1e-5 * np.max(b)), (H, W, a, b)
+    assert np.all(np.abs(a - b) <= 3.5e-4 * np.abs(b) + 1e-5 * np.max(b)), (H, W, a, b)   # measured <= 1.14e-4
 
 
 @pytest.mark.parametrize("H,W", [(17, 123), (36, 246), (66, 487), (40, 1000)])
@@ -53,9 +53,9 @@ def test_video_sizes_vs_oracle(H, W):
     m = fv.fvvdp(display_name="standard_fhd")
     q, st = m.predict(test, ref, dim_order="FHW", frames_per_second=fps)
     oq, ost = orc.Oracle("standard_fhd").predict(test, ref, dim_order="FHW", frames_per_second=fps)
-    assert abs(float(q) - float(oq)) < 2e-4
+    assert abs(float(q) - float(oq)) < 5e-6                                         # measured <= 9.5e-7
     a, b = st["Q_per_ch"].astype(np.float64), ost["Q_per_ch"].astype(np.float64)
-    assert np.all(np.abs(a - b) <= 5e-3 * np.abs(b) + 1e-5 * np.max(b)), (H, W)
+    assert np.all(np.abs(a - b) <= 3.5e-4 * np.abs(b) + 1e-5 * np.max(b)), (H, W)         # measured <= 1.04e-4
 
 
 @pytest.mark.gpu
