@@ -98,9 +98,9 @@ def stage_check(maps, exported, z, frames, n_bands, P):
                 if key in z.files:
                     gd, hd = z[key].astype(np.float64), maps[b]["D"][fi, cc].cpu().numpy().astype(np.float64)
                     rel = np.abs(hd - gd) / (np.abs(gd) + 1e-3 * np.max(gd) + 1e-12)
-                    # measured: max 8.7e-3 (single pixels whose contrast is ~1 ulp of the Gaussian levels), mean per map
-                    # <= 1.3e-4 (a 9x16-pixel coarse band; 3.8e-5 on average)
-                    assert np.max(rel) < 2e-2 and np.mean(rel) < 4e-4, key
+                    # measured: max 8.7e-3 (single pixels whose contrast is ~1 ulp of the Gaussian levels); mean per map
+                    # <= 4.1e-4 (a 5x8-pixel coarse band; 1.1e-4 at 135x240, 3.8e-5 on average over the maps)
+                    assert np.max(rel) < 2e-2 and np.mean(rel) < 1.2e-3, key
                     assert abs(hd.sum() / gd.sum() - 1) < (6e-5 if gd.size >= 4096 else 4e-4), key  # measured 2.0e-5 / 1.3e-4
         # Gaussian base band = last golden 'band'
         key = f"band_f{ff}_b{n_bands}"

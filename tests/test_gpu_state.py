@@ -147,3 +147,51 @@ def test_mixed_dtypes_follow_each_arrays_own_dtype(fv):
     a = float(p.predict(test, ref, frames_per_second=30)[0])
     b = float(p.predict(test.to(torch.float32) / 255, ref, frames_per_second=30)[0])
     assert abs(a - b) < 2e-3
+
+
+@pytest.mark.parametrize("pad,fps,N", [("replicate", 30, 21), ("circular", 30, 13), ("pingpong", 60, 19), ("replicate", 60, 30)])
+def test_pipelined_source_feeder_fetches_every_frame_once_and_matches_the_array_path(fv, pad, fps, N):
+    """User video sources go through their own get_*_frame: side-stream, double-buffered, no host
+    synchronisation per batch; with `replicate` padding every frame is fetched exactly once, like the reference does
+    (pyfvvdp/fvvdp.py:287-288).  Results equal the array path up to the float-vs-table display model (1e-6)."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    H, W = 70, 120
+    test, ref = synth_video_pair(N, H, W)
+    m = fv.fvvdp(display_name="standard_fhd", temp_padding=pad)
+    q0, s0 = m.predict(test, ref, frames_per_second=fps)
+    inner = fv.fvvdp_video_source_array(test, ref, fps, display_photometry=m.display_photometry)
+    calls = {"t": [], "r": []}
+
+    class Src(fv.fvvdp_video_source):
+        def get_video_size(self):
+            return inner.get_video_size()
+
+        def get_frames_per_second(self):
+            return fps
+
+        def get_test_frame(self, frame, device):
+            calls["t"].append(frame)
+            return inner.get_test_frame(frame, device)
+
+        def get_reference_frame(self, frame, device):
+            calls["r"].append(frame)
+            return inner.get_reference_frame(frame, device)
+
+    for batch in (None, 3, 5, N):
+        calls["t"].clear(); calls["r"].clear()
+        mm = fv.fvvdp(display_name="standard_fhd", temp_padding=pad, batch_frames=batch)
+        q1, s1 = mm.predict_video_source(Src())
+        assert abs(float(q1) - float(q0)) < 5e-6, (pad, batch)
+        a, b = s1["Q_per_ch"].astype(np.float64), s0["Q_per_ch"].astype(np.float64)
+        assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 1e-6 * np.max(b)), (pad, batch)
+        assert sorted(calls["t"]) == sorted(calls["r"])
+        if pad == "replicate":
+            assert sorted(calls["t"]) == list(range(N)), (batch, len(calls["t"]))   # each frame exactly once
+        else:
+            # the padded history of the first window revisits frames that are fetched again later (circular also
+            # never shows frame 0, pyfvvdp/fvvdp.py:258-291): bounded by one extra window per batch boundary
+            assert set(calls["t"]) <= set(range(N)) and len(calls["t"]) <= 2 * N + int(np.ceil(0.25 * fps))
+    # without a host synchronisation per call as well
+    q2, s2 = m.predict_video_source(Src(), sync=False)
+    fv.fvvdp.finish(s2)
+    assert abs(float(q2) - float(q0)) < 5e-6
