@@ -101,6 +101,9 @@ struct BandArgs {
     const float* mvx;       // map mode (user geometry): view direction x,y [h][w] in degrees and resolution
     const float* mvy;       //   magnification [h][w] of this band, evaluated by the caller with the user's
     const float* mrm;       //   geometry object; nullptr = stock geometry computed in-kernel
+    const float4* rmap;     // stock geometry: per pixel PAIR (columns 2J, 2J+1) {fraction, interval} x 2 of the rho axis of
+                            //   the band's LUT slice -- frame-invariant, built once per geometry by fov_rho_map_kernel
+    int rmap_w;             //   pixel pairs per row of rmap = (w + 1) / 2
     float size_m0, size_m1, dist_m, cos_delta, delta_rad;
     float rho_band, rho_lo, rho_hi, ecc_lo, ecc_hi;
     float inv_step[3], first[3];   // uniform-grid estimates of the three axes
@@ -108,14 +111,60 @@ struct BandArgs {
 };
 
 
+// Foveated mode, frame-invariant part of the CSF query: the spatial frequency of a pixel is rho_band times the
+// resolution magnification at its view angle (fvvdp.py:424-442, fvvdp_display_model.py:475-526) -- a function of the
+// pixel position only.  Its place on the rho axis of the band's LUT slice (interval and fraction, interp.py:11-20)
+// is evaluated ONCE per geometry here, with exactly the operations band_kernel used per pixel and frame before
+// (4 transcendentals and ~25 VALU instructions per pixel and frame saved in a VALU-bound kernel for 8 B/pixel of reads).
+struct RhoMapArgs {
+    float4* out;            // [h][(w+1)/2] {f(2J), k(2J), f(2J+1), k(2J+1)}, k = interval - i_lo as a float
+    int w, h;
+    float size_m0, size_m1, dist_m, cos_delta, delta_rad;
+    float rho_band, rho_lo, rho_hi, first, inv_step;
+    int i_lo, rw;
+    const float* axis;      // [32] rho_log knots
+};
+__global__ __launch_bounds__(256) void fov_rho_map_kernel(const RhoMapArgs a) {
+    const int J = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    const int pw = (a.w + 1) / 2;
+    if (J >= pw) return;
+    const float kyb = a.size_m1 / (float)a.h / a.dist_m;
+    const float yp = ((float)y + 0.5f) + (-(float)a.h / 2.0f);
+    const float vy = atanf(-yp * kyb) * 57.29577951308232f;
+    const float kx = a.size_m0 / (float)a.w / a.dist_m;
+    float r[4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int X = 2 * J + i;
+        const float xa = ((float)X + 0.5f) + (-(float)a.w / 2.0f);
+        const float vx = atanf(xa * kx) * 57.29577951308232f;
+        const float va = fminf(__builtin_amdgcn_sqrtf(vx * vx + vy * vy), 89.9f) * 0.017453292519943295f;
+        const float rm = a.cos_delta * fast_rcp(__cosf(va) * __cosf(va + a.delta_rad));
+        const float rho = a.rho_band * rm;
+        const float rq = fast_log2(fminf(fmaxf(rho, a.rho_lo), a.rho_hi));
+        const int k = min(max((int)floorf((rq - a.first) * a.inv_step), a.i_lo), a.i_lo + a.rw - 1);
+        const float x0 = a.axis[k], x1 = a.axis[k + 1 < FVVDP_LUT_N ? k + 1 : k];
+        const float f = fmaxf((rq - x0) * (1.0f / (x1 - x0 + 0.000001f)), 0.0f);
+        r[2 * i] = f;
+        r[2 * i + 1] = (float)(k - a.i_lo);
+    }
+    a.out[(size_t)y * pw + J] = make_float4(r[0], r[1], r[2], r[3]);
+}
+
+
+#ifndef FOV_WPB
 #define FOV_WPB 4            // foveated mode: 4 independent waves per workgroup share the band's LUT slice in LDS
+#endif
+#ifndef FOV_MINW
+#define FOV_MINW 2
+#endif
 extern __shared__ __attribute__((aligned(16))) float4 s_lut_dyn[];
 
 // FOVM: 0 = non-foveated, 1 = foveated with the band's LUT slice in (dynamic) LDS, 2 = foveated, LUT slice in global
 // memory (slice too large, or the map-writing variant).  A compile-time choice: with a run-time flag the compiler
 // merges the two look-ups into one flat load, which is slower than ds_read_b128.
 template <int P, bool DBG, int FOVM>
-__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, (FOVM || DBG) ? 2 : 4) void band_kernel(const BandArgs a) {
+__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 2 : 4)) void band_kernel(const BandArgs a) {
     constexpr bool FOV = FOVM != 0;
     constexpr bool LUT_LDS = FOVM == 1;
     constexpr int HP = P / 2;   // (test, ref) pairs = temporal channels
@@ -308,8 +357,9 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, (FOVM || DBG) ? 2 : 4) vo
     const float lg_mask = a.lg_gain + a.lg_k;      // log2(k*S)
 
     // per-pixel tail: contrast, CSF, masking, pooling  (fvvdp_lpyr_dec.py:259-269, fvvdp.py:395-467)
-    auto band_px = [&](const Px<P>& g, const Px<P>& e, bool valid, int y, int x, float vx, float vy, float res_mag) {
-        (void)x; (void)res_mag;
+    auto band_px = [&](const Px<P>& g, const Px<P>& e, bool valid, int y, int x, float vx, float vy, float res_mag,
+                       float pre_fR = 0.0f, float pre_kR = -1.0f) {
+        (void)x; (void)res_mag; (void)pre_fR; (void)pre_kR;
         const float lb = fmaxf(e.h[0].y, a.lbkg_min);                  // plane 1 = reference (sustained)
         // contrast = min((g-e)/lb, cmax) * m.  Dividing by lb>0 commutes with |.|, min and the clamp, so the
         // division is carried as -log2(lb) in the log domain below: no reciprocal, no per-plane multiply.
@@ -337,8 +387,6 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, (FOVM || DBG) ? 2 : 4) vo
             // does not lose digits to the reference's fp32 finite difference (whose noise, ~5e-4, bounds parity).
             const float dx = vx - gx, dy = vy - gy;
             const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
-            const float rho = a.rho_band * res_mag;
-            const float rq = fast_log2(fminf(fmaxf(rho, a.rho_lo), a.rho_hi));
             const float eq = __builtin_amdgcn_sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
             // interval on each (uniform) axis from the grid, fraction from the stored knots incl. interp.py:16's +1e-6
             auto axis = [&](int ax, float q, int lo, int hi, int& k, float& f) {
@@ -349,7 +397,14 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, (FOVM || DBG) ? 2 : 4) vo
             int kY, kR, kE;
             float fY, fR, fE;
             axis(0, yq, 0, FVVDP_LUT_N - 2, kY, fY);
-            axis(1, rq, a.i_lo, a.i_lo + a.rw - 1, kR, fR);
+            if (pre_kR >= 0.0f) {                  // rho axis: frame-invariant, from the map (wave-uniform branch)
+                kR = (int)pre_kR + a.i_lo;
+                fR = pre_fR;
+            } else {
+                const float rho = a.rho_band * res_mag;
+                const float rq = fast_log2(fminf(fmaxf(rho, a.rho_lo), a.rho_hi));
+                axis(1, rq, a.i_lo, a.i_lo + a.rw - 1, kR, fR);
+            }
             axis(2, eq, 0, FVVDP_LUT_N - 2, kE, fE);
             const int so = (kE * FVVDP_LUT_N + kY) * a.rw + (kR - a.i_lo);
             const int sj = a.rw, sk = FVVDP_LUT_N * a.rw;
@@ -481,17 +536,23 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, (FOVM || DBG) ? 2 : 4) vo
                     vy4[i] = a.mvy[o[i]];
                     rm4[i] = a.mrm[o[i]];
                 }
-            } else {
+            } else if (!a.rmap) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float va = fminf(__builtin_amdgcn_sqrtf(vx4[i] * vx4[i] + vy4[i] * vy4[i]), 89.9f) * 0.017453292519943295f;
                     rm4[i] = a.cos_delta * fast_rcp(__cosf(va) * __cosf(va + a.delta_rad));
                 }
             }
-            band_px(W[0][0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0]);
-            band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1]);
-            band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vx4[2], vy4[2], rm4[2]);
-            band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vx4[3], vy4[3], rm4[3]);
+            float4 ra = make_float4(0.0f, -1.0f, 0.0f, -1.0f), rb = ra;      // {f, k} of columns X0, X1 in rows 2c, 2c+1
+            if (a.rmap && !a.mvx) {
+                const int jj = min(max(J, 0), a.rmap_w - 1);
+                ra = a.rmap[(size_t)min(2 * c, h - 1) * a.rmap_w + jj];
+                rb = a.rmap[(size_t)min(2 * c + 1, h - 1) * a.rmap_w + jj];
+            }
+            band_px(W[0][0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0], ra.x, ra.y);
+            band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1], ra.z, ra.w);
+            band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vx4[2], vy4[2], rm4[2], rb.x, rb.y);
+            band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vx4[3], vy4[3], rm4[3], rb.z, rb.w);
         } else {
             band_px(W[0][0], x00, active, 2 * c, X0, 0.0f, 0.0f, 1.0f);
             band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, 0.0f, 0.0f, 1.0f);

@@ -68,6 +68,7 @@ struct fvvdp_ctx {
     float h_axes[3][FVVDP_LUT_N]{};            // Y_log, rho_log, ecc_sqrt
     float* d_axes = nullptr;                   // [3][32]
     float4* sublut[FVVDP_MAX_BANDS]{};         // per-band rho slices, rebuilt when the geometry changes
+    float4* rmap[FVVDP_MAX_BANDS]{};           // per-band rho-axis coordinates of every pixel pair (stock geometry)
     int sub_rw[FVVDP_MAX_BANDS]{}, sub_ilo[FVVDP_MAX_BANDS]{};
     fvvdp_geom sub_geom{};
     const float* map_vx[FVVDP_MAX_BANDS]{};    // user-geometry maps (owned by the caller)
@@ -258,8 +259,10 @@ extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     if (c->d_taps) (void)hipFree(c->d_taps);
     if (c->d_idx) (void)hipFree(c->d_idx);
     if (c->d_axes) (void)hipFree(c->d_axes);
-    for (int b = 0; b < FVVDP_MAX_BANDS; ++b)
+    for (int b = 0; b < FVVDP_MAX_BANDS; ++b) {
         if (c->sublut[b]) (void)hipFree(c->sublut[b]);
+        if (c->rmap[b]) (void)hipFree(c->rmap[b]);
+    }
     for (auto& v : c->ev)
         for (auto& pr : v) {
             (void)hipEventDestroy(pr.first);
@@ -684,6 +687,33 @@ static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
         HIP_TRY(hipMemcpy(c->sublut[b], h.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         c->sub_rw[b] = rw;
         c->sub_ilo[b] = i_lo;
+        if (g && !getenv("FVVDP_FOV_NO_RHOMAP")) {   // frame-invariant rho-axis coordinates of every pixel (stock geometry)
+            const int pw = (c->lw[b] + 1) / 2;
+            if (!c->rmap[b]) {
+                int rc = dev_alloc(c, &c->rmap[b], (size_t)pw * c->lh[b]);
+                if (rc != FVVDP_OK) return rc;
+            }
+            RhoMapArgs ra;
+            memset(&ra, 0, sizeof(ra));
+            ra.out = c->rmap[b];
+            ra.w = c->lw[b];
+            ra.h = c->lh[b];
+            ra.size_m0 = g->display_size_m[0];
+            ra.size_m1 = g->display_size_m[1];
+            ra.dist_m = g->distance_m;
+            const double delta = (1.0 / (double)g->ppd_centre) / 2.0 * M_PI / 180.0;
+            ra.delta_rad = (float)delta;
+            ra.cos_delta = (float)cos(delta);
+            ra.rho_band = (float)c->rho_band[b];
+            ra.rho_lo = c->rho_lo;
+            ra.rho_hi = c->rho_hi;
+            ra.first = c->h_axes[1][0];
+            ra.inv_step = (float)(FVVDP_LUT_N - 1) / (c->h_axes[1][FVVDP_LUT_N - 1] - c->h_axes[1][0]);
+            ra.i_lo = i_lo;
+            ra.rw = rw;
+            ra.axis = c->d_axes + FVVDP_LUT_N;
+            hipLaunchKernelGGL(fov_rho_map_kernel, dim3((pw + 255) / 256, c->lh[b]), dim3(256), 0, st, ra);
+        }
     }
     c->sub_geom = key;
     c->sub_valid = true;
@@ -854,6 +884,8 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
             }
             a.frame_w = c->W;
             a.frame_h = c->H;
+            a.rmap = (geom && !getenv("FVVDP_FOV_NO_RHOMAP")) ? c->rmap[b] : nullptr;
+            a.rmap_w = (c->lw[b] + 1) / 2;
         }
         const int nblk = a.n_strips * a.n_chunks;
         if (nblk > c->max_blk[b]) return fail(FVVDP_ESTATE, "internal: partial buffer too small");
