@@ -389,7 +389,7 @@ extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const v
     if (c->P == 2 && fl != 1) return fail(FVVDP_EINVAL, "still-image context (planes == 2) needs fl == 1");
     if (n_out < 1 || slot0 < 0 || slot0 + n_out > c->max_frames) return fail(FVVDP_EINVAL, "slots [%d,%d) exceed max_frames %d", slot0, slot0 + n_out, c->max_frames);
     if (eotf->kind == FVVDP_EOTF_LUT && (dtype == FVVDP_F32 || !eotf->d_lut)) return fail(FVVDP_EINVAL, "FVVDP_EOTF_LUT needs an integer source and a table");
-    if (eotf->kind != FVVDP_EOTF_LUT && dtype != FVVDP_F32) return fail(FVVDP_EINVAL, "integer sources need FVVDP_EOTF_LUT");
+    if (eotf->kind != FVVDP_EOTF_LUT && dtype == FVVDP_U8) return fail(FVVDP_EINVAL, "uint8 sources need FVVDP_EOTF_LUT (uint16: table or closed form)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int HW = c->W * c->H;
     Timed tm(c, 0, st);
@@ -421,7 +421,13 @@ extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const v
                 a.idx[u] = h_frame_idx[src < 0 ? 0 : src];
             }
             // vector path needs the lane's PX consecutive samples to be naturally aligned
-            const int PXv = FL == 8 ? 4 : 2;
+#ifndef K1_PX16
+#define K1_PX16 2
+#endif
+#ifndef K1_PX32
+#define K1_PX32 2
+#endif
+            const int PXv = FL == 8 ? 4 : (FL == 16 ? K1_PX16 : K1_PX32);
             const int es = dtype == FVVDP_U8 ? 1 : (dtype == FVVDP_U16 ? 2 : 4);
             const bool vec_ok = !getenv("FVVDP_TEMPORAL_SCALAR") && (HW % PXv == 0) && (HW >= PXv) &&
                                 (chan_stride % PXv == 0) && (frame_stride % PXv == 0) &&
@@ -429,8 +435,8 @@ extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const v
                                 (reinterpret_cast<uintptr_t>(d_ref) % (size_t)(es * PXv) == 0);
             if (vec_ok) {
                 if (FL == 8) launch_vec<8, 4>(dtype, a, st);
-                else if (FL == 16) launch_vec<16, 2>(dtype, a, st);
-                else launch_vec<32, 2>(dtype, a, st);
+                else if (FL == 16) launch_vec<16, K1_PX16>(dtype, a, st);
+                else launch_vec<32, K1_PX32>(dtype, a, st);
             } else {
                 if (FL == 8) launch_ring<8, 4>(dtype, a, st);
                 else if (FL == 16) launch_ring<16, 4>(dtype, a, st);
@@ -585,7 +591,7 @@ extern "C" int fvvdp_pu21_sse(const void* d_test, const void* d_ref, int dtype, 
     if (n_frames < 1 || n_frames > 65535) return fail(FVVDP_EINVAL, "n_frames %d out of range (1..65535 per call)", n_frames);
     if (n_pixels < 1 || n_pixels > 0x7FFFFFFFu) return fail(FVVDP_EINVAL, "n_pixels out of range");
     if (eotf->kind == FVVDP_EOTF_LUT && (dtype == FVVDP_F32 || !eotf->d_lut)) return fail(FVVDP_EINVAL, "FVVDP_EOTF_LUT needs an integer source and a table");
-    if (eotf->kind != FVVDP_EOTF_LUT && dtype != FVVDP_F32) return fail(FVVDP_EINVAL, "integer sources need FVVDP_EOTF_LUT");
+    if (eotf->kind != FVVDP_EOTF_LUT && dtype == FVVDP_U8) return fail(FVVDP_EINVAL, "uint8 sources need FVVDP_EOTF_LUT (uint16: table or closed form)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     Pu21Args a;
     memset(&a, 0, sizeof(a));

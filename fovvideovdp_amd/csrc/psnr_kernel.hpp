@@ -60,7 +60,13 @@ __global__ __launch_bounds__(256) void pu21_sse_kernel(const Pu21Args a) {
         S[1].lum(foff + p, lr, bad);
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
-            const float d = pu21_encode(lt[i], a) - pu21_encode(lr[i], a);
+            // The encoded values must be ROUNDED before they are subtracted.  pu21_encode ends in a product; fused into
+            // fma(p6, x_t, -(p6 * x_r)) the difference of identical inputs is that product's rounding error instead of 0
+            // (the reference returns an infinite PSNR, pupsnr.py:74).  __fmul_rn is a plain `*` in HIP, so the values go
+            // through an opaque register move the contraction cannot see through.
+            float et = pu21_encode(lt[i], a), er = pu21_encode(lr[i], a);
+            asm volatile("" : "+v"(et), "+v"(er));
+            const float d = et - er;
             acc += (double)(d * d);              // (img1 - img2)**2 in fp32 like the reference, summed in fp64
         }
     }

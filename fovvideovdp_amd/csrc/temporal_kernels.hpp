@@ -123,8 +123,13 @@ struct Sampler {
                 code[0] = *q;
             }
             const float wc = (c == 0) ? w0 : ((c == 1) ? w1 : w2);
+            if (e.kind != FVVDP_EOTF_LUT) {           // closed-form display model on code / 65535 (see frame_lum)
 #pragma unroll
-            for (int i = 0; i < PX; ++i) o[i] = __fmul_rn(lut16[code[i]], wc);
+                for (int i = 0; i < PX; ++i) o[i] = __fmul_rn(eotf_f32((float)code[i] * (1.0f / 65535.0f), e, bad), wc);
+            } else {
+#pragma unroll
+                for (int i = 0; i < PX; ++i) o[i] = __fmul_rn(lut16[code[i]], wc);
+            }
         } else {
             const float* q = reinterpret_cast<const float*>(p) + off;
             float V[PX];
@@ -253,6 +258,29 @@ __device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lu
             float t[PX];
 #pragma unroll
             for (int i = 0; i < PX; ++i) t[i] = f.ch[0].value(i);
+            eotf_apply<PX>(t, e, bad);
+#pragma unroll
+            for (int i = 0; i < PX; ++i) v[0][i] = __fmul_rn(t[i], w[0]);
+        }
+    } else if (SRC == SRC_U16 && e.kind != FVVDP_EOTF_LUT) {
+        // 16-bit codes through the closed-form display model (code / 65535 as the reference unpacks it,
+        // video_source.py:186-196): the 65536-entry table lives in global memory and its 6 gathers per pixel made this
+        // kernel 2.6x slower than for 8-bit input; same arithmetic as a float source from here on (<= 1e-6 relative)
+        if (C == 3) {
+            float t[3 * PX];
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < PX; ++i) t[c * PX + i] = (float)f.ch[c].code(i) * (1.0f / 65535.0f);
+            eotf_apply<3 * PX>(t, e, bad);
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+#pragma unroll
+                for (int i = 0; i < PX; ++i) v[c][i] = __fmul_rn(t[c * PX + i], w[c]);
+        } else {
+            float t[PX];
+#pragma unroll
+            for (int i = 0; i < PX; ++i) t[i] = (float)f.ch[0].code(i) * (1.0f / 65535.0f);
             eotf_apply<PX>(t, e, bad);
 #pragma unroll
             for (int i = 0; i < PX; ++i) v[0][i] = __fmul_rn(t[i], w[0]);

@@ -594,12 +594,17 @@ class fvvdp:
             else:
                 raise RuntimeError("Only uint8, uint16 and float32 is currently supported")
             C_ch, N = test.shape[1], test.shape[2]
-            desc = native_eotf(vs.dm_photometry) if dtype == nat.FVVDP_F32 else None
+            # uint8: 256-entry table through the model's own forward() (exact, lives in LDS).  uint16: the 65536-entry
+            # table sits in global memory (6 gathers per pixel: K1 98 vs 37 us/frame at 4K), so stock display models are
+            # evaluated in closed form on code/65535 like float input (<= 1e-6 relative); `exact_uint16 = True` on the
+            # metric, or a user photometry class, keeps the table.
+            use_closed = dtype == nat.FVVDP_F32 or (dtype == nat.FVVDP_U16 and not getattr(self, "exact_uint16", False))
+            desc = native_eotf(vs.dm_photometry) if use_closed else None
             if dtype != nat.FVVDP_F32 or desc is not None:
                 test_d = test.to(self.device).contiguous()
                 ref_d = ref.to(self.device).contiguous()
                 e = nat.Eotf()
-                if dtype != nat.FVVDP_F32:
+                if desc is None:
                     lut = self._code_lut(vs.dm_photometry, nbits)
                     e.kind, e.d_lut = nat.EOTF_LUT, lut.data_ptr()
                 else:
@@ -609,7 +614,7 @@ class fvvdp:
                     e.gamma = desc[1].get("gamma", 1.0)
                     e.L_min = desc[1].get("L_min", 0.0)
                     e.L_max = desc[1].get("L_max", 0.0)
-                    if e.kind == nat.EOTF_ABSOLUTE and float(torch.maximum(test_d.max(), ref_d.max())) < 1:
+                    if e.kind == nat.EOTF_ABSOLUTE and dtype == nat.FVVDP_F32 and float(torch.maximum(test_d.max(), ref_d.max())) < 1:
                         logging.warning('Pixel values are very low. Perhaps images are not scaled in the absolute units of cd/m^2.')
                 w = np.asarray(vs.color_to_luminance, dtype=np.float32)
 

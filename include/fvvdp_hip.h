@@ -63,7 +63,8 @@ enum { FVVDP_U8 = 0, FVVDP_U16 = 1, FVVDP_F32 = 2 };
 
 /* Display photometry applied per colour channel (pyfvvdp/fvvdp_display_model.py:147-165, :203-212). */
 enum {
-    FVVDP_EOTF_LUT = 0,       /* integer sources only: L = d_lut[code], table built by the caller            */
+    FVVDP_EOTF_LUT = 0,       /* integer sources only: L = d_lut[code], table built by the caller (required for
+                               * uint8; uint16 may also use a closed-form kind, evaluated on code / 65535)    */
     FVVDP_EOTF_SRGB = 1,      /* (Y_peak-Y_black)*srgb2lin(V)+Y_black                 :155-156, :17-19        */
     FVVDP_EOTF_GAMMA = 2,     /* (Y_peak-Y_black)*V^gamma+Y_black                     :157-158                */
     FVVDP_EOTF_PQ = 3,        /* clip(pq2lin(V),0.005,Y_peak)+Y_black                 :159-160, :100-112      */
