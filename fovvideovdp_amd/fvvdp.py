@@ -625,7 +625,8 @@ class fvvdp:
                         nat.fptr(taps), fl, n_out, 0, C.c_void_p(oob.data_ptr()), stream))
                 return feed
         if (isinstance(vs, fvvdp_video_source_yuv_frames) and native_eotf(vs.dm_photometry) is not None
-                and not (hasattr(vs, "_resizing") and vs._resizing())):
+                and not (hasattr(vs, "_resizing") and vs._resizing())
+                and int(np.ceil(250.0 / (1000.0 / max(vs.get_frames_per_second(), 1e-9)))) <= 32):   # > 128 fps: generic path
             # raw planar YUV: unpacking, chroma upsampling, colour matrix and display model run in the HIP kernel
             test_d = vs.test_yuv.to(self.device).contiguous()
             ref_d = vs.reference_yuv.to(self.device).contiguous()

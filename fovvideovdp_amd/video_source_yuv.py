@@ -130,15 +130,15 @@ def create_yuv_fname(basename, vprops):
 class fvvdp_video_source_yuv_file(fvvdp_video_source_yuv_frames):
     """Test / reference pair of raw planar .yuv files (the reference's `fvvdp_video_source_yuv_file`,
     pyfvvdp/video_source_yuv.py:238-292, whose constructor cannot run: it logs attributes its reader does not have).
-    The frames are memory-mapped, uploaded as they are (1.5 or 3 bytes per pixel and stream for 8 bit) and unpacked by
-    the fused ingest kernel.  With `full_screen_resize` the frames are resized in RGB with torch (`get_*_frame`, as the
+    The frames are read into host memory as they are stored (1.5 or 3 bytes per pixel and stream for 8 bit), uploaded in
+    that form and unpacked by the fused ingest kernel.  With `full_screen_resize` the frames are resized in RGB with torch (`get_*_frame`, as the
     reference does) and the metric takes luminance frames from there."""
 
     def __init__(self, test_fname, reference_fname, display_photometry='standard_4k', color_space_name='auto', frames=-1,
                  full_screen_resize=None, resize_resolution=None, verbose=False):
         import os
         tp, rp = decode_video_props(test_fname), decode_video_props(reference_fname)
-        for k in ("width", "height", "bit_depth", "chroma_ss"):
+        for k in ("width", "height", "bit_depth", "chroma_ss", "color_space", "fps"):   # one YCbCr matrix / frame rate for both
             if tp[k] != rp[k]:
                 raise RuntimeError("Test and reference .yuv files differ in %s (%s vs %s)" % (k, tp[k], rp[k]))
         for fn in (test_fname, reference_fname):

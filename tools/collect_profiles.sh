@@ -14,6 +14,19 @@ python $R/tools/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) --band-l
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf -o f -- python $R/tools/gpu_bandonly.py > /tmp/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw -o w -- python $R/tools/gpu_bandonly.py > /tmp/pw.log 2>&1
 python $R/tools/pmc_level0.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) $OUT/pmc_level0.json > /dev/null
+# the same two passes for the one-level kernels (FVVDP_BAND_FUSE=0), and their kernel trace: the A/B of the two-level kernel on this box
+FVVDP_BAND_FUSE=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf0 -o f -- python $R/tools/gpu_bandonly.py > /tmp/pf0.log 2>&1
+FVVDP_BAND_FUSE=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw0 -o w -- python $R/tools/gpu_bandonly.py > /tmp/pw0.log 2>&1
+python $R/tools/pmc_level0.py $(find /tmp/pf0 -name "*.db" | head -1) $(find /tmp/pw0 -name "*.db" | head -1) $OUT/pmc_level0_onelevel.json > /dev/null
+FVVDP_BAND_FUSE=0 rocprofv3 --kernel-trace --stats -d /tmp/kt0 -o bench0 -- python $R/bench.py --no-cpu-baseline --no-h2d > $OUT/bench_profiled_onelevel.json 2> /tmp/kt0.err
+python $R/tools/rocpd_summary.py $(find /tmp/kt0 -name "*.db" | head -1) --band-levels 7 > $OUT/kernel_trace_bench_onelevel.md
+python $R/tools/gpu_bandonly_speed.py 12 > $OUT/bandonly_fused.txt 2>/dev/null
+FVVDP_BAND_FUSE=0 python $R/tools/gpu_bandonly_speed.py 12 > $OUT/bandonly_onelevel.txt 2>/dev/null
+$R/build_variants/mix > $OUT/mix.txt 2>&1
+python $R/tools/gpu_parity_report.py > $OUT/parity.md 2>/dev/null
+python $R/tools/gpu_fps.py > $OUT/fps_probe.txt 2>/dev/null
+python $R/tools/gpu_feeder.py > $OUT/feeder_probe.txt 2>/dev/null
+python $R/bench.py --pairs-per-gpu 8 --no-cpu-baseline --no-h2d > $OUT/bench_pairs8.json 2>/dev/null
 # K1 (temporal kernel): HBM traffic per 60-frame launch from the same two counters (algorithmic: 67 frames read x 49.8 MB + 60 x 132.7 MB written)
 STAGE=all REPS=2 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf1 -o f -- python $R/tools/gpu_bandonly.py > /tmp/pf1.log 2>&1
 STAGE=all REPS=2 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw1 -o w -- python $R/tools/gpu_bandonly.py > /tmp/pw1.log 2>&1
