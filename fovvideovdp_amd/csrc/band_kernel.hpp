@@ -480,6 +480,81 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
         }
     };
 
+    // Foveated mode, plain evaluation (no maps written): the four pixels of a step in two phases, so that all LDS reads of
+    // the step (per pixel: 2 axis knots + the 4 corners of the LUT cell) are issued back to back and waited for once,
+    // instead of 8 dependent LDS round trips per step.  Same operations, in the same order, as band_px above.
+    struct FovQ {
+        float4 v00, v10, v01, v11;
+        float2 knY, knE;
+        float yq, eq, fR, llb;
+        v2f d[HP];
+    };
+    auto fov_a = [&](const Px<P>& g, const Px<P>& e, float vx, float vy, float pre_fR, float pre_kR) -> FovQ {
+        FovQ q;
+        const float lb = fmaxf(e.h[0].y, a.lbkg_min);
+        const float dcap = a.cmax * lb;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) {
+            const v2f t = g.h[k] - e.h[k];
+            q.d[k] = v2f{fminf(t.x, dcap), fminf(t.y, dcap)};
+        }
+        q.llb = fast_log2(lb);
+        q.yq = fminf(fmaxf(q.llb, a.ly_lo), a.ly_hi);
+        const float dx = vx - gx, dy = vy - gy;
+        const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
+        q.eq = __builtin_amdgcn_sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
+        const int kY = min(max((int)floorf((q.yq - a.first[0]) * a.inv_step[0]), 0), FVVDP_LUT_N - 2);
+        const int kE = min(max((int)floorf((q.eq - a.first[2]) * a.inv_step[2]), 0), FVVDP_LUT_N - 2);
+        q.knY = s_ax[kY];
+        q.knE = s_ax[2 * FVVDP_LUT_N + kE];
+        q.fR = pre_fR;
+        const int so = (kE * FVVDP_LUT_N + kY) * a.rw + (int)pre_kR;
+        const int sj = a.rw, sk = FVVDP_LUT_N * a.rw;
+        q.v00 = s_lut_dyn[so];
+        q.v10 = s_lut_dyn[so + sj];
+        q.v01 = s_lut_dyn[so + sk];
+        q.v11 = s_lut_dyn[so + sk + sj];
+        return q;
+    };
+    auto fov_b = [&](const FovQ& q, bool valid) {
+        const float fY = fmaxf((q.yq - q.knY.x) * q.knY.y, 0.0f);
+        const float fE = fmaxf((q.eq - q.knE.x) * q.knE.y, 0.0f);
+        const float fR = q.fR;
+        const float gR = 1.0f - fR, gY = 1.0f - fY, gE = 1.0f - fE;
+        // interp3 (interp.py:53-57), same association (rho, then Y, then ecc); both temporal channels as one packed pair
+        auto rho_blend = [&](const float4& v) { return pfma(v2f{v.z, v.w}, fR, v2f{v.x, v.y} * gR); };
+        const v2f r00 = rho_blend(q.v00), r10 = rho_blend(q.v10), r01 = rho_blend(q.v01), r11 = rho_blend(q.v11);
+        const v2f y0 = pfma(r10, fY, r00 * gY), y1 = pfma(r11, fY, r01 * gY);
+        const v2f sl2 = pfma(y1, fE, y0 * gE);
+        const float s0 = sl2.x, s1 = sl2.y;
+        const float vm = valid ? 1.0f : 0.0f;
+        const float lcn = lg_bm - q.llb;
+        if constexpr (HP == 2) {
+            const v2f sl = v2f{s0, s1};
+            const v2f lsb = sl + splat(lcn + lg_base);
+            const v2f lsm = sl + splat(lcn + lg_mask);
+            const v2f ldiff = v2f{fast_log2(fabsf(q.d[0].x - q.d[0].y)), fast_log2(fabsf(q.d[1].x - q.d[1].y))};
+            const v2f lmin = v2f{fast_log2(fminf(fabsf(q.d[0].x), fabsf(q.d[0].y))), fast_log2(fminf(fabsf(q.d[1].x), fabsf(q.d[1].y)))};
+            const v2f ld = (ldiff + lsb) * splat(a.p);
+            const v2f lm = (lmin + lsm) * v2f{a.q0, a.q1};
+            const v2f one_mq = v2f{fast_exp2(lm.x), fast_exp2(lm.y)} + splat(1.0f);
+            const v2f t = ld - v2f{fast_log2(one_mq.x), fast_log2(one_mq.y)};
+            const v2f ldd = v2f{fminf(t.x, a.lg_dmax), fminf(t.y, a.lg_dmax)};
+            const v2f bl = ldd * splat(a.beta);
+            const v2f term = v2f{fast_exp2(bl.x), fast_exp2(bl.y)};
+            const v2f av = __builtin_elementwise_fma(term, splat(vm), v2f{acc[0], acc[1]});
+            acc[0] = av.x;
+            acc[1] = av.y;
+        } else {
+            const float dT = q.d[0].x, dR = q.d[0].y;
+            const float ls = s0 + lcn;
+            const float ld = a.p * (fast_log2(fabsf(dT - dR)) + (ls + lg_base));
+            const float mq = fast_exp2(a.q0 * (fast_log2(fminf(fabsf(dT), fabsf(dR))) + (ls + lg_mask)));
+            const float ldd = fminf(ld - fast_log2(1.0f + mq), a.lg_dmax);
+            acc[0] = fmaf(fast_exp2(a.beta * ldd), vm, acc[0]);
+        }
+    };
+
     // ---- main loop: band rows 2c, 2c+1 for c in [ca, cb) ------------------------------------------------
     for (int c = ca; c < cb; ++c) {
         shift_window(nx0, nx1);               // window = fine rows 2c .. 2c+4
@@ -549,10 +624,28 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
                 ra = a.rmap[(size_t)min(2 * c, h - 1) * a.rmap_w + jj];
                 rb = a.rmap[(size_t)min(2 * c + 1, h - 1) * a.rmap_w + jj];
             }
-            band_px(W[0][0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0], ra.x, ra.y);
-            band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1], ra.z, ra.w);
-            band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vx4[2], vy4[2], rm4[2], rb.x, rb.y);
-            band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vx4[3], vy4[3], rm4[3], rb.z, rb.w);
+            if constexpr (LUT_LDS && !DBG) {
+                if (a.rmap && !a.mvx) {                   // stock geometry: phased evaluation (see fov_a / fov_b)
+                    const FovQ q0 = fov_a(W[0][0], x00, vx4[0], vy4[0], ra.x, ra.y);
+                    const FovQ q1 = fov_a(W[0][1], x01, vx4[1], vy4[1], ra.z, ra.w);
+                    const FovQ q2 = fov_a(W[1][0], x10, vx4[2], vy4[2], rb.x, rb.y);
+                    const FovQ q3 = fov_a(W[1][1], x11, vx4[3], vy4[3], rb.z, rb.w);
+                    fov_b(q0, active);
+                    fov_b(q1, active && col1_ok);
+                    fov_b(q2, active && row1_ok);
+                    fov_b(q3, active && row1_ok && col1_ok);
+                } else {
+                    band_px(W[0][0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0], ra.x, ra.y);
+                    band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1], ra.z, ra.w);
+                    band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vx4[2], vy4[2], rm4[2], rb.x, rb.y);
+                    band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vx4[3], vy4[3], rm4[3], rb.z, rb.w);
+                }
+            } else {
+                band_px(W[0][0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0], ra.x, ra.y);
+                band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1], ra.z, ra.w);
+                band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vx4[2], vy4[2], rm4[2], rb.x, rb.y);
+                band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vx4[3], vy4[3], rm4[3], rb.z, rb.w);
+            }
         } else {
             band_px(W[0][0], x00, active, 2 * c, X0, 0.0f, 0.0f, 1.0f);
             band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, 0.0f, 0.0f, 1.0f);
