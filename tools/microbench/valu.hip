@@ -20,10 +20,9 @@ static const char* names[T_COUNT] = {"v_fma_f32", "v_pk_fma_f32", "v_pk_mul_f32"
                                      "v_permlane32_swap"};
 
 template <int T>
-__global__ __launch_bounds__(64) void k(float* out, long long* cyc, int iters) {
+__global__ __launch_bounds__(512) void k(float* out, long long* cyc, int iters) {
     __shared__ float4 lds[256];
-    lds[threadIdx.x] = make_float4(1.f, 2.f, 3.f, 4.f);
-    lds[threadIdx.x + 64] = lds[threadIdx.x];
+    lds[threadIdx.x & 255] = make_float4(1.f, 2.f, 3.f, 4.f);
     __syncthreads();
     float a[8], b[8];
     v2f p[8], q[8];
@@ -38,7 +37,7 @@ __global__ __launch_bounds__(64) void k(float* out, long long* cyc, int iters) {
     }
     const float c0 = 0.999f, c1 = 1e-4f;
     const v2f pc = v2f{c0, c0};
-    unsigned int addr = threadIdx.x * 16;
+    unsigned int addr = (threadIdx.x & 255) * 16;
     const long long t0 = __builtin_amdgcn_s_memtime();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -96,40 +95,28 @@ __global__ __launch_bounds__(64) void k(float* out, long long* cyc, int iters) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += a[i] + b[i] + p[i].x + p[i].y + q[i].x + l4[i].x + l4[i].w;
     if (s == 123.456f) out[0] = s;
-    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
 
 template <int T>
 static void run(float* out, long long* d_cyc, int cus) {
-    const int iters = 2000;
-    const int per_body = (T == T_EXPFMA) ? 32 : 64;      // "instructions" per loop iteration (EXPFMA: 8 groups x 4... counted per group of 4 below)
+    const int iters = 4000;
     printf("%-28s", names[T]);
-    for (int wps : {1, 2, 4, 8}) {
-        const int blocks = cus * 4 * wps;
-        std::vector<long long> h(blocks);
-        k<T><<<blocks, 64>>>(out, d_cyc, 10);
+    for (int wps : {2, 4, 8}) {                        // waves per SIMD: 512-thread blocks = 2 waves on each of the 4 SIMDs
+        const int blocks = cus * (wps / 2);
+        std::vector<long long> h((size_t)blocks * 8);
+        k<T><<<blocks, 512>>>(out, d_cyc, 10);
         hipDeviceSynchronize();
-        hipEvent_t e0, e1;
-        hipEventCreate(&e0);
-        hipEventCreate(&e1);
-        hipEventRecord(e0);
-        k<T><<<blocks, 64>>>(out, d_cyc, iters);
-        hipEventRecord(e1);
+        k<T><<<blocks, 512>>>(out, d_cyc, iters);
         hipDeviceSynchronize();
-        float ms = 0;
-        hipEventElapsedTime(&ms, e0, e1);
-        hipMemcpy(h.data(), d_cyc, blocks * sizeof(long long), hipMemcpyDeviceToHost);
+        hipMemcpy(h.data(), d_cyc, h.size() * sizeof(long long), hipMemcpyDeviceToHost);
         double avg = 0;
         for (auto v : h) avg += (double)v;
-        avg /= blocks;
+        avg /= (double)h.size();
         const double ninstr = (double)iters * (T == T_EXPFMA ? 8 : 64);
-        // cycles of SIMD time per wave-instruction = wave's elapsed cycles / instructions / co-resident waves
-        printf("  w%d: %6.2f cyc (%.0f MHz eff)", wps, avg / ninstr / wps, avg / (ms * 1e-3) / 1e6);
-        hipEventDestroy(e0);
-        hipEventDestroy(e1);
+        printf("  %d waves/SIMD: %6.2f cyc", wps, avg / ninstr / wps);
     }
     printf("\n");
-    (void)per_body;
 }
 
 template <int T>
@@ -142,11 +129,11 @@ int main() {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
     const int cus = prop.multiProcessorCount;
-    printf("device %s, %d CUs; cycles are SIMD issue cycles per wave64 instruction (s_memtime ticks), EXPFMA row is per group of {1 exp + 3 fma}\n", prop.name, cus);
+    printf("device %s, %d CUs; SIMD cycles per wave64 instruction = wave elapsed cycles (s_memtime) / instructions / co-resident waves; 512-thread blocks, all resident; EXPFMA row is per group of {1 exp + 3 fma}\n", prop.name, cus);
     float* out;
     long long* d_cyc;
     hipMalloc(&out, 1024);
-    hipMalloc(&d_cyc, sizeof(long long) * cus * 4 * 8);
+    hipMalloc(&d_cyc, sizeof(long long) * cus * 4 * 8 * 8);
     run_all<0>(out, d_cyc, cus);
     return 0;
 }
