@@ -13,6 +13,7 @@ SRC_PATH = os.path.join(_HERE, "csrc", "fvvdp_hip.hip")
 INCLUDE_DIR = os.path.join(ROOT, "include")
 
 FVVDP_U8, FVVDP_U16, FVVDP_F32 = 0, 1, 2
+FVVDP_EUNSUPPORTED = -5
 EOTF_LUT, EOTF_SRGB, EOTF_GAMMA, EOTF_PQ, EOTF_LINEAR, EOTF_ABSOLUTE, EOTF_NONE = range(7)
 PSNR_SLICES = 256            # FVVDP_PSNR_SLICES
 MAX_BANDS = 16
@@ -66,6 +67,9 @@ SYMBOLS = {
     "fvvdp_temporal_channels": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t,
                                           C.POINTER(Eotf), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                           C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "fvvdp_temporal_channels_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int,
+                                                 C.c_size_t, C.POINTER(Eotf), C.POINTER(C.c_float), C.POINTER(C.c_int32),
+                                                 C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "fvvdp_temporal_channels_yuv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(YuvFormat), C.c_size_t,
                                               C.POINTER(Eotf), C.POINTER(C.c_float), C.POINTER(C.c_int32),
                                               C.POINTER(C.c_float), C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

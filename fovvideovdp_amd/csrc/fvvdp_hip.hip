@@ -377,10 +377,11 @@ static void launch_generic(int dtype, const GenericArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((temporal_generic_kernel<SRC_F32, P>), grid, block, 0, st, a);
 }
 
-extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const void* d_ref, int dtype, int C,
-                                       size_t chan_stride, size_t frame_stride, const fvvdp_eotf* eotf,
-                                       const float* h_rgb2y, const int32_t* h_frame_idx, const float* h_taps, int fl,
-                                       int n_out, int slot0, int32_t* d_oob_flag, void* stream) {
+// h_frame_idx1: per-stream frame indices of the reference stream, or nullptr = the same as h_frame_idx
+static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* d_ref, int dtype, int C,
+                                  size_t chan_stride, size_t frame_stride, const fvvdp_eotf* eotf,
+                                  const float* h_rgb2y, const int32_t* h_frame_idx, const int32_t* h_frame_idx1,
+                                  const float* h_taps, int fl, int n_out, int slot0, int32_t* d_oob_flag, void* stream) {
     if (!c || !d_test || !d_ref || !eotf || !h_frame_idx || !h_taps) return fail(FVVDP_EINVAL, "null argument");
     if (dtype < FVVDP_U8 || dtype > FVVDP_F32) return fail(FVVDP_EINVAL, "Only uint8, uint16 and float32 is currently supported");
     if (C != 1 && C != 3) return fail(FVVDP_EINVAL, "The content must have either 1 or 3 colour channels.");
@@ -419,6 +420,7 @@ extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const v
             for (int u = 0; u < FL - 1 + nn; ++u) {
                 const int src = t0 + u - pad;         // index into h_frame_idx
                 a.idx[u] = h_frame_idx[src < 0 ? 0 : src];
+                a.idx1[u] = h_frame_idx1 ? h_frame_idx1[src < 0 ? 0 : src] : a.idx[u];
             }
             // vector path needs the lane's PX consecutive samples to be naturally aligned
 #ifndef K1_PX16
@@ -445,6 +447,7 @@ extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const v
         }
     } else {
         // images, fl > 32 and frame sizes without 4-sample alignment: one thread per pixel and output frame
+        if (h_frame_idx1) return fail(FVVDP_EINVAL, "per-frame source pointers are supported for video with fl <= 32 only");
         if (fl - 1 + n_out > c->max_frames + FVVDP_MAX_TAPS) return fail(FVVDP_EINVAL, "too many frames for one call");
         GenericArgs a;
         memset(&a, 0, sizeof(a));
@@ -477,6 +480,61 @@ extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const v
     }
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;
+}
+
+extern "C" int fvvdp_temporal_channels(fvvdp_ctx* c, const void* d_test, const void* d_ref, int dtype, int C,
+                                       size_t chan_stride, size_t frame_stride, const fvvdp_eotf* eotf,
+                                       const float* h_rgb2y, const int32_t* h_frame_idx, const float* h_taps, int fl,
+                                       int n_out, int slot0, int32_t* d_oob_flag, void* stream) {
+    return temporal_channels_core(c, d_test, d_ref, dtype, C, chan_stride, frame_stride, eotf, h_rgb2y, h_frame_idx, nullptr,
+                                  h_taps, fl, n_out, slot0, d_oob_flag, stream);
+}
+
+extern "C" int fvvdp_temporal_channels_frames(fvvdp_ctx* c, const void* const* h_test_frames, const void* const* h_ref_frames,
+                                              int n_frames, int dtype, int C, size_t chan_stride, const fvvdp_eotf* eotf,
+                                              const float* h_rgb2y, const int32_t* h_frame_idx, const float* h_taps, int fl,
+                                              int n_out, int slot0, int32_t* d_oob_flag, void* stream) {
+    if (!c || !h_test_frames || !h_ref_frames || !h_frame_idx) return fail(FVVDP_EINVAL, "null argument");
+    if (n_frames < 1 || n_frames > 65536) return fail(FVVDP_EINVAL, "n_frames out of range");
+    if (dtype < FVVDP_U8 || dtype > FVVDP_F32) return fail(FVVDP_EINVAL, "Only uint8, uint16 and float32 is currently supported");
+    if (fl < 1 || fl > 32 || c->P != 4) return fail(FVVDP_EUNSUPPORTED, "per-frame source pointers: video contexts with fl <= 32 only");
+    const size_t es = dtype == FVVDP_U8 ? 1 : (dtype == FVVDP_U16 ? 2 : 4);
+    // every frame is addressed as base + index * frame_stride with ONE base per stream: base = lowest frame address,
+    // frame_stride = the coarsest granule (4 elements, else 1) that divides every distance; indices are 31-bit
+    const void* const* fr[2] = {h_test_frames, h_ref_frames};
+    uintptr_t base[2];
+    size_t gran = 4;
+    for (int s = 0; s < 2; ++s) {
+        base[s] = UINTPTR_MAX;
+        for (int i = 0; i < n_frames; ++i) {
+            if (!fr[s][i]) return fail(FVVDP_EINVAL, "null frame pointer");
+            const uintptr_t p = reinterpret_cast<uintptr_t>(fr[s][i]);
+            if (p % es) return fail(FVVDP_EINVAL, "frame pointer not aligned to its element size");
+            if (p < base[s]) base[s] = p;
+        }
+        for (int i = 0; i < n_frames; ++i)
+            if ((reinterpret_cast<uintptr_t>(fr[s][i]) - base[s]) % (es * 4)) gran = 1;
+    }
+    std::vector<int32_t> off[2];
+    for (int s = 0; s < 2; ++s) {
+        off[s].resize(n_frames);
+        for (int i = 0; i < n_frames; ++i) {
+            const uintptr_t d = (reinterpret_cast<uintptr_t>(fr[s][i]) - base[s]) / (es * gran);
+            if (d > 0x7FFFFFFFu) return fail(FVVDP_EUNSUPPORTED, "frames are too far apart in memory for 31-bit frame indices");
+            off[s][i] = (int32_t)d;
+        }
+    }
+    const int total = fl - 1 + n_out;
+    std::vector<int32_t> i0(total), i1(total);
+    for (int u = 0; u < total; ++u) {
+        const int f = h_frame_idx[u];
+        if (f < 0 || f >= n_frames) return fail(FVVDP_EINVAL, "frame index %d out of range", f);
+        i0[u] = off[0][f];
+        i1[u] = off[1][f];
+    }
+    return temporal_channels_core(c, reinterpret_cast<const void*>(base[0]), reinterpret_cast<const void*>(base[1]), dtype, C,
+                                  chan_stride, gran, eotf, h_rgb2y, i0.data(), i1.data(), h_taps, fl, n_out, slot0, d_oob_flag,
+                                  stream);
 }
 
 template <int FL, int PX>

@@ -176,6 +176,8 @@ struct TemporalArgs {
     int* oob;
     float taps[2][32];
     int idx[T_MAX_IDX];    // [FL-1+n_out], entries before the true history are padded with a valid frame
+    int idx1[T_MAX_IDX];   // the same for stream 1 (reference): equal to idx for one array per stream, different when the
+                           // frames of a stream are separate allocations (fvvdp_temporal_channels_frames)
 };
 
 __device__ __forceinline__ void build_lutw(float* lutw, const float* lut, int C, const float* w, int tid, int nthreads) {
@@ -341,8 +343,9 @@ __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a
 #pragma unroll
     for (int d = 0; d < TDIST; ++d) {
         const size_t off = (size_t)a.idx[d < total ? d : total - 1] * a.frame_stride;
+        const size_t off1 = (size_t)a.idx1[d < total ? d : total - 1] * a.frame_stride;
         nx[d][0] = fetch_frame<SRC, PX>(a.src[0], off, a.chan_stride, a.C, px);
-        nx[d][1] = fetch_frame<SRC, PX>(a.src[1], off, a.chan_stride, a.C, px);
+        nx[d][1] = fetch_frame<SRC, PX>(a.src[1], off1, a.chan_stride, a.C, px);
     }
     for (int v0 = 0; v0 < total; v0 += FL) {
 #pragma unroll
@@ -352,8 +355,9 @@ __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a
                 const RawFrame<SRC, PX> cur0 = nx[u % TDIST][0], cur1 = nx[u % TDIST][1];
                 if (v + TDIST < total) {
                     const size_t off = (size_t)a.idx[v + TDIST] * a.frame_stride;
+                    const size_t off1 = (size_t)a.idx1[v + TDIST] * a.frame_stride;
                     nx[u % TDIST][0] = fetch_frame<SRC, PX>(a.src[0], off, a.chan_stride, a.C, px);
-                    nx[u % TDIST][1] = fetch_frame<SRC, PX>(a.src[1], off, a.chan_stride, a.C, px);
+                    nx[u % TDIST][1] = fetch_frame<SRC, PX>(a.src[1], off1, a.chan_stride, a.C, px);
                 }
                 frame_lum<SRC, PX, RawFrame<SRC, PX>>(cur0, a.C, lutw, a.e.lut, w, a.e, ring[0][u], bad);
                 frame_lum<SRC, PX, RawFrame<SRC, PX>>(cur1, a.C, lutw, a.e.lut, w, a.e, ring[1][u], bad);
@@ -470,8 +474,9 @@ __global__ __launch_bounds__(64) void temporal_vec_kernel(const TemporalArgs a) 
 #pragma unroll
     for (int d = 0; d < TD; ++d) {
         const size_t off = (size_t)a.idx[d < total ? d : total - 1] * a.frame_stride + pl;
+        const size_t off1 = (size_t)a.idx1[d < total ? d : total - 1] * a.frame_stride + pl;
         nx[d][0] = fetch_vec<SRC, PX>(a.src[0], off, a.chan_stride, a.C);
-        nx[d][1] = fetch_vec<SRC, PX>(a.src[1], off, a.chan_stride, a.C);
+        nx[d][1] = fetch_vec<SRC, PX>(a.src[1], off1, a.chan_stride, a.C);
     }
     for (int v0 = 0; v0 < total; v0 += FL) {
 #pragma unroll
@@ -481,8 +486,9 @@ __global__ __launch_bounds__(64) void temporal_vec_kernel(const TemporalArgs a) 
                 const RawVecFrame<SRC, PX> cur0 = nx[u % TD][0], cur1 = nx[u % TD][1];
                 if (v + TD < total) {
                     const size_t off = (size_t)a.idx[v + TD] * a.frame_stride + pl;
+                    const size_t off1 = (size_t)a.idx1[v + TD] * a.frame_stride + pl;
                     nx[u % TD][0] = fetch_vec<SRC, PX>(a.src[0], off, a.chan_stride, a.C);
-                    nx[u % TD][1] = fetch_vec<SRC, PX>(a.src[1], off, a.chan_stride, a.C);
+                    nx[u % TD][1] = fetch_vec<SRC, PX>(a.src[1], off1, a.chan_stride, a.C);
                 }
                 frame_lum<SRC, PX, RawVecFrame<SRC, PX>>(cur0, a.C, lutw, a.e.lut, w, a.e, ring[0][u], bad);
                 frame_lum<SRC, PX, RawVecFrame<SRC, PX>>(cur1, a.C, lutw, a.e.lut, w, a.e, ring[1][u], bad);

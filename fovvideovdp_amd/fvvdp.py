@@ -662,9 +662,11 @@ class _PipelinedSourceFeeder:
     """Frame supply for sources whose frames only exist behind their own `get_*_frame`.
 
     The reference fetches synchronously inside its frame loop (pyfvvdp/fvvdp.py:287-288).  Here every source frame is
-    still fetched exactly once, but on a side stream into one of two device staging buffers, and nothing waits on the
-    host: while the kernels of batch b run, the Python code of the source (and its copies / kernels) already produces
-    batch b+1.  History frames of the temporal window move between the two buffers with device-to-device copies."""
+    still fetched exactly once (on a side stream), nothing waits on the host -- while the kernels of batch b run, the
+    Python code of the source already produces batch b+1 -- and nothing is copied: the temporal kernel reads the
+    luminance tensors the source returned where they are (fvvdp_temporal_channels_frames; frames of the temporal window
+    that were fetched for an earlier batch are simply kept alive).  Sources whose tensors the kernel cannot address
+    (too far apart in memory, filters longer than 32 taps) go through one stacking copy per stream and batch instead."""
 
     preferred_batch = 16       # frames per batch when the caller did not choose (>= 2 batches are needed to overlap; per-batch
                                # launch overhead ~0.15 ms: 8 -> 2.8 ms, 16 -> 2.15 ms on 1080p x60)
@@ -673,58 +675,68 @@ class _PipelinedSourceFeeder:
         self.m, self.vs, self.W, self.H = metric, vs, width, height
         self.dev = metric.device
         self.side = torch.cuda.Stream(device=self.dev)
-        self.buf = [None, None]           # [2 streams (test, ref)][slots][H][W] fp32 luminance
-        self.pos = [{}, {}]               # source frame -> slot
-        self.read_done = [None, None]     # the temporal kernel has finished reading buffer i
-        self.turn = 0
+        self.frames = {}                  # source frame -> (test luminance [H*W], reference luminance) fp32 on the device
+        self.prev_done = None             # kernels of the previous batch have finished reading their frames
+        self.retired = []                 # tensors of frames that left the window: freed once prev_done has passed
         self.eotf = nat.Eotf()
         self.eotf.kind = nat.EOTF_NONE
 
+    def _fetch(self, f):
+        H, W = self.H, self.W
+        out = []
+        for get in (self.vs.get_test_frame, self.vs.get_reference_frame):
+            t = get(f, device=self.dev)
+            if not (isinstance(t, torch.Tensor) and t.dtype is torch.float32 and t.device == self.dev and t.is_contiguous()):
+                t = torch.as_tensor(t).to(device=self.dev, dtype=torch.float32).contiguous()
+            if t.numel() != H * W:
+                raise RuntimeError("get_*_frame must return one luminance frame of %dx%d pixels" % (W, H))
+            out.append(t.reshape(-1))
+        return tuple(out)
+
     def __call__(self, ctx, idx, taps, fl, n_out, oob, stream):
-        i, prev = self.turn, 1 - self.turn
         uniq = sorted(set(int(f) for f in idx))
         main = torch.cuda.current_stream(self.dev)
-        H, W = self.H, self.W
         with torch.cuda.stream(self.side):
-            if self.read_done[i] is not None:
-                self.side.wait_event(self.read_done[i])          # buffer i was last read two batches ago
-            if self.buf[i] is None or self.buf[i].shape[1] < len(uniq):
-                self.buf[i] = torch.empty((2, len(uniq), H, W), dtype=torch.float32, device=self.dev)
-            b = self.buf[i]
-            pp = self.pos[prev]
-            # slots: frames kept from the previous batch first (moved with as few device copies as possible: runs of
-            # consecutive slots), then the frames the source has to deliver (one stacking kernel per stream and batch)
-            kept = [f for f in uniq if f in pp]
-            fresh = [f for f in uniq if f not in pp]
-            pos = {f: k for k, f in enumerate(kept + fresh)}
-            k = 0
-            while k < len(kept):
-                run = 1
-                while k + run < len(kept) and pp[kept[k + run]] == pp[kept[k]] + run:
-                    run += 1
-                b[:, k:k + run].copy_(self.buf[prev][:, pp[kept[k]]:pp[kept[k]] + run], non_blocking=True)
-                k += run
-            if fresh:
-                k0 = len(kept)
-                ft = [self.vs.get_test_frame(f, device=self.dev) for f in fresh]
-                fr = [self.vs.get_reference_frame(f, device=self.dev) for f in fresh]
-                for s_i, frames in ((0, ft), (1, fr)):
-                    if all(t.dtype is torch.float32 and t.device == self.dev and t.numel() == H * W for t in frames):
-                        torch.stack([t.reshape(H, W) for t in frames], out=b[s_i, k0:k0 + len(frames)])
-                    else:                                         # anything else: per-frame converting copies
-                        for j, t in enumerate(frames):
-                            b[s_i, k0 + j].copy_(t.reshape(H, W), non_blocking=True)
+            fresh = [f for f in uniq if f not in self.frames]
+            for f in fresh:
+                self.frames[f] = self._fetch(f)
             ready = torch.cuda.Event()
             ready.record(self.side)
         main.wait_event(ready)
-        b.record_stream(main)                                     # read by kernels torch does not know about
+        pos = {f: k for k, f in enumerate(uniq)}
         ridx = np.asarray([pos[int(f)] for f in idx], dtype=np.int32)
-        nat.check(nat.lib().fvvdp_temporal_channels(
-            ctx.handle, C.c_void_p(b[0].data_ptr()), C.c_void_p(b[1].data_ptr()), nat.FVVDP_F32, 1, 0, H * W,
-            C.byref(self.eotf), None, ridx.ctypes.data_as(C.POINTER(C.c_int32)), nat.fptr(taps), fl, n_out, 0,
-            C.c_void_p(oob.data_ptr()), stream))
+        tp = (C.c_void_p * len(uniq))(*[self.frames[f][0].data_ptr() for f in uniq])
+        rp = (C.c_void_p * len(uniq))(*[self.frames[f][1].data_ptr() for f in uniq])
+        lib = nat.lib()
+        rc = lib.fvvdp_temporal_channels_frames(
+            ctx.handle, tp, rp, len(uniq), nat.FVVDP_F32, 1, 0, C.byref(self.eotf), None,
+            ridx.ctypes.data_as(C.POINTER(C.c_int32)), nat.fptr(taps), fl, n_out, 0, C.c_void_p(oob.data_ptr()), stream)
+        if rc == nat.FVVDP_EUNSUPPORTED:          # one array per stream, then the general entry point
+            with torch.cuda.stream(self.side):
+                bt = torch.stack([self.frames[f][0] for f in uniq])
+                br = torch.stack([self.frames[f][1] for f in uniq])
+                ready = torch.cuda.Event()
+                ready.record(self.side)
+            main.wait_event(ready)
+            for b in (bt, br):
+                b.record_stream(main)
+            nat.check(lib.fvvdp_temporal_channels(
+                ctx.handle, C.c_void_p(bt.data_ptr()), C.c_void_p(br.data_ptr()), nat.FVVDP_F32, 1, 0, self.H * self.W,
+                C.byref(self.eotf), None, ridx.ctypes.data_as(C.POINTER(C.c_int32)), nat.fptr(taps), fl, n_out, 0,
+                C.c_void_p(oob.data_ptr()), stream))
+        else:
+            nat.check(rc)
+        # the frames were allocated on the side stream and are read by kernels torch does not know about
+        for f in uniq:
+            for t in self.frames[f]:
+                t.record_stream(main)
+        # keep only what later batches can still ask for: frames of this batch's window
+        keep = set(uniq)
+        for f in [f for f in self.frames if f not in keep]:
+            self.retired.append(self.frames.pop(f))
         done = torch.cuda.Event()
         done.record(main)
-        self.read_done[i] = done
-        self.pos[i] = pos
-        self.turn = prev
+        if self.prev_done is not None and self.prev_done.query():
+            self.retired.clear()
+        self.prev_done = done
+

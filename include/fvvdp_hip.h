@@ -38,6 +38,7 @@ extern "C" {
 #define FVVDP_EHIP (-2)     /* a HIP runtime call failed */
 #define FVVDP_ENOMEM (-3)   /* scratch allocation failed */
 #define FVVDP_ESTATE (-4)   /* call order violated (e.g. CSF table not set) */
+#define FVVDP_EUNSUPPORTED (-5)   /* valid request outside this entry point's domain: use the general one */
 
 #define FVVDP_MAX_BANDS 16
 #define FVVDP_MAX_TAPS 256
@@ -160,6 +161,17 @@ int fvvdp_temporal_channels(fvvdp_ctx* ctx, const void* d_test, const void* d_re
                             size_t chan_stride, size_t frame_stride, const fvvdp_eotf* eotf,
                             const float* h_rgb2y, const int32_t* h_frame_idx, const float* h_taps, int fl,
                             int n_out, int slot0, int32_t* d_oob_flag, void* stream);
+
+/* The same for sources whose frames are SEPARATE allocations (what fvvdp_video_source.get_test_frame / get_reference_frame
+ * of a user class return, video_source.py:14-36): h_test_frames / h_ref_frames are host arrays of n_frames device
+ * pointers, one frame [C][H*W] each (channel c at c*chan_stride); h_frame_idx indexes those arrays.  No staging copy:
+ * the kernels read the frames where they are.  Video contexts with fl <= 32; returns FVVDP_EUNSUPPORTED when the frames
+ * lie more than 2^31 elements (x4 when every distance is a multiple of 4 elements) apart, or for other contexts -- the
+ * caller then copies the frames into one array and uses fvvdp_temporal_channels.                                   */
+int fvvdp_temporal_channels_frames(fvvdp_ctx* ctx, const void* const* h_test_frames, const void* const* h_ref_frames,
+                                   int n_frames, int dtype, int C, size_t chan_stride, const fvvdp_eotf* eotf,
+                                   const float* h_rgb2y, const int32_t* h_frame_idx, const float* h_taps, int fl, int n_out,
+                                   int slot0, int32_t* d_oob_flag, void* stream);
 
 /* Raw planar YUV sources (what video_reader_yuv_pytorch receives from ffmpeg's rawvideo pipe,
  * video_source_file.py:166-217): every frame is the Y plane [H][W] followed by the U and V planes ([H/2][W/2] for
