@@ -149,13 +149,13 @@ def test_mixed_dtypes_follow_each_arrays_own_dtype(fv):
     assert abs(a - b) < 2e-3
 
 
+@pytest.mark.parametrize("H,W", [(70, 120), (37, 53)])       # 37x53: frames 4 bytes apart modulo 16 -> scalar temporal kernel
 @pytest.mark.parametrize("pad,fps,N", [("replicate", 30, 21), ("circular", 30, 13), ("pingpong", 60, 19), ("replicate", 60, 30)])
-def test_pipelined_source_feeder_fetches_every_frame_once_and_matches_the_array_path(fv, pad, fps, N):
+def test_pipelined_source_feeder_fetches_every_frame_once_and_matches_the_array_path(fv, pad, fps, N, H, W):
     """User video sources go through their own get_*_frame: side-stream, double-buffered, no host
     synchronisation per batch; with `replicate` padding every frame is fetched exactly once, like the reference does
     (pyfvvdp/fvvdp.py:287-288).  Results equal the array path up to the float-vs-table display model (1e-6)."""
     from fovvideovdp_amd.synth import synth_video_pair
-    H, W = 70, 120
     test, ref = synth_video_pair(N, H, W)
     m = fv.fvvdp(display_name="standard_fhd", temp_padding=pad)
     q0, s0 = m.predict(test, ref, frames_per_second=fps)
@@ -195,3 +195,32 @@ def test_pipelined_source_feeder_fetches_every_frame_once_and_matches_the_array_
     q2, s2 = m.predict_video_source(Src(), sync=False)
     fv.fvvdp.finish(s2)
     assert abs(float(q2) - float(q0)) < 5e-6
+
+
+def test_user_source_with_a_filter_longer_than_32_taps_and_host_frames(fv):
+    """144 fps -> 36 taps: beyond fvvdp_temporal_channels_frames (the feeder stacks the frames and takes the general
+    entry point); and a source that returns host float64 tensors of another shape (converted on the way in)."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    N, H, W, fps = 40, 36, 64, 144
+    test, ref = synth_video_pair(N, H, W)
+    m = fv.fvvdp(display_name="standard_fhd")
+    q0, s0 = m.predict(test, ref, frames_per_second=fps)
+    inner = fv.fvvdp_video_source_array(test, ref, fps, display_photometry=m.display_photometry)
+
+    class Src(fv.fvvdp_video_source):
+        def get_video_size(self):
+            return (H, W, N)
+
+        def get_frames_per_second(self):
+            return fps
+
+        def get_test_frame(self, frame, device):
+            return inner.get_test_frame(frame, torch.device("cpu")).to(torch.float64).reshape(H, W)
+
+        def get_reference_frame(self, frame, device):
+            return inner.get_reference_frame(frame, torch.device("cpu")).to(torch.float64).reshape(H, W)
+
+    q1, s1 = m.predict_video_source(Src())
+    assert abs(float(q1) - float(q0)) < 5e-6
+    a, b = s1["Q_per_ch"].astype(np.float64), s0["Q_per_ch"].astype(np.float64)
+    assert np.all(np.abs(a - b) <= 4e-3 * np.abs(b) + 1e-6 * np.max(b))      # 36x64: every band is tiny
