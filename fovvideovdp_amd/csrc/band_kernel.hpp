@@ -158,6 +158,9 @@ __global__ __launch_bounds__(256) void fov_rho_map_kernel(const RhoMapArgs a) {
 #ifndef FOV_MINW
 #define FOV_MINW 2
 #endif
+#ifndef FOV_PHASE
+#define FOV_PHASE 4          // pixels whose LDS reads are batched (4: all of a step, 254 VGPRs; 2: pairs)
+#endif
 extern __shared__ __attribute__((aligned(16))) float4 s_lut_dyn[];
 
 // FOVM: 0 = non-foveated, 1 = foveated with the band's LUT slice in (dynamic) LDS, 2 = foveated, LUT slice in global
@@ -626,6 +629,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
             }
             if constexpr (LUT_LDS && !DBG) {
                 if (a.rmap && !a.mvx) {                   // stock geometry: phased evaluation (see fov_a / fov_b)
+#if FOV_PHASE == 4
                     const FovQ q0 = fov_a(W[0][0], x00, vx4[0], vy4[0], ra.x, ra.y);
                     const FovQ q1 = fov_a(W[0][1], x01, vx4[1], vy4[1], ra.z, ra.w);
                     const FovQ q2 = fov_a(W[1][0], x10, vx4[2], vy4[2], rb.x, rb.y);
@@ -634,6 +638,23 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
                     fov_b(q1, active && col1_ok);
                     fov_b(q2, active && row1_ok);
                     fov_b(q3, active && row1_ok && col1_ok);
+#else               // two pixels per phase: half the registers in flight; the scheduler may not interleave the phases
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        const FovQ q0 = fov_a(W[0][0], x00, vx4[0], vy4[0], ra.x, ra.y);
+                        const FovQ q1 = fov_a(W[0][1], x01, vx4[1], vy4[1], ra.z, ra.w);
+                        fov_b(q0, active);
+                        fov_b(q1, active && col1_ok);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        const FovQ q2 = fov_a(W[1][0], x10, vx4[2], vy4[2], rb.x, rb.y);
+                        const FovQ q3 = fov_a(W[1][1], x11, vx4[3], vy4[3], rb.z, rb.w);
+                        fov_b(q2, active && row1_ok);
+                        fov_b(q3, active && row1_ok && col1_ok);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#endif
                 } else {
                     band_px(W[0][0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0], ra.x, ra.y);
                     band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1], ra.z, ra.w);
