@@ -628,7 +628,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
                 rb = a.rmap[(size_t)min(2 * c + 1, h - 1) * a.rmap_w + jj];
             }
             if constexpr (LUT_LDS && !DBG) {
-                if (a.rmap && !a.mvx) {                   // stock geometry: phased evaluation (see fov_a / fov_b)
+                if (FOV_PHASE != 0 && a.rmap && !a.mvx) {   // stock geometry: phased evaluation (see fov_a / fov_b)
 #if FOV_PHASE == 4
                     const FovQ q0 = fov_a(W[0][0], x00, vx4[0], vy4[0], ra.x, ra.y);
                     const FovQ q1 = fov_a(W[0][1], x01, vx4[1], vy4[1], ra.z, ra.w);
