@@ -357,7 +357,13 @@ static void launch_ring(int dtype, const TemporalArgs& a, hipStream_t st) {
 template <int FL, int PX>
 static void launch_vec(int dtype, const TemporalArgs& a, hipStream_t st) {
     dim3 grid((a.HW + 64 * PX - 1) / (64 * PX)), block(64);
-    constexpr int TD = 1;
+#ifndef K1_TD16
+#define K1_TD16 1
+#endif
+#ifndef K1_TD32
+#define K1_TD32 1
+#endif
+    constexpr int TD = FL == 16 ? K1_TD16 : (FL == 32 ? K1_TD32 : 1);
     if (dtype == FVVDP_U8)
         hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_U8, TD>), grid, block, 0, st, a);
     else if (dtype == FVVDP_U16)
