@@ -84,3 +84,19 @@ def test_large_level_takes_the_two_level_kernel_by_default(monkeypatch):
     _close(Q1, Q0)
     # default takes band2 for level 0+1 only; forced takes it for every pair: the first two bands are bit-identical
     assert np.array_equal(std["Q_per_ch"][:2], Q1[:2].astype(np.float32))
+
+
+def test_large_still_image_takes_the_two_level_kernel(monkeypatch):
+    """A 4K still image (2 planes per pixel, one frame per launch) is above the size threshold as well."""
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair
+    test, ref = synth_video_pair(1, 2160, 3840, device="cuda")
+    t, r = test[0, :, 0].permute(1, 2, 0).contiguous(), ref[0, :, 0].permute(1, 2, 0).contiguous()     # HWC uint8
+    monkeypatch.delenv("FVVDP_BAND_FUSE", raising=False)
+    qd, sd = fv.fvvdp(display_name="standard_4k").predict(t, r, dim_order="HWC")
+    q0, Q0 = _run(monkeypatch, t, r, 0, dim_order="HWC")
+    q1, Q1 = _run(monkeypatch, t, r, 1, dim_order="HWC")
+    assert abs(float(qd) - q0) < 2e-6 and abs(q1 - q0) < 2e-6
+    _close(sd["Q_per_ch"].astype(np.float64), Q0)
+    _close(Q1, Q0)
+    assert np.array_equal(sd["Q_per_ch"][:2], Q1[:2].astype(np.float32))       # default == forced for levels 0+1
