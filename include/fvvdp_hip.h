@@ -248,7 +248,9 @@ int fvvdp_heatmap_colorize(fvvdp_ctx* ctx, int n, const float* d_dmap, const flo
 /* ---- introspection (tests, profiling) --------------------------------------------------------------------- */
 
 /* Copy Gaussian level `level` of slots [0,n) to planar fp32 d_out[n][P][h][w] (gaussian_pyramid_dec,
- * fvvdp_lpyr_dec.py:144-158). */
+ * fvvdp_lpyr_dec.py:144-158).  Levels that fvvdp_bands_forward kept on the chip (the middle level of a two-levels-per-
+ * launch pass: large levels in plain evaluation; never with difference maps requested or FVVDP_BAND_FUSE=0 in the
+ * environment) are not materialised and hold stale data. */
 int fvvdp_export_level(fvvdp_ctx* ctx, int level, int n, float* d_out, void* stream);
 
 /* Per-kernel HIP-event timing of the most recent calls.  When enabled, every kernel launch is bracketed by
