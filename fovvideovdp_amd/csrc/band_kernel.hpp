@@ -94,7 +94,7 @@ struct BandArgs {
     float* dL;
     float* dS;
     // foveated (FOV == true)
-    const float4* sublut;   // per band: [32 ecc][32 Y][rw] of {S_log0[i], S_log1[i], S_log0[i+1], S_log1[i+1]} (i = rho knot)
+    const float4* sublut;   // per band: [32 ecc][32 Y][rw] of {S_log0[i], S_log1[i], S_log0[i+1]-S_log0[i], S_log1[i+1]-S_log1[i]} (i = rho knot)
     const float* axes;      // [3][32] knots: Y_log, rho_log, ecc_sqrt
     int rw, i_lo;           // rho knots covered by the band's sub-LUT: [i_lo, i_lo+rw]
     const float* fix;       // device [n][2]: gaze in frame pixels, or gaze view direction in degrees (map mode)
@@ -153,6 +153,13 @@ __global__ __launch_bounds__(256) void fov_rho_map_kernel(const RhoMapArgs a) {
 
 
 #ifndef FOV_WPB
+// (int)floorf(x) as ONE instruction (the compiler emits v_floor_f32 + v_cvt_i32_f32)
+__device__ __forceinline__ int floor_to_int(float x) {
+    int r;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(r) : "v"(x));
+    return r;
+}
+
 #define FOV_WPB 4            // foveated mode: 4 independent waves per workgroup share the band's LUT slice in LDS
 #endif
 #ifndef FOV_MINW
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
             const float eq = __builtin_amdgcn_sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
             // interval on each (uniform) axis from the grid, fraction from the stored knots incl. interp.py:16's +1e-6
             auto axis = [&](int ax, float q, int lo, int hi, int& k, float& f) {
-                k = min(max((int)floorf((q - a.first[ax]) * a.inv_step[ax]), lo), hi);
+                k = min(max(floor_to_int((q - a.first[ax]) * a.inv_step[ax]), lo), hi);
                 const float2 kn = s_ax[ax * FVVDP_LUT_N + k];
                 f = fmaxf((q - kn.x) * kn.y, 0.0f);
             };
@@ -409,7 +416,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
                 axis(1, rq, a.i_lo, a.i_lo + a.rw - 1, kR, fR);
             }
             axis(2, eq, 0, FVVDP_LUT_N - 2, kE, fE);
-            const int so = (kE * FVVDP_LUT_N + kY) * a.rw + (kR - a.i_lo);
+            const int so = __mul24(kE * FVVDP_LUT_N + kY, a.rw) + (kR - a.i_lo);
             const int sj = a.rw, sk = FVVDP_LUT_N * a.rw;
             float4 v00, v10, v01, v11;                                                      // v[dj][dk]
             if constexpr (LUT_LDS) {
@@ -418,12 +425,13 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
                 const float4* sb = a.sublut + so;
                 v00 = sb[0]; v10 = sb[sj]; v01 = sb[sk]; v11 = sb[sk + sj];
             }
-            const float gR = 1.0f - fR, gY = 1.0f - fY, gE = 1.0f - fE;
-            // interp3 (interp.py:53-57), same association: rho blend, then Y, then ecc
-            slog[0] = ((v00.x * gR + v00.z * fR) * gY + (v10.x * gR + v10.z * fR) * fY) * gE +
-                      ((v01.x * gR + v01.z * fR) * gY + (v11.x * gR + v11.z * fR) * fY) * fE;
-            slog[1] = ((v00.y * gR + v00.w * fR) * gY + (v10.y * gR + v10.w * fR) * fY) * gE +
-                      ((v01.y * gR + v01.w * fR) * gY + (v11.y * gR + v11.w * fR) * fY) * fE;
+            const float gY = 1.0f - fY, gE = 1.0f - fE;
+            // interp3 (interp.py:53-57), same association: rho blend, then Y, then ecc.  The LUT slice stores the rho
+            // blend in slope form {v[i], v[i+1] - v[i]}: v[i] + f * dv instead of v[i] * (1-f) + v[i+1] * f (1 ulp)
+            slog[0] = (fmaf(v00.z, fR, v00.x) * gY + fmaf(v10.z, fR, v10.x) * fY) * gE +
+                      (fmaf(v01.z, fR, v01.x) * gY + fmaf(v11.z, fR, v11.x) * fY) * fE;
+            slog[1] = (fmaf(v00.w, fR, v00.y) * gY + fmaf(v10.w, fR, v10.y) * fY) * gE +
+                      (fmaf(v01.w, fR, v01.y) * gY + fmaf(v11.w, fR, v11.y) * fY) * fE;
         }
         const float vm = valid ? 1.0f : 0.0f;
         const float lcn = lg_bm - llb;                                   // log2(m / lb)
@@ -506,12 +514,12 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
         const float dx = vx - gx, dy = vy - gy;
         const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
         q.eq = __builtin_amdgcn_sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
-        const int kY = min(max((int)floorf((q.yq - a.first[0]) * a.inv_step[0]), 0), FVVDP_LUT_N - 2);
-        const int kE = min(max((int)floorf((q.eq - a.first[2]) * a.inv_step[2]), 0), FVVDP_LUT_N - 2);
+        const int kY = min(max(floor_to_int((q.yq - a.first[0]) * a.inv_step[0]), 0), FVVDP_LUT_N - 2);
+        const int kE = min(max(floor_to_int((q.eq - a.first[2]) * a.inv_step[2]), 0), FVVDP_LUT_N - 2);
         q.knY = s_ax[kY];
         q.knE = s_ax[2 * FVVDP_LUT_N + kE];
         q.fR = pre_fR;
-        const int so = (kE * FVVDP_LUT_N + kY) * a.rw + (int)pre_kR;
+        const int so = __mul24(kE * FVVDP_LUT_N + kY, a.rw) + (int)pre_kR;
         const int sj = a.rw, sk = FVVDP_LUT_N * a.rw;
         q.v00 = s_lut_dyn[so];
         q.v10 = s_lut_dyn[so + sj];
@@ -523,9 +531,10 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
         const float fY = fmaxf((q.yq - q.knY.x) * q.knY.y, 0.0f);
         const float fE = fmaxf((q.eq - q.knE.x) * q.knE.y, 0.0f);
         const float fR = q.fR;
-        const float gR = 1.0f - fR, gY = 1.0f - fY, gE = 1.0f - fE;
-        // interp3 (interp.py:53-57), same association (rho, then Y, then ecc); both temporal channels as one packed pair
-        auto rho_blend = [&](const float4& v) { return pfma(v2f{v.z, v.w}, fR, v2f{v.x, v.y} * gR); };
+        const float gY = 1.0f - fY, gE = 1.0f - fE;
+        // interp3 (interp.py:53-57), same association (rho, then Y, then ecc); both temporal channels as one packed pair;
+        // rho blend in slope form (see band_px)
+        auto rho_blend = [&](const float4& v) { return pfma(v2f{v.z, v.w}, fR, v2f{v.x, v.y}); };
         const v2f r00 = rho_blend(q.v00), r10 = rho_blend(q.v10), r01 = rho_blend(q.v01), r11 = rho_blend(q.v11);
         const v2f y0 = pfma(r10, fY, r00 * gY), y1 = pfma(r11, fY, r01 * gY);
         const v2f sl2 = pfma(y1, fE, y0 * gE);

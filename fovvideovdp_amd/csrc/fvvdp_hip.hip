@@ -704,7 +704,8 @@ extern "C" int fvvdp_export_level(fvvdp_ctx* c, int level, int n, float* d_out, 
 // Foveated mode: slice of the 32^3 LUT that band b can reach.  rho = rho_band*res_mag with res_mag in
 // [1, res_mag(corner of the screen)], so only a few rho knots are live per band; the slice is stored as
 // [ecc][Y][rho] of float4 {S0[i], S1[i], S0[i+1], S1[i+1]} so that one aligned 16-byte load returns the two rho
-// corners of both temporal channels and neighbouring pixels (similar ecc, Y) share cache lines.
+// corners of both temporal channels (value at knot i and the step to knot i+1: v[i] + f*(v[i+1]-v[i])) and neighbouring
+// pixels (similar ecc, Y) share cache lines.
 static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
     fvvdp_geom key;
     memset(&key, 0, sizeof(key));
@@ -752,7 +753,7 @@ static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
                 for (int i = 0; i < rw; ++i) {
                     const size_t s0 = ((size_t)j * FVVDP_LUT_N + (i_lo + i)) * FVVDP_LUT_N + k;       // [Y][rho][ecc]
                     const size_t s1 = ((size_t)j * FVVDP_LUT_N + (i_lo + i + 1)) * FVVDP_LUT_N + k;
-                    h[((size_t)k * FVVDP_LUT_N + j) * rw + i] = make_float4(L0[s0], L1[s0], L0[s1], L1[s1]);
+                    h[((size_t)k * FVVDP_LUT_N + j) * rw + i] = make_float4(L0[s0], L1[s0], L0[s1] - L0[s0], L1[s1] - L1[s0]);   // slope form
                 }
         HIP_TRY(hipMemcpy(c->sublut[b], h.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         c->sub_rw[b] = rw;

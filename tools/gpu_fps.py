@@ -13,6 +13,10 @@ for fps, N, kind in cases:
     test, ref = synth_video_pair(N, H, W, device="cuda")
     if kind == "u16":
         test = (test.to(torch.int32) * 257).to(torch.int16); ref = (ref.to(torch.int32) * 257).to(torch.int16)
+    elif kind == "f32gray":
+        test = test[:, 1:2].to(torch.float32) / 255; ref = ref[:, 1:2].to(torch.float32) / 255
+    elif kind == "f32rgb":
+        test = test.to(torch.float32) / 255; ref = ref.to(torch.float32) / 255
     m = fv.fvvdp(display_name="standard_4k"); m.timing = True
     best = 1e9
     for it in range(4):
