@@ -196,21 +196,28 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         p1 = ld_px<P>(row + (size_t)xc1 * P);
     };
 
-    Px<P> W[5][2];
-    auto coarse_step = [&]() -> Px<P> {          // level-B row from the current 5-row window of level A
+    // Level-A rows live in an 8-slot register ring: row r of the chunk sits in slot r & 7, a step's window is slots
+    // base .. base+4 and the two rows of the next step are fetched into slots base+5, base+6.  The base advances by 2 per
+    // step, so two stages (4 steps) bring it back: the stage body is instantiated for both phases and nothing is moved
+    // (a 5-row window that is shifted costs 24 v_mov_b64 per stage on a VALU-bound kernel).
+    Px<P> S[8][2];
+    auto coarse_step = [&](auto base) -> Px<P> {          // level-B row from the 5-row window of level A at slot `base`
+        constexpr int B = decltype(base)::value;
+        Px<P>(&W0)[2] = S[(B + 0) & 7]; Px<P>(&W1)[2] = S[(B + 1) & 7]; Px<P>(&W2)[2] = S[(B + 2) & 7];
+        Px<P>(&W3)[2] = S[(B + 3) & 7]; Px<P>(&W4)[2] = S[(B + 4) & 7];
         Px<P> c, va, vb;
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
-            v2f a0 = W[0][0].h[k] * K0;
-            a0 = pfma(W[1][0].h[k], K1, a0);
-            a0 = pfma(W[2][0].h[k], K2, a0);
-            a0 = pfma(W[3][0].h[k], K3, a0);
-            va.h[k] = pfma(W[4][0].h[k], K4, a0);
-            v2f b0 = W[0][1].h[k] * K0;
-            b0 = pfma(W[1][1].h[k], K1, b0);
-            b0 = pfma(W[2][1].h[k], K2, b0);
-            b0 = pfma(W[3][1].h[k], K3, b0);
-            vb.h[k] = pfma(W[4][1].h[k], K4, b0);
+            v2f a0 = W0[0].h[k] * K0;
+            a0 = pfma(W1[0].h[k], K1, a0);
+            a0 = pfma(W2[0].h[k], K2, a0);
+            a0 = pfma(W3[0].h[k], K3, a0);
+            va.h[k] = pfma(W4[0].h[k], K4, a0);
+            v2f b0 = W0[1].h[k] * K0;
+            b0 = pfma(W1[1].h[k], K1, b0);
+            b0 = pfma(W2[1].h[k], K2, b0);
+            b0 = pfma(W3[1].h[k], K3, b0);
+            vb.h[k] = pfma(W4[1].h[k], K4, b0);
         }
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
@@ -220,17 +227,6 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         }
         return c;
     };
-    auto shift_window = [&](const Px<P> (&n0)[2], const Px<P> (&n1)[2]) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            W[0][j] = W[2][j];
-            W[1][j] = W[3][j];
-            W[2][j] = W[4][j];
-            W[3][j] = n0[j];
-            W[4][j] = n1[j];
-        }
-    };
-
     float accA[2] = {0.0f, 0.0f}, accB[2] = {0.0f, 0.0f};
     const float lg_base = a.lg_gain;
     const float lg_mask = a.lg_gain + a.lg_k;
@@ -287,7 +283,9 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
     };
 
     // band A for level-A rows 2c, 2c+1 (window rows 0, 1), expand from level-B rows c-1, c, c+1
-    auto band_a_rows = [&](int c, const Px<P>& Bm1, const Px<P>& B0, const Px<P>& Bp1) {
+    auto band_a_rows = [&](auto base, int c, const Px<P>& Bm1, const Px<P>& B0, const Px<P>& Bp1) {
+        constexpr int B = decltype(base)::value;
+        Px<P>(&W0)[2] = S[(B + 0) & 7]; Px<P>(&W1)[2] = S[(B + 1) & 7];
         Px<P> x00, x01, x10, x11, evE, evO;
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
@@ -306,29 +304,32 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
             dpp_expand_taps(evO.h[k], el, er, orr, x10.h[k], x11.h[k]);
         }
         const bool row1_ok = (2 * c + 1) < h;
-        tail(W[0][0], x00, owned, 0, accA);
-        tail(W[0][1], x01, owned && col1_ok, 0, accA);
-        tail(W[1][0], x10, owned && row1_ok, 0, accA);
-        tail(W[1][1], x11, owned && row1_ok && col1_ok, 0, accA);
+        tail(W0[0], x00, owned, 0, accA);
+        tail(W0[1], x01, owned && col1_ok, 0, accA);
+        tail(W1[0], x10, owned && row1_ok, 0, accA);
+        tail(W1[1], x11, owned && row1_ok && col1_ok, 0, accA);
     };
 
     // ---- prologue: level-B row 2*ks and the window of the first step ---------------------------------------
     const int ks = max(ka - 2, 0);
     const bool last_chunk = kb >= hc;
     const int kend = last_chunk ? hc - 1 : kb;
-    {
+    typedef std::integral_constant<int, 0> I0;
+    typedef std::integral_constant<int, 2> I2;
+    typedef std::integral_constant<int, 4> I4;
+    typedef std::integral_constant<int, 6> I6;
+    {   // level-A rows 4ks-2 .. 4ks+2 into slots 6, 7, 0, 1, 2: row 4ks + j sits in slot j
         const int r0 = 4 * ks - 2;
 #pragma unroll
-        for (int k = 0; k < 5; ++k) load_row(r0 + k, W[k][0], W[k][1]);
+        for (int k = 0; k < 5; ++k) load_row(r0 + k, S[(6 + k) & 7][0], S[(6 + k) & 7][1]);
     }
     Px<P> R[5];                       // level-B rows 2k-2 .. 2k+2 of the running stage (newest last)
-    R[4] = coarse_step();
+    R[4] = coarse_step(I6());
     R[0] = R[1] = R[2] = R[3] = R[4];
     Px<P> CH[3];                      // level-C rows k-2, k-1, k
     CH[0] = CH[1] = CH[2] = R[4];
-    Px<P> nx0[2], nx1[2];
-    load_row(4 * ks + 3, nx0[0], nx0[1]);
-    load_row(4 * ks + 4, nx1[0], nx1[1]);
+    load_row(4 * ks + 3, S[3][0], S[3][1]);
+    load_row(4 * ks + 4, S[4][0], S[4][1]);
 
     // band B for level-B rows g0 (even), g1 (odd) from the level-C history
     auto band_b_rows = [&](const Px<P>& g0, const Px<P>& g1, int row0) {
@@ -350,25 +351,24 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
     };
 
     // ---- main loop: stage k = steps c = 2k, 2k+1, then level-C row k and band B of level-B rows 2k-2, 2k-1 ------
-    for (int k = ks; k <= kend; ++k) {
+    auto stage = [&](auto basea, auto baseb, int k) {     // basea / baseb: ring slot of level-A row 4k / 4k+2
+        constexpr int BA = decltype(basea)::value, BB = decltype(baseb)::value;
         Px<P> Be, Bo;
         {   // step c = 2k: level-B row 2k+1
             const int c = 2 * k;
-            shift_window(nx0, nx1);
-            load_row(2 * c + 5, nx0[0], nx0[1]);
-            load_row(2 * c + 6, nx1[0], nx1[1]);
-            Be = coarse_step();
+            load_row(2 * c + 5, S[(BA + 5) & 7][0], S[(BA + 5) & 7][1]);
+            load_row(2 * c + 6, S[(BA + 6) & 7][0], S[(BA + 6) & 7][1]);
+            Be = coarse_step(basea);
             if (c + 1 >= hb) Be = R[4];                               // B[hb] = B[hb-1]
-            if (c >= ca && c < cb) band_a_rows(c, R[3], R[4], Be);
+            if (c >= ca && c < cb) band_a_rows(basea, c, R[3], R[4], Be);
         }
         {   // step c = 2k+1: level-B row 2k+2
             const int c = 2 * k + 1;
-            shift_window(nx0, nx1);
-            load_row(2 * c + 5, nx0[0], nx0[1]);
-            load_row(2 * c + 6, nx1[0], nx1[1]);
-            Bo = coarse_step();
+            load_row(2 * c + 5, S[(BB + 5) & 7][0], S[(BB + 5) & 7][1]);
+            load_row(2 * c + 6, S[(BB + 6) & 7][0], S[(BB + 6) & 7][1]);
+            Bo = coarse_step(baseb);
             if (c + 1 >= hb) Bo = (c + 1 == hb) ? Be : R[3];          // B[hb] = B[hb-1];  B[hb+1] = B[hb-2]
-            if (c >= ca && c < cb) band_a_rows(c, R[4], Be, Bo);
+            if (c >= ca && c < cb) band_a_rows(baseb, c, R[4], Be, Bo);
         }
         // level-B window of this stage: rows 2k-2 .. 2k+2 (top: rows -2, -1 mirror to 1, 0)
         R[0] = R[2];
@@ -398,6 +398,14 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         if (k == 0) CH[1] = Cn;                                       // C[-1] = C[0] (index clamp of the expand)
         const int row0 = 2 * k - 2;
         if (row0 >= ca && row0 < cb) band_b_rows(R[0], R[1], row0);
+    };
+    {
+        int k = ks;
+        for (; k + 1 <= kend; k += 2) {
+            stage(I0(), I2(), k);
+            stage(I4(), I6(), k + 1);
+        }
+        if (k <= kend) stage(I0(), I2(), k);
     }
     // ---- bottom of the image: the last level-B rows against C[hc] = C[hc-1] ---------------------------------
     if (last_chunk) {
