@@ -12,7 +12,8 @@ value = Mpixels/s (test+ref) = 2*W*H*N*pairs*steps*n_gpus / wall seconds.
 
 One JSON line on rank 0.  `roofline`: the dominant kernel (two-level pyramid kernel, levels 0+1), timed per launch
 with HIP events inside the library on the kernels' stream (median/min/max over >= 10 launches); `graded_pass`: all
-pyramid levels + finalize against SURVEY 8(d)'s 221.2 MB per 4K frame; `cpu_baseline`: the numpy oracle on a bounded
+pyramid levels + finalize against SURVEY 8(d)'s 221.2 MB per 4K frame; `roofline.traffic`: HBM bytes per launch of that
+kernel from two rocprofv3 --pmc passes run from here (fallback: the committed profile); `cpu_baseline`: the numpy oracle on a bounded
 sample of the same workload; `value_h2d_inclusive`: the same call on pageable host arrays (never `value`).
 """
 import argparse
@@ -55,6 +56,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the host-array (PCIe-inclusive) timing")
     ap.add_argument("--timing-reps", type=int, default=12, help="launches of each kernel timed with HIP events")
+    ap.add_argument("--no-measure-traffic", action="store_true", help="do not collect roofline.traffic live (two rocprofv3 --pmc "
+                    "passes, FETCH_SIZE and WRITE_SIZE, of tools/gpu_bandonly.py in subprocesses, ~10 s); the committed "
+                    "profiles/rNN_pmc_level0.json of the same kernel and launch shape is quoted instead")
+    ap.add_argument("--measure-traffic", action="store_true", help=argparse.SUPPRESS)      # the default now
     ap.add_argument("--cpu-frames", type=int, default=2)
     ap.add_argument("--cpu-procs", type=int, default=8, help="processes of the CPU baseline (1 = time the oracle in-process)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
@@ -165,7 +170,12 @@ def main():
         # committed rocprofv3 --pmc passes of the same kernel and launch shape (tools/pmc_level0.py, profiles/)
         pdir = os.path.join(ROOT, "profiles")
         pmc = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_level0.json")) if os.path.isdir(pdir) else []
-        if pmc and (W, H, int(frames_per_launch)) == (3840, 2160, 60):
+        live = measure_traffic_live() if (world == 1 and not args.no_measure_traffic and
+                                          (W, H, int(frames_per_launch)) == (3840, 2160, 60)) else None
+        if live is not None and ("band2" in live.get("kernel", "")) == fused01:
+            roof["traffic"] = int(live["traffic_bytes"])
+            roof["traffic_source"] = "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_bandonly.py (FETCH_SIZE x2 + WRITE_SIZE)"
+        elif pmc and (W, H, int(frames_per_launch)) == (3840, 2160, 60):
             with open(os.path.join(pdir, pmc[-1])) as f:
                 pj = json.load(f)
             if ("band2" in pj.get("kernel", "")) == fused01:
@@ -266,6 +276,37 @@ def main():
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measure_traffic_live():
+    """FETCH_SIZE and WRITE_SIZE of the dominant pyramid kernel, each in its own rocprofv3 --pmc pass (counters only with
+    --kernel-trace, as MI355X_MICROARCH.md prescribes), on the same 4K x60 workload.  Returns the dict of tools/pmc_level0.py
+    or None when rocprofv3 is not available / a pass fails (the caller then falls back to the committed profile)."""
+    import glob, shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    d = tempfile.mkdtemp(prefix="fvvdp_pmc_")
+    try:
+        dbs = []
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(d, ctr)
+            subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", out, "-o", "p", "--", sys.executable,
+                            os.path.join(ROOT, "tools", "gpu_bandonly.py")], check=True, timeout=90, cwd=d,
+                           env=dict(os.environ, TMPDIR=d), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            found = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+            if not found:
+                return None
+            dbs.append(found[0])
+        res = os.path.join(d, "pmc.json")
+        subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_level0.py"), dbs[0], dbs[1], res], check=True,
+                       timeout=60, stdout=subprocess.DEVNULL)
+        with open(res) as f:
+            return json.load(f)
+    except Exception as e:
+        sys.stderr.write("live traffic measurement failed (%s); using the committed profile\n" % e)
+        return None
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
 
 
 def fl_guard(fps):

@@ -9,7 +9,7 @@ OUT=$R/gpurun_out/prof_bundle
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
-rocprofv3 --kernel-trace --stats -d /tmp/kt -o bench -- python $R/bench.py --no-cpu-baseline > $OUT/bench_profiled.json 2> /tmp/kt.err
+rocprofv3 --kernel-trace --stats -d /tmp/kt -o bench -- python $R/bench.py --no-cpu-baseline --no-measure-traffic > $OUT/bench_profiled.json 2> /tmp/kt.err
 python $R/tools/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) --band-levels 7 > $OUT/kernel_trace_bench.md
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf -o f -- python $R/tools/gpu_bandonly.py > /tmp/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw -o w -- python $R/tools/gpu_bandonly.py > /tmp/pw.log 2>&1
@@ -18,7 +18,7 @@ python $R/tools/pmc_level0.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp
 FVVDP_BAND_FUSE=0 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf0 -o f -- python $R/tools/gpu_bandonly.py > /tmp/pf0.log 2>&1
 FVVDP_BAND_FUSE=0 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw0 -o w -- python $R/tools/gpu_bandonly.py > /tmp/pw0.log 2>&1
 python $R/tools/pmc_level0.py $(find /tmp/pf0 -name "*.db" | head -1) $(find /tmp/pw0 -name "*.db" | head -1) $OUT/pmc_level0_onelevel.json > /dev/null
-FVVDP_BAND_FUSE=0 rocprofv3 --kernel-trace --stats -d /tmp/kt0 -o bench0 -- python $R/bench.py --no-cpu-baseline --no-h2d > $OUT/bench_profiled_onelevel.json 2> /tmp/kt0.err
+FVVDP_BAND_FUSE=0 rocprofv3 --kernel-trace --stats -d /tmp/kt0 -o bench0 -- python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_profiled_onelevel.json 2> /tmp/kt0.err
 python $R/tools/rocpd_summary.py $(find /tmp/kt0 -name "*.db" | head -1) --band-levels 7 > $OUT/kernel_trace_bench_onelevel.md
 python $R/tools/gpu_bandonly_speed.py 12 > $OUT/bandonly_fused.txt 2>/dev/null
 FVVDP_BAND_FUSE=0 python $R/tools/gpu_bandonly_speed.py 12 > $OUT/bandonly_onelevel.txt 2>/dev/null
