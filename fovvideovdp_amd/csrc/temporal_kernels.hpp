@@ -418,18 +418,21 @@ __device__ __forceinline__ RawVec<SRC, PX> load_vec(const void* base, size_t off
     constexpr int ES = RawVec<SRC, PX>::ES;
     constexpr int BYTES = ES * PX;
     const char* q = reinterpret_cast<const char*>(base) + off * ES;
+    // every source sample is read exactly once by exactly one lane: non-temporal loads (measured -2 % on K1 at 4K)
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
     if constexpr (BYTES == 16) {
-        const uint4 t = *reinterpret_cast<const uint4*>(q);
+        const u4v t = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(q));
         r.wd[0] = t.x; r.wd[1] = t.y; r.wd[2] = t.z; r.wd[3] = t.w;
     } else if constexpr (BYTES == 8) {
-        const uint2 t = *reinterpret_cast<const uint2*>(q);
+        const u2v t = __builtin_nontemporal_load(reinterpret_cast<const u2v*>(q));
         r.wd[0] = t.x; r.wd[1] = t.y;
     } else if constexpr (BYTES == 4) {
-        r.wd[0] = *reinterpret_cast<const unsigned int*>(q);
+        r.wd[0] = __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(q));
     } else if constexpr (BYTES == 2) {
-        r.wd[0] = *reinterpret_cast<const unsigned short*>(q);
+        r.wd[0] = __builtin_nontemporal_load(reinterpret_cast<const unsigned short*>(q));
     } else {
-        r.wd[0] = *reinterpret_cast<const unsigned char*>(q);
+        r.wd[0] = __builtin_nontemporal_load(reinterpret_cast<const unsigned char*>(q));
     }
     return r;
 }
