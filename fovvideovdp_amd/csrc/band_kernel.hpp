@@ -45,12 +45,7 @@ __device__ __forceinline__ Px<2> ld_px<2>(const float* p) {
 // drops.  This keeps the store in straight-line code: behind a branch, the compiler has to wait for vmcnt(0) at the
 // top of the next step (loads and stores share one in-order counter on gfx9), i.e. every step would wait for the
 // previous step's store to be acknowledged before its own prefetched rows are usable.
-typedef int v4i __attribute__((ext_vector_type(4)));
-typedef int v2i __attribute__((ext_vector_type(2)));
-#define FVVDP_NO_STORE 0xFFFFFFFFu
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t level_rsrc(float* base, unsigned int bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
-}
+// (level_rsrc / FVVDP_NO_STORE: device_common.hpp)
 __device__ __forceinline__ void st_px(__amdgpu_buffer_rsrc_t r, unsigned int byte_off, const Px<4>& a) {
     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{a.h[0].x, a.h[0].y, a.h[1].x, a.h[1].y}), r, byte_off, 0, 2 /*nt*/);
 }

@@ -41,6 +41,14 @@ __device__ __forceinline__ float wave_sum(float v) {
 // so they are kept as a 2-vector and the compiler emits v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 for them.
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+// Stores in straight-line code: a buffer resource covering the destination, and an out-of-range byte offset (dropped by
+// the hardware) for lanes or waves that must not write.  See band_kernel.hpp for why this matters (s_waitcnt vmcnt(N)).
+#define FVVDP_NO_STORE 0xFFFFFFFFu
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t level_rsrc(float* base, unsigned int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
+}
 __device__ __forceinline__ v2f splat(float s) { return v2f{s, s}; }
 __device__ __forceinline__ v2f pfma(v2f a, float s, v2f c) { return __builtin_elementwise_fma(a, splat(s), c); }
 // clamp to [lo, hi] as one v_med3_f32 per component (fminf(fmaxf()) costs three: IEEE max first canonicalises its input)

@@ -354,22 +354,46 @@ static void launch_ring(int dtype, const TemporalArgs& a, hipStream_t st) {
         hipLaunchKernelGGL((temporal_ring_kernel<FL, PX, SRC_F32>), grid, block, 0, st, a);
 }
 
-template <int FL, int PX>
-static void launch_vec(int dtype, const TemporalArgs& a, hipStream_t st) {
-    dim3 grid((a.HW + 64 * PX - 1) / (64 * PX)), block(64);
+// Pixels per lane (PX) and frames of raw samples in flight (TD) of temporal_vec_kernel, per ring length and sample type.
+// Measured at 4K (tools/gpu_fps.py): the long rings are register-bound (2*FL*PX ring registers), float samples are 4x
+// wider than 8-bit ones in the prefetch registers.
+#ifndef K1_PX8
+#define K1_PX8 4
+#endif
+#ifndef K1_PXF8
+#define K1_PXF8 4         // float samples, 8-slot ring
+#endif
+#ifndef K1_PX16
+#define K1_PX16 2
+#endif
+#ifndef K1_PX32
+#define K1_PX32 2
+#endif
+#ifndef K1_TD8
+#define K1_TD8 1
+#endif
 #ifndef K1_TD16
 #define K1_TD16 1
 #endif
 #ifndef K1_TD32
 #define K1_TD32 1
 #endif
-    constexpr int TD = FL == 16 ? K1_TD16 : (FL == 32 ? K1_TD32 : 1);
-    if (dtype == FVVDP_U8)
-        hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_U8, TD>), grid, block, 0, st, a);
-    else if (dtype == FVVDP_U16)
-        hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_U16, TD>), grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC_F32, TD>), grid, block, 0, st, a);
+static constexpr int k1_px(int FL, int dtype) {
+    return FL == 8 ? (dtype == FVVDP_F32 ? K1_PXF8 : K1_PX8) : (FL == 16 ? K1_PX16 : K1_PX32);
+}
+template <int FL, int DT>
+static void launch_vec(const TemporalArgs& a, hipStream_t st) {
+    constexpr int PX = k1_px(FL, DT);
+    constexpr int TD = FL == 8 ? K1_TD8 : (FL == 16 ? K1_TD16 : K1_TD32);
+    constexpr int SRC = DT == FVVDP_U8 ? SRC_U8 : (DT == FVVDP_U16 ? SRC_U16 : SRC_F32);
+    dim3 grid((a.HW + 64 * PX - 1) / (64 * PX)), block(64);
+    hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC, TD>), grid, block, 0, st, a);
+}
+template <int FL>
+static void launch_vec(int dtype, const TemporalArgs& a, hipStream_t st) {
+    if (dtype == FVVDP_U8) launch_vec<FL, FVVDP_U8>(a, st);
+    else if (dtype == FVVDP_U16) launch_vec<FL, FVVDP_U16>(a, st);
+    else launch_vec<FL, FVVDP_F32>(a, st);
 }
 
 template <int P>
@@ -429,22 +453,16 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
                 a.idx1[u] = h_frame_idx1 ? h_frame_idx1[src < 0 ? 0 : src] : a.idx[u];
             }
             // vector path needs the lane's PX consecutive samples to be naturally aligned
-#ifndef K1_PX16
-#define K1_PX16 2
-#endif
-#ifndef K1_PX32
-#define K1_PX32 2
-#endif
-            const int PXv = FL == 8 ? 4 : (FL == 16 ? K1_PX16 : K1_PX32);
+            const int PXv = k1_px(FL, dtype);
             const int es = dtype == FVVDP_U8 ? 1 : (dtype == FVVDP_U16 ? 2 : 4);
             const bool vec_ok = !getenv("FVVDP_TEMPORAL_SCALAR") && (HW % PXv == 0) && (HW >= PXv) &&
                                 (chan_stride % PXv == 0) && (frame_stride % PXv == 0) &&
                                 (reinterpret_cast<uintptr_t>(d_test) % (size_t)(es * PXv) == 0) &&
                                 (reinterpret_cast<uintptr_t>(d_ref) % (size_t)(es * PXv) == 0);
             if (vec_ok) {
-                if (FL == 8) launch_vec<8, 4>(dtype, a, st);
-                else if (FL == 16) launch_vec<16, K1_PX16>(dtype, a, st);
-                else launch_vec<32, K1_PX32>(dtype, a, st);
+                if (FL == 8) launch_vec<8>(dtype, a, st);
+                else if (FL == 16) launch_vec<16>(dtype, a, st);
+                else launch_vec<32>(dtype, a, st);
             } else {
                 if (FL == 8) launch_ring<8, 4>(dtype, a, st);
                 else if (FL == 16) launch_ring<16, 4>(dtype, a, st);

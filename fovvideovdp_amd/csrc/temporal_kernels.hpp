@@ -64,8 +64,14 @@ __device__ __forceinline__ float eotf_f32(float V, const EotfDev& e, bool& bad) 
 // N samples at once with ONE (wave-uniform) branch on the display model: in the register-ring kernels the per-sample
 // switch of eotf_f32 is replicated FL x PX x 3 x 2 times, which made their code several times larger than the
 // instruction cache although only one case ever runs.
-template <int N>
+// KIND >= 0: the display model is known at compile time (straight-line code, no branch at all).
+template <int N, int KIND = -1>
 __device__ __forceinline__ void eotf_apply(float (&V)[N], const EotfDev& e, bool& bad) {
+    if constexpr (KIND >= 0) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) V[i] = eotf_one<KIND>(V[i], e, bad);
+        return;
+    }
 #define FVVDP_EOTF_CASE(K)                                             \
     case K: {                                                          \
         _Pragma("unroll") for (int i = 0; i < N; ++i) V[i] = eotf_one<K>(V[i], e, bad); \
@@ -240,7 +246,7 @@ __device__ __forceinline__ RawFrame<SRC, PX> fetch_frame(const void* base, size_
     return f;
 }
 
-template <int SRC, int PX, typename FRAME>
+template <int SRC, int PX, typename FRAME, int KIND = -1>
 __device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lutw, const float* lut16,
                                           const float (&w)[3], const EotfDev& e, float (&L)[PX], bool& bad) {
     float v[3][PX];
@@ -251,7 +257,7 @@ __device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lu
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int i = 0; i < PX; ++i) t[c * PX + i] = f.ch[c].value(i);
-            eotf_apply<3 * PX>(t, e, bad);
+            eotf_apply<3 * PX, KIND>(t, e, bad);
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -260,11 +266,11 @@ __device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lu
             float t[PX];
 #pragma unroll
             for (int i = 0; i < PX; ++i) t[i] = f.ch[0].value(i);
-            eotf_apply<PX>(t, e, bad);
+            eotf_apply<PX, KIND>(t, e, bad);
 #pragma unroll
             for (int i = 0; i < PX; ++i) v[0][i] = __fmul_rn(t[i], w[0]);
         }
-    } else if (SRC == SRC_U16 && e.kind != FVVDP_EOTF_LUT) {
+    } else if (SRC == SRC_U16 && (KIND >= 0 ? KIND != FVVDP_EOTF_LUT : e.kind != FVVDP_EOTF_LUT)) {
         // 16-bit codes through the closed-form display model (code / 65535 as the reference unpacks it,
         // video_source.py:186-196): the 65536-entry table lives in global memory and its 6 gathers per pixel made this
         // kernel 2.6x slower than for 8-bit input; same arithmetic as a float source from here on (<= 1e-6 relative)
@@ -274,7 +280,7 @@ __device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lu
             for (int c = 0; c < 3; ++c)
 #pragma unroll
                 for (int i = 0; i < PX; ++i) t[c * PX + i] = (float)f.ch[c].code(i) * (1.0f / 65535.0f);
-            eotf_apply<3 * PX>(t, e, bad);
+            eotf_apply<3 * PX, KIND>(t, e, bad);
 #pragma unroll
             for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -283,7 +289,7 @@ __device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lu
             float t[PX];
 #pragma unroll
             for (int i = 0; i < PX; ++i) t[i] = (float)f.ch[0].code(i) * (1.0f / 65535.0f);
-            eotf_apply<PX>(t, e, bad);
+            eotf_apply<PX, KIND>(t, e, bad);
 #pragma unroll
             for (int i = 0; i < PX; ++i) v[0][i] = __fmul_rn(t[i], w[0]);
         }
@@ -451,89 +457,204 @@ __device__ __forceinline__ RawVecFrame<SRC, PX> fetch_vec(const void* base, size
     return f;
 }
 
-// TD = frames of raw samples in flight per lane (prefetch distance); 1 everywhere: deeper prefetch measured +3..9 % on
-// the 16-slot ring and -15 % on the 32-slot ring.  The long rings are occupancy-bound (2*FL*PX ring registers): the
-// 16-slot ring therefore runs with PX = 2 (5 waves/SIMD, 47 us/frame at 4K against 56 with PX = 4); splitting the two
-// streams over the half waves (same ring size as PX = 2) measured slower (63 us).
-template <int FL, int PX, int SRC, int TD = 1>
-__global__ __launch_bounds__(64) void temporal_vec_kernel(const TemporalArgs a) {
-    __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
-    __shared__ float4 s_t[64 * (PX + 1)];          // one padded row of PX float4 per lane
+// The loop body is straight-line code (no branch, no workgroup barrier), so that the compiler can count outstanding memory
+// operations (s_waitcnt vmcnt(N)) instead of draining them (vmcnt(0)) in every step: with the drain, each step waited for
+// the previous step's stores AND its own prefetch, and the long rings (3-4 waves per SIMD) ran latency-bound --
+// 4K: 46 -> 34 us/frame at 60 fps, 74 -> 44 us/frame at 120 fps; the 8-slot ring was and stays at the HBM mix ceiling.
+// What that takes: colour-channel count and display model as template constants, stores through a buffer resource with
+// out-of-range offsets for pixels past the frame, prefetches clamped to the last frame, wave-level LDS ordering, the
+// argument block read from the kernel-argument segment, history frames requested in batches.
+// TD = frames of raw samples in flight per lane (prefetch distance): 1; 2 measured the same (16-slot) or slower (32-slot).
+// The long rings are register-bound (2*FL*PX ring registers): PX = 2 there (PX = 4 on the 16-slot ring: 59 us/frame).
+// One wave per block: LDS traffic of the transposes only needs program order (a wave's DS instructions execute in
+// order), not a workgroup barrier.  __syncthreads() would also put a release/acquire fence pair around s_barrier, i.e.
+// s_waitcnt vmcnt(0): every step would wait for the previous step's stores to be acknowledged and for its own prefetch.
+__device__ __forceinline__ void wave_lds_order() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// CC = number of colour channels as a compile-time constant (3 or 1): with a run-time `C == 3` around the loads and the
+// table look-ups, every step has control-flow joins and the compiler falls back to s_waitcnt vmcnt(0).
+template <int FL, int PX, int SRC, int TD, int CC, int KIND>
+__device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const float* lutw, float4* s_t) {
+    // the window index lists are the only dynamically indexed members of the argument block: read them straight from the
+    // kernel-argument segment (scalar loads), otherwise the whole 2.9 KB block can end up copied to scratch
+    typedef const int __attribute__((address_space(4)))* karg_int_p;
+    typedef const char __attribute__((address_space(4)))* karg_p;
+    const karg_p ka = (karg_p)__builtin_amdgcn_kernarg_segment_ptr();
+    const karg_int_p idx0 = (karg_int_p)(ka + offsetof(TemporalArgs, idx));
+    const karg_int_p idx1 = (karg_int_p)(ka + offsetof(TemporalArgs, idx1));
     const int lane = threadIdx.x;
-    if constexpr (SRC == SRC_U8) build_lutw(lutw, a.e.lut, a.C, a.w, lane, 64);
-    __syncthreads();
     const int p0 = blockIdx.x * (64 * PX);          // first pixel of this wave
     const int pl = min(p0 + lane * PX, a.HW - PX);  // this lane's PX consecutive pixels (clamped: loads stay in range)
-    const float w[3] = {a.C == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};
+    const float w[3] = {CC == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};
     bool bad = false;
-    float ring[2][FL][PX];
-#pragma unroll
-    for (int u = 0; u < FL; ++u)
-#pragma unroll
-        for (int i = 0; i < PX; ++i) ring[0][u][i] = ring[1][u][i] = 0.0f;
+    // .x = test, .y = reference: one register pair, one v_pk_fma per tap.  Not initialised: every slot is written before
+    // its first read (history: slots 0..FL-2, first output step: slot FL-1), so a slot costs registers only once filled.
+    v2f ring[FL][PX];
+    // virtual time v = 0 .. FL-2 is the history, v = FL-1+t the newest frame of output t; ring slot = v % FL.
     const int total = FL - 1 + a.n_out;
     static_assert(FL % TD == 0, "prefetch slots are indexed with the unrolled ring position");
     RawVecFrame<SRC, PX> nx[TD][2];
+    // The loop bodies below are straight-line code: prefetches past the end re-read the last frame (unused), stores of
+    // pixels past the frame get an out-of-range buffer offset.  Behind branches the compiler waits for vmcnt(0).
+    auto prefetch = [&](int v, RawVecFrame<SRC, PX>& f0, RawVecFrame<SRC, PX>& f1) {
+        const int vv = min(v, total - 1);
+        f0 = fetch_vec<SRC, PX>(a.src[0], (size_t)idx0[vv] * a.frame_stride + pl, a.chan_stride, CC);
+        f1 = fetch_vec<SRC, PX>(a.src[1], (size_t)idx1[vv] * a.frame_stride + pl, a.chan_stride, CC);
+    };
+    // newest frame -> ring slot u.  The pair is pinned where it is produced: the compiler otherwise sinks the channel sums
+    // to their first use (many steps later), keeping three table values per pixel alive instead of one luminance.
+    auto push = [&](const RawVecFrame<SRC, PX>& c0, const RawVecFrame<SRC, PX>& c1, v2f (&slot)[PX]) {
+        float L0[PX], L1[PX];
+        frame_lum<SRC, PX, RawVecFrame<SRC, PX>, KIND>(c0, CC, lutw, a.e.lut, w, a.e, L0, bad);
+        frame_lum<SRC, PX, RawVecFrame<SRC, PX>, KIND>(c1, CC, lutw, a.e.lut, w, a.e, L1, bad);
 #pragma unroll
-    for (int d = 0; d < TD; ++d) {
-        const size_t off = (size_t)a.idx[d < total ? d : total - 1] * a.frame_stride + pl;
-        const size_t off1 = (size_t)a.idx1[d < total ? d : total - 1] * a.frame_stride + pl;
-        nx[d][0] = fetch_vec<SRC, PX>(a.src[0], off, a.chan_stride, a.C);
-        nx[d][1] = fetch_vec<SRC, PX>(a.src[1], off1, a.chan_stride, a.C);
+        for (int i = 0; i < PX; ++i) {
+            slot[i] = v2f{L0[i], L1[i]};
+            asm volatile("" : "+v"(slot[i]));
+        }
+    };
+    // History (no output yet, almost no arithmetic): HB frames are requested at once, otherwise this phase is one memory
+    // latency per frame -- a third of all frames at 120 fps.  The first output frames are requested with the last batch.
+    constexpr int HB_REGS = (FL == 32 && RawVec<SRC, PX>::WORDS > 1) ? 24 : 48;   // registers of raw samples per batch
+    constexpr int HB = (HB_REGS / (6 * RawVec<SRC, PX>::WORDS)) > 0 ? (HB_REGS / (6 * RawVec<SRC, PX>::WORDS)) : 1;
+#pragma unroll
+    for (int u0 = 0; u0 < FL - 1; u0 += HB) {
+        RawVecFrame<SRC, PX> h[HB][2];
+#pragma unroll
+        for (int d = 0; d < HB; ++d)
+            if (u0 + d < FL - 1) prefetch(u0 + d, h[d][0], h[d][1]);
+        if (u0 + HB >= FL - 1) {
+#pragma unroll
+            for (int d = 0; d < TD; ++d) prefetch(FL - 1 + d, nx[(FL - 1 + d) % TD][0], nx[(FL - 1 + d) % TD][1]);
+        }
+#pragma unroll
+        for (int d = 0; d < HB; ++d)
+            if (u0 + d < FL - 1) push(h[d][0], h[d][1], ring[u0 + d]);
+        __builtin_amdgcn_sched_barrier(0);          // keep the batches apart: hoisting across them costs registers (spills)
     }
-    for (int v0 = 0; v0 < total; v0 += FL) {
+    unsigned int soff[PX];                          // byte offset of this lane's i-th store inside an output frame
 #pragma unroll
-        for (int u = 0; u < FL; ++u) {
-            const int v = v0 + u;
-            if (v < total) {
+    for (int i = 0; i < PX; ++i) soff[i] = (p0 + i * 64 + lane < a.HW) ? (unsigned int)(p0 + i * 64 + lane) * 16u : FVVDP_NO_STORE;
+    const unsigned int frame_bytes = (unsigned int)a.HW * 16u;      // <= 531 MB (8K)
+    for (int t0 = 0; t0 < a.n_out; t0 += FL) {
+#pragma unroll
+        for (int j = 0; j < FL; ++j) {
+            const int t = t0 + j;
+            if (t >= a.n_out) break;
+            const int u = (FL - 1 + j) % FL;         // ring slot of the newest frame (compile-time after unrolling)
+            // The next frame is requested before this one is converted when a frame is a few registers (8-bit samples); wide
+            // samples (12-24 registers per frame pair) are requested after the conversion has freed the registers.
+            if constexpr (RawVec<SRC, PX>::WORDS == 1) {
                 const RawVecFrame<SRC, PX> cur0 = nx[u % TD][0], cur1 = nx[u % TD][1];
-                if (v + TD < total) {
-                    const size_t off = (size_t)a.idx[v + TD] * a.frame_stride + pl;
-                    const size_t off1 = (size_t)a.idx1[v + TD] * a.frame_stride + pl;
-                    nx[u % TD][0] = fetch_vec<SRC, PX>(a.src[0], off, a.chan_stride, a.C);
-                    nx[u % TD][1] = fetch_vec<SRC, PX>(a.src[1], off1, a.chan_stride, a.C);
-                }
-                frame_lum<SRC, PX, RawVecFrame<SRC, PX>>(cur0, a.C, lutw, a.e.lut, w, a.e, ring[0][u], bad);
-                frame_lum<SRC, PX, RawVecFrame<SRC, PX>>(cur1, a.C, lutw, a.e.lut, w, a.e, ring[1][u], bad);
-                if (v >= FL - 1) {
-                    float acc[4][PX];
+                prefetch(FL - 1 + t + TD, nx[u % TD][0], nx[u % TD][1]);
+                push(cur0, cur1, ring[u]);
+            } else {
+                push(nx[u % TD][0], nx[u % TD][1], ring[u]);
+                __builtin_amdgcn_sched_barrier(0);
+                prefetch(FL - 1 + t + TD, nx[u % TD][0], nx[u % TD][1]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            v2f accS[PX], accT[PX];                  // (test, reference) of the sustained / the transient channel
 #pragma unroll
-                    for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
+            for (int i = 0; i < PX; ++i) accS[i] = accT[i] = v2f{0.0f, 0.0f};
 #ifdef K1_ABLATE_FIR
 #pragma unroll
-                    for (int k = 1; k >= 0; --k) {
+            for (int k = 1; k >= 0; --k) {
 #else
 #pragma unroll
-                    for (int k = FL - 1; k >= 0; --k) {      // oldest tap first, like the reference's sum over the window
+            for (int k = FL - 1; k >= 0; --k) {      // oldest tap first, like the reference's sum over the window
 #endif
-                        const int sl = (u - k + 2 * FL) % FL;
-                        const float f0 = a.taps[0][k], f1 = a.taps[1][k];
+                const int sl = (u - k + 2 * FL) % FL;
+                const float f0 = a.taps[0][k], f1 = a.taps[1][k];
 #pragma unroll
-                        for (int i = 0; i < PX; ++i) {
-                            acc[0][i] = fmaf(ring[0][sl][i], f0, acc[0][i]);
-                            acc[1][i] = fmaf(ring[1][sl][i], f0, acc[1][i]);
-                            acc[2][i] = fmaf(ring[0][sl][i], f1, acc[2][i]);
-                            acc[3][i] = fmaf(ring[1][sl][i], f1, acc[3][i]);
-                        }
-                    }
-                    // transpose through LDS: lane l holds pixels l*PX..l*PX+PX-1, store i writes pixels i*64+l
-                    __syncthreads();                         // single wave: orders the LDS accesses only
-#pragma unroll
-                    for (int i = 0; i < PX; ++i)
-                        s_t[lane * (PX + 1) + i] = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
-                    __syncthreads();
-                    float4* o = reinterpret_cast<float4*>(a.out) + (size_t)(v - (FL - 1)) * a.HW + p0;
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) {
-                        const int q = i * 64 + lane;
-                        const float4 val = s_t[(q / PX) * (PX + 1) + (q % PX)];
-                        if (p0 + q < a.HW) __builtin_nontemporal_store(v4f{val.x, val.y, val.z, val.w}, reinterpret_cast<v4f*>(o + q));
-                    }
+                for (int i = 0; i < PX; ++i) {
+                    accS[i] = pfma(ring[sl][i], f0, accS[i]);
+                    accT[i] = pfma(ring[sl][i], f1, accT[i]);
                 }
             }
+            // transpose through LDS: lane l holds pixels l*PX..l*PX+PX-1, store i writes pixels i*64+l
+            wave_lds_order();
+#pragma unroll
+            for (int i = 0; i < PX; ++i)
+                s_t[lane * (PX + 1) + i] = make_float4(accS[i].x, accS[i].y, accT[i].x, accT[i].y);
+            wave_lds_order();
+            const __amdgpu_buffer_rsrc_t o = level_rsrc(a.out + (size_t)t * a.HW * 4, frame_bytes);
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                const int q = i * 64 + lane;
+                const float4 val = s_t[(q / PX) * (PX + 1) + (q % PX)];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{val.x, val.y, val.z, val.w}), o, soff[i], 0, 2 /*nt*/);
+            }
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     if (bad && a.oob) atomicOr(a.oob, 1);
+}
+
+template <int FL, int PX, int SRC, int TD, int KIND>
+__device__ __forceinline__ void temporal_vec_cc(const TemporalArgs& a, const float* lutw, float4* s_t) {
+    if (a.C == 3) temporal_vec_body<FL, PX, SRC, TD, 3, KIND>(a, lutw, s_t);
+    else temporal_vec_body<FL, PX, SRC, TD, 1, KIND>(a, lutw, s_t);
+}
+
+// waves per SIMD the register allocation aims at (uint8: 116 / 128 / 168 VGPRs for the 8 / 16 / 32-slot ring)
+#ifndef K1_WAVES8
+#define K1_WAVES8 4
+#endif
+#ifndef K1_WAVES16
+#define K1_WAVES16 4
+#endif
+#ifndef K1_WAVES32
+#define K1_WAVES32 3
+#endif
+#ifndef K1_WAVESX8
+#define K1_WAVESX8 3     // uint16 / float sources: wider raw samples in flight, closed-form display model
+#endif
+#ifndef K1_WAVESF8
+#define K1_WAVESF8 3     // float source, 8-slot ring
+#endif
+#ifndef K1_WAVESX16
+#define K1_WAVESX16 4
+#endif
+#ifndef K1_WAVESX32
+#define K1_WAVESX32 2
+#endif
+constexpr int k1_waves(int FL, int SRC) {
+    return SRC == SRC_U8 ? (FL == 8 ? K1_WAVES8 : (FL == 16 ? K1_WAVES16 : K1_WAVES32))
+                         : (FL == 8 ? (SRC == SRC_F32 ? K1_WAVESF8 : K1_WAVESX8) : (FL == 16 ? K1_WAVESX16 : K1_WAVESX32));
+}
+template <int FL, int PX, int SRC, int TD = 1>
+__global__ __launch_bounds__(64, k1_waves(FL, SRC))
+void temporal_vec_kernel(const TemporalArgs a_byval) {
+    // All reads of the argument block go to the kernel-argument segment itself (scalar loads).  Through the by-value
+    // parameter the compiler starts from a private copy and, in the largest instantiations, fails to remove it: 2.9 KB of
+    // scratch per lane and every filter tap reloaded from it.
+    const TemporalArgs& a = *(const TemporalArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)a_byval;
+    __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
+    __shared__ float4 s_t[64 * (PX + 1)];          // one padded row of PX float4 per lane
+    if constexpr (SRC == SRC_U8) build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 64);
+    __syncthreads();
+    // colour-channel count and display model as compile-time constants of the loop body (see temporal_vec_body)
+    if constexpr (SRC == SRC_U8) {
+        temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LUT>(a, lutw, s_t);
+    } else {
+        switch (a.e.kind) {
+            case FVVDP_EOTF_SRGB: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_SRGB>(a, lutw, s_t); break;
+            case FVVDP_EOTF_GAMMA: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_GAMMA>(a, lutw, s_t); break;
+            case FVVDP_EOTF_PQ: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_PQ>(a, lutw, s_t); break;
+            case FVVDP_EOTF_LINEAR: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LINEAR>(a, lutw, s_t); break;
+            case FVVDP_EOTF_ABSOLUTE: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_ABSOLUTE>(a, lutw, s_t); break;
+            case FVVDP_EOTF_LUT:
+                if constexpr (SRC == SRC_U16) temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LUT>(a, lutw, s_t);
+                break;                               // (a table for a float source is refused by the host side)
+            default: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_NONE>(a, lutw, s_t); break;   // luminances already
+        }
+    }
 }
 
 // ---- planar YUV ingest fused with the temporal filter ---------------------------------------------------------

@@ -29,6 +29,37 @@ __global__ __launch_bounds__(256) void mix(const vf4* __restrict__ in, vf4* __re
     }
 }
 
+// write-heavy mixes (the temporal kernel: 6 B read, 16 B written per pixel): 1 float4 read, WN float4 written per thread
+template <int WN>
+__global__ __launch_bounds__(256) void wmix(const vf4* __restrict__ in, vf4* __restrict__ out, size_t n_in4) {
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n_in4; i += stride) {
+        const size_t wave = i >> 6, lane = i & 63;
+        const vf4 v = in[i];
+#pragma unroll
+        for (int r = 0; r < WN; ++r) __builtin_nontemporal_store(v, out + (wave * WN + r) * 64 + lane);
+    }
+}
+
+template <int WN>
+static void runw(const vf4* in, vf4* out, size_t n_out4_total) {
+    const size_t n_in4 = n_out4_total / WN;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int blocks : {4096, 16384}) {
+        float best = 1e9;
+        for (int rep = 0; rep < 5; ++rep) {
+            CK(hipEventRecord(e0));
+            hipLaunchKernelGGL((wmix<WN>), dim3(blocks), dim3(256), 0, 0, in, out, n_in4);
+            CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+            if (rep && ms < best) best = ms;
+        }
+        const double rd = (double)n_in4 * 16, wr = (double)n_in4 * WN * 16;
+        printf("R:W =  1:%d nt store     blocks %5d: %.3f ms  read %.2f + write %.2f = %.2f TB/s\n", WN, blocks, best, rd / best / 1e9,
+               wr / best / 1e9, (rd + wr) / best / 1e9);
+    }
+}
+
 template <int R, int NT, int WR>
 static void run(const vf4* in, vf4* out, size_t n_in4, const char* tag) {
     const size_t n_out4 = n_in4 / R;
@@ -61,5 +92,9 @@ int main() {
     run<8, 1, 1>(p, q, n4, "nt store");
     run<16, 1, 1>(p, q, n4, "nt store");
     run<16, 0, 1>(p, q, n4, "plain store");
+    runw<2>(p, q, n4);
+    runw<3>(p, q, n4);
+    runw<4>(p, q, n4);
+    runw<8>(p, q, n4);
     return 0;
 }
