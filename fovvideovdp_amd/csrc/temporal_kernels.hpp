@@ -894,11 +894,11 @@ __device__ __forceinline__ void yuv_pair_rgb(const YuvRaw<T, C420>& r0, const Yu
 
 // Display model on N (test, reference) pairs whose values are already inside [0,1]; one wave-uniform branch.
 // The affine parts run packed; scale*lin and +y_black keep their separate roundings (fvvdp_display_model.py:160-165).
-template <int N>
+template <int N, int KIND>
 __device__ __forceinline__ void eotf_apply_pairs(v2f (&V)[N], const EotfDev& e) {
 #pragma clang fp contract(off)
     bool bad = false;
-    switch (e.kind) {
+    switch (KIND) {                                  // compile-time: one case survives, the loop body stays branch-free
         case FVVDP_EOTF_SRGB: {
 #pragma unroll
             for (int i = 0; i < N; ++i) {
@@ -945,10 +945,21 @@ __device__ __forceinline__ v2f lum_pair(v2f r, v2f g, v2f b, float w0, float w1,
 }
 
 #define YUV_QUADS 62     // pixel quads (4 consecutive pixels) written per wave
-template <int FL, typename T, bool C420>
-__global__ __launch_bounds__(64) void temporal_yuv_vec_kernel(const YuvArgs a) {
+#ifndef YUV_TD
+#define YUV_TD 2         // frames of raw samples in flight per lane
+#endif
+// One rolled loop over the frames, straight-line inside (see temporal_vec_kernel for why: counted waits instead of
+// drains).  The last FL luminance pairs of the lane's 4 pixels sit in a register window that is SHIFTED by one slot per
+// frame (FL*4-4 64-bit moves): the slots the FIR reads are then compile-time constants without unrolling the frame loop
+// FL times -- the conversion of a frame is a few hundred instructions, FL copies of it do not fit the instruction cache.
+// The FIR also runs during the history frames (its result is dropped by an out-of-range store offset).
+template <int FL, typename T, bool C420, int KIND>
+__device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* s_t) {
     constexpr int PX = 4;
-    __shared__ float4 s_t[64 * (PX + 1)];
+    constexpr int TD = YUV_TD;
+    typedef const int __attribute__((address_space(4)))* karg_int_p;
+    typedef const char __attribute__((address_space(4)))* karg_p;
+    const karg_int_p idx = (karg_int_p)((karg_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(YuvArgs, idx));
     const int lane = threadIdx.x;
     const int HW = a.W * a.H;
     const int uvplane = a.uvw * a.uvh;
@@ -984,74 +995,92 @@ __global__ __launch_bounds__(64) void temporal_yuv_vec_kernel(const YuvArgs a) {
             g.left_own = g.right_own = false;
         }
     }
-    v2f ring[FL][PX];                                     // (test, reference) luminance of the last FL frames
+    v2f win[FL][PX];                                      // (test, reference) luminance; win[FL-1] = newest frame
 #pragma unroll
     for (int u = 0; u < FL; ++u)
 #pragma unroll
-        for (int i = 0; i < PX; ++i) ring[u][i] = splat(0.0f);
+        for (int i = 0; i < PX; ++i) win[u][i] = splat(0.0f);
     const int total = FL - 1 + a.n_out;
-    YuvRaw<T, C420> nx[2];
-    {
-        const size_t off = (size_t)a.idx[0] * a.frame_stride;
-        nx[0] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[0]) + off, g, HW, uvplane);
-        nx[1] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[1]) + off, g, HW, uvplane);
+    auto prefetch = [&](int v, YuvRaw<T, C420>& f0, YuvRaw<T, C420>& f1) {
+        const size_t off = (size_t)idx[min(v, total - 1)] * a.frame_stride;      // past the end: the last frame again (unused)
+        f0 = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[0]) + off, g, HW, uvplane);
+        f1 = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[1]) + off, g, HW, uvplane);
+    };
+    YuvRaw<T, C420> nx[TD][2];
+#pragma unroll
+    for (int d = 0; d < TD; ++d) prefetch(d, nx[d][0], nx[d][1]);
+    // store i of the lane writes pixel i*64+lane of the wave's 248-pixel run (row `lane` of the LDS tile = quad lane-1)
+    unsigned int soff[PX];
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        const int q = i * 64 + lane;
+        soff[i] = (q < YUV_QUADS * PX && p0 + q < HW) ? (unsigned int)(p0 + q) * 16u : FVVDP_NO_STORE;
     }
-    // The conversion of a frame (the expensive part) exists once in the code; only the ring update + FIR, whose
-    // register slots must be compile-time constants, is replicated FL times and selected by a wave-uniform branch.
-    // (Unrolling the whole body FL times, as the RGB kernels do with their tiny LUT conversion, makes this kernel
-    // larger than the instruction cache.)
-    int u = 0;                                            // ring slot of frame v (= v % FL)
-    for (int v = 0; v < total; ++v) {
-        const YuvRaw<T, C420> cur0 = nx[0], cur1 = nx[1];
-        if (v + 1 < total) {
-            const size_t off = (size_t)a.idx[v + 1] * a.frame_stride;
-            nx[0] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[0]) + off, g, HW, uvplane);
-            nx[1] = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[1]) + off, g, HW, uvplane);
-        }
-        v2f rgb[12];
-        yuv_pair_rgb<T, C420>(cur0, cur1, a, g, g_fy, g_gy, g_fx0, g_gx0, rgb);
-        eotf_apply_pairs<12>(rgb, a.e);
-        v2f L[PX];
+    const unsigned int frame_bytes = (unsigned int)HW * 16u;
+    for (int v0 = 0; v0 < total; v0 += TD) {
 #pragma unroll
-        for (int i = 0; i < PX; ++i) L[i] = lum_pair(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], a.w[0], a.w[1], a.w[2]);
-        v2f acc_s[PX], acc_t[PX];                         // sustained / transient channel of (test, reference)
+        for (int d = 0; d < TD; ++d) {
+            const int v = v0 + d;                         // v >= total (last group only): computed, not stored
+            const YuvRaw<T, C420> cur0 = nx[d][0], cur1 = nx[d][1];
+            prefetch(v + TD, nx[d][0], nx[d][1]);
+            v2f rgb[12];
+            yuv_pair_rgb<T, C420>(cur0, cur1, a, g, g_fy, g_gy, g_fx0, g_gx0, rgb);
+            eotf_apply_pairs<12, KIND>(rgb, a.e);
 #pragma unroll
-        for (int uu = 0; uu < FL; ++uu) {
-            if (uu == u) {
+            for (int u = 0; u + 1 < FL; ++u)
+#pragma unroll
+                for (int i = 0; i < PX; ++i) win[u][i] = win[u + 1][i];
+#pragma unroll
+            for (int i = 0; i < PX; ++i) win[FL - 1][i] = lum_pair(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], a.w[0], a.w[1], a.w[2]);
+            v2f acc_s[PX], acc_t[PX];                     // sustained / transient channel of (test, reference)
+#pragma unroll
+            for (int i = 0; i < PX; ++i) acc_s[i] = acc_t[i] = splat(0.0f);
+#pragma unroll
+            for (int k = FL - 1; k >= 0; --k) {           // oldest tap first, like the reference's sum over the window
+                const float t0 = a.taps[0][k], t1 = a.taps[1][k];
 #pragma unroll
                 for (int i = 0; i < PX; ++i) {
-                    ring[uu][i] = L[i];
-                    acc_s[i] = acc_t[i] = splat(0.0f);
-                }
-#pragma unroll
-                for (int k = FL - 1; k >= 0; --k) {      // oldest tap first, like the reference's sum over the window
-                    const int sl = (uu - k + 2 * FL) % FL;
-                    const float t0 = a.taps[0][k], t1 = a.taps[1][k];
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) {
-                        acc_s[i] = pfma(ring[sl][i], t0, acc_s[i]);
-                        acc_t[i] = pfma(ring[sl][i], t1, acc_t[i]);
-                    }
+                    acc_s[i] = pfma(win[FL - 1 - k][i], t0, acc_s[i]);
+                    acc_t[i] = pfma(win[FL - 1 - k][i], t1, acc_t[i]);
                 }
             }
-        }
-        u = (u + 1 == FL) ? 0 : u + 1;
-        if (v >= FL - 1) {
-            __syncthreads();                              // single wave: orders the LDS accesses only
+            wave_lds_order();
 #pragma unroll
             for (int i = 0; i < PX; ++i)
-                s_t[lane * (PX + 1) + i] = make_float4(acc_s[i].x, acc_s[i].y, acc_t[i].x, acc_t[i].y);   // row `lane` = quad lane-1
-            __syncthreads();
-            float4* o = reinterpret_cast<float4*>(a.out) + (size_t)(v - (FL - 1)) * HW + p0;
+                s_t[lane * (PX + 1) + i] = make_float4(acc_s[i].x, acc_s[i].y, acc_t[i].x, acc_t[i].y);
+            wave_lds_order();
+            const bool live = (v >= FL - 1) && (v < total);
+            const __amdgpu_buffer_rsrc_t o = level_rsrc(a.out + (size_t)max(v - (FL - 1), 0) * HW * 4, frame_bytes);
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
-                const int q = i * 64 + lane;              // pixel of the wave's 248-pixel run
-                const int qq = min(q, YUV_QUADS * PX - 1);
+                const int qq = min(i * 64 + lane, YUV_QUADS * PX - 1);
                 const float4 val = s_t[(qq / PX + 1) * (PX + 1) + (qq % PX)];
-                if (q < YUV_QUADS * PX && p0 + q < HW)
-                    __builtin_nontemporal_store(v4f{val.x, val.y, val.z, val.w}, reinterpret_cast<v4f*>(o + q));
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{val.x, val.y, val.z, val.w}), o,
+                                                       live ? soff[i] : FVVDP_NO_STORE, 0, 2 /*nt*/);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
+    }
+}
+
+#ifndef YUV_WAVES8
+#define YUV_WAVES8 3
+#endif
+#ifndef YUV_WAVES16
+#define YUV_WAVES16 2
+#endif
+template <int FL, typename T, bool C420>
+__global__ __launch_bounds__(64, (FL == 8 ? YUV_WAVES8 : YUV_WAVES16)) void temporal_yuv_vec_kernel(const YuvArgs a_byval) {
+    const YuvArgs& a = *(const YuvArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // see temporal_vec_kernel
+    (void)a_byval;
+    __shared__ float4 s_t[64 * (4 + 1)];
+    switch (a.e.kind) {
+        case FVVDP_EOTF_SRGB: temporal_yuv_vec_body<FL, T, C420, FVVDP_EOTF_SRGB>(a, s_t); break;
+        case FVVDP_EOTF_GAMMA: temporal_yuv_vec_body<FL, T, C420, FVVDP_EOTF_GAMMA>(a, s_t); break;
+        case FVVDP_EOTF_PQ: temporal_yuv_vec_body<FL, T, C420, FVVDP_EOTF_PQ>(a, s_t); break;
+        case FVVDP_EOTF_LINEAR: temporal_yuv_vec_body<FL, T, C420, FVVDP_EOTF_LINEAR>(a, s_t); break;
+        case FVVDP_EOTF_ABSOLUTE: temporal_yuv_vec_body<FL, T, C420, FVVDP_EOTF_ABSOLUTE>(a, s_t); break;
+        default: temporal_yuv_vec_body<FL, T, C420, FVVDP_EOTF_NONE>(a, s_t); break;
     }
 }
 
