@@ -38,7 +38,7 @@ def timeit(fn, reps=5):
 
 a = timeit(lambda: m.predict(test, ref, frames_per_second=fps))
 print("array source (device uint8)              : %7.2f ms  JOD %.6f" % a)
-for batch in (None, 4, 8, 16, 60):
+for batch in [None if b == "None" else int(b) for b in os.environ.get("BATCHES", "None,4,8,16,60").split(",")]:
     mm = fv.fvvdp(display_name="standard_fhd", batch_frames=batch)
     b = timeit(lambda: mm.predict_video_source(Resident()))
     c = timeit(lambda: mm.predict_video_source(Decoding()))
