@@ -370,6 +370,53 @@ def test_other_frame_rates_vs_oracle(fv, fps, N):
         check_q(stats["Q_per_ch"], ostats["Q_per_ch"], coarse=4e-3, fine=4e-3)   # 36x64 frame: every band is tiny, the noise does not average
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("fps,N", [(30, 9), (60, 20), (120, 34)])
+def test_temporal_kernel_instantiations_vs_oracle(fv, fps, N):
+    """The register-ring temporal kernel is instantiated per ring length (8/16/32 slots), sample type (uint8 / uint16 /
+    float), channel count (3 / 1) and display model (compile-time constant of the loop body): every combination that has
+    its own code, against the oracle.  uint8 RGB at these rates is covered by test_other_frame_rates_vs_oracle and the goldens."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    H, W = 36, 64
+    t3, r3 = synth_video_pair(N, H, W)
+    t1, r1 = synth_video_pair(N, H, W, C=1)
+    f3, g3, f1, g1 = t3.float() / 255, r3.float() / 255, t1.float() / 255, r1.float() / 255
+    gm_kw = dict(Y_peak=300, contrast=2000, EOTF="gamma", gamma=2.4, E_ambient=100)
+
+    class OAbs:
+        def forward(self, V):
+            return np.clip(V, np.float32(0.005), np.float32(10000)).astype(np.float32), False
+
+    def u16(x):
+        return x.numpy().astype(np.uint16) * 257
+
+    cases = [
+        ("f32 rgb sRGB", dict(display_name="standard_fhd"), orc.Oracle("standard_fhd"), f3, g3, {}),
+        ("f32 gray sRGB", dict(display_name="standard_fhd"), orc.Oracle("standard_fhd"), f1, g1, {}),
+        ("f32 rgb PQ", dict(display_name="standard_hdr_pq"), orc.Oracle("standard_hdr_pq"), f3, g3, {}),
+        ("f32 gray linear", dict(display_name="standard_hdr_linear"), orc.Oracle("standard_hdr_linear"), f1 * 900.0, g1 * 900.0, {}),
+        ("f32 rgb gamma", dict(display_name="standard_fhd", display_photometry=fv.fvvdp_display_photo_eotf(
+            gm_kw["Y_peak"], contrast=2000, EOTF="gamma", gamma=2.4, E_ambient=100)),
+         orc.Oracle("standard_fhd", photometry=orc.Photometry(300, contrast=2000, EOTF="gamma", gamma=2.4, E_ambient=100)), f3, g3, {}),
+        ("f32 gray absolute", dict(display_name="standard_4k", display_photometry=fv.fvvdp_display_photo_absolute()),
+         orc.Oracle("standard_4k", photometry=OAbs()), f1 * 400.0 + 0.5, g1 * 400.0 + 0.5, {}),
+        ("u16 rgb closed form", dict(display_name="standard_fhd"), orc.Oracle("standard_fhd"), u16(t3), u16(r3), {}),
+        ("u16 gray closed form PQ", dict(display_name="standard_hdr_pq"), orc.Oracle("standard_hdr_pq"), u16(t1), u16(r1), {}),
+        ("u16 rgb table", dict(display_name="standard_fhd"), orc.Oracle("standard_fhd"), u16(t3), u16(r3), {"exact_uint16": True}),
+        ("u8 gray", dict(display_name="standard_fhd"), orc.Oracle("standard_fhd"), t1, r1, {}),
+    ]
+    for name, kw, o, t, r, attrs in cases:
+        m = fv.fvvdp(**kw)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        q, stats = m.predict(t, r, frames_per_second=fps)
+        tn, rn = (t, r) if isinstance(t, np.ndarray) else (t.numpy(), r.numpy())
+        oq, ostats = o.predict(tn, rn, frames_per_second=fps)
+        assert abs(float(q) - float(oq)) < 2e-4, (name, fps)
+        check_q(stats["Q_per_ch"], ostats["Q_per_ch"], coarse=4e-3, fine=4e-3)   # 36x64 frame: tiny bands, the noise does not average
+
+
 def test_misaligned_sizes_take_the_scalar_temporal_kernel(fv):
     """Frame sizes with H*W not a multiple of 4 use per-pixel loads; results must not change."""
     from fovvideovdp_amd.synth import synth_video_pair
