@@ -93,16 +93,34 @@ _lib = None
 
 
 def build(force=False, verbose=False):
-    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU)."""
+    """Compile the HIP library in-tree for gfx950 (hipcc cross-compiles without a GPU).  Five translation units -- the band /
+    pooling / side-metric kernels with the C ABI, and the temporal kernels once per sample type (temporal_launch.hip with
+    -DK1_PART=0..3) -- are compiled concurrently and linked into one shared library."""
     csrc = os.path.dirname(SRC_PATH)
-    deps = [os.path.join(csrc, f) for f in os.listdir(csrc)] + [os.path.join(INCLUDE_DIR, "fvvdp_hip.h")]
+    deps = [os.path.join(csrc, f) for f in os.listdir(csrc) if not f.startswith("_")] + [os.path.join(INCLUDE_DIR, "fvvdp_hip.h")]
     if not force and os.path.isfile(LIB_PATH) and os.path.getmtime(LIB_PATH) >= max(os.path.getmtime(f) for f in deps):
         return LIB_PATH
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     # -pragma-unroll-threshold: the temporal kernels keep their filter window in registers and rely on FULL unrolling
     # of the tap loops (static ring slots); the default size cap silently falls back to scratch-memory indexing
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-mllvm",
-           "-pragma-unroll-threshold=1000000", "-I" + INCLUDE_DIR, "-I" + os.path.dirname(SRC_PATH), SRC_PATH, "-o", LIB_PATH]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-mllvm", "-pragma-unroll-threshold=1000000",
+             "-I" + INCLUDE_DIR, "-I" + csrc] + os.environ.get("FVVDP_HIPCC_FLAGS", "").split()
+    objdir = os.path.join(csrc, "_build")
+    os.makedirs(objdir, exist_ok=True)
+    units = [(SRC_PATH, [], os.path.join(objdir, "fvvdp_hip.o"))]
+    units += [(os.path.join(csrc, "temporal_launch.hip"), ["-DK1_PART=%d" % k], os.path.join(objdir, "temporal_part%d.o" % k))
+              for k in range(4)]
+    procs = []
+    for src, extra, obj in units:
+        cmd = [hipcc] + flags + extra + ["-c", src, "-o", obj]
+        if verbose:
+            print(" ".join(cmd), file=sys.stderr)
+        procs.append((cmd, subprocess.Popen(cmd)))
+    for cmd, pr in procs:
+        if pr.wait() != 0:
+            raise subprocess.CalledProcessError(pr.returncode, cmd)
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-Wl,--version-script=" + os.path.join(csrc, "exports.map")] + \
+          [u[2] for u in units] + ["-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)

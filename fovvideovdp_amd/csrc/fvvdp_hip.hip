@@ -42,6 +42,7 @@ extern "C" const char* fvvdp_last_error(void) { return g_err; }
 
 #include "device_common.hpp"
 #include "temporal_kernels.hpp"
+#include "temporal_launch.hpp"
 #include "band_kernel.hpp"
 #include "band2_kernel.hpp"
 #include "aux_kernels.hpp"
@@ -343,70 +344,6 @@ static EotfDev make_eotf(const fvvdp_eotf* e) {
     return d;
 }
 
-template <int FL, int PX>
-static void launch_ring(int dtype, const TemporalArgs& a, hipStream_t st) {
-    dim3 grid((a.HW + 256 * PX - 1) / (256 * PX)), block(256);
-    if (dtype == FVVDP_U8)
-        hipLaunchKernelGGL((temporal_ring_kernel<FL, PX, SRC_U8>), grid, block, 0, st, a);
-    else if (dtype == FVVDP_U16)
-        hipLaunchKernelGGL((temporal_ring_kernel<FL, PX, SRC_U16>), grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL((temporal_ring_kernel<FL, PX, SRC_F32>), grid, block, 0, st, a);
-}
-
-// Pixels per lane (PX) and frames of raw samples in flight (TD) of temporal_vec_kernel, per ring length and sample type.
-// Measured at 4K (tools/gpu_fps.py): the long rings are register-bound (2*FL*PX ring registers), float samples are 4x
-// wider than 8-bit ones in the prefetch registers.
-#ifndef K1_PX8
-#define K1_PX8 4
-#endif
-#ifndef K1_PXF8
-#define K1_PXF8 4         // float samples, 8-slot ring
-#endif
-#ifndef K1_PX16
-#define K1_PX16 2
-#endif
-#ifndef K1_PX32
-#define K1_PX32 2
-#endif
-#ifndef K1_TD8
-#define K1_TD8 1
-#endif
-#ifndef K1_TD16
-#define K1_TD16 1
-#endif
-#ifndef K1_TD32
-#define K1_TD32 1
-#endif
-static constexpr int k1_px(int FL, int dtype) {
-    return FL == 8 ? (dtype == FVVDP_F32 ? K1_PXF8 : K1_PX8) : (FL == 16 ? K1_PX16 : K1_PX32);
-}
-template <int FL, int DT>
-static void launch_vec(const TemporalArgs& a, hipStream_t st) {
-    constexpr int PX = k1_px(FL, DT);
-    constexpr int TD = FL == 8 ? K1_TD8 : (FL == 16 ? K1_TD16 : K1_TD32);
-    constexpr int SRC = DT == FVVDP_U8 ? SRC_U8 : (DT == FVVDP_U16 ? SRC_U16 : SRC_F32);
-    dim3 grid((a.HW + 64 * PX - 1) / (64 * PX)), block(64);
-    hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC, TD>), grid, block, 0, st, a);
-}
-template <int FL>
-static void launch_vec(int dtype, const TemporalArgs& a, hipStream_t st) {
-    if (dtype == FVVDP_U8) launch_vec<FL, FVVDP_U8>(a, st);
-    else if (dtype == FVVDP_U16) launch_vec<FL, FVVDP_U16>(a, st);
-    else launch_vec<FL, FVVDP_F32>(a, st);
-}
-
-template <int P>
-static void launch_generic(int dtype, const GenericArgs& a, hipStream_t st) {
-    dim3 grid((a.HW + 255) / 256, a.n_out), block(256);
-    if (dtype == FVVDP_U8)
-        hipLaunchKernelGGL((temporal_generic_kernel<SRC_U8, P>), grid, block, 0, st, a);
-    else if (dtype == FVVDP_U16)
-        hipLaunchKernelGGL((temporal_generic_kernel<SRC_U16, P>), grid, block, 0, st, a);
-    else
-        hipLaunchKernelGGL((temporal_generic_kernel<SRC_F32, P>), grid, block, 0, st, a);
-}
-
 // h_frame_idx1: per-stream frame indices of the reference stream, or nullptr = the same as h_frame_idx
 static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* d_ref, int dtype, int C,
                                   size_t chan_stride, size_t frame_stride, const fvvdp_eotf* eotf,
@@ -453,20 +390,16 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
                 a.idx1[u] = h_frame_idx1 ? h_frame_idx1[src < 0 ? 0 : src] : a.idx[u];
             }
             // vector path needs the lane's PX consecutive samples to be naturally aligned
-            const int PXv = k1_px(FL, dtype);
+            const int PXv = k1_px(FL, dtype);        // temporal_launch.hpp
             const int es = dtype == FVVDP_U8 ? 1 : (dtype == FVVDP_U16 ? 2 : 4);
             const bool vec_ok = !getenv("FVVDP_TEMPORAL_SCALAR") && (HW % PXv == 0) && (HW >= PXv) &&
                                 (chan_stride % PXv == 0) && (frame_stride % PXv == 0) &&
                                 (reinterpret_cast<uintptr_t>(d_test) % (size_t)(es * PXv) == 0) &&
                                 (reinterpret_cast<uintptr_t>(d_ref) % (size_t)(es * PXv) == 0);
             if (vec_ok) {
-                if (FL == 8) launch_vec<8>(dtype, a, st);
-                else if (FL == 16) launch_vec<16>(dtype, a, st);
-                else launch_vec<32>(dtype, a, st);
+                k1_launch_vec(FL, dtype, a, st);
             } else {
-                if (FL == 8) launch_ring<8, 4>(dtype, a, st);
-                else if (FL == 16) launch_ring<16, 4>(dtype, a, st);
-                else launch_ring<32, 2>(dtype, a, st);
+                k1_launch_ring(FL, dtype, a, st);
             }
         }
     } else {
@@ -499,8 +432,7 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
         a.oob = d_oob_flag;
         a.taps = c->d_taps;
         a.idx = c->d_idx;
-        if (c->P == 2) launch_generic<2>(dtype, a, st);
-        else launch_generic<4>(dtype, a, st);
+        k1_launch_generic(c->P, dtype, a, st);
     }
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;
@@ -561,27 +493,6 @@ extern "C" int fvvdp_temporal_channels_frames(fvvdp_ctx* c, const void* const* h
                                   stream);
 }
 
-template <int FL, int PX>
-static void launch_yuv(int bytes, const YuvArgs& a, hipStream_t st) {
-    const int HW = a.W * a.H;
-    dim3 grid((HW + 256 * PX - 1) / (256 * PX)), block(256);
-    if (bytes == 1) hipLaunchKernelGGL((temporal_yuv_kernel<FL, PX, unsigned char>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((temporal_yuv_kernel<FL, PX, unsigned short>), grid, block, 0, st, a);
-}
-
-template <int FL>
-static void launch_yuv_vec(int bytes, bool c420, const YuvArgs& a, hipStream_t st) {
-    const int HW = a.W * a.H;
-    dim3 grid((HW / 4 + YUV_QUADS - 1) / YUV_QUADS), block(64);
-    if (bytes == 1) {
-        if (c420) hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned char, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned char, false>), grid, block, 0, st, a);
-    } else {
-        if (c420) hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned short, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned short, false>), grid, block, 0, st, a);
-    }
-}
-
 extern "C" int fvvdp_temporal_channels_yuv(fvvdp_ctx* c, const void* d_test, const void* d_ref, const fvvdp_yuv_format* fmt,
                                            size_t frame_stride, const fvvdp_eotf* eotf, const float* h_rgb2y,
                                            const int32_t* h_frame_idx, const float* h_taps, int fl, int n_out, int slot0,
@@ -631,11 +542,10 @@ extern "C" int fvvdp_temporal_channels_yuv(fvvdp_ctx* c, const void* d_test, con
         const bool vec_ok = !getenv("FVVDP_TEMPORAL_SCALAR") && FL <= 16 && (c->W % 4 == 0) && (frame_stride % 4 == 0) &&
                             (reinterpret_cast<uintptr_t>(d_test) % al == 0) && (reinterpret_cast<uintptr_t>(d_ref) % al == 0);
         if (vec_ok) {
-            if (FL == 8) launch_yuv_vec<8>(bytes, a.chroma420 != 0, a, st);
-            else launch_yuv_vec<16>(bytes, a.chroma420 != 0, a, st);
-        } else if (FL == 8) launch_yuv<8, 2>(bytes, a, st);
-        else if (FL == 16) launch_yuv<16, 2>(bytes, a, st);
-        else launch_yuv<32, 1>(bytes, a, st);
+            k1_launch_yuv_vec(FL, bytes, a.chroma420 != 0, a, st);
+        } else {
+            k1_launch_yuv(FL, bytes, a, st);
+        }
     }
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;

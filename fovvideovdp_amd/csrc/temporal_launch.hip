@@ -1,0 +1,116 @@
+// Instantiations + launchers of the stage-1 kernels; compiled once per K1_PART (see temporal_launch.hpp).
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <cstddef>
+#include <cstdint>
+#include <type_traits>
+
+#include "fvvdp_hip.h"
+#include "device_common.hpp"
+#include "temporal_launch.hpp"
+
+#ifndef K1_PART
+#error "compile with -DK1_PART=0..3"
+#endif
+
+#if K1_PART <= 2
+static constexpr int DT = K1_PART;                     // FVVDP_U8 / FVVDP_U16 / FVVDP_F32
+static constexpr int SRC = DT == FVVDP_U8 ? SRC_U8 : (DT == FVVDP_U16 ? SRC_U16 : SRC_F32);
+
+template <int FL>
+static void launch_vec(const TemporalArgs& a, hipStream_t st) {
+    constexpr int PX = k1_px(FL, DT);
+    constexpr int TD = FL == 8 ? K1_TD8 : (FL == 16 ? K1_TD16 : K1_TD32);
+    dim3 grid((a.HW + 64 * PX - 1) / (64 * PX)), block(64);
+    hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC, TD>), grid, block, 0, st, a);
+}
+template <int FL, int PX>
+static void launch_ring(const TemporalArgs& a, hipStream_t st) {
+    dim3 grid((a.HW + 256 * PX - 1) / (256 * PX)), block(256);
+    hipLaunchKernelGGL((temporal_ring_kernel<FL, PX, SRC>), grid, block, 0, st, a);
+}
+template <int P>
+static void launch_generic(const GenericArgs& a, hipStream_t st) {
+    dim3 grid((a.HW + 255) / 256, a.n_out), block(256);
+    hipLaunchKernelGGL((temporal_generic_kernel<SRC, P>), grid, block, 0, st, a);
+}
+
+#if K1_PART == 0
+#define K1_NAME(f) f##_u8
+#elif K1_PART == 1
+#define K1_NAME(f) f##_u16
+#else
+#define K1_NAME(f) f##_f32
+#endif
+void K1_NAME(k1_vec)(int FL, const TemporalArgs& a, hipStream_t st) {
+    if (FL == 8) launch_vec<8>(a, st);
+    else if (FL == 16) launch_vec<16>(a, st);
+    else launch_vec<32>(a, st);
+}
+void K1_NAME(k1_ring)(int FL, const TemporalArgs& a, hipStream_t st) {
+    if (FL == 8) launch_ring<8, 4>(a, st);
+    else if (FL == 16) launch_ring<16, 4>(a, st);
+    else launch_ring<32, 2>(a, st);
+}
+void K1_NAME(k1_generic)(int planes, const GenericArgs& a, hipStream_t st) {
+    if (planes == 2) launch_generic<2>(a, st);
+    else launch_generic<4>(a, st);
+}
+#endif
+
+#if K1_PART == 3
+void k1_vec_u8(int, const TemporalArgs&, hipStream_t);
+void k1_vec_u16(int, const TemporalArgs&, hipStream_t);
+void k1_vec_f32(int, const TemporalArgs&, hipStream_t);
+void k1_ring_u8(int, const TemporalArgs&, hipStream_t);
+void k1_ring_u16(int, const TemporalArgs&, hipStream_t);
+void k1_ring_f32(int, const TemporalArgs&, hipStream_t);
+void k1_generic_u8(int, const GenericArgs&, hipStream_t);
+void k1_generic_u16(int, const GenericArgs&, hipStream_t);
+void k1_generic_f32(int, const GenericArgs&, hipStream_t);
+
+void k1_launch_vec(int FL, int dtype, const TemporalArgs& a, hipStream_t st) {
+    if (dtype == FVVDP_U8) k1_vec_u8(FL, a, st);
+    else if (dtype == FVVDP_U16) k1_vec_u16(FL, a, st);
+    else k1_vec_f32(FL, a, st);
+}
+void k1_launch_ring(int FL, int dtype, const TemporalArgs& a, hipStream_t st) {
+    if (dtype == FVVDP_U8) k1_ring_u8(FL, a, st);
+    else if (dtype == FVVDP_U16) k1_ring_u16(FL, a, st);
+    else k1_ring_f32(FL, a, st);
+}
+void k1_launch_generic(int planes, int dtype, const GenericArgs& a, hipStream_t st) {
+    if (dtype == FVVDP_U8) k1_generic_u8(planes, a, st);
+    else if (dtype == FVVDP_U16) k1_generic_u16(planes, a, st);
+    else k1_generic_f32(planes, a, st);
+}
+
+template <int FL, int PX>
+static void launch_yuv(int bytes, const YuvArgs& a, hipStream_t st) {
+    const int HW = a.W * a.H;
+    dim3 grid((HW + 256 * PX - 1) / (256 * PX)), block(256);
+    if (bytes == 1) hipLaunchKernelGGL((temporal_yuv_kernel<FL, PX, unsigned char>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((temporal_yuv_kernel<FL, PX, unsigned short>), grid, block, 0, st, a);
+}
+template <int FL>
+static void launch_yuv_vec(int bytes, bool c420, const YuvArgs& a, hipStream_t st) {
+    const int HW = a.W * a.H;
+    dim3 grid((HW / 4 + YUV_QUADS - 1) / YUV_QUADS), block(64);
+    if (bytes == 1) {
+        if (c420) hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned char, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned char, false>), grid, block, 0, st, a);
+    } else {
+        if (c420) hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned short, true>), grid, block, 0, st, a);
+        else hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned short, false>), grid, block, 0, st, a);
+    }
+}
+void k1_launch_yuv_vec(int FL, int bytes, bool c420, const YuvArgs& a, hipStream_t st) {
+    if (FL == 8) launch_yuv_vec<8>(bytes, c420, a, st);
+    else launch_yuv_vec<16>(bytes, c420, a, st);
+}
+void k1_launch_yuv(int FL, int bytes, const YuvArgs& a, hipStream_t st) {
+    if (FL == 8) launch_yuv<8, 2>(bytes, a, st);
+    else if (FL == 16) launch_yuv<16, 2>(bytes, a, st);
+    else launch_yuv<32, 1>(bytes, a, st);
+}
+#endif
