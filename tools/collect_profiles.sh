@@ -24,9 +24,13 @@ python $R/tools/gpu_bandonly_speed.py 12 > $OUT/bandonly_fused.txt 2>/dev/null
 FVVDP_BAND_FUSE=0 python $R/tools/gpu_bandonly_speed.py 12 > $OUT/bandonly_onelevel.txt 2>/dev/null
 $R/build_variants/mix > $OUT/mix.txt 2>&1
 python $R/tools/gpu_parity_report.py > $OUT/parity.md 2>/dev/null
-python $R/tools/gpu_fps.py > $OUT/fps_probe.txt 2>/dev/null
-python $R/tools/gpu_feeder.py > $OUT/feeder_probe.txt 2>/dev/null
+python $R/tools/gpu_fps.py 30:60:u8 60:120:u8 120:120:u8 30:60:u16 60:60:u16 30:60:f32rgb 30:60:f32gray 2>/dev/null | grep -v Warn > $OUT/fps_probe.txt
+python $R/tools/gpu_k1_ab.py 30:60:u8:5 60:60:u8:5 120:60:u8:5 2>/dev/null | grep -v Warn >> $OUT/fps_probe.txt
+BATCHES=None,60 python $R/tools/gpu_feeder.py 2>/dev/null | cut -c1-110 > $OUT/feeder_probe.txt
+HH=2160 WW=3840 BATCHES=None,60 python $R/tools/gpu_feeder.py 2>/dev/null | cut -c1-110 >> $OUT/feeder_probe.txt
 python $R/bench.py --pairs-per-gpu 8 --no-cpu-baseline --no-h2d > $OUT/bench_pairs8.json 2>/dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/kr -o rates -- python $R/tools/gpu_fps.py 60:120:u8 120:120:u8 30:60:u16 > /dev/null 2> /tmp/kr.err
+python $R/tools/rocpd_summary.py $(find /tmp/kr -name "*.db" | head -1) --only temporal_vec > $OUT/kernel_trace_rates.md
 # K1 (temporal kernel): HBM traffic per 60-frame launch from the same two counters (algorithmic: 67 frames read x 49.8 MB + 60 x 132.7 MB written)
 STAGE=all REPS=2 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf1 -o f -- python $R/tools/gpu_bandonly.py > /tmp/pf1.log 2>&1
 STAGE=all REPS=2 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw1 -o w -- python $R/tools/gpu_bandonly.py > /tmp/pw1.log 2>&1

@@ -128,13 +128,19 @@ launch: 60 x 132.7 MB = 7.96 GB written; 67 source frames x 49.8 MB = 3.33 GB re
 
 ## Other frame rates and input types, frame sources (same call)
 
-`tools/gpu_fps.py` (4K; K1 = temporal kernel per frame):
+`tools/gpu_fps.py` (4K; K1 = temporal kernel per frame, HIP events, mean of 4 calls incl. the first) and `tools/gpu_k1_ab.py`
+(median over fresh allocations, warm-up call dropped):
 
 ```
 {rd('fps_probe.txt')}
 ```
 
-`tools/gpu_feeder.py` (1080p x60; user video sources through their own get_*_frame, SURVEY 8(f) rank 3):
+K1 at 60 / 120 fps and for uint16 input under rocprofv3 (`tools/gpu_fps.py 60:120:u8 120:120:u8 30:60:u16`; one launch = 120 / 120 / 60
+output frames, 4 calls each):
+
+{rd('kernel_trace_rates.md')}
+
+`tools/gpu_feeder.py` (1080p x60, then 4K x60; user video sources through their own get_*_frame, SURVEY 8(f) rank 3):
 
 ```
 {rd('feeder_probe.txt')}
