@@ -119,3 +119,42 @@ def test_yuv_other_frame_rates_and_widths_vs_oracle(H, W, bd, css, fps, N):
     assert abs(float(q) - float(oq)) < 2e-4, (float(q), float(oq))
     a, b = st["Q_per_ch"].astype(np.float64), ost["Q_per_ch"].astype(np.float64)
     assert np.all(np.abs(a - b) <= 5e-3 * np.abs(b) + 1e-5 * np.max(b))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fps,kind", [(30, "u8"), (60, "u8"), (120, "u8"), (60, "u16"), (120, "f32")])
+def test_full_size_temporal_vector_kernel_equals_scalar_kernel(fps, kind, monkeypatch):
+    """BASELINE's 4K frame size at the three ring lengths: the register-ring vector kernel (straight-line loop, 4 or 2
+    consecutive pixels per lane, LDS transpose) against the per-pixel ring kernel (kept for misaligned sizes) on the same
+    clip -- a size-independent property, the oracle needs minutes at this size.  Same arithmetic in the same order:
+    the temporal channels agree to a few ulp (the kernels may contract different multiply-adds), pixel by pixel."""
+    import ctypes as C
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd import _native as nat
+    from fovvideovdp_amd.synth import synth_video_pair
+    N, H, W = 10, 2160, 3840
+    test, ref = synth_video_pair(N, H, W, device="cuda")
+    if kind == "u16":
+        test, ref = (test.to(torch.int32) * 257).to(torch.int16), (ref.to(torch.int32) * 257).to(torch.int16)
+    elif kind == "f32":
+        test, ref = test.float() / 255, ref.float() / 255
+    m = fv.fvvdp(display_name="standard_4k")
+
+    def channels():
+        out = torch.empty((N, 4, H, W), dtype=torch.float32, device="cuda")
+        nat.check(nat.lib().fvvdp_export_level(m._ctx.handle, 0, N, C.c_void_p(out.data_ptr()),
+                                               C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+        return out
+
+    q_vec, s_vec = m.predict(test, ref, frames_per_second=fps)
+    r_vec = channels()
+    monkeypatch.setenv("FVVDP_TEMPORAL_SCALAR", "1")
+    q_sca, s_sca = m.predict(test, ref, frames_per_second=fps)
+    r_sca = channels()
+    monkeypatch.delenv("FVVDP_TEMPORAL_SCALAR")
+    assert bool(torch.isfinite(r_vec).all()) and float(r_sca[:, :2].min()) > 0
+    scale = torch.clamp(r_sca[:, :2].abs(), min=1e-3)
+    assert float(((r_vec[:, :2] - r_sca[:, :2]).abs() / scale).max()) < 2e-6      # sustained channels (test, reference)
+    assert float(((r_vec[:, 2:] - r_sca[:, 2:]).abs() / scale).max()) < 2e-6      # transient channels, relative to the luminance
+    assert np.allclose(s_vec["Q_per_ch"], s_sca["Q_per_ch"], rtol=1e-4, atol=1e-6 * float(np.max(s_sca["Q_per_ch"])))
+    assert abs(float(q_vec) - float(q_sca)) < 1e-5
