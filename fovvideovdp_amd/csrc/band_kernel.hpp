@@ -102,6 +102,7 @@ struct BandArgs {
     float size_m0, size_m1, dist_m, cos_delta, delta_rad;
     float rho_band, rho_lo, rho_hi, ecc_lo, ecc_hi;
     float inv_step[3], first[3];   // uniform-grid estimates of the three axes
+    float frac_scale[3];           // step / (step + 1e-6): fraction inside an interval from the grid position (interp.py:16)
     int frame_w, frame_h;
 };
 
@@ -112,7 +113,8 @@ struct BandArgs {
 // is evaluated ONCE per geometry here, with exactly the operations band_kernel used per pixel and frame before
 // (4 transcendentals and ~25 VALU instructions per pixel and frame saved in a VALU-bound kernel for 8 B/pixel of reads).
 struct RhoMapArgs {
-    float4* out;            // [h][(w+1)/2] {f(2J), k(2J), f(2J+1), k(2J+1)}, k = interval - i_lo as a float
+    float4* out;            // [h][(w+1)/2] {f(2J), k(2J), f(2J+1), k(2J+1)}, k = (interval - i_lo) * 1024 as a float =
+                            //   entry offset of the interval's 32 x 32 (ecc, Y) plane in the band's LUT slice
     int w, h;
     float size_m0, size_m1, dist_m, cos_delta, delta_rad;
     float rho_band, rho_lo, rho_hi, first, inv_step;
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256) void fov_rho_map_kernel(const RhoMapArgs a) {
         const float x0 = a.axis[k], x1 = a.axis[k + 1 < FVVDP_LUT_N ? k + 1 : k];
         const float f = fmaxf((rq - x0) * (1.0f / (x1 - x0 + 0.000001f)), 0.0f);
         r[2 * i] = f;
-        r[2 * i + 1] = (float)(k - a.i_lo);
+        r[2 * i + 1] = (float)((k - a.i_lo) * (FVVDP_LUT_N * FVVDP_LUT_N));
     }
     a.out[(size_t)y * pw + J] = make_float4(r[0], r[1], r[2], r[3]);
 }
@@ -402,17 +404,21 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
             int kY, kR, kE;
             float fY, fR, fE;
             axis(0, yq, 0, FVVDP_LUT_N - 2, kY, fY);
+            int soR;                               // entry offset of the rho interval's (ecc, Y) plane
             if (pre_kR >= 0.0f) {                  // rho axis: frame-invariant, from the map (wave-uniform branch)
-                kR = (int)pre_kR + a.i_lo;
+                soR = (int)pre_kR;
                 fR = pre_fR;
             } else {
                 const float rho = a.rho_band * res_mag;
                 const float rq = fast_log2(fminf(fmaxf(rho, a.rho_lo), a.rho_hi));
                 axis(1, rq, a.i_lo, a.i_lo + a.rw - 1, kR, fR);
+                soR = (kR - a.i_lo) * (FVVDP_LUT_N * FVVDP_LUT_N);
             }
+            (void)kR;
             axis(2, eq, 0, FVVDP_LUT_N - 2, kE, fE);
-            const int so = __mul24(kE * FVVDP_LUT_N + kY, a.rw) + (kR - a.i_lo);
-            const int sj = a.rw, sk = FVVDP_LUT_N * a.rw;
+            // LUT slice [rho interval][ecc][Y]: the Y and ecc neighbours of a cell sit at compile-time distances
+            const int so = soR + kE * FVVDP_LUT_N + kY;
+            constexpr int sj = 1, sk = FVVDP_LUT_N;
             float4 v00, v10, v01, v11;                                                      // v[dj][dk]
             if constexpr (LUT_LDS) {
                 v00 = s_lut_dyn[so]; v10 = s_lut_dyn[so + sj]; v01 = s_lut_dyn[so + sk]; v11 = s_lut_dyn[so + sk + sj];
@@ -491,8 +497,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
     // instead of 8 dependent LDS round trips per step.  Same operations, in the same order, as band_px above.
     struct FovQ {
         float4 v00, v10, v01, v11;
-        float2 knY, knE;
-        float yq, eq, fR, llb;
+        float fY, fE, fR, llb;
         v2f d[HP];
     };
     auto fov_a = [&](const Px<P>& g, const Px<P>& e, float vx, float vy, float pre_fR, float pre_kR) -> FovQ {
@@ -505,17 +510,22 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
             q.d[k] = v2f{fminf(t.x, dcap), fminf(t.y, dcap)};
         }
         q.llb = fast_log2(lb);
-        q.yq = fminf(fmaxf(q.llb, a.ly_lo), a.ly_hi);
+        const float yq = fminf(fmaxf(q.llb, a.ly_lo), a.ly_hi);
         const float dx = vx - gx, dy = vy - gy;
         const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
-        q.eq = __builtin_amdgcn_sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
-        const int kY = min(max(floor_to_int((q.yq - a.first[0]) * a.inv_step[0]), 0), FVVDP_LUT_N - 2);
-        const int kE = min(max(floor_to_int((q.eq - a.first[2]) * a.inv_step[2]), 0), FVVDP_LUT_N - 2);
-        q.knY = s_ax[kY];
-        q.knE = s_ax[2 * FVVDP_LUT_N + kE];
+        const float eq = __builtin_amdgcn_sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
+        // Y and ecc axes are uniform: interval = floor of the grid position t, fraction = (t - interval) * step/(step+1e-6)
+        // (interp.py:11-20 computes (q - knot)/(knot' - knot + 1e-6) from the stored knots: equal to ~2e-6 of an interval,
+        // which band_px, the map-writing path, still does).  No LDS look-up, no dependent round trip before the cell reads.
+        const float tY = (yq - a.first[0]) * a.inv_step[0];
+        const float tE = (eq - a.first[2]) * a.inv_step[2];
+        const float iY = __builtin_amdgcn_fmed3f(floorf(tY), 0.0f, (float)(FVVDP_LUT_N - 2));
+        const float iE = __builtin_amdgcn_fmed3f(floorf(tE), 0.0f, (float)(FVVDP_LUT_N - 2));
+        q.fY = (tY - iY) * a.frac_scale[0];
+        q.fE = (tE - iE) * a.frac_scale[2];
         q.fR = pre_fR;
-        const int so = __mul24(kE * FVVDP_LUT_N + kY, a.rw) + (int)pre_kR;
-        const int sj = a.rw, sk = FVVDP_LUT_N * a.rw;
+        const int so = (int)pre_kR + ((int)iE * FVVDP_LUT_N + (int)iY);
+        constexpr int sj = 1, sk = FVVDP_LUT_N;
         q.v00 = s_lut_dyn[so];
         q.v10 = s_lut_dyn[so + sj];
         q.v01 = s_lut_dyn[so + sk];
@@ -523,16 +533,13 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
         return q;
     };
     auto fov_b = [&](const FovQ& q, bool valid) {
-        const float fY = fmaxf((q.yq - q.knY.x) * q.knY.y, 0.0f);
-        const float fE = fmaxf((q.eq - q.knE.x) * q.knE.y, 0.0f);
-        const float fR = q.fR;
-        const float gY = 1.0f - fY, gE = 1.0f - fE;
+        const float fY = q.fY, fE = q.fE, fR = q.fR;
         // interp3 (interp.py:53-57), same association (rho, then Y, then ecc); both temporal channels as one packed pair;
-        // rho blend in slope form (see band_px)
+        // every blend in slope form a + f * (b - a) (the reference's a * (1 - f) + b * f to 1 ulp)
         auto rho_blend = [&](const float4& v) { return pfma(v2f{v.z, v.w}, fR, v2f{v.x, v.y}); };
         const v2f r00 = rho_blend(q.v00), r10 = rho_blend(q.v10), r01 = rho_blend(q.v01), r11 = rho_blend(q.v11);
-        const v2f y0 = pfma(r10, fY, r00 * gY), y1 = pfma(r11, fY, r01 * gY);
-        const v2f sl2 = pfma(y1, fE, y0 * gE);
+        const v2f y0 = pfma(r10 - r00, fY, r00), y1 = pfma(r11 - r01, fY, r01);
+        const v2f sl2 = pfma(y1 - y0, fE, y0);
         const float s0 = sl2.x, s1 = sl2.y;
         const float vm = valid ? 1.0f : 0.0f;
         const float lcn = lg_bm - q.llb;

@@ -681,7 +681,8 @@ static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
                 for (int i = 0; i < rw; ++i) {
                     const size_t s0 = ((size_t)j * FVVDP_LUT_N + (i_lo + i)) * FVVDP_LUT_N + k;       // [Y][rho][ecc]
                     const size_t s1 = ((size_t)j * FVVDP_LUT_N + (i_lo + i + 1)) * FVVDP_LUT_N + k;
-                    h[((size_t)k * FVVDP_LUT_N + j) * rw + i] = make_float4(L0[s0], L1[s0], L0[s1] - L0[s0], L1[s1] - L1[s0]);   // slope form
+                    // slice layout [rho interval i][ecc k][Y j]; rho blend in slope form {v[i], v[i+1] - v[i]}
+                    h[((size_t)i * FVVDP_LUT_N + k) * FVVDP_LUT_N + j] = make_float4(L0[s0], L1[s0], L0[s1] - L0[s0], L1[s1] - L1[s0]);
                 }
         HIP_TRY(hipMemcpy(c->sublut[b], h.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         c->sub_rw[b] = rw;
@@ -880,6 +881,8 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
             for (int ax = 0; ax < 3; ++ax) {
                 a.first[ax] = c->h_axes[ax][0];
                 a.inv_step[ax] = (float)(FVVDP_LUT_N - 1) / (c->h_axes[ax][FVVDP_LUT_N - 1] - c->h_axes[ax][0]);
+                const double step = ((double)c->h_axes[ax][FVVDP_LUT_N - 1] - (double)c->h_axes[ax][0]) / (FVVDP_LUT_N - 1);
+                a.frac_scale[ax] = (float)(step / (step + 1e-6));
             }
             a.frame_w = c->W;
             a.frame_h = c->H;
