@@ -43,43 +43,7 @@ struct Band2Args {
     float* partialB;
 };
 
-// ---- horizontal taps with the DPP shift folded into the multiply-add (v_fmac_f32_dpp) ------------------------------
-// The compiler keeps `v_mov_b32_dpp` + `v_pk_fma_f32` for update_dpp() followed by fmaf (its DPP combiner does not fold
-// wave shifts on gfx950), i.e. one extra full-rate VALU instruction per neighbour value; this kernel is VALU-bound, so
-// the taps are written out.  Hazard: a DPP source operand written by a VALU instruction needs 2 wait states, which the
-// compiler cannot see inside an asm statement -> every block opens with `s_nop 1`, and temporaries produced inside a
-// block are read at least 3 instructions later.  Accumulation order = the order of the fma chain it replaces.
-#define DPP_SHR " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-#define DPP_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
-// acc += w0*left(va); acc += w1*left(vb); acc += w4*right(va)            (reduce, taps 0, 1, 4)
-__device__ __forceinline__ v2f dpp_reduce_taps(v2f acc, v2f va, v2f vb, float w0, float w1, float w4) {
-    float x = acc.x, y = acc.y;
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f32_dpp %0, %2, %6" DPP_SHR "\n\t"
-                 "v_fmac_f32_dpp %1, %3, %6" DPP_SHR "\n\t"
-                 "v_fmac_f32_dpp %0, %4, %7" DPP_SHR "\n\t"
-                 "v_fmac_f32_dpp %1, %5, %7" DPP_SHR "\n\t"
-                 "v_fmac_f32_dpp %0, %2, %8" DPP_SHL "\n\t"
-                 "v_fmac_f32_dpp %1, %3, %8" DPP_SHL
-                 : "+v"(x), "+v"(y)
-                 : "v"(va.x), "v"(va.y), "v"(vb.x), "v"(vb.y), "v"(w0), "v"(w1), "v"(w4));
-    return v2f{x, y};
-}
-// even += el*left(e); even += er*right(e); odd += orr*right(e)           (expand from columns J-1, J, J+1)
-__device__ __forceinline__ void dpp_expand_taps(v2f e, float el, float er, float orr, v2f& even, v2f& odd) {
-    float ex = even.x, ey = even.y, ox = odd.x, oy = odd.y;
-    asm volatile("s_nop 1\n\t"
-                 "v_fmac_f32_dpp %0, %4, %6" DPP_SHR "\n\t"
-                 "v_fmac_f32_dpp %1, %5, %6" DPP_SHR "\n\t"
-                 "v_fmac_f32_dpp %0, %4, %7" DPP_SHL "\n\t"
-                 "v_fmac_f32_dpp %1, %5, %7" DPP_SHL "\n\t"
-                 "v_fmac_f32_dpp %2, %4, %8" DPP_SHL "\n\t"
-                 "v_fmac_f32_dpp %3, %5, %8" DPP_SHL
-                 : "+v"(ex), "+v"(ey), "+v"(ox), "+v"(oy)
-                 : "v"(e.x), "v"(e.y), "v"(el), "v"(er), "v"(orr));
-    even = v2f{ex, ey};
-    odd = v2f{ox, oy};
-}
+// (dpp_reduce_taps / dpp_expand_taps: band_kernel.hpp)
 // acc += u3*right(v); acc += u0*left2(v); acc += u1*left(v); acc += u4*right2(v); result of the even lane of each pair
 __device__ __forceinline__ v2f dpp_reduce5_pair(v2f acc, v2f v, float u0, float u1, float u3, float u4) {
     float x = acc.x, y = acc.y, l1x, l1y, r1x, r1y, ox, oy;

@@ -53,19 +53,42 @@ __device__ __forceinline__ void st_px(__amdgpu_buffer_rsrc_t r, unsigned int byt
     __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, a.h[0]), r, byte_off, 0, 2 /*nt*/);
 }
 
-// value held by the lane to the left / right (0 at the wave's ends)
-__device__ __forceinline__ float from_left(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x138 /*wave_shr:1*/, 0xf, 0xf, true));
+// ---- horizontal taps with the DPP shift folded into the multiply-add (v_fmac_f32_dpp) ------------------------------
+// The compiler keeps `v_mov_b32_dpp` + `v_pk_fma_f32` for update_dpp() followed by fmaf (its DPP combiner does not fold
+// wave shifts on gfx950), i.e. one extra full-rate VALU instruction per neighbour value; the pyramid kernels are VALU-bound, so
+// the taps are written out.  Hazard: a DPP source operand written by a VALU instruction needs 2 wait states, which the
+// compiler cannot see inside an asm statement -> every block opens with `s_nop 1`, and temporaries produced inside a
+// block are read at least 3 instructions later.  Accumulation order = the order of the fma chain it replaces.
+#define DPP_SHR " wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+#define DPP_SHL " wave_shl:1 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+// acc += w0*left(va); acc += w1*left(vb); acc += w4*right(va)            (reduce, taps 0, 1, 4)
+__device__ __forceinline__ v2f dpp_reduce_taps(v2f acc, v2f va, v2f vb, float w0, float w1, float w4) {
+    float x = acc.x, y = acc.y;
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %2, %6" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %1, %3, %6" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %0, %4, %7" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %1, %5, %7" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %0, %2, %8" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %1, %3, %8" DPP_SHL
+                 : "+v"(x), "+v"(y)
+                 : "v"(va.x), "v"(va.y), "v"(vb.x), "v"(vb.y), "v"(w0), "v"(w1), "v"(w4));
+    return v2f{x, y};
 }
-__device__ __forceinline__ float from_right(float x) {
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), 0x130 /*wave_shl:1*/, 0xf, 0xf, true));
-}
-// acc + w * neighbour(x), per component (v_fmac_f32 with a DPP source)
-__device__ __forceinline__ v2f fma_left(v2f x, float w, v2f acc) {
-    return v2f{fmaf(from_left(x.x), w, acc.x), fmaf(from_left(x.y), w, acc.y)};
-}
-__device__ __forceinline__ v2f fma_right(v2f x, float w, v2f acc) {
-    return v2f{fmaf(from_right(x.x), w, acc.x), fmaf(from_right(x.y), w, acc.y)};
+// even += el*left(e); even += er*right(e); odd += orr*right(e)           (expand from columns J-1, J, J+1)
+__device__ __forceinline__ void dpp_expand_taps(v2f e, float el, float er, float orr, v2f& even, v2f& odd) {
+    float ex = even.x, ey = even.y, ox = odd.x, oy = odd.y;
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f32_dpp %0, %4, %6" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %1, %5, %6" DPP_SHR "\n\t"
+                 "v_fmac_f32_dpp %0, %4, %7" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %1, %5, %7" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %2, %4, %8" DPP_SHL "\n\t"
+                 "v_fmac_f32_dpp %3, %5, %8" DPP_SHL
+                 : "+v"(ex), "+v"(ey), "+v"(ox), "+v"(oy)
+                 : "v"(e.x), "v"(e.y), "v"(el), "v"(er), "v"(orr));
+    even = v2f{ex, ey};
+    odd = v2f{ox, oy};
 }
 
 struct BandArgs {
@@ -301,9 +324,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
         for (int k = 0; k < HP; ++k) {
             v2f acc = va.h[k] * wq2;
             acc = pfma(vb.h[k], wq3, acc);
-            acc = fma_left(va.h[k], wq0, acc);
-            acc = fma_left(vb.h[k], wq1, acc);
-            c.h[k] = fma_right(va.h[k], wq4, acc);
+            c.h[k] = dpp_reduce_taps(acc, va.h[k], vb.h[k], wq0, wq1, wq4);
         }
         return c;
     };
@@ -593,14 +614,12 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
         }
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
-            v2f t = evE.h[k] * ec;
-            t = fma_left(evE.h[k], el, t);
-            x00.h[k] = fma_right(evE.h[k], er, t);
-            x01.h[k] = fma_right(evE.h[k], orr, evE.h[k] * oc);
-            t = evO.h[k] * ec;
-            t = fma_left(evO.h[k], el, t);
-            x10.h[k] = fma_right(evO.h[k], er, t);
-            x11.h[k] = fma_right(evO.h[k], orr, evO.h[k] * oc);
+            x00.h[k] = evE.h[k] * ec;
+            x01.h[k] = evE.h[k] * oc;
+            dpp_expand_taps(evE.h[k], el, er, orr, x00.h[k], x01.h[k]);
+            x10.h[k] = evO.h[k] * ec;
+            x11.h[k] = evO.h[k] * oc;
+            dpp_expand_taps(evO.h[k], el, er, orr, x10.h[k], x11.h[k]);
         }
         const bool row1_ok = (2 * c + 1) < h;
 #if defined(BAND_ABLATE) && BAND_ABLATE >= 1      // profiling ablation: no per-pixel tail, keep the data flow alive
