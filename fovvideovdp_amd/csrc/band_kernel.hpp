@@ -172,7 +172,6 @@ __global__ __launch_bounds__(256) void fov_rho_map_kernel(const RhoMapArgs a) {
 }
 
 
-#ifndef FOV_WPB
 // (int)floorf(x) as ONE instruction (the compiler emits v_floor_f32 + v_cvt_i32_f32)
 __device__ __forceinline__ int floor_to_int(float x) {
     int r;
@@ -180,6 +179,7 @@ __device__ __forceinline__ int floor_to_int(float x) {
     return r;
 }
 
+#ifndef FOV_WPB
 #define FOV_WPB 4            // foveated mode: 4 independent waves per workgroup share the band's LUT slice in LDS
 #endif
 #ifndef FOV_MINW
@@ -196,7 +196,10 @@ extern __shared__ __attribute__((aligned(16))) float4 s_lut_dyn[];
 template <int P, bool DBG, int FOVM>
 __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 2 : 4)) void band_kernel(const BandArgs a) {
     constexpr bool FOV = FOVM != 0;
-    constexpr bool LUT_LDS = FOVM == 1;
+    constexpr bool LUT_LDS = FOVM == 1 || FOVM == 3;
+    // FOVM 1: stock geometry with the frame-invariant rho map (the fast path: no code for the other cases in the loop);
+    // FOVM 3: LUT slice in LDS, user geometry maps or no rho map;  FOVM 2: LUT slice in global memory (any case, DBG)
+    constexpr bool LEAN = FOVM == 1;
     constexpr int HP = P / 2;   // (test, ref) pairs = temporal channels
     constexpr int WPB = FOV ? FOV_WPB : 1;
     __shared__ float4 s_csf[FVVDP_LUT_N];
@@ -635,7 +638,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
         }
         if constexpr (FOV) {
             float vx4[4] = {vxa, vxb, vxa, vxb}, vy4[4] = {vy0, vy0, vy1, vy1}, rm4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-            if (a.mvx) {                          // user geometry: maps evaluated by the caller
+            if (!LEAN && a.mvx) {                 // user geometry: maps evaluated by the caller
                 const int ya = min(2 * c, h - 1), yb = min(2 * c + 1, h - 1);
                 const size_t o[4] = {(size_t)ya * w + xc0, (size_t)ya * w + xc1, (size_t)yb * w + xc0, (size_t)yb * w + xc1};
 #pragma unroll
@@ -644,7 +647,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
                     vy4[i] = a.mvy[o[i]];
                     rm4[i] = a.mrm[o[i]];
                 }
-            } else if (!a.rmap) {
+            } else if (!LEAN && !a.rmap) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const float va = fminf(__builtin_amdgcn_sqrtf(vx4[i] * vx4[i] + vy4[i] * vy4[i]), 89.9f) * 0.017453292519943295f;
@@ -652,13 +655,13 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
                 }
             }
             float4 ra = make_float4(0.0f, -1.0f, 0.0f, -1.0f), rb = ra;      // {f, k} of columns X0, X1 in rows 2c, 2c+1
-            if (a.rmap && !a.mvx) {
+            if (LEAN || (a.rmap && !a.mvx)) {
                 const int jj = min(max(J, 0), a.rmap_w - 1);
                 ra = a.rmap[(size_t)min(2 * c, h - 1) * a.rmap_w + jj];
                 rb = a.rmap[(size_t)min(2 * c + 1, h - 1) * a.rmap_w + jj];
             }
             if constexpr (LUT_LDS && !DBG) {
-                if (FOV_PHASE != 0 && a.rmap && !a.mvx) {   // stock geometry: phased evaluation (see fov_a / fov_b)
+                if (FOV_PHASE != 0 && (LEAN || (a.rmap && !a.mvx))) {   // stock geometry: phased evaluation (see fov_a / fov_b)
 #if FOV_PHASE == 4
                     const FovQ q0 = fov_a(W[0][0], x00, vx4[0], vy4[0], ra.x, ra.y);
                     const FovQ q1 = fov_a(W[0][1], x01, vx4[1], vy4[1], ra.z, ra.w);

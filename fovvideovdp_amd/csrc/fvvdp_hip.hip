@@ -729,7 +729,8 @@ static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, hipS
         const size_t lds_vy = (size_t)a.h * sizeof(float);
         const size_t lds_lut = (size_t)FVVDP_LUT_N * FVVDP_LUT_N * a.rw * sizeof(float4);
         if (dbg) hipLaunchKernelGGL((band_kernel<P, true, 2>), gridf, blockf, lds_vy, st, a);
-        else if (a.lut_lds) hipLaunchKernelGGL((band_kernel<P, false, 1>), gridf, blockf, lds_lut + lds_vy, st, a);
+        else if (a.lut_lds && a.rmap && !a.mvx) hipLaunchKernelGGL((band_kernel<P, false, 1>), gridf, blockf, lds_lut + lds_vy, st, a);
+        else if (a.lut_lds) hipLaunchKernelGGL((band_kernel<P, false, 3>), gridf, blockf, lds_lut + lds_vy, st, a);
         else hipLaunchKernelGGL((band_kernel<P, false, 2>), gridf, blockf, lds_vy, st, a);
     } else {
         if (dbg) hipLaunchKernelGGL((band_kernel<P, true, 0>), grid, block, 0, st, a);
