@@ -125,6 +125,7 @@ struct BandArgs {
     float size_m0, size_m1, dist_m, cos_delta, delta_rad;
     float rho_band, rho_lo, rho_hi, ecc_lo, ecc_hi;
     float inv_step[3], first[3];   // uniform-grid estimates of the three axes
+    float grid_off[3];             // -first * inv_step
     float frac_scale[3];           // step / (step + 1e-6): fraction inside an interval from the grid position (interp.py:16)
     int frame_w, frame_h;
 };
@@ -541,14 +542,15 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
         // Y and ecc axes are uniform: interval = floor of the grid position t, fraction = (t - interval) * step/(step+1e-6)
         // (interp.py:11-20 computes (q - knot)/(knot' - knot + 1e-6) from the stored knots: equal to ~2e-6 of an interval,
         // which band_px, the map-writing path, still does).  No LDS look-up, no dependent round trip before the cell reads.
-        const float tY = (yq - a.first[0]) * a.inv_step[0];
-        const float tE = (eq - a.first[2]) * a.inv_step[2];
+        const float tY = fmaf(yq, a.inv_step[0], a.grid_off[0]);
+        const float tE = fmaf(eq, a.inv_step[2], a.grid_off[2]);
         const float iY = __builtin_amdgcn_fmed3f(floorf(tY), 0.0f, (float)(FVVDP_LUT_N - 2));
         const float iE = __builtin_amdgcn_fmed3f(floorf(tE), 0.0f, (float)(FVVDP_LUT_N - 2));
         q.fY = (tY - iY) * a.frac_scale[0];
         q.fE = (tE - iE) * a.frac_scale[2];
         q.fR = pre_fR;
-        const int so = (int)pre_kR + ((int)iE * FVVDP_LUT_N + (int)iY);
+        // entry index (rho plane + ecc * 32 + Y) in float: small integers are exact, one conversion instead of three
+        const int so = (int)fmaf(iE, (float)FVVDP_LUT_N, iY + pre_kR);
         constexpr int sj = 1, sk = FVVDP_LUT_N;
         q.v00 = s_lut_dyn[so];
         q.v10 = s_lut_dyn[so + sj];

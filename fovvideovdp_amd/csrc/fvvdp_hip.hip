@@ -884,6 +884,7 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
                 a.inv_step[ax] = (float)(FVVDP_LUT_N - 1) / (c->h_axes[ax][FVVDP_LUT_N - 1] - c->h_axes[ax][0]);
                 const double step = ((double)c->h_axes[ax][FVVDP_LUT_N - 1] - (double)c->h_axes[ax][0]) / (FVVDP_LUT_N - 1);
                 a.frac_scale[ax] = (float)(step / (step + 1e-6));
+                a.grid_off[ax] = -a.first[ax] * a.inv_step[ax];
             }
             a.frame_w = c->W;
             a.frame_h = c->H;
