@@ -766,7 +766,7 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
     // two-level kernel is VALU-bound (its strips own 54 of 64 lanes), so small levels stay on the one-level kernel
     // (960x540 + 480x270: 3.1 vs 2.95 us).  FVVDP_BAND_FUSE=0 / 1 forces never / wherever valid (tests, A/B runs).
     const char* fuse_env = getenv("FVVDP_BAND_FUSE");
-    const int fuse_mode = fuse_env ? atoi(fuse_env) : -1;
+    const int fuse_mode = (fuse_env && (fuse_env[0] == '0' || fuse_env[0] == '1')) ? fuse_env[0] - '0' : -1;   // anything else: automatic
     const bool fuse_ok = !fov && !any_maps && fuse_mode != 0;
     for (int b = 0; b < c->n_bands; ++b) {
         const bool big = (long long)c->lw[b] * c->lh[b] >= 1500000;
