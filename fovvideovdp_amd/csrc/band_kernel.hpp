@@ -186,8 +186,11 @@ __device__ __forceinline__ int floor_to_int(float x) {
 #ifndef FOV_MINW
 #define FOV_MINW 2
 #endif
+#ifndef FOV_MINW_LEAN
+#define FOV_MINW_LEAN 3     // the stock-geometry instantiation (FOVM == 1): 168 VGPRs, 3 waves per SIMD
+#endif
 #ifndef FOV_PHASE
-#define FOV_PHASE 4          // pixels whose LDS reads are batched (4: all of a step, 254 VGPRs; 2: pairs)
+#define FOV_PHASE 2          // pixels whose LDS reads are batched: pairs (160 VGPRs, 3 waves per SIMD); 4 = all of a step (181 VGPRs)
 #endif
 extern __shared__ __attribute__((aligned(16))) float4 s_lut_dyn[];
 
@@ -195,7 +198,7 @@ extern __shared__ __attribute__((aligned(16))) float4 s_lut_dyn[];
 // memory (slice too large, or the map-writing variant).  A compile-time choice: with a run-time flag the compiler
 // merges the two look-ups into one flat load, which is slower than ds_read_b128.
 template <int P, bool DBG, int FOVM>
-__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 2 : 4)) void band_kernel(const BandArgs a) {
+__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_MINW_LEAN : FOV_MINW) : (DBG ? 2 : 4)) void band_kernel(const BandArgs a) {
     constexpr bool FOV = FOVM != 0;
     constexpr bool LUT_LDS = FOVM == 1 || FOVM == 3;
     // FOVM 1: stock geometry with the frame-invariant rho map (the fast path: no code for the other cases in the loop);
@@ -213,7 +216,9 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
     {
         const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
         bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
-        if constexpr (FOV) bid = bid * WPB + (threadIdx.x >> 6);
+        // the wave number is the same in all lanes: say so, otherwise every quantity derived from the work item (rows,
+        // loop counter, row addresses, the store descriptor) lives in vector registers and is recomputed by the VALU
+        if constexpr (FOV) bid = bid * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     }
     const bool wave_has_work = !FOV || bid < a.n_items;
     const int strip = bid % a.n_strips;
@@ -531,14 +536,15 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? FOV_MINW : (DBG ? 
         const float dcap = a.cmax * lb;
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
-            const v2f t = g.h[k] - e.h[k];
-            q.d[k] = v2f{fminf(t.x, dcap), fminf(t.y, dcap)};
+            // component-wise on purpose: the expanded level comes out of the DPP blocks as single registers, a packed
+            // subtraction would need them copied into a register pair first
+            q.d[k] = v2f{fminf(g.h[k].x - e.h[k].x, dcap), fminf(g.h[k].y - e.h[k].y, dcap)};
         }
         q.llb = fast_log2(lb);
-        const float yq = fminf(fmaxf(q.llb, a.ly_lo), a.ly_hi);
+        const float yq = __builtin_amdgcn_fmed3f(q.llb, a.ly_lo, a.ly_hi);
         const float dx = vx - gx, dy = vy - gy;
         const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
-        const float eq = __builtin_amdgcn_sqrtf(fminf(fmaxf(ecc, a.ecc_lo), a.ecc_hi));
+        const float eq = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fmed3f(ecc, a.ecc_lo, a.ecc_hi));
         // Y and ecc axes are uniform: interval = floor of the grid position t, fraction = (t - interval) * step/(step+1e-6)
         // (interp.py:11-20 computes (q - knot)/(knot' - knot + 1e-6) from the stored knots: equal to ~2e-6 of an interval,
         // which band_px, the map-writing path, still does).  No LDS look-up, no dependent round trip before the cell reads.
