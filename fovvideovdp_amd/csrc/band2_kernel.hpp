@@ -208,11 +208,11 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         v2f d[HP];
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
-            const v2f t = g.h[k] - e.h[k];
-            d[k] = v2f{fminf(t.x, dcap), fminf(t.y, dcap)};
+            // component-wise: the expanded level leaves the DPP blocks in single registers (no pair to subtract from)
+            d[k] = v2f{fminf(g.h[k].x - e.h[k].x, dcap), fminf(g.h[k].y - e.h[k].y, dcap)};   // upper clamp only (fvvdp_lpyr_dec.py:266)
         }
         const float llb = fast_log2(lb);
-        const float yq = fminf(fmaxf(llb, a.ly_lo), a.ly_hi);
+        const float yq = __builtin_amdgcn_fmed3f(llb, a.ly_lo, a.ly_hi);
         const float t = (yq - a.y_first) * a.y_inv_step;
         const float fi = fminf(fmaxf(floorf(t), 0.0f), (float)(FVVDP_LUT_N - 2));
         const float4 r = s_csf[band][(int)fi];

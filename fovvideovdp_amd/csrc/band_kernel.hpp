@@ -404,11 +404,11 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
         v2f d[HP];
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
-            const v2f t = g.h[k] - e.h[k];
-            d[k] = v2f{fminf(t.x, dcap), fminf(t.y, dcap)};            // upper clamp only (fvvdp_lpyr_dec.py:266)
+            // component-wise: the expanded level leaves the DPP blocks in single registers (no pair to subtract from)
+            d[k] = v2f{fminf(g.h[k].x - e.h[k].x, dcap), fminf(g.h[k].y - e.h[k].y, dcap)};   // upper clamp only (fvvdp_lpyr_dec.py:266)
         }
         const float llb = fast_log2(lb);
-        const float yq = fminf(fmaxf(llb, a.ly_lo), a.ly_hi);          // = log2(clamp(lb, Y[0], Y[-1]))  (fvvdp.py:530)
+        const float yq = __builtin_amdgcn_fmed3f(llb, a.ly_lo, a.ly_hi);          // = log2(clamp(lb, Y[0], Y[-1]))  (fvvdp.py:530)
         float slog[2] = {0.0f, 0.0f};
         if constexpr (!FOV) {
             // 1-D table over log2(L_bkg) (uniform knots): interval from the grid, value = v[i] + f*(v[i+1]-v[i])
