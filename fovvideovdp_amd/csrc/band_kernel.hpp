@@ -137,8 +137,8 @@ struct BandArgs {
 // is evaluated ONCE per geometry here, with exactly the operations band_kernel used per pixel and frame before
 // (4 transcendentals and ~25 VALU instructions per pixel and frame saved in a VALU-bound kernel for 8 B/pixel of reads).
 struct RhoMapArgs {
-    float4* out;            // [h][(w+1)/2] {f(2J), k(2J), f(2J+1), k(2J+1)}, k = (interval - i_lo) * 1024 as a float =
-                            //   entry offset of the interval's 32 x 32 (ecc, Y) plane in the band's LUT slice
+    float4* out;            // [h][(w+1)/2] {f(2J), k(2J), f(2J+1), k(2J+1)}, k = (interval - i_lo) * 16384 as a float =
+                            //   BYTE offset of the interval's 32 x 32 (ecc, Y) plane of float4 entries in the band's LUT slice
     int w, h;
     float size_m0, size_m1, dist_m, cos_delta, delta_rad;
     float rho_band, rho_lo, rho_hi, first, inv_step;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256) void fov_rho_map_kernel(const RhoMapArgs a) {
         const float x0 = a.axis[k], x1 = a.axis[k + 1 < FVVDP_LUT_N ? k + 1 : k];
         const float f = fmaxf((rq - x0) * (1.0f / (x1 - x0 + 0.000001f)), 0.0f);
         r[2 * i] = f;
-        r[2 * i + 1] = (float)((k - a.i_lo) * (FVVDP_LUT_N * FVVDP_LUT_N));
+        r[2 * i + 1] = (float)((k - a.i_lo) * (FVVDP_LUT_N * FVVDP_LUT_N * 16));
     }
     a.out[(size_t)y * pw + J] = make_float4(r[0], r[1], r[2], r[3]);
 }
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
             axis(0, yq, 0, FVVDP_LUT_N - 2, kY, fY);
             int soR;                               // entry offset of the rho interval's (ecc, Y) plane
             if (pre_kR >= 0.0f) {                  // rho axis: frame-invariant, from the map (wave-uniform branch)
-                soR = (int)pre_kR;
+                soR = (int)pre_kR >> 4;
                 fR = pre_fR;
             } else {
                 const float rho = a.rho_band * res_mag;
@@ -555,13 +555,14 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
         q.fY = (tY - iY) * a.frac_scale[0];
         q.fE = (tE - iE) * a.frac_scale[2];
         q.fR = pre_fR;
-        // entry index (rho plane + ecc * 32 + Y) in float: small integers are exact, one conversion instead of three
-        const int so = (int)fmaf(iE, (float)FVVDP_LUT_N, iY + pre_kR);
+        // byte offset of the cell (rho plane + ecc * 512 + Y * 16) in float: small integers are exact, one conversion
+        const int bo = (int)fmaf(iE, (float)(FVVDP_LUT_N * 16), fmaf(iY, 16.0f, pre_kR));
+        const float4* cell = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_lut_dyn) + bo);
         constexpr int sj = 1, sk = FVVDP_LUT_N;
-        q.v00 = s_lut_dyn[so];
-        q.v10 = s_lut_dyn[so + sj];
-        q.v01 = s_lut_dyn[so + sk];
-        q.v11 = s_lut_dyn[so + sk + sj];
+        q.v00 = cell[0];
+        q.v10 = cell[sj];
+        q.v01 = cell[sk];
+        q.v11 = cell[sk + sj];
         return q;
     };
     auto fov_b = [&](const FovQ& q, bool valid) {
