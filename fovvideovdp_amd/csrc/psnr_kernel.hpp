@@ -36,28 +36,32 @@ __global__ __launch_bounds__(256) void pu21_sse_kernel(const Pu21Args a) {
         build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 256);
         __syncthreads();
     }
-    Sampler<SRC, PX> S[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        S[s].base = a.src[s];
-        S[s].chan_stride = a.chan_stride;
-        S[s].C = a.C;
-        S[s].lutw = lutw;
-        S[s].lut16 = a.e.lut;
-        S[s].w0 = a.C == 3 ? a.w[0] : 1.0f;
-        S[s].w1 = a.w[1];
-        S[s].w2 = a.w[2];
-        S[s].e = a.e;
-    }
+    const float w[3] = {a.C == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};
     const unsigned int beg = blockIdx.x * a.chunk;
     const unsigned int end = min(beg + a.chunk, a.HW);
     const size_t foff = (size_t)blockIdx.y * a.frame_stride;
     bool bad = false;
     double acc = 0.0;
-    for (unsigned int p = beg + threadIdx.x * PX; p < end; p += 256 * PX) {
+    unsigned int p = beg + threadIdx.x * PX;
+    // raw samples of the next iteration are requested before the current ones are converted (the conversion is ~130
+    // cycles per pixel; without this every iteration started with a full memory round trip)
+    RawVecFrame<SRC, PX> n0, n1;
+    {
+        const size_t o = foff + (p < end ? p : beg);
+        n0 = fetch_vec<SRC, PX>(a.src[0], o, a.chan_stride, a.C);
+        n1 = fetch_vec<SRC, PX>(a.src[1], o, a.chan_stride, a.C);
+    }
+    for (; p < end; p += 256 * PX) {
+        const RawVecFrame<SRC, PX> c0 = n0, c1 = n1;
+        {
+            const unsigned int pn = p + 256 * PX;
+            const size_t o = foff + (pn < end ? pn : p);          // past the end: the current samples again (unused)
+            n0 = fetch_vec<SRC, PX>(a.src[0], o, a.chan_stride, a.C);
+            n1 = fetch_vec<SRC, PX>(a.src[1], o, a.chan_stride, a.C);
+        }
         float lt[PX], lr[PX];
-        S[0].lum(foff + p, lt, bad);
-        S[1].lum(foff + p, lr, bad);
+        frame_lum<SRC, PX, RawVecFrame<SRC, PX>>(c0, a.C, lutw, a.e.lut, w, a.e, lt, bad);
+        frame_lum<SRC, PX, RawVecFrame<SRC, PX>>(c1, a.C, lutw, a.e.lut, w, a.e, lr, bad);
 #pragma unroll
         for (int i = 0; i < PX; ++i) {
             // The encoded values must be ROUNDED before they are subtracted.  pu21_encode ends in a product; fused into
