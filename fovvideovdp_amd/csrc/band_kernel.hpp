@@ -112,7 +112,7 @@ struct BandArgs {
     float* dL;
     float* dS;
     // foveated (FOV == true)
-    const float4* sublut;   // per band: [32 ecc][32 Y][rw] of {S_log0[i], S_log1[i], S_log0[i+1]-S_log0[i], S_log1[i+1]-S_log1[i]} (i = rho knot)
+    const float4* sublut;   // per band: [rw rho intervals][32 ecc][32 Y] of {S_log0[i], S_log1[i], S_log0[i+1]-S_log0[i], S_log1[i+1]-S_log1[i]} (i = rho knot)
     const float* axes;      // [3][32] knots: Y_log, rho_log, ecc_sqrt
     int rw, i_lo;           // rho knots covered by the band's sub-LUT: [i_lo, i_lo+rw]
     const float* fix;       // device [n][2]: gaze in frame pixels, or gaze view direction in degrees (map mode)
@@ -522,8 +522,8 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
         }
     };
 
-    // Foveated mode, plain evaluation (no maps written): the four pixels of a step in two phases, so that all LDS reads of
-    // the step (per pixel: 2 axis knots + the 4 corners of the LUT cell) are issued back to back and waited for once,
+    // Foveated mode, plain evaluation (no maps written): the pixels of a step in two phases (FOV_PHASE at a time), so that
+    // their LDS reads (the 4 corners of the LUT cell per pixel) are issued back to back and waited for once,
     // instead of 8 dependent LDS round trips per step.  Same operations, in the same order, as band_px above.
     struct FovQ {
         float4 v00, v10, v01, v11;
@@ -680,7 +680,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
                     fov_b(q1, active && col1_ok);
                     fov_b(q2, active && row1_ok);
                     fov_b(q3, active && row1_ok && col1_ok);
-#else               // two pixels per phase: half the registers in flight; the scheduler may not interleave the phases
+#else               // two pixels per phase (default): half the registers in flight; the scheduler may not interleave the phases
                     __builtin_amdgcn_sched_barrier(0);
                     {
                         const FovQ q0 = fov_a(W[0][0], x00, vx4[0], vy4[0], ra.x, ra.y);
