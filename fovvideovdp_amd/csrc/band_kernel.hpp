@@ -524,7 +524,8 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
 
     // Foveated mode, plain evaluation (no maps written): the pixels of a step in two phases (FOV_PHASE at a time), so that
     // their LDS reads (the 4 corners of the LUT cell per pixel) are issued back to back and waited for once,
-    // instead of 8 dependent LDS round trips per step.  Same operations, in the same order, as band_px above.
+    // instead of dependent LDS round trips per pixel.  The same formula as band_px above; it differs from it by rounding only
+    // (fractions from the grid position, blends in slope form: ~2e-6 of an interval, 1 ulp per blend).
     struct FovQ {
         float4 v00, v10, v01, v11;
         float fY, fE, fR, llb;
