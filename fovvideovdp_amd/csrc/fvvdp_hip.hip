@@ -361,9 +361,13 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int HW = c->W * c->H;
     Timed tm(c, 0, st);
-    const bool ring_ok = (c->P == 4) && (fl <= 32);
+    // register-ring kernels: up to 32 taps for every sample type, up to 64 taps (129-256 fps) for uint8 sources, whose
+    // 1-pixel-per-lane ring needs no alignment (the 64-slot ring is not instantiated for the other types; they take the
+    // generic kernel, which re-reads the window for every output frame)
+    const bool ring64 = (c->P == 4) && fl > 32 && fl <= 64 && dtype == FVVDP_U8 && !getenv("FVVDP_TEMPORAL_SCALAR");
+    const bool ring_ok = ((c->P == 4) && (fl <= 32)) || ring64;
     if (ring_ok) {
-        const int FL = fl <= 8 ? 8 : (fl <= 16 ? 16 : 32);
+        const int FL = fl <= 8 ? 8 : (fl <= 16 ? 16 : (fl <= 32 ? 32 : 64));
         const int max_out = T_MAX_IDX - (FL - 1);
         for (int t0 = 0; t0 < n_out; t0 += max_out) {
             const int nn = (n_out - t0) < max_out ? (n_out - t0) : max_out;
@@ -404,7 +408,7 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
         }
     } else {
         // images, fl > 32 and frame sizes without 4-sample alignment: one thread per pixel and output frame
-        if (h_frame_idx1) return fail(FVVDP_EINVAL, "per-frame source pointers are supported for video with fl <= 32 only");
+        if (h_frame_idx1) return fail(FVVDP_EINVAL, "per-frame source pointers are supported for video with fl <= 32 (uint8: 64) only");
         if (fl - 1 + n_out > c->max_frames + FVVDP_MAX_TAPS) return fail(FVVDP_EINVAL, "too many frames for one call");
         GenericArgs a;
         memset(&a, 0, sizeof(a));

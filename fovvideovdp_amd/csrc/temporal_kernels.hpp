@@ -180,7 +180,7 @@ struct TemporalArgs {
     int fl;                // true filter length (<= FL)
     float* out;            // level 0 of the first output slot: [n_out][HW][4]
     int* oob;
-    float taps[2][32];
+    float taps[2][64];
     int idx[T_MAX_IDX];    // [FL-1+n_out], entries before the true history are padded with a valid frame
     int idx1[T_MAX_IDX];   // the same for stream 1 (reference): equal to idx for one array per stream, different when the
                            // frames of a stream are separate allocations (fvvdp_temporal_channels_frames)
@@ -611,6 +611,9 @@ __device__ __forceinline__ void temporal_vec_cc(const TemporalArgs& a, const flo
 #ifndef K1_WAVES32
 #define K1_WAVES32 3
 #endif
+#ifndef K1_WAVES64
+#define K1_WAVES64 3     // 64-slot ring (uint8 only, 1 pixel per lane): above 128 fps
+#endif
 #ifndef K1_WAVESX8
 #define K1_WAVESX8 3     // uint16 / float sources: wider raw samples in flight, closed-form display model
 #endif
@@ -624,7 +627,7 @@ __device__ __forceinline__ void temporal_vec_cc(const TemporalArgs& a, const flo
 #define K1_WAVESX32 2
 #endif
 constexpr int k1_waves(int FL, int SRC) {
-    return SRC == SRC_U8 ? (FL == 8 ? K1_WAVES8 : (FL == 16 ? K1_WAVES16 : K1_WAVES32))
+    return SRC == SRC_U8 ? (FL == 8 ? K1_WAVES8 : (FL == 16 ? K1_WAVES16 : (FL == 32 ? K1_WAVES32 : K1_WAVES64)))
                          : (FL == 8 ? (SRC == SRC_F32 ? K1_WAVESF8 : K1_WAVESX8) : (FL == 16 ? K1_WAVESX16 : K1_WAVESX32));
 }
 template <int FL, int PX, int SRC, int TD = 1>

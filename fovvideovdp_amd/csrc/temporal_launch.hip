@@ -20,7 +20,7 @@ static constexpr int SRC = DT == FVVDP_U8 ? SRC_U8 : (DT == FVVDP_U16 ? SRC_U16 
 template <int FL>
 static void launch_vec(const TemporalArgs& a, hipStream_t st) {
     constexpr int PX = k1_px(FL, DT);
-    constexpr int TD = FL == 8 ? K1_TD8 : (FL == 16 ? K1_TD16 : K1_TD32);
+    constexpr int TD = FL == 8 ? K1_TD8 : (FL == 16 ? K1_TD16 : (FL == 32 ? K1_TD32 : 1));
     dim3 grid((a.HW + 64 * PX - 1) / (64 * PX)), block(64);
     hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC, TD>), grid, block, 0, st, a);
 }
@@ -45,6 +45,9 @@ static void launch_generic(const GenericArgs& a, hipStream_t st) {
 void K1_NAME(k1_vec)(int FL, const TemporalArgs& a, hipStream_t st) {
     if (FL == 8) launch_vec<8>(a, st);
     else if (FL == 16) launch_vec<16>(a, st);
+#if K1_PART == 0
+    else if (FL == 64) launch_vec<64>(a, st);     // uint8 only (compile time: the loop is unrolled FL times per display model)
+#endif
     else launch_vec<32>(a, st);
 }
 void K1_NAME(k1_ring)(int FL, const TemporalArgs& a, hipStream_t st) {

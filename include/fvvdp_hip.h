@@ -155,8 +155,9 @@ int fvvdp_ctx_set_view_maps(fvvdp_ctx* ctx, int band, const float* d_view_x, con
  *                   k steps in the past.  planes == 2 (still image): fl must be 1 and only h_taps[0] is used.
  *   d_oob_flag      optional int: set to 1 if a float sample was outside [0,1] (the caller re-emits the
  *                   reference's warning "Pixel outside the valid range 0-1")
- * Asynchronous; only fl > 32 or more than 320 window entries (tables too large for the kernel arguments) make the call
- * synchronise the stream for two small uploads.                                                              */
+ * Asynchronous.  Filters of up to 32 taps (uint8 sources: 64 taps, i.e. up to 256 fps) run on the register-ring kernels;
+ * longer ones take a generic kernel that re-reads the window per output frame (an order of magnitude slower) and, like
+ * more than 320 window entries in a still-image context, synchronises the stream for two small table uploads.   */
 int fvvdp_temporal_channels(fvvdp_ctx* ctx, const void* d_test, const void* d_ref, int dtype, int C,
                             size_t chan_stride, size_t frame_stride, const fvvdp_eotf* eotf,
                             const float* h_rgb2y, const int32_t* h_frame_idx, const float* h_taps, int fl,

@@ -354,10 +354,11 @@ def test_foveated_pq_golden(fv):
     assert float(q1) == float(q2)
 
 
-@pytest.mark.parametrize("fps,N", [(120, 34), (144, 40), (25, 9)])
+@pytest.mark.parametrize("fps,N", [(120, 34), (144, 40), (240, 66), (25, 9)])
 def test_other_frame_rates_vs_oracle(fv, fps, N):
     """Filter lengths that take the other kernel instantiations: 120 fps -> 30 taps (FL=32 ring, 2 px per lane),
-    144 fps -> 36 taps (generic kernel, fl > 32), 25 fps -> 7 taps (zero-padded to FL=8)."""
+    144 / 240 fps -> 36 / 60 taps (uint8: 64-slot ring, 1 px per lane; float input: generic kernel, fl > 32),
+    25 fps -> 7 taps (zero-padded to FL=8)."""
     from fovvideovdp_amd.synth import synth_video_pair
     from oracle import fvvdp_oracle as orc
     H, W = 36, 64
@@ -368,6 +369,9 @@ def test_other_frame_rates_vs_oracle(fv, fps, N):
         oq, ostats = orc.Oracle("standard_fhd", temp_padding=pad).predict(test.numpy(), ref.numpy(), frames_per_second=fps)
         assert abs(float(q) - float(oq)) < 1e-4, (fps, pad)
         check_q(stats["Q_per_ch"], ostats["Q_per_ch"], coarse=4e-3, fine=4e-3)   # 36x64 frame: every band is tiny, the noise does not average
+        if fps > 128 and pad == "replicate":          # the same clip as float RGB: more than 32 taps -> generic kernel
+            qf, sf = m.predict(test.float() / 255, ref.float() / 255, frames_per_second=fps)
+            assert abs(float(qf) - float(oq)) < 1e-4, (fps, "float")
 
 
 @pytest.mark.gpu

@@ -122,11 +122,12 @@ def test_yuv_other_frame_rates_and_widths_vs_oracle(H, W, bd, css, fps, N):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("fps,kind", [(30, "u8"), (60, "u8"), (120, "u8"), (60, "u16"), (120, "f32")])
+@pytest.mark.parametrize("fps,kind", [(30, "u8"), (60, "u8"), (120, "u8"), (240, "u8"), (60, "u16"), (120, "f32")])
 def test_full_size_temporal_vector_kernel_equals_scalar_kernel(fps, kind, monkeypatch):
     """BASELINE's 4K frame size at the three ring lengths: the register-ring vector kernel (straight-line loop, 4 or 2
     consecutive pixels per lane, LDS transpose) against the per-pixel ring kernel (kept for misaligned sizes) on the same
-    clip -- a size-independent property, the oracle needs minutes at this size.  Same arithmetic in the same order:
+    clip (240 fps: the 64-slot ring against the generic kernel) -- a size-independent property, the oracle needs minutes at
+    this size.  Same arithmetic in the same order:
     the temporal channels agree to a few ulp (the kernels may contract different multiply-adds), pixel by pixel."""
     import ctypes as C
     import fovvideovdp_amd as fv
