@@ -628,7 +628,7 @@ __device__ __forceinline__ void temporal_vec_cc(const TemporalArgs& a, const flo
 #endif
 constexpr int k1_waves(int FL, int SRC) {
     return SRC == SRC_U8 ? (FL == 8 ? K1_WAVES8 : (FL == 16 ? K1_WAVES16 : (FL == 32 ? K1_WAVES32 : K1_WAVES64)))
-                         : (FL == 8 ? (SRC == SRC_F32 ? K1_WAVESF8 : K1_WAVESX8) : (FL == 16 ? K1_WAVESX16 : K1_WAVESX32));
+                         : FL == 64 ? K1_WAVES64 : (FL == 8 ? (SRC == SRC_F32 ? K1_WAVESF8 : K1_WAVESX8) : (FL == 16 ? K1_WAVESX16 : K1_WAVESX32));
 }
 template <int FL, int PX, int SRC, int TD = 1>
 __global__ __launch_bounds__(64, k1_waves(FL, SRC))
@@ -645,6 +645,9 @@ void temporal_vec_kernel(const TemporalArgs a_byval) {
     // colour-channel count and display model as compile-time constants of the loop body (see temporal_vec_body)
     if constexpr (SRC == SRC_U8) {
         temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LUT>(a, lutw, s_t);
+    } else if constexpr (FL == 64) {
+        // 64-slot ring for float input: luminance frames only (what custom video sources deliver; the host checks)
+        if (a.e.kind == FVVDP_EOTF_NONE && a.C == 1) temporal_vec_body<FL, PX, SRC, TD, 1, FVVDP_EOTF_NONE>(a, lutw, s_t);
     } else {
         switch (a.e.kind) {
             case FVVDP_EOTF_SRGB: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_SRGB>(a, lutw, s_t); break;

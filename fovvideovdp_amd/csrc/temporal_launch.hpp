@@ -32,7 +32,8 @@ static constexpr int k1_px(int FL, int dtype) {
     return FL == 8 ? (dtype == FVVDP_F32 ? K1_PXF8 : K1_PX8) : (FL == 16 ? K1_PX16 : (FL == 32 ? K1_PX32 : 1));
 }
 
-// FL in {8, 16, 32}; dtype FVVDP_U8 / U16 / F32.  FL = 64 (temporal filters of 33-64 taps, i.e. 129-256 fps): uint8 only.
+// FL in {8, 16, 32}; dtype FVVDP_U8 / U16 / F32.  FL = 64 (temporal filters of 33-64 taps, i.e. 129-256 fps): uint8, or float
+// luminance frames (C == 1, FVVDP_EOTF_NONE).
 void k1_launch_vec(int FL, int dtype, const TemporalArgs& a, hipStream_t st);     // aligned sizes (see the call site)
 void k1_launch_ring(int FL, int dtype, const TemporalArgs& a, hipStream_t st);    // any size
 void k1_launch_generic(int planes, int dtype, const GenericArgs& a, hipStream_t st);

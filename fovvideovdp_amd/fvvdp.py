@@ -674,7 +674,7 @@ class _PipelinedSourceFeeder:
     Python code of the source already produces batch b+1 -- and nothing is copied: the temporal kernel reads the
     luminance tensors the source returned where they are (fvvdp_temporal_channels_frames; frames of the temporal window
     that were fetched for an earlier batch are simply kept alive).  Sources whose tensors the kernel cannot address
-    (too far apart in memory, filters longer than 32 taps) go through one stacking copy per stream and batch instead."""
+    (too far apart in memory, filters longer than 64 taps) go through one stacking copy per stream and batch instead."""
 
     preferred_batch = 64       # largest batch when the caller did not choose (see batch_schedule)
 

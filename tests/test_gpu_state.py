@@ -197,11 +197,13 @@ def test_pipelined_source_feeder_fetches_every_frame_once_and_matches_the_array_
     assert abs(float(q2) - float(q0)) < 5e-6
 
 
-def test_user_source_with_a_filter_longer_than_32_taps_and_host_frames(fv):
-    """144 fps -> 36 taps: beyond fvvdp_temporal_channels_frames (the feeder stacks the frames and takes the general
-    entry point); and a source that returns host float64 tensors of another shape (converted on the way in)."""
+@pytest.mark.parametrize("fps", [144, 300])
+def test_user_source_with_a_filter_longer_than_32_taps_and_host_frames(fv, fps):
+    """144 fps -> 36 taps: the 64-slot ring behind fvvdp_temporal_channels_frames; 300 fps -> 75 taps: beyond it (the feeder
+    stacks the frames and takes the general entry point, generic kernel); and a source that returns host float64 tensors
+    of another shape (converted on the way in)."""
     from fovvideovdp_amd.synth import synth_video_pair
-    N, H, W, fps = 40, 36, 64, 144
+    N, H, W = 40, 36, 64
     test, ref = synth_video_pair(N, H, W)
     m = fv.fvvdp(display_name="standard_fhd")
     q0, s0 = m.predict(test, ref, frames_per_second=fps)
