@@ -361,11 +361,11 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int HW = c->W * c->H;
     Timed tm(c, 0, st);
-    // register-ring kernels: up to 32 taps for every sample type, up to 64 taps (129-256 fps) for uint8 sources and for float
-    // luminance frames (custom video sources); the 1-pixel-per-lane ring needs no alignment.  The 64-slot ring is not instantiated
+    // register-ring kernels: up to 32 taps for every sample type, up to 64 taps (129-256 fps) for the cases of k1_ring64_ok()
+    // (uint8; 16-bit / float RGB behind an sRGB or PQ display; float luminance frames); the 1-pixel-per-lane ring needs no alignment.  The 64-slot ring is not instantiated
     // for the other cases; they take the generic kernel, which re-reads the window for every output frame
     const bool ring64 = (c->P == 4) && fl > 32 && fl <= 64 && !getenv("FVVDP_TEMPORAL_SCALAR") &&
-                        (dtype == FVVDP_U8 || (dtype == FVVDP_F32 && C == 1 && eotf->kind == FVVDP_EOTF_NONE));
+                        k1_ring64_ok(dtype, C, eotf->kind);
     const bool ring_ok = ((c->P == 4) && (fl <= 32)) || ring64;
     if (ring_ok) {
         const int FL = fl <= 8 ? 8 : (fl <= 16 ? 16 : (fl <= 32 ? 32 : 64));
@@ -458,8 +458,7 @@ extern "C" int fvvdp_temporal_channels_frames(fvvdp_ctx* c, const void* const* h
     if (!c || !h_test_frames || !h_ref_frames || !h_frame_idx) return fail(FVVDP_EINVAL, "null argument");
     if (n_frames < 1 || n_frames > 65536) return fail(FVVDP_EINVAL, "n_frames out of range");
     if (dtype < FVVDP_U8 || dtype > FVVDP_F32) return fail(FVVDP_EINVAL, "Only uint8, uint16 and float32 is currently supported");
-    const bool lum64 = dtype == FVVDP_F32 && C == 1 && eotf && eotf->kind == FVVDP_EOTF_NONE;
-    if (fl < 1 || fl > ((dtype == FVVDP_U8 || lum64) ? 64 : 32) || c->P != 4)
+    if (fl < 1 || fl > ((eotf && k1_ring64_ok(dtype, C, eotf->kind)) ? 64 : 32) || c->P != 4)
         return fail(FVVDP_EUNSUPPORTED, "per-frame source pointers: video contexts with fl <= 32 (uint8, float luminance: 64) only");
     const size_t es = dtype == FVVDP_U8 ? 1 : (dtype == FVVDP_U16 ? 2 : 4);
     // every frame is addressed as base + index * frame_stride with ONE base per stream: base = lowest frame address,

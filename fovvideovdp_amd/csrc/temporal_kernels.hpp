@@ -646,8 +646,13 @@ void temporal_vec_kernel(const TemporalArgs a_byval) {
     if constexpr (SRC == SRC_U8) {
         temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LUT>(a, lutw, s_t);
     } else if constexpr (FL == 64) {
-        // 64-slot ring for float input: luminance frames only (what custom video sources deliver; the host checks)
-        if (a.e.kind == FVVDP_EOTF_NONE && a.C == 1) temporal_vec_body<FL, PX, SRC, TD, 1, FVVDP_EOTF_NONE>(a, lutw, s_t);
+        // 64-slot ring for 16-bit / float input (k1_ring64_ok() is the host-side list): RGB behind an sRGB or PQ display,
+        // and float luminance frames (what custom video sources deliver).  Everything else above 128 fps: generic kernel.
+        if (a.C == 3 && a.e.kind == FVVDP_EOTF_SRGB) temporal_vec_body<FL, PX, SRC, TD, 3, FVVDP_EOTF_SRGB>(a, lutw, s_t);
+        else if (a.C == 3 && a.e.kind == FVVDP_EOTF_PQ) temporal_vec_body<FL, PX, SRC, TD, 3, FVVDP_EOTF_PQ>(a, lutw, s_t);
+        else if constexpr (SRC == SRC_F32) {
+            if (a.C == 1 && a.e.kind == FVVDP_EOTF_NONE) temporal_vec_body<FL, PX, SRC, TD, 1, FVVDP_EOTF_NONE>(a, lutw, s_t);
+        }
     } else {
         switch (a.e.kind) {
             case FVVDP_EOTF_SRGB: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_SRGB>(a, lutw, s_t); break;

@@ -45,9 +45,7 @@ static void launch_generic(const GenericArgs& a, hipStream_t st) {
 void K1_NAME(k1_vec)(int FL, const TemporalArgs& a, hipStream_t st) {
     if (FL == 8) launch_vec<8>(a, st);
     else if (FL == 16) launch_vec<16>(a, st);
-#if K1_PART == 0 || K1_PART == 2
-    else if (FL == 64) launch_vec<64>(a, st);     // uint8, and float luminance frames (compile time: the loop is unrolled FL times per display model)
-#endif
+    else if (FL == 64) launch_vec<64>(a, st);     // the cases of k1_ring64_ok() only (compile time: the loop is unrolled FL times per case)
     else launch_vec<32>(a, st);
 }
 void K1_NAME(k1_ring)(int FL, const TemporalArgs& a, hipStream_t st) {

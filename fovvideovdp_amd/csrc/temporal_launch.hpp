@@ -28,12 +28,17 @@
 #ifndef K1_TD32
 #define K1_TD32 1
 #endif
+// what the 64-slot ring (temporal filters of 33-64 taps, 129-256 fps) is instantiated for
+static inline bool k1_ring64_ok(int dtype, int C, int eotf_kind) {
+    if (dtype == FVVDP_U8) return true;
+    if (C == 3 && (eotf_kind == FVVDP_EOTF_SRGB || eotf_kind == FVVDP_EOTF_PQ)) return true;      // uint16 (closed form) / float RGB
+    return dtype == FVVDP_F32 && C == 1 && eotf_kind == FVVDP_EOTF_NONE;                          // luminance frames
+}
 static constexpr int k1_px(int FL, int dtype) {
     return FL == 8 ? (dtype == FVVDP_F32 ? K1_PXF8 : K1_PX8) : (FL == 16 ? K1_PX16 : (FL == 32 ? K1_PX32 : 1));
 }
 
-// FL in {8, 16, 32}; dtype FVVDP_U8 / U16 / F32.  FL = 64 (temporal filters of 33-64 taps, i.e. 129-256 fps): uint8, or float
-// luminance frames (C == 1, FVVDP_EOTF_NONE).
+// FL in {8, 16, 32}; dtype FVVDP_U8 / U16 / F32.  FL = 64: see k1_ring64_ok().
 void k1_launch_vec(int FL, int dtype, const TemporalArgs& a, hipStream_t st);     // aligned sizes (see the call site)
 void k1_launch_ring(int FL, int dtype, const TemporalArgs& a, hipStream_t st);    // any size
 void k1_launch_generic(int planes, int dtype, const GenericArgs& a, hipStream_t st);

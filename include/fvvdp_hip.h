@@ -155,7 +155,8 @@ int fvvdp_ctx_set_view_maps(fvvdp_ctx* ctx, int band, const float* d_view_x, con
  *                   k steps in the past.  planes == 2 (still image): fl must be 1 and only h_taps[0] is used.
  *   d_oob_flag      optional int: set to 1 if a float sample was outside [0,1] (the caller re-emits the
  *                   reference's warning "Pixel outside the valid range 0-1")
- * Asynchronous.  Filters of up to 32 taps (uint8 sources: 64 taps, i.e. up to 256 fps) run on the register-ring kernels;
+ * Asynchronous.  Filters of up to 32 taps (64 taps, i.e. up to 256 fps, for uint8 sources, 16-bit / float RGB behind an sRGB or
+ * PQ display model and float luminance) run on the register-ring kernels;
  * longer ones take a generic kernel that re-reads the window per output frame (an order of magnitude slower) and, like
  * more than 320 window entries in a still-image context, synchronises the stream for two small table uploads.   */
 int fvvdp_temporal_channels(fvvdp_ctx* ctx, const void* d_test, const void* d_ref, int dtype, int C,
