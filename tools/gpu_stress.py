@@ -14,7 +14,7 @@ worst_q = (0.0, None)
 fails = 0
 for case in range(n_cases):
     H, W = int(rng.integers(17, 150)), int(rng.integers(17, 260))
-    fps = int(rng.choice([0, 24, 25, 30, 50, 60, 120]))
+    fps = int(rng.choice([0, 24, 25, 30, 50, 60, 120, 144, 240]))
     N = 1 if fps == 0 else int(rng.integers(2, 14))
     pad = str(rng.choice(["replicate", "circular", "pingpong"]))
     dt = str(rng.choice(["u8", "u16", "f32"]))
