@@ -375,6 +375,35 @@ def test_other_frame_rates_vs_oracle(fv, fps, N):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("fps,N", [(120, 34), (144, 40), (240, 64)])
+def test_high_frame_rates_golden(fv, fps, N):
+    """The 32- and 64-slot temporal rings (30 / 36 / 60 taps) for uint8, uint16, float RGB behind a PQ display and float gray
+    input against the reference's own results (golden g9, tools/gen_golden.py)."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    z = load("g9_high_frame_rates")
+    H, W = 72, 128
+    test, ref = synth_video_pair(N, H, W)
+    t1, r1 = synth_video_pair(N, H, W, C=1)
+    cases = {
+        "u8": (test, ref, "standard_fhd"),
+        "u16": (test.numpy().astype(np.uint16) * 257, ref.numpy().astype(np.uint16) * 257, "standard_fhd"),
+        "f32pq": (test.float() / 255, ref.float() / 255, "standard_hdr_pq"),
+        "f32gray": (t1.float() / 255, r1.float() / 255, "standard_4k"),
+    }
+    for tag, (t, r, disp) in cases.items():
+        m = fv.fvvdp(display_name=disp)
+        q, stats = m.predict(t, r, frames_per_second=fps)
+        assert m.filter_len == int(z[f"{tag}_{fps}_taps"])
+        assert abs(float(q) - float(z[f"{tag}_{fps}_jod"])) < 2.5e-5, (fps, tag)         # measured <= 7.6e-6 (PQ), 0 otherwise; north-star bound 1e-3
+        gq = z[f"{tag}_{fps}_Q"].astype(np.float64)
+        qq = stats["Q_per_ch"].astype(np.float64)
+        # 72x128: the coarse bands pool 9x16 pixels; relative to |Q| + 1e-3 max(Q) like the oracle's own check of g9
+        # measured (tools/gpu_g9_report.py): <= 1.3e-4, float RGB behind PQ <= 6.1e-4 (the pow pair at the dark end, see
+        # test_float_sources_all_eotfs_vs_oracle)
+        assert np.max(np.abs(qq - gq) / (np.abs(gq) + 1e-3 * np.max(gq))) < (1.5e-3 if tag == "f32pq" else 4e-4), (fps, tag)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fps,N", [(30, 9), (60, 20), (120, 34), (240, 64)])
 def test_temporal_kernel_instantiations_vs_oracle(fv, fps, N):
     """The register-ring temporal kernel is instantiated per ring length (8/16/32 slots), sample type (uint8 / uint16 /

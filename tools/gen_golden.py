@@ -426,6 +426,34 @@ def g8(pyfvvdp):
     save("g8_pu_psnr", out)
 
 
+def g9(pyfvvdp):
+    """Frame rates beyond the two of g2 (120, 144, 240 fps: 30, 36 and 60 temporal taps) and the sample types next to uint8
+    at those rates (uint16 RGB, float RGB behind a PQ display, float gray): pins the long register rings of the HIP path
+    against the reference itself, not only against the oracle.  Only JOD, Q_per_ch and the filters are kept."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    out_all = {}
+    H, W = 72, 128
+    for fps, N in ((120, 34), (144, 40), (240, 64)):
+        test, ref = synth_video_pair(N, H, W)
+        t1, r1 = synth_video_pair(N, H, W, C=1)
+        cases = {
+            "u8": (test, ref, "standard_fhd"),
+            "u16": (test.numpy().astype(np.uint16) * 257, ref.numpy().astype(np.uint16) * 257, "standard_fhd"),
+            "f32pq": (test.float() / 255, ref.float() / 255, "standard_hdr_pq"),
+            "f32gray": (t1.float() / 255, r1.float() / 255, "standard_4k"),
+        }
+        for tag, (t, r, disp) in cases.items():
+            if isinstance(t, np.ndarray):                     # the reference takes uint16 as numpy (int16-packed on the torch side)
+                o = run_case(pyfvvdp, t, r, "BCFHW", fps, disp, keep_maps=False)
+            else:
+                o = run_case(pyfvvdp, t, r, "BCFHW", fps, disp, keep_maps=False)
+            print("g9", fps, tag, "JOD", o["jod"], "taps", o["filter_len"], flush=True)
+            out_all[f"{tag}_{fps}_jod"] = o["jod"]
+            out_all[f"{tag}_{fps}_Q"] = o["Q_per_ch"]
+            out_all[f"{tag}_{fps}_taps"] = o["filter_len"]
+    save("g9_high_frame_rates", out_all)
+
+
 def main():
     which = sys.argv[1:] or ["g0", "g1", "g2", "g5"]
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
@@ -454,6 +482,8 @@ def main():
             g7(pyfvvdp)
         elif w == "g8":
             g8(pyfvvdp)
+        elif w == "g9":
+            g9(pyfvvdp)
         else:
             raise SystemExit("unknown case " + w)
         print(w, "done in %.1f s" % (time.time() - t0), flush=True)
