@@ -375,6 +375,28 @@ def test_other_frame_rates_vs_oracle(fv, fps, N):
 
 
 @pytest.mark.gpu
+def test_display_models_golden(fv):
+    """Every other display model the reference ships (head-mounted displays with field-of-view geometry, phones, tablets,
+    HDR linear), plain and foveated with a moving gaze, against the reference's own results (golden g10).  Measured on
+    MI355X (tools/gpu_g10_report.py): JOD <= 9.5e-7 plain / 7.6e-6 foveated; Q_per_ch relative to |Q| + 1e-3 max(Q):
+    <= 2.0e-4 plain (6.0e-4 for the linear HDR display: float input), <= 9.3e-4 foveated (the reference's fp32 geometry noise)."""
+    from test_oracle_golden import G10_DISPLAYS, g10_inputs
+    z = load("g10_displays")
+    for disp in G10_DISPLAYS:
+        t, r, gaze = g10_inputs(disp)
+        for fov in (False, True):
+            tag = disp + ("_fov" if fov else "")
+            m = fv.fvvdp(display_name=disp, foveated=fov)
+            q, stats = m.predict(t, r, frames_per_second=30, fixation_point=gaze.numpy() if fov else None)
+            assert np.allclose(stats["rho_band"], z[tag + "_rho"], rtol=1e-6)
+            assert abs(float(q) - float(z[tag + "_jod"])) < (2.5e-5 if fov else 3e-6), tag
+            gq = z[tag + "_Q"].astype(np.float64)
+            qq = stats["Q_per_ch"].astype(np.float64)
+            tol = 2.5e-3 if fov else (1.8e-3 if disp == "standard_hdr_linear" else 6e-4)
+            assert np.max(np.abs(qq - gq) / (np.abs(gq) + 1e-3 * np.max(gq))) < tol, tag
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("fps,N", [(120, 34), (144, 40), (240, 64)])
 def test_high_frame_rates_golden(fv, fps, N):
     """The 32- and 64-slot temporal rings (30 / 36 / 60 taps) for uint8, uint16, float RGB behind a PQ display and float gray

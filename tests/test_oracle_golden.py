@@ -198,6 +198,37 @@ def test_f32_gray_and_u16_inputs_g2():
     assert relerr(stats["Q_per_ch"][:, 0, 0], z["Q_per_ch"][:, 0, 0]) < 2e-4
 
 
+G10_DISPLAYS = ("htc_vive_pro", "ipad_pro_12_9", "iphone_12_pro", "lg_oled_2017_hdr", "lg_oled_2017_sdr", "macbook_pro_16",
+                "sdr_4k_30", "sdr_fhd_24", "standard_hmd", "standard_phone", "standard_hdr_linear")
+
+
+def g10_inputs(disp):
+    from fovvideovdp_amd.synth import synth_gaze
+    N, H, W = 10, 90, 160
+    test, ref = synth_video_pair(N, H, W)
+    if disp == "standard_hdr_linear":
+        return test.float() / 255 * 900.0 + 0.5, ref.float() / 255 * 900.0 + 0.5, synth_gaze(N, H, W)
+    return test, ref, synth_gaze(N, H, W)
+
+
+@pytest.mark.parametrize("disp", G10_DISPLAYS)
+def test_display_models_g10(disp):
+    """Every other display model of the reference (head-mounted with field-of-view geometry, phones, tablets, HDR linear),
+    plain and foveated with a moving gaze: the oracle against the reference's own runs (tools/gen_golden.py g10)."""
+    z = load("g10_displays")
+    t, r, gaze = g10_inputs(disp)
+    assert np.array_equal(gaze.numpy(), z["gaze"])
+    for fov in (False, True):
+        tag = disp + ("_fov" if fov else "")
+        o = orc.Oracle(disp, foveated=fov)
+        jod, stats = o.predict(t.numpy(), r.numpy(), frames_per_second=30, fixation_point=gaze.numpy() if fov else None)
+        assert np.allclose(stats["rho_band"], z[tag + "_rho"], rtol=1e-6)
+        assert abs(float(jod) - float(z[tag + "_jod"])) < 5e-5, tag
+        gq = z[tag + "_Q"]
+        # foveated: the reference's own fp32 noise in the resolution magnification (see test_foveated_pq_g4_small)
+        assert relerr(stats["Q_per_ch"], gq, floor=1e-3 * float(np.max(gq))) < (3e-3 if fov else 6e-4), tag
+
+
 def _g9_inputs(fps, N, tag):
     H, W = 72, 128
     test, ref = synth_video_pair(N, H, W)

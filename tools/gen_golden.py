@@ -454,6 +454,34 @@ def g9(pyfvvdp):
     save("g9_high_frame_rates", out_all)
 
 
+G10_DISPLAYS = ("htc_vive_pro", "ipad_pro_12_9", "iphone_12_pro", "lg_oled_2017_hdr", "lg_oled_2017_sdr", "macbook_pro_16",
+                "sdr_4k_30", "sdr_fhd_24", "standard_hmd", "standard_phone", "standard_hdr_linear")
+
+
+def g10(pyfvvdp):
+    """Every display model the reference ships that the other goldens do not use (head-mounted displays with their
+    field-of-view geometry, phones, tablets, HDR linear), plain and foveated with a moving gaze: 90x160 x10 frames at 30 fps.
+    Only JOD and Q_per_ch are kept."""
+    from fovvideovdp_amd.synth import synth_video_pair, synth_gaze
+    N, H, W = 10, 90, 160
+    test, ref = synth_video_pair(N, H, W)
+    gaze = synth_gaze(N, H, W)
+    out_all = {"gaze": gaze.numpy()}
+    for disp in G10_DISPLAYS:
+        if disp == "standard_hdr_linear":                    # linear display: the frames hold absolute luminance
+            t, r = test.float() / 255 * 900.0 + 0.5, ref.float() / 255 * 900.0 + 0.5
+        else:
+            t, r = test, ref
+        for fov in (False, True):
+            o = run_case(pyfvvdp, t, r, "BCFHW", 30, disp, keep_maps=False, foveated=fov, fixation=gaze if fov else None)
+            tag = disp + ("_fov" if fov else "")
+            print("g10", tag, "JOD", o["jod"], "bands", o["Q_per_ch"].shape[0], flush=True)
+            out_all[tag + "_jod"] = o["jod"]
+            out_all[tag + "_Q"] = o["Q_per_ch"]
+            out_all[tag + "_rho"] = o["rho_band"]
+    save("g10_displays", out_all)
+
+
 def main():
     which = sys.argv[1:] or ["g0", "g1", "g2", "g5"]
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
@@ -484,6 +512,8 @@ def main():
             g8(pyfvvdp)
         elif w == "g9":
             g9(pyfvvdp)
+        elif w == "g10":
+            g10(pyfvvdp)
         else:
             raise SystemExit("unknown case " + w)
         print(w, "done in %.1f s" % (time.time() - t0), flush=True)
