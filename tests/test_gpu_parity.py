@@ -375,6 +375,32 @@ def test_other_frame_rates_vs_oracle(fv, fps, N):
 
 
 @pytest.mark.gpu
+def test_custom_display_objects_golden(fv):
+    """Photometry / geometry objects built by the caller (ambient light, GOG, gamma and PQ curves; size and distance given in
+    every way the geometry constructor accepts; 1.5 to 9 pixels per degree, i.e. two to four bands), plain and foveated,
+    against the reference's own results (golden g11).  Measured on MI355X (tools/gpu_g11_report.py): JOD <= 4.8e-6,
+    Q_per_ch relative to |Q| + 1e-3 max(Q) <= 2.5e-5 plain, <= 3.7e-5 foveated."""
+    from fovvideovdp_amd.synth import synth_video_pair, synth_gaze
+    from test_oracle_golden import G11_CASES
+    z = load("g11_custom_display_objects")
+    N, H, W = 10, 90, 160
+    test, ref = synth_video_pair(N, H, W)
+    gaze = synth_gaze(N, H, W)
+    for tag, pcls, pkw, gkw in G11_CASES:
+        for fov in (False, True):
+            t = tag + ("_fov" if fov else "")
+            geom = fv.fvvdp_display_geometry((W, H), **gkw)
+            assert abs(geom.get_ppd() - float(z[t + "_ppd"])) < 1e-9 * float(z[t + "_ppd"])
+            m = fv.fvvdp(display_name="standard_4k", display_photometry=getattr(fv, pcls)(**pkw), display_geometry=geom, foveated=fov)
+            q, stats = m.predict(test, ref, frames_per_second=30, fixation_point=gaze.numpy() if fov else None)
+            assert np.allclose(stats["rho_band"], z[t + "_rho"], rtol=1e-6)
+            assert abs(float(q) - float(z[t + "_jod"])) < 1.5e-5, t
+            gq = z[t + "_Q"].astype(np.float64)
+            qq = stats["Q_per_ch"].astype(np.float64)
+            assert np.max(np.abs(qq - gq) / (np.abs(gq) + 1e-3 * np.max(gq))) < 1.2e-4, t
+
+
+@pytest.mark.gpu
 def test_display_models_golden(fv):
     """Every other display model the reference ships (head-mounted displays with field-of-view geometry, phones, tablets,
     HDR linear), plain and foveated with a moving gaze, against the reference's own results (golden g10).  Measured on

@@ -229,6 +229,40 @@ def test_display_models_g10(disp):
         assert relerr(stats["Q_per_ch"], gq, floor=1e-3 * float(np.max(gq))) < (3e-3 if fov else 6e-4), tag
 
 
+G11_CASES = (   # (tag, photometry class, photometry kwargs, geometry kwargs) -- the table of tools/gen_golden.py g11
+    ("eotf_srgb_amb", "fvvdp_display_photo_eotf", dict(Y_peak=400, contrast=500, EOTF="sRGB", E_ambient=250), dict(distance_m=0.5, diagonal_size_inches=7)),
+    ("gog_24", "fvvdp_display_photo_gog", dict(Y_peak=300, contrast=2000, gamma=2.4, E_ambient=100), dict(distance_display_heights=2.5, diagonal_size_inches=20)),
+    ("eotf_gamma_fovh", "fvvdp_display_photo_eotf", dict(Y_peak=150, contrast=800, EOTF="gamma", gamma=2.0), dict(fov_horizontal=70)),
+    ("eotf_srgb_fovv", "fvvdp_display_photo_eotf", dict(Y_peak=1000, contrast=100000, EOTF="sRGB"), dict(fov_vertical=35, distance_m=1.0)),
+    ("eotf_pq_fovd", "fvvdp_display_photo_eotf", dict(Y_peak=4000, contrast=1000000, EOTF="PQ"), dict(fov_diagonal=95)),
+)
+
+
+@pytest.mark.parametrize("case", G11_CASES, ids=[c[0] for c in G11_CASES])
+def test_custom_display_objects_g11(case):
+    """Photometry / geometry objects built by the caller -- every way the geometry constructor takes size and distance,
+    ambient light, gain-offset-gamma, gamma and PQ curves; 1.5 to 9 pixels per degree, i.e. one to three bands -- plain and
+    foveated: the oracle against the reference's own runs (tools/gen_golden.py g11)."""
+    from fovvideovdp_amd.synth import synth_gaze
+    tag, pcls, pkw, gkw = case
+    z = load("g11_custom_display_objects")
+    N, H, W = 10, 90, 160
+    test, ref = synth_video_pair(N, H, W)
+    gaze = synth_gaze(N, H, W)
+    for fov in (False, True):
+        t = tag + ("_fov" if fov else "")
+        okw = dict(pkw)
+        if pcls == "fvvdp_display_photo_gog":                   # GOG with gamma != -1 is the gamma EOTF (fvvdp_display_model.py:263-276)
+            okw["EOTF"] = "gamma"
+        o = orc.Oracle("standard_4k", photometry=orc.Photometry(**okw), geometry=orc.Geometry((W, H), **gkw), foveated=fov)
+        assert abs(o.geometry.get_ppd() - float(z[t + "_ppd"])) < 1e-9 * float(z[t + "_ppd"])
+        jod, stats = o.predict(test.numpy(), ref.numpy(), frames_per_second=30, fixation_point=gaze.numpy() if fov else None)
+        assert np.allclose(stats["rho_band"], z[t + "_rho"], rtol=1e-6)
+        assert abs(float(jod) - float(z[t + "_jod"])) < 5e-5, t
+        gq = z[t + "_Q"]
+        assert relerr(stats["Q_per_ch"], gq, floor=1e-3 * float(np.max(gq))) < (3e-3 if fov else 6e-4), t
+
+
 def _g9_inputs(fps, N, tag):
     H, W = 72, 128
     test, ref = synth_video_pair(N, H, W)

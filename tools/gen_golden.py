@@ -482,6 +482,43 @@ def g10(pyfvvdp):
     save("g10_displays", out_all)
 
 
+G11_CASES = (   # (tag, photometry class, photometry kwargs, geometry kwargs)
+    ("eotf_srgb_amb", "fvvdp_display_photo_eotf", dict(Y_peak=400, contrast=500, EOTF="sRGB", E_ambient=250), dict(distance_m=0.5, diagonal_size_inches=7)),
+    ("gog_24", "fvvdp_display_photo_gog", dict(Y_peak=300, contrast=2000, gamma=2.4, E_ambient=100), dict(distance_display_heights=2.5, diagonal_size_inches=20)),
+    ("eotf_gamma_fovh", "fvvdp_display_photo_eotf", dict(Y_peak=150, contrast=800, EOTF="gamma", gamma=2.0), dict(fov_horizontal=70)),
+    ("eotf_srgb_fovv", "fvvdp_display_photo_eotf", dict(Y_peak=1000, contrast=100000, EOTF="sRGB"), dict(fov_vertical=35, distance_m=1.0)),
+    ("eotf_pq_fovd", "fvvdp_display_photo_eotf", dict(Y_peak=4000, contrast=1000000, EOTF="PQ"), dict(fov_diagonal=95)),
+)
+
+
+def g11(pyfvvdp):
+    """Display photometry / geometry OBJECTS built by the caller (every way the geometry constructor accepts its size and
+    distance, ambient light, GOG and gamma / PQ curves), plain and foveated: 90x160 x10 frames at 30 fps, JOD and Q_per_ch."""
+    from fovvideovdp_amd.synth import synth_video_pair, synth_gaze
+    N, H, W = 10, 90, 160
+    test, ref = synth_video_pair(N, H, W)
+    gaze = synth_gaze(N, H, W)
+    out_all = {}
+    dm = sys.modules[pyfvvdp.fvvdp.__module__.rsplit(".", 1)[0] + ".fvvdp_display_model"] if hasattr(pyfvvdp.fvvdp, "__module__") else None
+    import importlib
+    dm = importlib.import_module("pyfvvdp.fvvdp_display_model")
+    for tag, pcls, pkw, gkw in G11_CASES:
+        for fov in (False, True):
+            photo = getattr(dm, pcls)(**pkw)
+            geom = dm.fvvdp_display_geometry((W, H), **gkw)
+            fv = pyfvvdp.fvvdp(display_name="standard_4k", display_photometry=photo, display_geometry=geom, heatmap=None,
+                               device=torch.device("cpu"), foveated=fov, quiet=True)
+            with torch.no_grad():
+                q, stats = fv.predict(test, ref, dim_order="BCFHW", frames_per_second=30, fixation_point=gaze if fov else None)
+            t = tag + ("_fov" if fov else "")
+            print("g11", t, "JOD", q.item(), "ppd", geom.get_ppd(), flush=True)
+            out_all[t + "_jod"] = np.float32(q.item())
+            out_all[t + "_Q"] = stats["Q_per_ch"]
+            out_all[t + "_rho"] = np.asarray(stats["rho_band"])
+            out_all[t + "_ppd"] = np.float64(geom.get_ppd())
+    save("g11_custom_display_objects", out_all)
+
+
 def main():
     which = sys.argv[1:] or ["g0", "g1", "g2", "g5"]
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
@@ -514,6 +551,8 @@ def main():
             g9(pyfvvdp)
         elif w == "g10":
             g10(pyfvvdp)
+        elif w == "g11":
+            g11(pyfvvdp)
         else:
             raise SystemExit("unknown case " + w)
         print(w, "done in %.1f s" % (time.time() - t0), flush=True)
