@@ -545,6 +545,30 @@ def test_heatmaps_golden(fv):
     assert torch.equal(st1["heatmap"], st2["heatmap"])
 
 
+def test_heatmaps_foveated_golden(fv):
+    """Difference maps in foveated mode (moving gaze on a tiny odd-size video, fixed gaze on an image behind a PQ display)
+    against the reference's maps (golden g12).  fp16 storage: 1 ulp is 1e-3 relative.  Measured (tools/gpu_g12_report.py):
+    max relative (floor 2e-3) 9.7e-4, mean absolute 2.2e-6 on a mean map value of 4.5e-2, JOD 5.7e-6."""
+    from fovvideovdp_amd.synth import synth_video_pair, synth_gaze
+    z = load("g12_heatmaps_foveated")
+    N, H, W = 6, 68, 121
+    test, ref = synth_video_pair(N, H, W)
+    gaze = synth_gaze(N, H, W)
+    assert np.array_equal(gaze.numpy(), z["gaze"])
+    m = fv.fvvdp(display_name="standard_fhd", heatmap="raw", foveated=True)
+    q, st = m.predict(test, ref, frames_per_second=30, fixation_point=gaze.numpy())
+    t2, r2 = synth_video_pair(1, 135, 240)
+    m2 = fv.fvvdp(display_name="standard_hdr_pq", heatmap="raw", foveated=True)
+    q2, st2 = m2.predict(t2[0, :, 0], r2[0, :, 0], dim_order="CHW", fixation_point=np.array([60, 40]))
+    for tag, qq, stt in (("video", q, st), ("image", q2, st2)):
+        hm, g = stt["heatmap"], z[tag + "_raw"]
+        assert hm.dtype == torch.float16 and tuple(hm.shape) == g.shape
+        assert abs(float(qq) - float(z[tag + "_raw_jod"])) < 2e-5, tag
+        d = np.abs(hm.float().numpy() - g.astype(np.float32))
+        assert np.max(d / (np.abs(g.astype(np.float32)) + 2e-3)) < 3e-3, tag
+        assert np.mean(d) < 7e-6, tag
+
+
 @pytest.mark.parametrize("tag,H,W,disp", [("fhd", 1080, 1920, "standard_fhd"), ("uhd", 2160, 3840, "standard_4k")])
 def test_full_size_synthetic_video_golden(fv, tag, H, W, disp):
     """BASELINE configs[1] and [2] at full size: 60-frame synthetic uint8 RGB pair against the reference's JOD and

@@ -519,6 +519,29 @@ def g11(pyfvvdp):
     save("g11_custom_display_objects", out_all)
 
 
+def g12(pyfvvdp):
+    """Heat maps in foveated mode (moving gaze): raw on a tiny odd-size video, raw on an image with a fixed gaze."""
+    from fovvideovdp_amd.synth import synth_video_pair, synth_gaze
+    out = {}
+    N, H, W = 6, 68, 121
+    test, ref = synth_video_pair(N, H, W)
+    gaze = synth_gaze(N, H, W)
+    fv = pyfvvdp.fvvdp(display_name="standard_fhd", heatmap="raw", device=torch.device("cpu"), foveated=True, quiet=True)
+    with torch.no_grad():
+        q, st = fv.predict(test, ref, dim_order="BCFHW", frames_per_second=30, fixation_point=gaze)
+    out["video_raw"] = st["heatmap"].numpy()
+    out["video_raw_jod"] = np.float32(q.item())
+    out["gaze"] = gaze.numpy()
+    t2, r2 = synth_video_pair(1, 135, 240)
+    fv = pyfvvdp.fvvdp(display_name="standard_hdr_pq", heatmap="raw", device=torch.device("cpu"), foveated=True, quiet=True)
+    with torch.no_grad():
+        q, st = fv.predict(t2[0, :, 0], r2[0, :, 0], dim_order="CHW", fixation_point=torch.tensor([60, 40]))
+    out["image_raw"] = st["heatmap"].numpy()
+    out["image_raw_jod"] = np.float32(q.item())
+    print("g12 JOD", out["video_raw_jod"], out["image_raw_jod"], out["video_raw"].shape, out["image_raw"].shape)
+    save("g12_heatmaps_foveated", out)
+
+
 def main():
     which = sys.argv[1:] or ["g0", "g1", "g2", "g5"]
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
@@ -553,6 +576,8 @@ def main():
             g10(pyfvvdp)
         elif w == "g11":
             g11(pyfvvdp)
+        elif w == "g12":
+            g12(pyfvvdp)
         else:
             raise SystemExit("unknown case " + w)
         print(w, "done in %.1f s" % (time.time() - t0), flush=True)
