@@ -24,7 +24,7 @@ python $R/tools/gpu_bandonly_speed.py 12 > $OUT/bandonly_fused.txt 2>/dev/null
 FVVDP_BAND_FUSE=0 python $R/tools/gpu_bandonly_speed.py 12 > $OUT/bandonly_onelevel.txt 2>/dev/null
 $R/build_variants/mix > $OUT/mix.txt 2>&1
 python $R/tools/gpu_parity_report.py > $OUT/parity.md 2>/dev/null
-( python $R/tools/gpu_g9_report.py; python $R/tools/gpu_g10_report.py; python $R/tools/gpu_g11_report.py ) 2>/dev/null | grep -v Warn > $OUT/parity_goldens.txt
+( python $R/tools/gpu_g9_report.py; python $R/tools/gpu_g10_report.py; python $R/tools/gpu_g11_report.py; python $R/tools/gpu_g12_report.py ) 2>/dev/null | grep -v Warn > $OUT/parity_goldens.txt
 python $R/tools/gpu_fps.py 30:60:u8 60:120:u8 120:120:u8 144:120:u8 240:120:u8 30:60:u16 60:60:u16 144:60:u16 30:60:f32rgb 30:60:f32gray 2>/dev/null | grep -v Warn > $OUT/fps_probe.txt
 python $R/tools/gpu_k1_ab.py 30:60:u8:5 60:60:u8:5 120:60:u8:5 2>/dev/null | grep -v Warn >> $OUT/fps_probe.txt
 BATCHES=None,60 python $R/tools/gpu_feeder.py 2>/dev/null | cut -c1-110 > $OUT/feeder_probe.txt

@@ -197,7 +197,7 @@ numbers below (each bound quotes its measured value).  JOD: north-star bound 1e-
 {rd('parity.md')}
 
 End to end against the goldens g9 (120 / 144 / 240 fps; uint8, uint16, float RGB behind PQ, float gray) g10 (the other
-eleven display models, plain and foveated) and g11 (caller-built photometry / geometry objects), `tools/gpu_g9_report.py` /
+eleven display models, plain and foveated) g11 (caller-built photometry / geometry objects) and g12 (foveated heat maps), `tools/gpu_g9_report.py` /
 `gpu_g10_report.py` / `gpu_g11_report.py`; dQ = max |Q - Q_ref| / (|Q_ref| + 1e-3 max Q_ref):
 
 ```
