@@ -392,6 +392,9 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
     const float lg_bm = __log2f(a.band_mul);
     const float lg_base = a.lg_gain;              // log2(S) = interp + log2(gain)      (fvvdp.py:447)
     const float lg_mask = a.lg_gain + a.lg_k;      // log2(k*S)
+    // constant factors of the log-domain tail, folded into fused multiply-adds (see band2_kernel.hpp)
+    const float pb = a.p * a.beta, pb_base = lg_base * pb, b_dmax = a.beta * a.lg_dmax, inv_beta = 1.0f / a.beta;
+    const float y_off = -a.y_first * a.y_inv_step;
 
     // per-pixel tail: contrast, CSF, masking, pooling  (fvvdp_lpyr_dec.py:259-269, fvvdp.py:395-467)
     auto band_px = [&](const Px<P>& g, const Px<P>& e, bool valid, int y, int x, float vx, float vy, float res_mag,
@@ -412,8 +415,8 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
         float slog[2] = {0.0f, 0.0f};
         if constexpr (!FOV) {
             // 1-D table over log2(L_bkg) (uniform knots): interval from the grid, value = v[i] + f*(v[i+1]-v[i])
-            const float t = (yq - a.y_first) * a.y_inv_step;
-            const float fi = fminf(fmaxf(floorf(t), 0.0f), (float)(FVVDP_LUT_N - 2));
+            const float t = fmaf(yq, a.y_inv_step, y_off);               // (yq - y_first) * y_inv_step
+            const float fi = __builtin_amdgcn_fmed3f(floorf(t), 0.0f, (float)(FVVDP_LUT_N - 2));
             const float4 r = s_csf[(int)fi];                           // {v0[i], v1[i], v0[i+1]-v0[i], v1[i+1]-v1[i]}
             const float f = t - fi;
             slog[0] = fmaf(f, r.z, r.x);
@@ -472,22 +475,21 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
         float ldd_dbg[2] = {0.0f, 0.0f};
         if constexpr (HP == 2) {
             const v2f sl = v2f{slog[0], slog[1]};
-            const v2f lsb = sl + splat(lcn + lg_base);                   // log2(S * m / lb)
+            const v2f A = pfma(sl, pb, splat(fmaf(lcn, pb, pb_base)));   // beta * p * log2(S * m / lb)
             const v2f lsm = sl + splat(lcn + lg_mask);                   // log2(k * S * m / lb)
             const v2f ldiff = v2f{fast_log2(fabsf(d[0].x - d[0].y)), fast_log2(fabsf(d[1].x - d[1].y))};
             const v2f lmin = v2f{fast_log2(fminf(fabsf(d[0].x), fabsf(d[0].y))), fast_log2(fminf(fabsf(d[1].x), fabsf(d[1].y)))};
-            const v2f ld = (ldiff + lsb) * splat(a.p);
+            const v2f ldb = pfma(ldiff, pb, A);                           // beta * p * (log2|T'-R'|)
             const v2f lm = (lmin + lsm) * v2f{a.q0, a.q1};
             const v2f one_mq = v2f{fast_exp2(lm.x), fast_exp2(lm.y)} + splat(1.0f);
-            const v2f t = ld - v2f{fast_log2(one_mq.x), fast_log2(one_mq.y)};
-            const v2f ldd = v2f{fminf(t.x, a.lg_dmax), fminf(t.y, a.lg_dmax)};
-            const v2f bl = ldd * splat(a.beta);
+            const v2f tb = pfma(v2f{fast_log2(one_mq.x), fast_log2(one_mq.y)}, -a.beta, ldb);   // beta * log2 D
+            const v2f bl = v2f{fminf(tb.x, b_dmax), fminf(tb.y, b_dmax)};                      // D <= d_max
             const v2f term = v2f{fast_exp2(bl.x), fast_exp2(bl.y)};      // D^beta for the spatial pooling (fvvdp.py:467,607)
             const v2f av = __builtin_elementwise_fma(term, splat(vm), v2f{acc[0], acc[1]});
             acc[0] = av.x;
             acc[1] = av.y;
-            ldd_dbg[0] = ldd.x;
-            ldd_dbg[1] = ldd.y;
+            ldd_dbg[0] = bl.x * inv_beta;
+            ldd_dbg[1] = bl.y * inv_beta;
         } else {
             const float dT = d[0].x, dR = d[0].y;
             const float ls = slog[0] + lcn;
@@ -579,16 +581,15 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
         const float lcn = lg_bm - q.llb;
         if constexpr (HP == 2) {
             const v2f sl = v2f{s0, s1};
-            const v2f lsb = sl + splat(lcn + lg_base);
+            const v2f A = pfma(sl, pb, splat(fmaf(lcn, pb, pb_base)));
             const v2f lsm = sl + splat(lcn + lg_mask);
             const v2f ldiff = v2f{fast_log2(fabsf(q.d[0].x - q.d[0].y)), fast_log2(fabsf(q.d[1].x - q.d[1].y))};
             const v2f lmin = v2f{fast_log2(fminf(fabsf(q.d[0].x), fabsf(q.d[0].y))), fast_log2(fminf(fabsf(q.d[1].x), fabsf(q.d[1].y)))};
-            const v2f ld = (ldiff + lsb) * splat(a.p);
+            const v2f ldb = pfma(ldiff, pb, A);
             const v2f lm = (lmin + lsm) * v2f{a.q0, a.q1};
             const v2f one_mq = v2f{fast_exp2(lm.x), fast_exp2(lm.y)} + splat(1.0f);
-            const v2f t = ld - v2f{fast_log2(one_mq.x), fast_log2(one_mq.y)};
-            const v2f ldd = v2f{fminf(t.x, a.lg_dmax), fminf(t.y, a.lg_dmax)};
-            const v2f bl = ldd * splat(a.beta);
+            const v2f tb = pfma(v2f{fast_log2(one_mq.x), fast_log2(one_mq.y)}, -a.beta, ldb);
+            const v2f bl = v2f{fminf(tb.x, b_dmax), fminf(tb.y, b_dmax)};
             const v2f term = v2f{fast_exp2(bl.x), fast_exp2(bl.y)};
             const v2f av = __builtin_elementwise_fma(term, splat(vm), v2f{acc[0], acc[1]});
             acc[0] = av.x;
