@@ -853,6 +853,14 @@ __device__ __forceinline__ YuvRaw<T, C420> yuv_fetch(const T* __restrict__ f, co
 // RGB (clipped to [0,1]) of the lane's 4 pixels for both streams at once: rgb[3*i+c] = (test, reference).
 // 4:2:0 chroma: the four source columns are blended vertically first, then horizontally (2 x fewer products than the
 // per-pixel form; the result differs from it by rounding order only).
+// a * s + c clipped to [0, 1], both components: v_pk_fma_f32 with the clamp modifier
+__device__ __forceinline__ v2f pfma_clamp01(v2f a, float s, v2f c) {
+    v2f r;
+    const v2f sv = splat(s);
+    asm("v_pk_fma_f32 %0, %1, %2, %3 clamp" : "=v"(r) : "v"(a), "s"(sv), "v"(c));      // the factor is wave-uniform: scalar register pair
+    return r;
+}
+
 template <typename T, bool C420>
 __device__ __forceinline__ void yuv_pair_rgb(const YuvRaw<T, C420>& r0, const YuvRaw<T, C420>& r1, const YuvArgs& a,
                                              const YuvGeom& g, float fy, float gy, float fx0, float gx0, v2f (&rgb)[12]) {
@@ -892,13 +900,13 @@ __device__ __forceinline__ void yuv_pair_rgb(const YuvRaw<T, C420>& r0, const Yu
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const v2f Yf = clamp2(pfma(v2f{r0.ysample(i), r1.ysample(i)}, a.wy, splat(-(16.0f / 219.0f))), 0.0f, 1.0f);
+        // the [0,1] clips ride on the multiply-add that produces the value (VOP3P clamp bit): one instruction instead of three
+        const v2f Yf = pfma_clamp01(v2f{r0.ysample(i), r1.ysample(i)}, a.wy, splat(-(16.0f / 219.0f)));
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
             v2f v = Yf * a.m[3 * c];
             v = pfma(uv[0][i], a.m[3 * c + 1], v);
-            v = pfma(uv[1][i], a.m[3 * c + 2], v);
-            rgb[3 * i + c] = clamp2(v, 0.0f, 1.0f);
+            rgb[3 * i + c] = pfma_clamp01(uv[1][i], a.m[3 * c + 2], v);
         }
     }
 }
@@ -1081,7 +1089,8 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
 #define YUV_WAVES16 2
 #endif
 template <int FL, typename T, bool C420>
-__global__ __launch_bounds__(64, (FL == 8 ? YUV_WAVES8 : YUV_WAVES16)) void temporal_yuv_vec_kernel(const YuvArgs a_byval) {
+__global__ __launch_bounds__(64, (FL == 8 ? ((sizeof(T) == 2 && !C420) ? 2 : YUV_WAVES8) : YUV_WAVES16))     // 16-bit 4:4:4: 8 raw dwords per frame pair more
+void temporal_yuv_vec_kernel(const YuvArgs a_byval) {
     const YuvArgs& a = *(const YuvArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // see temporal_vec_kernel
     (void)a_byval;
     __shared__ float4 s_t[64 * (4 + 1)];
