@@ -386,7 +386,7 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
             a.fl = fl;
             a.out = c->level[0] + (size_t)(slot0 + t0) * HW * 4;
             a.oob = d_oob_flag;
-            for (int k = 0; k < fl; ++k) { a.taps[0][k] = h_taps[k]; a.taps[1][k] = h_taps[fl + k]; }
+            for (int k = 0; k < fl; ++k) { a.taps2[k][0] = h_taps[k]; a.taps2[k][1] = h_taps[fl + k]; }
             // virtual time of h_frame_idx: entry (fl-1+t) is the newest frame of output t; pad older history
             const int pad = FL - fl;
             for (int u = 0; u < FL - 1 + nn; ++u) {
@@ -403,6 +403,9 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
                                 (reinterpret_cast<uintptr_t>(d_ref) % (size_t)(es * PXv) == 0);
             if (vec_ok) {
                 k1_launch_vec(FL, dtype, a, st);
+            } else if (FL == 64) {
+                // the 64-slot ring exists as the 1-pixel-per-lane vector kernel only; it needs nothing but element alignment
+                return fail(FVVDP_EINVAL, "source pointers must be aligned to their element size");
             } else {
                 k1_launch_ring(FL, dtype, a, st);
             }
@@ -536,7 +539,7 @@ extern "C" int fvvdp_temporal_channels_yuv(fvvdp_ctx* c, const void* d_test, con
         a.fl = fl;
         a.out = c->level[0] + (size_t)(slot0 + t0) * c->W * c->H * 4;
         a.oob = d_oob_flag;
-        for (int k = 0; k < fl; ++k) { a.taps[0][k] = h_taps[k]; a.taps[1][k] = h_taps[fl + k]; }
+        for (int k = 0; k < fl; ++k) { a.taps2[k][0] = h_taps[k]; a.taps2[k][1] = h_taps[fl + k]; }
         const int pad = FL - fl;
         for (int u = 0; u < FL - 1 + nn; ++u) {
             const int src = t0 + u - pad;

@@ -16,24 +16,38 @@ struct EotfDev {
     const float* lut;
 };
 
+// "Some sample was outside [0, 1]" (the reference's warning, video_source.py:200), two ways to carry it: a bool -- two
+// compares into scalar mask pairs and two scalar ORs per sample -- or, in the register-ring kernels, a running maximum of
+// max(V - 1, -V) in ONE vector register (v_add + v_max3 per sample, no scalar registers: those kernels have none to spare).
+struct OobMax {
+    float m = 0.0f;
+};
+__device__ __forceinline__ void note_oob(bool& b, float V) { b = b || (V > 1.0f) || (V < 0.0f); }
+__device__ __forceinline__ void note_oob(OobMax& b, float V) {
+    const float over = V - 1.0f;
+    asm("v_max3_f32 %0, %0, %1, -%2" : "+v"(b.m) : "v"(over), "v"(V));
+}
+__device__ __forceinline__ bool is_oob(bool b) { return b; }
+__device__ __forceinline__ bool is_oob(const OobMax& b) { return b.m > 0.0f; }
+
 // Per-channel display model on a float sample V (fvvdp_display_model.py:147-165).  `bad` is set when V was
 // outside [0,1] for an EOTF that clamps.
-template <int KIND>
-__device__ __forceinline__ float eotf_one(float V, const EotfDev& e, bool& bad) {
+template <int KIND, typename B>
+__device__ __forceinline__ float eotf_one(float V, const EotfDev& e, B& bad) {
     if constexpr (KIND == FVVDP_EOTF_SRGB) {
-        bad = bad || (V > 1.0f) || (V < 0.0f);
+        note_oob(bad, V);
         V = fminf(fmaxf(V, 0.0f), 1.0f);
         // constant divisions as reciprocal multiplies (<= 1 ulp, below the error of the fast log2/exp2 pair)
         const float hi = fast_exp2(2.4f * fast_log2((V + 0.055f) * (1.0f / 1.055f)));
         const float lin = V > 0.04045f ? hi : V * (1.0f / 12.92f);
         return __fadd_rn(__fmul_rn(e.scale, lin), e.y_black);
     } else if constexpr (KIND == FVVDP_EOTF_GAMMA) {
-        bad = bad || (V > 1.0f) || (V < 0.0f);
+        note_oob(bad, V);
         V = fminf(fmaxf(V, 0.0f), 1.0f);
         const float lin = V > 0.0f ? fast_exp2(e.gamma * fast_log2(V)) : 0.0f;
         return __fadd_rn(__fmul_rn(e.scale, lin), e.y_black);
     } else if constexpr (KIND == FVVDP_EOTF_PQ) {
-        bad = bad || (V > 1.0f) || (V < 0.0f);
+        note_oob(bad, V);
         V = fminf(fmaxf(V, 0.0f), 1.0f);
         const float m = 78.843750000000000f, n = 0.15930175781250000f;
         const float c1 = 0.83593750000000000f, c2 = 18.851562500000000f, c3 = 18.687500000000000f;
@@ -50,7 +64,8 @@ __device__ __forceinline__ float eotf_one(float V, const EotfDev& e, bool& bad) 
     }
 }
 
-__device__ __forceinline__ float eotf_f32(float V, const EotfDev& e, bool& bad) {
+template <typename B>
+__device__ __forceinline__ float eotf_f32(float V, const EotfDev& e, B& bad) {
     switch (e.kind) {
         case FVVDP_EOTF_SRGB: return eotf_one<FVVDP_EOTF_SRGB>(V, e, bad);
         case FVVDP_EOTF_GAMMA: return eotf_one<FVVDP_EOTF_GAMMA>(V, e, bad);
@@ -65,8 +80,8 @@ __device__ __forceinline__ float eotf_f32(float V, const EotfDev& e, bool& bad) 
 // switch of eotf_f32 is replicated FL x PX x 3 x 2 times, which made their code several times larger than the
 // instruction cache although only one case ever runs.
 // KIND >= 0: the display model is known at compile time (straight-line code, no branch at all).
-template <int N, int KIND = -1>
-__device__ __forceinline__ void eotf_apply(float (&V)[N], const EotfDev& e, bool& bad) {
+template <int N, int KIND = -1, typename B = bool>
+__device__ __forceinline__ void eotf_apply(float (&V)[N], const EotfDev& e, B& bad) {
     if constexpr (KIND >= 0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) V[i] = eotf_one<KIND>(V[i], e, bad);
@@ -180,7 +195,7 @@ struct TemporalArgs {
     int fl;                // true filter length (<= FL)
     float* out;            // level 0 of the first output slot: [n_out][HW][4]
     int* oob;
-    float taps[2][64];
+    float taps2[64][2];    // {sustained, transient} tap k (k frames in the past), zero beyond fl: one scalar register pair per tap
     int idx[T_MAX_IDX];    // [FL-1+n_out], entries before the true history are padded with a valid frame
     int idx1[T_MAX_IDX];   // the same for stream 1 (reference): equal to idx for one array per stream, different when the
                            // frames of a stream are separate allocations (fvvdp_temporal_channels_frames)
@@ -246,9 +261,9 @@ __device__ __forceinline__ RawFrame<SRC, PX> fetch_frame(const void* base, size_
     return f;
 }
 
-template <int SRC, int PX, typename FRAME, int KIND = -1>
+template <int SRC, int PX, typename FRAME, int KIND = -1, typename B = bool>
 __device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lutw, const float* lut16,
-                                          const float (&w)[3], const EotfDev& e, float (&L)[PX], bool& bad) {
+                                          const float (&w)[3], const EotfDev& e, float (&L)[PX], B& bad) {
     float v[3][PX];
     if constexpr (SRC == SRC_F32) {
         if (C == 3) {
@@ -375,7 +390,7 @@ __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a
 #pragma unroll
                     for (int k = FL - 1; k >= 0; --k) {
                         const int sl = (u - k + 2 * FL) % FL;
-                        const float f0 = a.taps[0][k], f1 = a.taps[1][k];
+                        const float f0 = a.taps2[k][0], f1 = a.taps2[k][1];
 #pragma unroll
                         for (int i = 0; i < PX; ++i) {
                             acc[0][i] = fmaf(ring[0][sl][i], f0, acc[0][i]);
@@ -475,6 +490,25 @@ __device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// One filter tap on one pixel: accS += x * f.x, accT += x * f.y for the (test, reference) pair x.  The tap pair f = {sustained,
+// transient} sits in ONE scalar register pair and is broadcast by the operand selects of the packed instruction.  Written out
+// because the compiler materialises a splat {f, f} pair per tap and channel instead: 4 scalar registers per tap, 256 for a
+// 64-tap filter -- they spilled into vector-register lanes and every multiply-add came with ~1.4 v_readlane (r2: 777-4619
+// spilled SGPRs in the 32- and 64-slot rings).
+__device__ __forceinline__ void fir_tap(v2f& accS, v2f& accT, v2f x, v2f f) {
+    asm("v_pk_fma_f32 %0, %2, %3, %0 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "+v"(accS), "+v"(accT) : "v"(x), "s"(f));
+}
+// TAPC taps = 2*TAPC floats of TemporalArgs::taps2 / YuvArgs::taps2, read from the kernel-argument segment with one scalar load
+#ifndef K1_TAPC
+#define K1_TAPC 4
+#endif
+constexpr int TAPC = K1_TAPC;
+typedef float vtapf __attribute__((ext_vector_type(2 * K1_TAPC)));
+typedef vtapf vtapf_a4 __attribute__((aligned(4)));
+typedef const vtapf_a4 __attribute__((address_space(4)))* karg_taps_p;
+
 // CC = number of colour channels as a compile-time constant (3 or 1): with a run-time `C == 3` around the loads and the
 // table look-ups, every step has control-flow joins and the compiler falls back to s_waitcnt vmcnt(0).
 template <int FL, int PX, int SRC, int TD, int CC, int KIND>
@@ -490,7 +524,7 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
     const int p0 = blockIdx.x * (64 * PX);          // first pixel of this wave
     const int pl = min(p0 + lane * PX, a.HW - PX);  // this lane's PX consecutive pixels (clamped: loads stay in range)
     const float w[3] = {CC == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};
-    bool bad = false;
+    OobMax bad;
     // .x = test, .y = reference: one register pair, one v_pk_fma per tap.  Not initialised: every slot is written before
     // its first read (history: slots 0..FL-2, first output step: slot FL-1), so a slot costs registers only once filled.
     v2f ring[FL][PX];
@@ -519,7 +553,8 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
     };
     // History (no output yet, almost no arithmetic): HB frames are requested at once, otherwise this phase is one memory
     // latency per frame -- a third of all frames at 120 fps.  The first output frames are requested with the last batch.
-    constexpr int HB_REGS = (FL == 32 && RawVec<SRC, PX>::WORDS > 1) ? 24 : 48;   // registers of raw samples per batch
+    // registers of raw samples per batch: what the ring leaves free when it is nearly full (the last batches)
+    constexpr int HB_REGS = FL == 64 ? 16 : ((FL == 32 && RawVec<SRC, PX>::WORDS > 1) ? 24 : 48);
     constexpr int HB = (HB_REGS / (6 * RawVec<SRC, PX>::WORDS)) > 0 ? (HB_REGS / (6 * RawVec<SRC, PX>::WORDS)) : 1;
 #pragma unroll
     for (int u0 = 0; u0 < FL - 1; u0 += HB) {
@@ -561,19 +596,26 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
             v2f accS[PX], accT[PX];                  // (test, reference) of the sustained / the transient channel
 #pragma unroll
             for (int i = 0; i < PX; ++i) accS[i] = accT[i] = v2f{0.0f, 0.0f};
+            // Taps: TAPC at a time from the kernel-argument segment (scalar cache), oldest first like the reference's sum over the
+            // window.  Long filters reload them in every step -- the pointer is laundered so that the loads cannot be hoisted out
+            // of the frame loop, where 2*FL scalar values would have to stay alive next to everything else (spills).
+            karg_p tp = ka + offsetof(TemporalArgs, taps2);
+            if constexpr (FL > 16) asm volatile("" : "+s"(tp));
 #ifdef K1_ABLATE_FIR
 #pragma unroll
-            for (int k = 1; k >= 0; --k) {
+            for (int c = 0; c >= 0; --c) {
 #else
 #pragma unroll
-            for (int k = FL - 1; k >= 0; --k) {      // oldest tap first, like the reference's sum over the window
+            for (int c = FL / TAPC - 1; c >= 0; --c) {
 #endif
-                const int sl = (u - k + 2 * FL) % FL;
-                const float f0 = a.taps[0][k], f1 = a.taps[1][k];
+                const vtapf tc = *(karg_taps_p)(tp + c * (8 * TAPC));
 #pragma unroll
-                for (int i = 0; i < PX; ++i) {
-                    accS[i] = pfma(ring[sl][i], f0, accS[i]);
-                    accT[i] = pfma(ring[sl][i], f1, accT[i]);
+                for (int kk = TAPC - 1; kk >= 0; --kk) {
+                    const int k = c * TAPC + kk;
+                    const int sl = (u - k + 2 * FL) % FL;
+                    const v2f f = v2f{tc[2 * kk], tc[2 * kk + 1]};
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) fir_tap(accS[i], accT[i], ring[sl][i], f);
                 }
             }
             // transpose through LDS: lane l holds pixels l*PX..l*PX+PX-1, store i writes pixels i*64+l
@@ -582,7 +624,11 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
             for (int i = 0; i < PX; ++i)
                 s_t[lane * (PX + 1) + i] = make_float4(accS[i].x, accS[i].y, accT[i].x, accT[i].y);
             wave_lds_order();
-            const __amdgpu_buffer_rsrc_t o = level_rsrc(a.out + (size_t)t * a.HW * 4, frame_bytes);
+            // the frame number is laundered: otherwise the FL per-step offsets j * HW * 16 (64 bit each) are pre-computed outside
+            // the loop and, in the long rings, spilled
+            int t_opaque = t;
+            asm volatile("" : "+s"(t_opaque));
+            const __amdgpu_buffer_rsrc_t o = level_rsrc(a.out + (size_t)t_opaque * a.HW * 4, frame_bytes);
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
                 const int q = i * 64 + lane;
@@ -592,7 +638,7 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
             __builtin_amdgcn_sched_barrier(0);
         }
     }
-    if (bad && a.oob) atomicOr(a.oob, 1);
+    if (is_oob(bad) && a.oob) atomicOr(a.oob, 1);
 }
 
 template <int FL, int PX, int SRC, int TD, int KIND>
@@ -686,7 +732,7 @@ struct YuvArgs {
     int n_out, fl;
     float* out;
     int* oob;
-    float taps[2][32];
+    float taps2[32][2];     // {sustained, transient} tap k, see TemporalArgs
     int idx[T_MAX_IDX];
 };
 
@@ -762,7 +808,7 @@ __global__ __launch_bounds__(256) void temporal_yuv_kernel(const YuvArgs a) {
 #pragma unroll
                     for (int k = FL - 1; k >= 0; --k) {
                         const int sl = (u - k + 2 * FL) % FL;
-                        const float t0 = a.taps[0][k], t1 = a.taps[1][k];
+                        const float t0 = a.taps2[k][0], t1 = a.taps2[k][1];
 #pragma unroll
                         for (int i = 0; i < PX; ++i) {
                             acc[0][i] = fmaf(ring[0][sl][i], t0, acc[0][i]);
@@ -964,8 +1010,11 @@ __device__ __forceinline__ v2f lum_pair(v2f r, v2f g, v2f b, float w0, float w1,
 }
 
 #define YUV_QUADS 62     // pixel quads (4 consecutive pixels) written per wave
-#ifndef YUV_TD
-#define YUV_TD 2         // frames of raw samples in flight per lane
+#ifndef YUV_TD8
+#define YUV_TD8 2        // frames of raw samples in flight per lane, 8-slot window
+#endif
+#ifndef YUV_TD16
+#define YUV_TD16 1       // 16-slot window: 128 registers of window leave room for one frame of raw samples (2 -> 2-11 spilled dwords)
 #endif
 // One rolled loop over the frames, straight-line inside (see temporal_vec_kernel for why: counted waits instead of
 // drains).  The last FL luminance pairs of the lane's 4 pixels sit in a register window that is SHIFTED by one slot per
@@ -975,7 +1024,7 @@ __device__ __forceinline__ v2f lum_pair(v2f r, v2f g, v2f b, float w0, float w1,
 template <int FL, typename T, bool C420, int KIND>
 __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* s_t) {
     constexpr int PX = 4;
-    constexpr int TD = YUV_TD;
+    constexpr int TD = FL <= 8 ? YUV_TD8 : YUV_TD16;
     typedef const int __attribute__((address_space(4)))* karg_int_p;
     typedef const char __attribute__((address_space(4)))* karg_p;
     const karg_int_p idx = (karg_int_p)((karg_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(YuvArgs, idx));
@@ -1054,13 +1103,17 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
             v2f acc_s[PX], acc_t[PX];                     // sustained / transient channel of (test, reference)
 #pragma unroll
             for (int i = 0; i < PX; ++i) acc_s[i] = acc_t[i] = splat(0.0f);
+            karg_p tp = (karg_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(YuvArgs, taps2);
+            if constexpr (FL > 8) asm volatile("" : "+s"(tp));      // reloaded per frame, see temporal_vec_body
 #pragma unroll
-            for (int k = FL - 1; k >= 0; --k) {           // oldest tap first, like the reference's sum over the window
-                const float t0 = a.taps[0][k], t1 = a.taps[1][k];
+            for (int c = FL / TAPC - 1; c >= 0; --c) {    // oldest tap first, like the reference's sum over the window
+                const vtapf tc = *(karg_taps_p)(tp + c * (8 * TAPC));
 #pragma unroll
-                for (int i = 0; i < PX; ++i) {
-                    acc_s[i] = pfma(win[FL - 1 - k][i], t0, acc_s[i]);
-                    acc_t[i] = pfma(win[FL - 1 - k][i], t1, acc_t[i]);
+                for (int kk = TAPC - 1; kk >= 0; --kk) {
+                    const int k = c * TAPC + kk;
+                    const v2f f = v2f{tc[2 * kk], tc[2 * kk + 1]};
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) fir_tap(acc_s[i], acc_t[i], win[FL - 1 - k][i], f);
                 }
             }
             wave_lds_order();

@@ -51,7 +51,8 @@ void K1_NAME(k1_vec)(int FL, const TemporalArgs& a, hipStream_t st) {
 void K1_NAME(k1_ring)(int FL, const TemporalArgs& a, hipStream_t st) {
     if (FL == 8) launch_ring<8, 4>(a, st);
     else if (FL == 16) launch_ring<16, 4>(a, st);
-    else launch_ring<32, 2>(a, st);
+    else if (FL == 32) launch_ring<32, 2>(a, st);
+    // FL == 64 has no per-pixel ring instantiation: the caller (temporal_channels_core) refuses it before it gets here
 }
 void K1_NAME(k1_generic)(int planes, const GenericArgs& a, hipStream_t st) {
     if (planes == 2) launch_generic<2>(a, st);

@@ -149,6 +149,7 @@ class fvvdp:
         if self._ctx is not None:
             self._ctx.close()
         self._ctx = None
+        self._chan_w = {}                # [1, w_transient] of do_pooling_and_jods: a model parameter like the rest
 
     def load_config(self):
         parameters = utils.config_files.load("fvvdp_parameters.json")
@@ -247,7 +248,11 @@ class fvvdp:
         fix = self._fixation(fixation_point, width, height, N_frames) if self.foveated else None
 
         n_out = f1 - f0
-        feeder = self._make_feeder(vid_source, width, height)
+        widx = window_frame_indices(N_frames, fl, self.temp_padding) if not is_image else np.zeros(1, np.int32)
+        # source frames this call touches: the windows of output frames [f0, f1) (frame sharding: a rank's own frames plus
+        # the fl-1 frames of temporal halo before them) -- host-resident sources upload these and nothing else
+        self.last_h2d_bytes = 0
+        feeder = self._make_feeder(vid_source, width, height, np.unique(widx[f0:f1 + fl - 1]))
         batch = self._batch_size(width, height, planes, n_out)
         schedule = None
         if self.batch_frames is None and getattr(feeder, "preferred_batch", None):
@@ -268,7 +273,6 @@ class fvvdp:
         res = torch.zeros(nq + 2, dtype=torch.float32, device=self.device)      # Q_per_ch | range flag | JOD
         Q = res[:nq].view(n_bands, 2, n_out)
         oob = res[nq:nq + 1].view(torch.int32)
-        widx = window_frame_indices(N_frames, fl, self.temp_padding) if not is_image else np.zeros(1, np.int32)
 
         if schedule is None:
             schedule = [min(batch, f1 - b0) for b0 in range(f0, f1, batch)]
@@ -579,8 +583,35 @@ class fvvdp:
             return (a.to(torch.int32) & 0xFFFF).to(torch.float32) / 65535
         raise RuntimeError("Only uint8, uint16 and float32 is currently supported")
 
-    def _make_feeder(self, vs, width, height):
-        """Returns feed(ctx, idx, taps, fl, n_out, oob, stream): fills pyramid level 0 of slots [0, n_out)."""
+    def _place_sources(self, test, ref, need):
+        """Source arrays [1, C, F, H, W] -> (test, ref) on the compute device plus the frame number -> position map (None:
+        all frames are there in place).  Arrays that are already resident are used where they lie (no copy).  If one of
+        them lives on the host, only the frames in `need` (sorted unique frame numbers) cross PCIe: with frame sharding a
+        rank uploads its own frames plus the fl-1 frames of temporal halo, not the clip."""
+        dev = self.device
+        F = test.shape[2]
+        if (test.device == dev and ref.device == dev) or len(need) >= F:
+            out, remap = [], None
+            for a in (test, ref):
+                if a.device != dev:
+                    self.last_h2d_bytes += a.numel() * a.element_size()
+                out.append(a.to(dev).contiguous())
+            return out[0], out[1], remap
+        lo, hi = int(need[0]), int(need[-1])
+        run = (hi - lo + 1 == len(need))               # one run of frames: a view; else (circular / pingpong history) a gather
+        out = []
+        for a in (test, ref):
+            sub = a[:, :, lo:hi + 1] if run else a.index_select(2, torch.as_tensor(np.asarray(need, dtype=np.int64), device=a.device))
+            if a.device != dev:
+                self.last_h2d_bytes += sub.numel() * sub.element_size()
+            out.append(sub.to(dev).contiguous())
+        remap = np.full(F, -1, dtype=np.int32)
+        remap[np.asarray(need, dtype=np.int64)] = np.arange(len(need), dtype=np.int32)
+        return out[0], out[1], remap
+
+    def _make_feeder(self, vs, width, height, need=None):
+        """Returns feed(ctx, idx, taps, fl, n_out, oob, stream): fills pyramid level 0 of slots [0, n_out).
+        `need`: sorted unique source frames the call will ask for (all frames when None)."""
         lib = nat.lib()
         HW = width * height
         if type(vs) is fvvdp_video_source_array or isinstance(vs, fvvdp_video_source_array):
@@ -601,7 +632,9 @@ class fvvdp:
                 dtype, nbits = nat.FVVDP_F32, 0
             else:
                 raise RuntimeError("Only uint8, uint16 and float32 is currently supported")
-            C_ch, N = test.shape[1], test.shape[2]
+            C_ch = test.shape[1]
+            if need is None:
+                need = np.arange(test.shape[2])
             # uint8: 256-entry table through the model's own forward() (exact, lives in LDS).  uint16: the 65536-entry
             # table sits in global memory (6 gathers per pixel: K1 98 vs 37 us/frame at 4K), so stock display models are
             # evaluated in closed form on code/65535 like float input (<= 1e-6 relative); `exact_uint16 = True` on the
@@ -609,8 +642,8 @@ class fvvdp:
             use_closed = dtype == nat.FVVDP_F32 or (dtype == nat.FVVDP_U16 and not getattr(self, "exact_uint16", False))
             desc = native_eotf(vs.dm_photometry) if use_closed else None
             if dtype != nat.FVVDP_F32 or desc is not None:
-                test_d = test.to(self.device).contiguous()
-                ref_d = ref.to(self.device).contiguous()
+                test_d, ref_d, remap = self._place_sources(test, ref, need)
+                N = test_d.shape[2]
                 e = nat.Eotf()
                 if desc is None:
                     lut = self._code_lut(vs.dm_photometry, nbits)
@@ -627,6 +660,8 @@ class fvvdp:
                 w = np.asarray(vs.color_to_luminance, dtype=np.float32)
 
                 def feed(ctx, idx, taps, fl, n_out, oob, stream):
+                    if remap is not None:
+                        idx = np.ascontiguousarray(remap[idx])
                     nat.check(lib.fvvdp_temporal_channels(
                         ctx.handle, C.c_void_p(test_d.data_ptr()), C.c_void_p(ref_d.data_ptr()), dtype, C_ch,
                         N * HW, HW, C.byref(e), nat.fptr(w), idx.ctypes.data_as(C.POINTER(C.c_int32)),
@@ -674,7 +709,14 @@ class _PipelinedSourceFeeder:
     Python code of the source already produces batch b+1 -- and nothing is copied: the temporal kernel reads the
     luminance tensors the source returned where they are (fvvdp_temporal_channels_frames; frames of the temporal window
     that were fetched for an earlier batch are simply kept alive).  Sources whose tensors the kernel cannot address
-    (too far apart in memory, filters longer than 64 taps) go through one stacking copy per stream and batch instead."""
+    (too far apart in memory, filters longer than 64 taps) go through one stacking copy per stream and batch instead.
+
+    Contract for user sources: a tensor returned by `get_*_frame` is read in place for up to filter_len - 1 + batch later
+    frames.  A source that decodes into a buffer it reuses (`return self._buf`) is detected -- a fresh frame arriving at
+    the address of a frame still in the window -- and from then on every frame is copied on arrival (the frames the reuse
+    overwrote are fetched again), which is what the reference does for every source (pyfvvdp/fvvdp.py:289-291).
+    The fetches run on a side stream that first waits for the caller's current stream, so frames produced asynchronously
+    on that stream just before the call (GPU-generated video, non_blocking uploads) are complete when they are read."""
 
     preferred_batch = 64       # largest batch when the caller did not choose (see batch_schedule)
 
@@ -708,29 +750,69 @@ class _PipelinedSourceFeeder:
         # ones for "batch finished" (the older one is still being polled when the newer one is recorded)
         self.ev_ready, self.ev_done = res[2], res[3]
         self.n_batches = 0
-        self.retired = []                 # tensors of frames that left the window: freed once prev_done has passed
-        self.retired_next = []
+        self.retired = []                 # tensors of frames that left the window: freed once their last reader has finished
+        self.live_ptrs = {}               # address -> source frame, of every tensor in self.frames (aliasing detection)
+        self.copy_mode = False            # the source reuses its buffers: clone on arrival
+        self.waited_main = False
         self.eotf = nat.Eotf()
         self.eotf.kind = nat.EOTF_NONE
 
+    def _conform(self, x):
+        dev, f32 = self.dev, torch.float32
+        if not (type(x) is torch.Tensor and x.dtype is f32 and x.is_cuda and x.device == dev and x.is_contiguous()):
+            x = torch.as_tensor(x).to(device=dev, dtype=f32).contiguous()
+        if x.numel() != self.H * self.W:
+            raise RuntimeError("get_*_frame must return one luminance frame of %dx%d pixels" % (self.W, self.H))
+        return x
+
     def _fetch(self, f):
         """One source frame of both streams (the per-frame host cost of a user source: kept to a few attribute reads)."""
-        dev, n = self.dev, self.H * self.W
-        t = self.vs.get_test_frame(f, device=dev)
-        r = self.vs.get_reference_frame(f, device=dev)
-        f32 = torch.float32
-        if not (type(t) is torch.Tensor and t.dtype is f32 and t.is_cuda and t.device == dev and t.is_contiguous()):
-            t = torch.as_tensor(t).to(device=dev, dtype=f32).contiguous()
-        if not (type(r) is torch.Tensor and r.dtype is f32 and r.is_cuda and r.device == dev and r.is_contiguous()):
-            r = torch.as_tensor(r).to(device=dev, dtype=f32).contiguous()
-        if t.numel() != n or r.numel() != n:
-            raise RuntimeError("get_*_frame must return one luminance frame of %dx%d pixels" % (self.W, self.H))
+        t = self._conform(self.vs.get_test_frame(f, device=self.dev))
+        if self.copy_mode:
+            t = t.clone()
+        r = self._conform(self.vs.get_reference_frame(f, device=self.dev))
+        if self.copy_mode:
+            r = r.clone()
+        tp, rp = t.data_ptr(), r.data_ptr()
+        if not self.copy_mode:
+            if tp in self.live_ptrs or rp in self.live_ptrs:
+                return self._buffer_reuse(t, r)
+            self.live_ptrs[tp] = f
+            self.live_ptrs[rp] = f
+        return (t, r, tp, rp)
+
+    def _buffer_reuse(self, t, r):
+        """The source handed out an address that a frame still in the temporal window occupies: it decodes into buffers it
+        reuses.  The new frame is intact right now (copied first); the held frames at the same addresses are not (fetched
+        again and copied); every other held frame is still intact and is copied before a later fetch can overwrite it."""
+        hit = sorted({self.live_ptrs[p] for p in (t.data_ptr(), r.data_ptr()) if p in self.live_ptrs})
+        self.copy_mode = True
+        self.live_ptrs = {}
+        t, r = t.clone(), r.clone()
+        for g in list(self.frames):
+            if g not in hit:
+                h = self.frames[g]
+                tt, rr = h[0].clone(), h[1].clone()
+                self.frames[g] = (tt, rr, tt.data_ptr(), rr.data_ptr())
+        for g in hit:
+            self.frames[g] = self._fetch(g)               # copy mode: cloned on arrival
         return (t, r, t.data_ptr(), r.data_ptr())
 
     def __call__(self, ctx, idx, taps, fl, n_out, oob, stream):
         uniq = sorted(set(int(f) for f in idx))
         main = torch.cuda.current_stream(self.dev)
+        if self.n_batches >= 2:
+            # Back-pressure and buffer safety in one: the host waits for the kernels of the batch before the previous one.
+            # The GPU still has the previous batch queued (nothing starves), at most ~3 batches of frames are alive however
+            # fast the source is, everything retired so far has no reader left, and a source that recycles a buffer of a
+            # retired frame writes it after its last reader.
+            self.ev_done[self.n_batches & 1].synchronize()
+            self.retired.clear()
         with torch.cuda.stream(self.side):
+            if not self.waited_main:
+                # frames may have been produced asynchronously on the caller's stream just before the call
+                self.side.wait_stream(main)
+                self.waited_main = True
             fresh = [f for f in uniq if f not in self.frames]
             for f in fresh:
                 self.frames[f] = self._fetch(f)
@@ -765,11 +847,10 @@ class _PipelinedSourceFeeder:
         # tensor and batch: 184 calls on a 60-frame clip); release() covers the tensors still held when the call ends.
         keep = set(uniq)
         for f in [f for f in self.frames if f not in keep]:
-            self.retired_next.append(self.frames.pop(f))
-        if self.prev_done is not None and self.prev_done.query():
-            self.retired.clear()                    # readers of everything retired before the previous batch are done
-        self.retired.extend(self.retired_next)
-        self.retired_next = []
+            h = self.frames.pop(f)
+            self.live_ptrs.pop(h[2], None)
+            self.live_ptrs.pop(h[3], None)
+            self.retired.append(h)                  # not in this batch's window: last read by the previous batch or earlier
         done = self.ev_done[self.n_batches & 1]
         self.n_batches += 1
         done.record(main)
@@ -780,10 +861,10 @@ class _PipelinedSourceFeeder:
         allocator is told that the main stream still reads the frames."""
         if not synced:
             main = torch.cuda.current_stream(self.dev)
-            for held in list(self.frames.values()) + self.retired + self.retired_next:
+            for held in list(self.frames.values()) + self.retired:
                 held[0].record_stream(main)
                 held[1].record_stream(main)
         self.frames.clear()
         self.retired.clear()
-        self.retired_next = []
+        self.live_ptrs = {}
 

@@ -68,15 +68,17 @@ def predict_frame_sharded(metric, vid_source, rank, world, fixation_point=None, 
     if stats is None:                       # more ranks than frames: this rank computed nothing
         stats = {"rho_band": rho_band, "frames_per_second": vid_source.get_frames_per_second(), "width": W, "height": H,
                  "N_frames": N}
+    # any rank saw an out-of-range pixel -> every rank warns, like the unsharded call.  EVERY rank takes part in the
+    # reduce, also one whose shard is empty (more ranks than frames: it computed nothing and has no flag of its own);
+    # a collective that only some ranks call hangs or pairs with a later one.
     flag = stats.pop("range_flag", None)
-    if flag is not None:                    # any rank saw an out-of-range pixel -> every rank warns, like the unsharded call
-        flag = flag.clone()
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+    flag = torch.zeros(1, dtype=torch.int32, device=metric.device) if flag is None else flag.clone()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
     jod = metric.do_pooling_and_jods(Q, None)
     stats["Q_per_ch"] = Q.cpu().numpy()
-    if flag is not None and int(flag.cpu()[0]) != 0:
+    if int(flag.cpu()[0]) != 0:
         import logging
         logging.warning("Pixel outside the valid range 0-1")
     return jod, stats

@@ -29,9 +29,11 @@ def _worker(argv):
 
 
 def timed_frames(test, ref, fps, display, fl, n_procs, tmp_dir, timeout=180.0):
-    """Evaluates output frames fl-1 .. fl-2+n_procs of the clip, one per subprocess, all at the same time.
+    """Evaluates n_procs output frames of the clip (frames fl-1, fl, ...; wrapping around when there are more processes than
+    full windows in the clip: every frame costs the same), one per subprocess, all at the same time.
     Returns (wall seconds from the common start to the last finish, per-frame seconds) or raises RuntimeError."""
-    need = fl - 1 + n_procs
+    n_win = max(1, test.shape[2] - fl + 1)             # distinct full temporal windows in the clip
+    need = fl - 1 + min(n_procs, n_win)
     tp, rp = os.path.join(tmp_dir, "cpu_t.npy"), os.path.join(tmp_dir, "cpu_r.npy")
     np.save(tp, np.ascontiguousarray(test[:, :, :need]))
     np.save(rp, np.ascontiguousarray(ref[:, :, :need]))
@@ -41,7 +43,7 @@ def timed_frames(test, ref, fps, display, fl, n_procs, tmp_dir, timeout=180.0):
     procs = []
     try:
         for k in range(n_procs):
-            procs.append(subprocess.Popen([sys.executable, "-m", "oracle.cpu_bench", tp, rp, str(k), str(fl), str(fps),
+            procs.append(subprocess.Popen([sys.executable, "-m", "oracle.cpu_bench", tp, rp, str(k % n_win), str(fl), str(fps),
                                            display, "%.6f" % start_at], cwd=root, env=env, stdout=subprocess.PIPE,
                                           stderr=subprocess.DEVNULL, text=True))
         deadline = time.time() + timeout

@@ -109,3 +109,37 @@ def test_use_checkpoints_flag_is_accepted_and_gradients_are_refused():
         m.predict(t, ref.to(torch.float32) / 255, frames_per_second=FPS)
     with torch.no_grad():
         m.predict(t, ref.to(torch.float32) / 255, frames_per_second=FPS)
+
+
+@pytest.mark.timeout(600)
+def test_bench_multi_rank_step_under_gloo():
+    """bench.py's own multi-rank step (pairs queued with sync=False -> gather_pair_results -> one pooling call), launched the
+    way the driver launches it (torch.distributed.run, one process per rank), here with 2 gloo ranks sharing the GPU.  The
+    nccl (RCCL) run differs by the backend string only.  The JSON line must carry n_gpus 2 and the 4 JODs of the 4 pairs,
+    equal to single-rank calls on the same pairs."""
+    import json
+    import subprocess
+    import sys
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    W, H, N, K = 960, 540, 20, 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
+           "--pairs-per-gpu", str(K), "--width", str(W), "--height", str(H), "--frames", str(N), "--steps", "2", "--warmup", "1",
+           "--no-cpu-baseline", "--no-h2d", "--no-measure-traffic"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=540)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]                   # ONE JSON line, from rank 0
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["config"]["pairs_per_gpu"] == K and out["value"] > 0 and out["higher_is_better"] is True
+    assert out["roofline"] is not None and out["roofline"]["bound"] == "hbm"
+    assert len(out["jod"]) == 2 * K
+    m = fv.fvvdp(display_name="standard_4k")
+    for pidx in range(2 * K):
+        t, r = synth_video_pair(N, H, W, device="cuda", pair=pidx)
+        q, _ = m.predict(t, r, frames_per_second=30)
+        assert abs(float(q) - out["jod"][pidx]) < 2e-6, (pidx, float(q), out["jod"][pidx])

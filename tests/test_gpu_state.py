@@ -156,9 +156,12 @@ def test_pipelined_source_feeder_fetches_every_frame_once_and_matches_the_array_
     synchronisation per batch; with `replicate` padding every frame is fetched exactly once, like the reference does
     (pyfvvdp/fvvdp.py:287-288).  Results equal the array path up to the float-vs-table display model (1e-6)."""
     from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
     test, ref = synth_video_pair(N, H, W)
     m = fv.fvvdp(display_name="standard_fhd", temp_padding=pad)
     q0, s0 = m.predict(test, ref, frames_per_second=fps)
+    # the parity statement of this row (SURVEY 8(f) rank 3): the CPU oracle on the same clip, at the array path's tolerances
+    oq, ost = orc.Oracle("standard_fhd", temp_padding=pad).predict(test.numpy(), ref.numpy(), frames_per_second=fps)
     inner = fv.fvvdp_video_source_array(test, ref, fps, display_photometry=m.display_photometry)
     calls = {"t": [], "r": []}
 
@@ -181,6 +184,9 @@ def test_pipelined_source_feeder_fetches_every_frame_once_and_matches_the_array_
         calls["t"].clear(); calls["r"].clear()
         mm = fv.fvvdp(display_name="standard_fhd", temp_padding=pad, batch_frames=batch)
         q1, s1 = mm.predict_video_source(Src())
+        assert abs(float(q1) - float(oq)) < 2e-5, (pad, batch, float(q1), float(oq))      # vs the oracle (array path: <= 7e-6 measured)
+        o = ost["Q_per_ch"].astype(np.float64)
+        assert np.all(np.abs(s1["Q_per_ch"] - o) <= 1e-3 * np.abs(o) + 1e-6 * np.max(o)), (pad, batch)   # check_q's end-to-end bound
         assert abs(float(q1) - float(q0)) < 5e-6, (pad, batch)
         a, b = s1["Q_per_ch"].astype(np.float64), s0["Q_per_ch"].astype(np.float64)
         assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 1e-6 * np.max(b)), (pad, batch)
@@ -223,6 +229,136 @@ def test_user_source_with_a_filter_longer_than_32_taps_and_host_frames(fv, fps):
             return inner.get_reference_frame(frame, torch.device("cpu")).to(torch.float64).reshape(H, W)
 
     q1, s1 = m.predict_video_source(Src())
+    from oracle import fvvdp_oracle as orc
+    oq, ost = orc.Oracle("standard_fhd").predict(test.numpy(), ref.numpy(), frames_per_second=fps)
+    assert abs(float(q1) - float(oq)) < 1e-4, (float(q1), float(oq))          # the bound of test_other_frame_rates_vs_oracle
+    o = ost["Q_per_ch"].astype(np.float64)
+    assert np.all(np.abs(s1["Q_per_ch"] - o) <= 4e-3 * np.abs(o) + 1e-6 * np.max(o))
     assert abs(float(q1) - float(q0)) < 5e-6
     a, b = s1["Q_per_ch"].astype(np.float64), s0["Q_per_ch"].astype(np.float64)
     assert np.all(np.abs(a - b) <= 4e-3 * np.abs(b) + 1e-6 * np.max(b))      # 36x64: every band is tiny
+
+
+def test_source_that_reuses_its_output_buffer(fv):
+    """a source that decodes every frame into ONE buffer per stream (`return self._buf`).  The zero-copy feeder holds
+    the returned tensors by reference for the whole temporal window; it must notice the recycled address, copy from then on
+    and re-fetch what the reuse overwrote -- the result equals the oracle's / the array path's, not a window of identical
+    frames.  Also a ring of 3 buffers (shorter than the window) and the same clip with sync=False."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    N, H, W, fps = 14, 70, 120, 30
+    test, ref = synth_video_pair(N, H, W)
+    m = fv.fvvdp(display_name="standard_fhd")
+    q0, s0 = m.predict(test, ref, frames_per_second=fps)
+    oq, ost = orc.Oracle("standard_fhd").predict(test.numpy(), ref.numpy(), frames_per_second=fps)
+    inner = fv.fvvdp_video_source_array(test, ref, fps, display_photometry=m.display_photometry)
+
+    class Reuser(fv.fvvdp_video_source):
+        def __init__(self, k):
+            self.k = k
+            self.bt = [torch.empty((1, 1, 1, H, W), device="cuda") for _ in range(k)]
+            self.br = [torch.empty((1, 1, 1, H, W), device="cuda") for _ in range(k)]
+            self.n = 0
+
+        def get_video_size(self):
+            return (H, W, N)
+
+        def get_frames_per_second(self):
+            return fps
+
+        def get_test_frame(self, frame, device):
+            b = self.bt[frame % self.k]
+            b.copy_(inner.get_test_frame(frame, device))
+            self.n += 1
+            return b
+
+        def get_reference_frame(self, frame, device):
+            b = self.br[frame % self.k]
+            b.copy_(inner.get_reference_frame(frame, device))
+            return b
+
+    for k in (1, 3):
+        for batch in (None, 4):
+            src = Reuser(k)
+            mm = fv.fvvdp(display_name="standard_fhd", batch_frames=batch)
+            q1, s1 = mm.predict_video_source(src)
+            assert abs(float(q1) - float(oq)) < 2e-5, (k, batch, float(q1), float(oq))
+            assert np.array_equal(s1["Q_per_ch"], s0["Q_per_ch"]) or np.allclose(s1["Q_per_ch"], s0["Q_per_ch"], rtol=2e-4, atol=1e-6 * s0["Q_per_ch"].max())
+            assert src.n <= N + k + 1                      # every frame once, plus the ones the reuse overwrote
+    q2, s2 = m.predict_video_source(Reuser(1), sync=False)
+    fv.fvvdp.finish(s2)
+    assert abs(float(q2) - float(q0)) < 5e-6
+
+
+def test_frames_produced_on_the_callers_stream_just_before_the_call(fv):
+    """the feeder's side stream waits for the caller's current stream.  The clip is generated on the GPU by a long
+    chain of kernels queued right before predict; without the wait the side stream reads it half-written."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    N, H, W, fps = 12, 270, 480, 30
+    test, ref = synth_video_pair(N, H, W, device="cuda")
+    m = fv.fvvdp(display_name="standard_fhd")
+    lt = m.display_photometry.forward(test.float() / 255)
+    lr = m.display_photometry.forward(ref.float() / 255)
+    w = torch.tensor([0.2126, 0.7152, 0.0722], device="cuda").view(1, 3, 1, 1, 1)
+    Lt0, Lr0 = (lt * w).sum(1, keepdim=True), (lr * w).sum(1, keepdim=True)
+
+    class Lum(fv.fvvdp_video_source):
+        def __init__(self, a, b):
+            self.a, self.b = a, b
+
+        def get_video_size(self):
+            return (H, W, N)
+
+        def get_frames_per_second(self):
+            return fps
+
+        def get_test_frame(self, frame, device):
+            return self.a[:, :, frame:frame + 1]
+
+        def get_reference_frame(self, frame, device):
+            return self.b[:, :, frame:frame + 1]
+
+    q_ref, _ = m.predict_video_source(Lum(Lt0.clone(), Lr0.clone()))
+    torch.cuda.synchronize()
+    for _ in range(3):
+        A = torch.zeros_like(Lt0)
+        B = torch.zeros_like(Lr0)
+        junk = torch.randn(4096, 4096, device="cuda")
+        for _ in range(6):                                # ~ms of queued work ahead of the writes below
+            junk = junk @ junk * 1e-4
+        A.copy_(Lt0 + 0.0 * junk[0, 0])
+        B.copy_(Lr0 + 0.0 * junk[0, 0])
+        q, _ = m.predict_video_source(Lum(A, B))          # no synchronisation in between
+        assert float(q) == float(q_ref)
+
+
+def test_frame_sharded_call_uploads_only_its_own_frames(fv):
+    """VERDICT r2 item 5 / SURVEY 8(e): with host-resident arrays a frame-sharded call moves its own frames plus the fl-1
+    frames of temporal halo over PCIe, not the clip; results are bit-equal to the unsharded call on resident arrays."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from fovvideovdp_amd.sharding import shard_range
+    from oracle import fvvdp_oracle as orc
+    N, H, W, fps, world = 64, 72, 128, 30, 8
+    fl = 8
+    test, ref = synth_video_pair(N, H, W)                 # host tensors
+    frame_bytes = 2 * 3 * H * W                           # both streams, uint8 RGB
+    m = fv.fvvdp(display_name="standard_fhd")
+    q_all, s_all = m.predict(test.cuda(), ref.cuda(), frames_per_second=fps)
+    assert m.last_h2d_bytes == 0
+    vs = fv.fvvdp_video_source_array(test, ref, fps, display_photometry=m.display_photometry)
+    Q = np.zeros_like(s_all["Q_per_ch"])
+    for pad in ("replicate", "circular"):
+        mm = fv.fvvdp(display_name="standard_fhd", temp_padding=pad)
+        qp, sp = mm.predict(test.cuda(), ref.cuda(), frames_per_second=fps)
+        for rank in range(world):
+            f0, f1 = shard_range(N, rank, world)
+            _, st = mm.predict_video_source(vs, frame_range=(f0, f1), pool=False)
+            share = (f1 - f0) * frame_bytes
+            halo = (fl - 1) * frame_bytes
+            assert mm.last_h2d_bytes <= 1.2 * share + halo, (pad, rank, mm.last_h2d_bytes, share, halo)
+            assert mm.last_h2d_bytes >= share
+            Q[:, :, f0:f1] = st["Q_per_ch"]
+        assert np.array_equal(Q, sp["Q_per_ch"]), pad
+    oq, ost = orc.Oracle("standard_fhd").predict(test.numpy(), ref.numpy(), frames_per_second=fps, frames=range(0, 10))
+    o = ost["Q_per_ch"].astype(np.float64)
+    assert np.all(np.abs(s_all["Q_per_ch"][:, :, :10] - o) <= 1e-3 * np.abs(o) + 1e-6 * np.max(o))

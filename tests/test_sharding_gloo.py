@@ -78,3 +78,75 @@ def test_frame_and_pair_sharding_world2(tmp_path):
         tp, rp = synth_video_pair(4, H, W, pair=k)
         _, stp = orc.Oracle("standard_fhd").predict(tp.numpy(), rp.numpy(), frames_per_second=fps)
         assert np.array_equal(res[0]["allq"][k], stp["Q_per_ch"])
+
+
+class _StubMetric:
+    """Stands in for the HIP metric on CPU: the contract of predict_video_source(frame_range=, pool=False, sync=False)
+    that predict_frame_sharded relies on (device Q_per_ch of the rank's frames + the out-of-range flag)."""
+    device = torch.device("cpu")
+    pix_per_deg = 37.8425
+
+    def __init__(self, flag_value):
+        self.flag_value = flag_value
+        self.calls = []
+
+    def predict_video_source(self, vs, fixation_point=None, frame_range=None, pool=True, sync=True):
+        from fovvideovdp_amd.fvvdp import band_frequencies
+        H, W, N = vs.get_video_size()
+        f0, f1 = frame_range
+        self.calls.append((f0, f1))
+        nb = band_frequencies(W, H, self.pix_per_deg)[0]
+        q = torch.arange(f0, f1, dtype=torch.float32).view(1, 1, -1).expand(nb, 2, f1 - f0) + 1.0
+        return None, {"Q_per_ch": q.clone(), "range_flag": torch.tensor([self.flag_value], dtype=torch.int32),
+                      "rho_band": None, "frames_per_second": vs.get_frames_per_second(), "width": W, "height": H, "N_frames": N}
+
+    def do_pooling_and_jods(self, Q, rho_band):
+        return Q.sum()
+
+
+class _StubSource:
+    def __init__(self, n):
+        self.n = n
+
+    def get_video_size(self):
+        return (40, 64, self.n)
+
+    def get_frames_per_second(self):
+        return 30
+
+
+def _worker_empty_shard(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fovvideovdp_amd.sharding import predict_frame_sharded
+        out = {}
+        for n in (1, 3):                         # 1 frame on 2 ranks: rank 1 has an empty shard and still joins both collectives
+            m = _StubMetric(flag_value=1 if rank == 0 else 0)
+            jod, stats = predict_frame_sharded(m, _StubSource(n), rank, world)
+            out["jod%d" % n] = float(jod)
+            out["Q%d" % n] = stats["Q_per_ch"]
+            out["calls%d" % n] = np.asarray(m.calls, dtype=np.int64).reshape(-1, 2)
+        # a later collective still pairs up (a mismatched all_reduce above would have consumed it or hung)
+        t = torch.tensor([float(rank + 1)])
+        dist.all_reduce(t)
+        out["after"] = float(t)
+        np.savez(os.path.join(out_dir, f"e{rank}.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(120)
+def test_frame_sharding_with_an_empty_shard_world2(tmp_path):
+    """More ranks than frames (a still image, a short clip on 8 GPUs): the rank that computes nothing must still take part in
+    the Q_per_ch all-reduce AND in the out-of-range-flag all-reduce (collective mismatch)."""
+    world = 2
+    mp.spawn(_worker_empty_shard, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), f"e{k}.npz")) for k in range(world)]
+    for k in range(world):
+        assert res[k]["after"] == 3.0
+        assert np.array_equal(res[k]["Q1"], res[0]["Q1"]) and res[k]["Q1"].shape[2] == 1 and np.all(res[k]["Q1"] == 1.0)
+        assert np.array_equal(res[k]["Q3"][0, 0], [1.0, 2.0, 3.0])
+        assert res[k]["jod1"] == res[0]["jod1"] and res[k]["jod3"] == res[0]["jod3"]
+    assert res[0]["calls1"].tolist() == [[0, 1]] and res[1]["calls1"].size == 0

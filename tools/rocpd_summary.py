@@ -1,21 +1,41 @@
 #!/usr/bin/env python3
 """Summarise a rocprofv3 (rocpd sqlite) kernel trace into the per-kernel table kept under profiles/.
-usage: tools/rocpd_summary.py <results.db> [--band-levels N] [--only substr]
+usage: tools/rocpd_summary.py <results.db> [--band-levels N] [--only substr] [--skip K] [--dispatches substr]
+
+Columns: calls, total, avg / median / min / max over ALL dispatches, and `steady med` = the median after dropping the first
+K dispatches of every kernel (--skip K, default 3: the launches that run while clocks and caches are cold).  The roofline
+numbers of DESIGN.md / bench.py are quoted on medians; the average is kept so that warm-up and disturbed launches stay visible.
 With --band-levels N the dispatches of band_kernel are labelled by pyramid level (they are issued in level order
-0..N-1 for every batch), so the dominant level-0 launch gets its own row."""
+0..N-1 for every batch), so the dominant level-0 launch gets its own row.
+--dispatches substr additionally lists every dispatch of the kernels whose label contains substr, in launch order, with the
+kernel that ran immediately before it (a launch behind a host->device copy or a different kernel mix shows up here)."""
 import sqlite3
 import sys
 
 
+def median(v):
+    v = sorted(v)
+    n = len(v)
+    return 0.0 if n == 0 else (v[n // 2] if n & 1 else 0.5 * (v[n // 2 - 1] + v[n // 2]))
+
+
+def opt(name, default=None):
+    return sys.argv[sys.argv.index(name) + 1] if name in sys.argv else default
+
+
 def main():
     db = sys.argv[1]
-    nlev = int(sys.argv[sys.argv.index("--band-levels") + 1]) if "--band-levels" in sys.argv else 0
-    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else ""
+    nlev = int(opt("--band-levels", 0))
+    only = opt("--only", "")
+    skip = int(opt("--skip", 3))
+    disp = opt("--dispatches", None)
     con = sqlite3.connect(db)
     rows = con.execute("select name, duration, vgpr_count, sgpr_count, lds_size, grid_x, workgroup_x, start "
                        "from kernels order by start").fetchall()
     agg, seq = {}, 0
-    for name, dur, vg, sg, lds, gx, wg, _ in rows:
+    order = []
+    prev = "(first kernel)"
+    for name, dur, vg, sg, lds, gx, wg, start in rows:
         label = name
         if nlev and "band2_kernel" in name:          # two levels per launch: counts as two positions of the level order
             label = "%s [levels %d+%d]" % (name, seq % nlev, seq % nlev + 1)
@@ -23,20 +43,31 @@ def main():
         elif nlev and "band_kernel" in name:
             label = "%s [level %d]" % (name, seq % nlev)
             seq += 1
-        a = agg.setdefault(label, [0, 0.0, 1e30, 0.0, vg, sg, lds, gx, wg])
-        a[0] += 1
-        a[1] += dur
-        a[2] = min(a[2], dur)
-        a[3] = max(a[3], dur)
-    total = sum(a[1] for a in agg.values()) or 1
-    print("| kernel | calls | total ms | avg us | min us | max us | % | vgpr | sgpr | lds B | grid_x | wg |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
-    for label, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+        a = agg.setdefault(label, {"d": [], "vg": vg, "sg": sg, "lds": lds, "gx": gx, "wg": wg})
+        a["d"].append(dur)
+        order.append((label, dur, start, prev))
+        prev = name
+    total = sum(sum(a["d"]) for a in agg.values()) or 1
+    print("| kernel | calls | total ms | avg us | median us | steady med us (first %d dropped) | min us | max us | %% | vgpr | sgpr | lds B | grid_x | wg |" % skip)
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for label, a in sorted(agg.items(), key=lambda kv: -sum(kv[1]["d"])):
         if only and only not in label:
             continue
+        d = a["d"]
         nm = label if len(label) < 110 else label[:107] + "..."
-        print("| `%s` | %d | %.3f | %.1f | %.1f | %.1f | %.1f | %s | %s | %s | %s | %s |" % (
-            nm, a[0], a[1] / 1e6, a[1] / a[0] / 1e3, a[2] / 1e3, a[3] / 1e3, 100.0 * a[1] / total, a[4], a[5], a[6], a[7], a[8]))
+        steady = d[skip:] if len(d) > skip else d
+        print("| `%s` | %d | %.3f | %.1f | %.1f | %.1f | %.1f | %.1f | %.1f | %s | %s | %s | %s | %s |" % (
+            nm, len(d), sum(d) / 1e6, sum(d) / len(d) / 1e3, median(d) / 1e3, median(steady) / 1e3, min(d) / 1e3, max(d) / 1e3,
+            100.0 * sum(d) / total, a["vg"], a["sg"], a["lds"], a["gx"], a["wg"]))
+    if disp:
+        print()
+        print("dispatches of `%s` in launch order (us; the kernel that ran before each):" % disp)
+        t0 = rows[0][7] if rows else 0
+        k = 0
+        for label, dur, start, before in order:
+            if disp in label:
+                print("  #%-3d t=%10.1f ms  dur %9.1f  after %s" % (k, (start - t0) / 1e6, dur / 1e3, before[:60]))
+                k += 1
 
 
 if __name__ == "__main__":
