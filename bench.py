@@ -61,8 +61,9 @@ def main():
                     "profiles/rNN_pmc_level0.json of the same kernel and launch shape is quoted instead")
     ap.add_argument("--measure-traffic", action="store_true", help=argparse.SUPPRESS)      # the default now
     ap.add_argument("--cpu-frames", type=int, default=2)
-    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the CPU baseline, one output frame each (0 = all host "
-                    "cores up to 64, bounded by free memory at ~3 GB per 4K worker; 1 = time the oracle in-process)")
+    ap.add_argument("--cpu-procs", type=int, default=0, help="processes of the CPU baseline, one output frame each (0 = every core "
+                    "the container may use (affinity mask and cgroup quota), up to 64, bounded by free memory at ~3 GB per 4K "
+                    "worker; 1 = time the oracle in-process)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
                     "dry-run the multi-rank code path on a single-GPU box)")
     args = ap.parse_args()
@@ -231,7 +232,7 @@ def main():
         fl = fl_guard(fps) + 1
         done = False
         if args.cpu_procs <= 0:
-            args.cpu_procs = max(1, min(os.cpu_count() or 1, 64, host_mem_available_gb() // 3))
+            args.cpu_procs = max(1, min(host_cpus_usable(), 64, host_mem_available_gb() // 3))
         if args.cpu_procs > 1:
             # the numpy oracle on several host cores: one output frame (with its own temporal window) per process,
             # all running concurrently (oracle/cpu_bench.py; plain subprocesses with a hard timeout)
@@ -244,8 +245,9 @@ def main():
                        "cores": args.cpu_procs, "kind": "port",
                        "sample": "%d output frames (from frame %d on, each incl. its %d-frame temporal window) of the same %dx%d "
                                  "pair, one per process, numpy fp32 oracle, %d processes concurrently (%.1f - %.1f s per frame, "
-                                 "%.1f s wall); host has %d cores (%s)" % (args.cpu_procs, fl - 1, fl, W, H,
-                                                                          args.cpu_procs, min(per), max(per), wall, os.cpu_count(), host_cpu_model())}
+                                 "%.1f s wall); host has %d cores (%s), of which this container may use %d (affinity / cgroup "
+                                 "cpu.max)" % (args.cpu_procs, fl - 1, fl, W, H, args.cpu_procs, min(per), max(per), wall,
+                                               os.cpu_count(), host_cpu_model(), host_cpus_usable())}
                 done = True
             except Exception as e:                      # never let the baseline leg break the benchmark line
                 sys.stderr.write("cpu baseline: parallel run failed (%s), timing a single process instead\n" % e)
@@ -321,6 +323,29 @@ def measure_traffic_live():
         return None
     finally:
         shutil.rmtree(d, ignore_errors=True)
+
+
+def host_cpus_usable():
+    """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota (cpu.max / cfs_quota_us) -- the GPU
+    boxes show all 256 cores of the host but grant the container 16 of them (64 oracle processes ran 15x slower each)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, p = f.read().split()[:2]
+            if q != "max":
+                n = min(n, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, p = int(f.read()), int(g.read())
+                if q > 0:
+                    n = min(n, max(1, q // p))
+        except (OSError, ValueError):
+            pass
+    return n
 
 
 def host_mem_available_gb():

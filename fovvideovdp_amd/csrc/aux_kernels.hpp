@@ -11,13 +11,8 @@ struct FinalizeArgs {
     float npx[FVVDP_MAX_BANDS];
 };
 
-__global__ __launch_bounds__(64) void finalize_kernel(const FinalizeArgs a) {
-    // one wave per (band, cc, slot); lane l adds partials l, l+64, ... in fp64, then a fixed shuffle tree
-    const int i = blockIdx.x;
-    const int lane = threadIdx.x;
-    const int s = i % a.n;
-    const int cc = (i / a.n) % 2;
-    const int b = i / (2 * a.n);
+// one wave: Q of (band b, temporal channel cc, frame slot s); lane l adds partials l, l+64, ... in fp64, then a fixed shuffle tree
+__device__ __forceinline__ void finalize_one(const FinalizeArgs& a, const int b, const int cc, const int s, const int lane) {
     float q = 0.0f;
     if (cc < a.tc) {
         const float* p = a.partial + a.off[b] + (size_t)s * a.nblk[b] * 2 + cc;
@@ -28,6 +23,12 @@ __global__ __launch_bounds__(64) void finalize_kernel(const FinalizeArgs a) {
         q = (float)pow(sum / (double)a.npx[b], (double)a.inv_beta);
     }
     if (lane == 0) a.Q[((size_t)b * 2 + cc) * a.q_stride + a.q_col0 + s] = q;
+}
+
+__global__ __launch_bounds__(64) void finalize_kernel(const FinalizeArgs a) {
+    // one wave per (band, cc, slot)
+    const int i = blockIdx.x;
+    finalize_one(a, i / (2 * a.n), (i / a.n) % 2, i % a.n, (int)threadIdx.x);
 }
 
 // Pooling of the per-band, per-channel, per-frame differences into one JOD value (do_pooling_and_jods,
@@ -43,34 +44,41 @@ struct PoolArgs {
 
 __device__ __forceinline__ float pool_pow(float x, float p) { return p == 1.0f ? x : powf(x, p); }
 
-__global__ __launch_bounds__(256) void pool_jod_kernel(const PoolArgs a) {
-    __shared__ double s_part[256];
+// by the first 256 threads of a workgroup of `nthreads` >= 256 threads (all of them reach the barriers); s_part: 256 doubles
+__device__ __forceinline__ void pool_jod_body(const PoolArgs& a, double* s_part, const int tid) {
     double acc = 0.0;
-    for (int f = threadIdx.x; f < a.n_frames; f += 256) {
-        float qt = 0.0f;
-        for (int c = 0; c < a.n_ch; ++c) {
-            const float wc = (a.n_ch == 2 && c == 1) ? a.w_transient : 1.0f;
-            float qs = 0.0f;
-            for (int b = 0; b < a.n_bands; ++b)
-                qs += pool_pow(fabsf(a.Q[((size_t)b * 2 + c) * a.q_stride + f] * wc), a.beta_sch);
-            qs = pool_pow(qs, 1.0f / a.beta_sch);
-            qt += pool_pow(qs, a.beta_tch);
+    if (tid < 256) {
+        for (int f = tid; f < a.n_frames; f += 256) {
+            float qt = 0.0f;
+            for (int c = 0; c < a.n_ch; ++c) {
+                const float wc = (a.n_ch == 2 && c == 1) ? a.w_transient : 1.0f;
+                float qs = 0.0f;
+                for (int b = 0; b < a.n_bands; ++b)
+                    qs += pool_pow(fabsf(a.Q[((size_t)b * 2 + c) * a.q_stride + f] * wc), a.beta_sch);
+                qs = pool_pow(qs, 1.0f / a.beta_sch);
+                qt += pool_pow(qs, a.beta_tch);
+            }
+            qt = pool_pow(qt, 1.0f / a.beta_tch);
+            acc += (double)pool_pow(qt, a.beta_t);
         }
-        qt = pool_pow(qt, 1.0f / a.beta_tch);
-        acc += (double)pool_pow(qt, a.beta_t);
+        s_part[tid] = acc;
     }
-    s_part[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o >= 1; o >>= 1) {
-        if ((int)threadIdx.x < o) s_part[threadIdx.x] += s_part[threadIdx.x + o];
+        if (tid < o) s_part[tid] += s_part[tid + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    if (tid == 0) {
         // lp_norm(..., normalize=True): norm / N^(1/p)   (fvvdp.py:598-607)
         const float q_all = pool_pow((float)(s_part[0] / (double)a.n_frames), 1.0f / a.beta_t);
         const float sgn = a.jod_a < 0.0f ? -1.0f : 1.0f;
         a.out[0] = sgn * powf(powf(fabsf(a.jod_a), 1.0f / a.beta_jod) * q_all, a.beta_jod) + 10.0f;
     }
+}
+
+__global__ __launch_bounds__(256) void pool_jod_kernel(const PoolArgs a) {
+    __shared__ double s_part[256];
+    pool_jod_body(a, s_part, (int)threadIdx.x);
 }
 
 // Heat-map reconstruction, one level: out = expand(coarse) + (D0 + w*D1)/m   [then ^beta_jod * |jod_a| on level 0]

@@ -91,6 +91,19 @@ __device__ __forceinline__ void dpp_expand_taps(v2f e, float el, float er, float
     odd = v2f{ox, oy};
 }
 
+// Layout of a band's slice of the CSF table (foveated mode): [rho interval][ecc][Y] of float4 records, the ecc rows padded
+// from 32 to FOV_ROW entries and every rho plane by 8 more.  ds_read_b128 serves a wave in four 16-lane groups and a group
+// runs at full rate only if its lanes' addresses are equal or fall into different 16-byte slots of the 256-byte bank row
+// (MI355X_MICROARCH.md, LDS): the slot of cell (r, e, y) is (8 r + 4 e + y) mod 16, so the cells a group typically touches --
+// a few adjacent Y intervals in one or two adjacent ecc intervals -- never collide.  Unpadded (row = 32 entries = two full
+// bank rows) every pair (e, y), (e + 1, y) did: one extra LDS cycle on almost every access (r2 PMC).
+#ifndef FOV_ROW
+#define FOV_ROW 36
+#endif
+#ifndef FOV_PLANE
+#define FOV_PLANE (FVVDP_LUT_N * FOV_ROW + 8)
+#endif
+
 struct BandArgs {
     const float* Gf;        // fine level   [n][h][w][P]
     float* Gc;              // coarse level [n][hc][wc][P]
@@ -112,7 +125,7 @@ struct BandArgs {
     float* dL;
     float* dS;
     // foveated (FOV == true)
-    const float4* sublut;   // per band: [rw rho intervals][32 ecc][32 Y] of {S_log0[i], S_log1[i], S_log0[i+1]-S_log0[i], S_log1[i+1]-S_log1[i]} (i = rho knot)
+    const float4* sublut;   // per band: [rw rho intervals][32 ecc, rows of FOV_ROW][32 Y] (FOV_PLANE entries per interval) of {S_log0[i], S_log1[i], S_log0[i+1]-S_log0[i], S_log1[i+1]-S_log1[i]} (i = rho knot)
     const float* axes;      // [3][32] knots: Y_log, rho_log, ecc_sqrt
     int rw, i_lo;           // rho knots covered by the band's sub-LUT: [i_lo, i_lo+rw]
     const float* fix;       // device [n][2]: gaze in frame pixels, or gaze view direction in degrees (map mode)
@@ -137,8 +150,8 @@ struct BandArgs {
 // is evaluated ONCE per geometry here, with exactly the operations band_kernel used per pixel and frame before
 // (4 transcendentals and ~25 VALU instructions per pixel and frame saved in a VALU-bound kernel for 8 B/pixel of reads).
 struct RhoMapArgs {
-    float4* out;            // [h][(w+1)/2] {f(2J), k(2J), f(2J+1), k(2J+1)}, k = (interval - i_lo) * 16384 as a float =
-                            //   BYTE offset of the interval's 32 x 32 (ecc, Y) plane of float4 entries in the band's LUT slice
+    float4* out;            // [h][(w+1)/2] {f(2J), k(2J), f(2J+1), k(2J+1)}, k = (interval - i_lo) * FOV_PLANE * 16 as a float =
+                            //   BYTE offset of the interval's (ecc, Y) plane of float4 entries in the band's LUT slice
     int w, h;
     float size_m0, size_m1, dist_m, cos_delta, delta_rad;
     float rho_band, rho_lo, rho_hi, first, inv_step;
@@ -167,7 +180,7 @@ __global__ __launch_bounds__(256) void fov_rho_map_kernel(const RhoMapArgs a) {
         const float x0 = a.axis[k], x1 = a.axis[k + 1 < FVVDP_LUT_N ? k + 1 : k];
         const float f = fmaxf((rq - x0) * (1.0f / (x1 - x0 + 0.000001f)), 0.0f);
         r[2 * i] = f;
-        r[2 * i + 1] = (float)((k - a.i_lo) * (FVVDP_LUT_N * FVVDP_LUT_N * 16));
+        r[2 * i + 1] = (float)((k - a.i_lo) * (FOV_PLANE * 16));
     }
     a.out[(size_t)y * pw + J] = make_float4(r[0], r[1], r[2], r[3]);
 }
@@ -194,37 +207,17 @@ __device__ __forceinline__ int floor_to_int(float x) {
 #endif
 extern __shared__ __attribute__((aligned(16))) float4 s_lut_dyn[];
 
-// FOVM: 0 = non-foveated, 1 = foveated with the band's LUT slice in (dynamic) LDS, 2 = foveated, LUT slice in global
-// memory (slice too large, or the map-writing variant).  A compile-time choice: with a run-time flag the compiler
-// merges the two look-ups into one flat load, which is slower than ds_read_b128.
+// One work item of a level: the wave streams down strip `strip` of frame `frame`, coarse rows of chunk `chunk`.  The tables
+// (s_csf; foveated: s_ax, the LUT slice and the row table in dynamic LDS) are loaded by the calling kernel.
 template <int P, bool DBG, int FOVM>
-__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_MINW_LEAN : FOV_MINW) : (DBG ? 2 : 4)) void band_kernel(const BandArgs a) {
+__device__ __forceinline__ void band_item(const BandArgs& a, const int strip, const int chunk, const int frame, const int lane,
+                                          const float4* s_csf, const float2* s_ax) {
     constexpr bool FOV = FOVM != 0;
     constexpr bool LUT_LDS = FOVM == 1 || FOVM == 3;
     // FOVM 1: stock geometry with the frame-invariant rho map (the fast path: no code for the other cases in the loop);
     // FOVM 3: LUT slice in LDS, user geometry maps or no rho map;  FOVM 2: LUT slice in global memory (any case, DBG)
     constexpr bool LEAN = FOVM == 1;
     constexpr int HP = P / 2;   // (test, ref) pairs = temporal channels
-    constexpr int WPB = FOV ? FOV_WPB : 1;
-    __shared__ float4 s_csf[FVVDP_LUT_N];
-
-    const int lane = FOV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
-    // XCD-aware work order: hardware places workgroup b on XCD b % 8 (speed only, never correctness).  Give each
-    // XCD a contiguous range of work items (strip fastest, then chunk, then frame) so that neighbouring strips,
-    // which share their 4+4 halo columns, run on the same XCD at about the same time and hit in its L2.
-    int bid;
-    {
-        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
-        bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
-        // the wave number is the same in all lanes: say so, otherwise every quantity derived from the work item (rows,
-        // loop counter, row addresses, the store descriptor) lives in vector registers and is recomputed by the VALU
-        if constexpr (FOV) bid = bid * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    }
-    const bool wave_has_work = !FOV || bid < a.n_items;
-    const int strip = bid % a.n_strips;
-    bid /= a.n_strips;
-    const int chunk = bid % a.n_chunks;
-    const int frame = bid / a.n_chunks;
     const int blk = chunk * a.n_strips + strip;
 
     const int w = a.w, h = a.h, wc = a.wc, hc = a.hc;
@@ -238,34 +231,6 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
     const int X0 = 2 * J, X1 = 2 * J + 1;
     const int xc0 = min(max(X0, 0), w - 1), xc1 = min(max(X1, 0), w - 1);
     const bool col1_ok = X1 < w;
-
-    __shared__ float2 s_ax[FOV ? 3 * FVVDP_LUT_N : 1];     // {knot k, 1/(knot k+1 - knot k + 1e-6)} of the three axes
-    if constexpr (!FOV) {
-        if (lane < FVVDP_LUT_N) s_csf[lane] = a.csf[lane];
-    } else {
-        for (int i = threadIdx.x; i < 3 * FVVDP_LUT_N; i += 64 * WPB) {
-            const int k = i % FVVDP_LUT_N;
-            const float x0 = a.axes[i];
-            const float x1 = a.axes[k + 1 < FVVDP_LUT_N ? i + 1 : i];
-            s_ax[i] = make_float2(x0, 1.0f / (x1 - x0 + 0.000001f));
-        }
-        if constexpr (LUT_LDS) {
-            const int nl = FVVDP_LUT_N * FVVDP_LUT_N * a.rw;
-            for (int i = threadIdx.x; i < nl; i += 64 * WPB) s_lut_dyn[i] = a.sublut[i];
-        }
-        // vertical view angle of every band row (pix2view_direction, fvvdp_display_model.py:498-510): one atan per
-        // row and workgroup instead of two per wave and step
-        float* s_vy = reinterpret_cast<float*>(s_lut_dyn + (LUT_LDS ? FVVDP_LUT_N * FVVDP_LUT_N * a.rw : 0));
-        const float kyb = a.size_m1 / (float)a.h / a.dist_m;
-        for (int i = threadIdx.x; i < a.h; i += 64 * WPB) {
-            const float yp = ((float)i + 0.5f) + (-(float)a.h / 2.0f);
-            s_vy[i] = atanf(-yp * kyb) * 57.29577951308232f;
-        }
-    }
-    __syncthreads();
-    if constexpr (FOV) {
-        if (!wave_has_work) return;
-    }
 
     // horizontal 5-tap weights of this lane's coarse column incl. the reference's edge fix-ups
     // (gausspyr_reduce, fvvdp_lpyr_dec.py:198-205; the right-edge branch is selected by the parity of the ROW
@@ -445,13 +410,13 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
                 const float rho = a.rho_band * res_mag;
                 const float rq = fast_log2(fminf(fmaxf(rho, a.rho_lo), a.rho_hi));
                 axis(1, rq, a.i_lo, a.i_lo + a.rw - 1, kR, fR);
-                soR = (kR - a.i_lo) * (FVVDP_LUT_N * FVVDP_LUT_N);
+                soR = (kR - a.i_lo) * FOV_PLANE;
             }
             (void)kR;
             axis(2, eq, 0, FVVDP_LUT_N - 2, kE, fE);
             // LUT slice [rho interval][ecc][Y]: the Y and ecc neighbours of a cell sit at compile-time distances
-            const int so = soR + kE * FVVDP_LUT_N + kY;
-            constexpr int sj = 1, sk = FVVDP_LUT_N;
+            const int so = soR + kE * FOV_ROW + kY;
+            constexpr int sj = 1, sk = FOV_ROW;
             float4 v00, v10, v01, v11;                                                      // v[dj][dk]
             if constexpr (LUT_LDS) {
                 v00 = s_lut_dyn[so]; v10 = s_lut_dyn[so + sj]; v01 = s_lut_dyn[so + sk]; v11 = s_lut_dyn[so + sk + sj];
@@ -559,9 +524,9 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
         q.fE = (tE - iE) * a.frac_scale[2];
         q.fR = pre_fR;
         // byte offset of the cell (rho plane + ecc * 512 + Y * 16) in float: small integers are exact, one conversion
-        const int bo = (int)fmaf(iE, (float)(FVVDP_LUT_N * 16), fmaf(iY, 16.0f, pre_kR));
+        const int bo = (int)fmaf(iE, (float)(FOV_ROW * 16), fmaf(iY, 16.0f, pre_kR));
         const float4* cell = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_lut_dyn) + bo);
-        constexpr int sj = 1, sk = FVVDP_LUT_N;
+        constexpr int sj = 1, sk = FOV_ROW;
         q.v00 = cell[0];
         q.v10 = cell[sj];
         q.v01 = cell[sk];
@@ -643,7 +608,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
         {
         float vy0 = 0.0f, vy1 = 0.0f;        // vertical view angle of the two fine rows (foveated)
         if constexpr (FOV) {
-            const float* s_vy = reinterpret_cast<const float*>(s_lut_dyn + (LUT_LDS ? FVVDP_LUT_N * FVVDP_LUT_N * a.rw : 0));
+            const float* s_vy = reinterpret_cast<const float*>(s_lut_dyn + (LUT_LDS ? FOV_PLANE * a.rw : 0));
             vy0 = s_vy[2 * c];
             vy1 = s_vy[min(2 * c + 1, h - 1)];
         }
@@ -731,3 +696,67 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
     }
 }
 
+// Tables of one level into LDS, by all `nthreads` threads of the workgroup (no barrier here): the 1-D CSF records, or in
+// foveated mode the axis knots, the band's LUT slice and the vertical view angle of every band row.
+template <int FOVM>
+__device__ __forceinline__ void band_load_tables(const BandArgs& a, float4* s_csf, float2* s_ax, const int tid, const int nthreads) {
+    constexpr bool FOV = FOVM != 0;
+    constexpr bool LUT_LDS = FOVM == 1 || FOVM == 3;
+    if constexpr (!FOV) {
+        if (tid < FVVDP_LUT_N) s_csf[tid] = a.csf[tid];
+    } else {
+        for (int i = tid; i < 3 * FVVDP_LUT_N; i += nthreads) {
+            const int k = i % FVVDP_LUT_N;
+            const float x0 = a.axes[i];
+            const float x1 = a.axes[k + 1 < FVVDP_LUT_N ? i + 1 : i];
+            s_ax[i] = make_float2(x0, 1.0f / (x1 - x0 + 0.000001f));
+        }
+        if constexpr (LUT_LDS) {
+            const int nl = FOV_PLANE * a.rw;
+            for (int i = tid; i < nl; i += nthreads) s_lut_dyn[i] = a.sublut[i];
+        }
+        // vertical view angle of every band row (pix2view_direction, fvvdp_display_model.py:498-510): one atan per
+        // row and workgroup instead of two per wave and step
+        float* s_vy = reinterpret_cast<float*>(s_lut_dyn + (LUT_LDS ? FOV_PLANE * a.rw : 0));
+        const float kyb = a.size_m1 / (float)a.h / a.dist_m;
+        for (int i = tid; i < a.h; i += nthreads) {
+            const float yp = ((float)i + 0.5f) + (-(float)a.h / 2.0f);
+            s_vy[i] = atanf(-yp * kyb) * 57.29577951308232f;
+        }
+    }
+}
+
+// FOVM: 0 = non-foveated, 1 = foveated with the band's LUT slice in (dynamic) LDS, 2 = foveated, LUT slice in global
+// memory (slice too large, or the map-writing variant).  A compile-time choice: with a run-time flag the compiler
+// merges the two look-ups into one flat load, which is slower than ds_read_b128.
+template <int P, bool DBG, int FOVM>
+__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_MINW_LEAN : FOV_MINW) : (DBG ? 2 : 4)) void band_kernel(const BandArgs a) {
+    constexpr bool FOV = FOVM != 0;
+    constexpr int WPB = FOV ? FOV_WPB : 1;
+    __shared__ float4 s_csf[FVVDP_LUT_N];
+    __shared__ float2 s_ax[FOV ? 3 * FVVDP_LUT_N : 1];     // {knot k, 1/(knot k+1 - knot k + 1e-6)} of the three axes
+
+    const int lane = FOV ? (int)(threadIdx.x & 63) : (int)threadIdx.x;
+    // XCD-aware work order: hardware places workgroup b on XCD b % 8 (speed only, never correctness).  Give each
+    // XCD a contiguous range of work items (strip fastest, then chunk, then frame) so that neighbouring strips,
+    // which share their 4+4 halo columns, run on the same XCD at about the same time and hit in its L2.
+    int bid;
+    {
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
+        bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
+        // the wave number is the same in all lanes: say so, otherwise every quantity derived from the work item (rows,
+        // loop counter, row addresses, the store descriptor) lives in vector registers and is recomputed by the VALU
+        if constexpr (FOV) bid = bid * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    }
+    const bool wave_has_work = !FOV || bid < a.n_items;
+    const int strip = bid % a.n_strips;
+    bid /= a.n_strips;
+    const int chunk = bid % a.n_chunks;
+    const int frame = bid / a.n_chunks;
+    band_load_tables<FOVM>(a, s_csf, s_ax, (int)threadIdx.x, 64 * WPB);
+    __syncthreads();
+    if constexpr (FOV) {
+        if (!wave_has_work) return;
+    }
+    band_item<P, DBG, FOVM>(a, strip, chunk, frame, lane, s_csf, s_ax);
+}

@@ -46,17 +46,24 @@ extern "C" const char* fvvdp_last_error(void) { return g_err; }
 #include "band_kernel.hpp"
 #include "band2_kernel.hpp"
 #include "aux_kernels.hpp"
+#include "tail_kernel.hpp"
 #include "psnr_kernel.hpp"
 
 // ------------------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------------------
+struct VmmBlock {               // a buffer that came from the virtual-memory API (see dev_alloc)
+    void* ptr;
+    size_t size;
+    hipMemGenericAllocationHandle_t handle;
+};
 struct fvvdp_ctx {
     int W = 0, H = 0, n_bands = 0, P = 0, max_frames = 0;
     fvvdp_params prm{};
     double rho_band[FVVDP_MAX_BANDS + 1]{};
     int lw[FVVDP_MAX_BANDS + 1]{}, lh[FVVDP_MAX_BANDS + 1]{};
     float* level[FVVDP_MAX_BANDS + 1]{};
+    float* level0_raw = nullptr;  // what dev_alloc returned for level 0 (level[0] may start later, FVVDP_L0_OFFSET_KB)
     float* partial = nullptr;
     long long partial_off[FVVDP_MAX_BANDS]{};
     int max_blk[FVVDP_MAX_BANDS]{};
@@ -83,9 +90,11 @@ struct fvvdp_ctx {
     float* d_fix = nullptr;       // [max_frames][2]
     float* d_taps = nullptr;      // [2][FVVDP_MAX_TAPS]
     int* d_idx = nullptr;         // [max_frames + FVVDP_MAX_TAPS]
+    unsigned int* d_ticket = nullptr;   // band_tail_kernel: workgroups that have published their frame (zero between launches)
     float* heat[FVVDP_MAX_BANDS + 1]{};   // heat-map accumulation images of levels >= 1, allocated on first use
     unsigned int* colour_ws = nullptr;    // colouring workspace per frame: range[2] + hist[1024] + curve[1024], then lin01[1024]
     size_t scratch = 0;
+    std::vector<VmmBlock> vmm;     // buffers that came from the virtual-memory API (freed by vmm_free_all)
     long long wave_capacity = 4096;   // resident single-wave workgroups of the band kernel on the whole chip
     long long wave_capacity2 = 4096;  // ... of the two-level kernel (band2_kernel)
     // timing
@@ -95,13 +104,26 @@ struct fvvdp_ctx {
     int t_cnt[FVVDP_MAX_BANDS + 2]{};
 };
 
+// Large buffers (the pyramid levels) can come from the virtual-memory API instead of hipMalloc: one physical allocation
+// of the recommended granularity mapped into a reserved range.  FVVDP_ALLOC=vmm selects it (placement experiments:
+// tools/gpu_k1_placement.py; the temporal kernel's speed depends on where the level-0 scratch lands physically).
+static int vmm_alloc(fvvdp_ctx* c, void** out, size_t bytes);
+static void vmm_free_all(fvvdp_ctx* c);
+
 template <typename T>
 static int dev_alloc(fvvdp_ctx* c, T** p, size_t count) {
     void* q = nullptr;
-    hipError_t e = hipMalloc(&q, count * sizeof(T));
-    if (e != hipSuccess) return fail(FVVDP_ENOMEM, "hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+    const size_t bytes = count * sizeof(T);
+    static const bool use_vmm = [] { const char* e = getenv("FVVDP_ALLOC"); return e && strcmp(e, "vmm") == 0; }();
+    if (use_vmm && bytes >= ((size_t)64 << 20)) {
+        int rc = vmm_alloc(c, &q, bytes);
+        if (rc != FVVDP_OK) return rc;
+    } else {
+        hipError_t e = hipMalloc(&q, bytes);
+        if (e != hipSuccess) return fail(FVVDP_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
+    }
     *p = reinterpret_cast<T*>(q);
-    c->scratch += count * sizeof(T);
+    c->scratch += bytes;
     return FVVDP_OK;
 }
 
@@ -124,6 +146,69 @@ struct Timed {
         }
     }
 };
+
+static int vmm_alloc(fvvdp_ctx* c, void** out, size_t bytes) {
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipMemAllocationProp prop;
+    memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = dev;
+    size_t gran = 0;
+    HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    if (gran == 0) gran = (size_t)2 << 20;
+    if (const char* g = getenv("FVVDP_VMM_ALIGN_MB")) {          // experiment: coarser alignment of the reserved range
+        const size_t a = (size_t)atoll(g) << 20;
+        if (a > gran && a % gran == 0) gran = a;
+    }
+    const size_t size = (bytes + gran - 1) / gran * gran;
+    VmmBlock b;
+    b.size = size;
+    b.ptr = nullptr;
+    hipError_t e = hipMemAddressReserve(&b.ptr, size, gran, nullptr, 0);
+    if (e != hipSuccess) return fail(FVVDP_ENOMEM, "hipMemAddressReserve(%zu) failed: %s", size, hipGetErrorString(e));
+    e = hipMemCreate(&b.handle, size, &prop, 0);
+    if (e != hipSuccess) {
+        (void)hipMemAddressFree(b.ptr, size);
+        return fail(FVVDP_ENOMEM, "hipMemCreate(%zu) failed: %s", size, hipGetErrorString(e));
+    }
+    e = hipMemMap(b.ptr, size, 0, b.handle, 0);
+    hipMemAccessDesc acc;
+    memset(&acc, 0, sizeof(acc));
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if (e == hipSuccess) e = hipMemSetAccess(b.ptr, size, &acc, 1);
+    if (e != hipSuccess) {
+        (void)hipMemUnmap(b.ptr, size);
+        (void)hipMemRelease(b.handle);
+        (void)hipMemAddressFree(b.ptr, size);
+        return fail(FVVDP_ENOMEM, "hipMemMap / hipMemSetAccess(%zu) failed: %s", size, hipGetErrorString(e));
+    }
+    c->vmm.push_back(b);
+    *out = b.ptr;
+    return FVVDP_OK;
+}
+
+static bool vmm_owns(const fvvdp_ctx* c, const void* p) {
+    for (const VmmBlock& b : c->vmm)
+        if (b.ptr == p) return true;
+    return false;
+}
+
+// buffers of the virtual-memory API are released together by vmm_free_all (context destruction)
+static void dev_free(fvvdp_ctx* c, void* p) {
+    if (p && !vmm_owns(c, p)) (void)hipFree(p);
+}
+
+static void vmm_free_all(fvvdp_ctx* c) {
+    for (VmmBlock& b : c->vmm) {
+        (void)hipMemUnmap(b.ptr, b.size);
+        (void)hipMemRelease(b.handle);
+        (void)hipMemAddressFree(b.ptr, b.size);
+    }
+    c->vmm.clear();
+}
 
 // strips cover coarse columns [0,62), [62,122), ... (see band_kernel)
 static int band_strips(int wc) { return wc <= 62 ? 1 : 1 + (wc - 62 + STRIP_J - 1) / STRIP_J; }
@@ -197,8 +282,21 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
         h = (h + 1) / 2;
     }
     int rc = FVVDP_OK;
-    for (int i = 0; i <= n_bands && rc == FVVDP_OK; ++i)
-        rc = dev_alloc(c, &c->level[i], (size_t)max_frames * c->lw[i] * c->lh[i] * planes);
+    for (int i = 0; i <= n_bands && rc == FVVDP_OK; ++i) {
+        size_t slack = 0, shift = 0;
+        if (i == 0) {
+            // placement experiments (tools/gpu_k1_placement.py): level 0 starts FVVDP_L0_OFFSET_KB into its allocation
+            if (const char* e = getenv("FVVDP_L0_OFFSET_KB")) {
+                shift = (size_t)atoll(e) * 1024 / sizeof(float);
+                slack = shift + 4096;
+            }
+        }
+        rc = dev_alloc(c, &c->level[i], (size_t)max_frames * c->lw[i] * c->lh[i] * planes + slack);
+        if (rc == FVVDP_OK && i == 0) {
+            c->level0_raw = c->level[0];
+            c->level[0] += shift;
+        }
+    }
     size_t off = 0;
     for (int b = 0; b < n_bands; ++b) {
         const int n_strips = band_strips(c->lw[b + 1]);
@@ -221,6 +319,8 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_fix, (size_t)max_frames * 2);
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_taps, (size_t)2 * FVVDP_MAX_TAPS);
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_idx, (size_t)max_frames + FVVDP_MAX_TAPS);
+    if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_ticket, (size_t)1);
+    if (rc == FVVDP_OK && hipMemset(c->d_ticket, 0, sizeof(unsigned int)) != hipSuccess) rc = fail(FVVDP_EHIP, "hipMemset failed");
     if (rc != FVVDP_OK) {
         fvvdp_ctx_destroy(c);
         return rc;
@@ -248,22 +348,26 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
 
 extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     if (!c) return;
+    (void)hipDeviceSynchronize();                  // nothing may still read the scratch
+    if (c->level0_raw) c->level[0] = c->level0_raw;
     for (int i = 0; i <= FVVDP_MAX_BANDS; ++i)
-        if (c->level[i]) (void)hipFree(c->level[i]);
-    if (c->partial) (void)hipFree(c->partial);
+        dev_free(c, c->level[i]);
+    dev_free(c, c->partial);
     if (c->csf) (void)hipFree(c->csf);
     if (c->csf_y) (void)hipFree(c->csf_y);
     for (int i = 0; i <= FVVDP_MAX_BANDS; ++i)
-        if (c->heat[i]) (void)hipFree(c->heat[i]);
+        dev_free(c, c->heat[i]);
     if (c->colour_ws) (void)hipFree(c->colour_ws);
     if (c->d_fix) (void)hipFree(c->d_fix);
     if (c->d_taps) (void)hipFree(c->d_taps);
     if (c->d_idx) (void)hipFree(c->d_idx);
+    if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->d_axes) (void)hipFree(c->d_axes);
     for (int b = 0; b < FVVDP_MAX_BANDS; ++b) {
-        if (c->sublut[b]) (void)hipFree(c->sublut[b]);
-        if (c->rmap[b]) (void)hipFree(c->rmap[b]);
+        dev_free(c, c->sublut[b]);
+        dev_free(c, c->rmap[b]);
     }
+    vmm_free_all(c);
     for (auto& v : c->ev)
         for (auto& pr : v) {
             (void)hipEventDestroy(pr.first);
@@ -677,12 +781,12 @@ static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
             (void)hipFree(c->sublut[b]);
             c->sublut[b] = nullptr;
         }
-        const size_t n = (size_t)FVVDP_LUT_N * FVVDP_LUT_N * rw;
+        const size_t n = (size_t)FOV_PLANE * rw;                 // padded layout, see FOV_ROW / FOV_PLANE (band_kernel.hpp)
         if (!c->sublut[b]) {
             int rc = dev_alloc(c, &c->sublut[b], n);
             if (rc != FVVDP_OK) return rc;
         }
-        std::vector<float4> h(n);
+        std::vector<float4> h(n, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
         const float* L0 = c->h_lut3[0].data();
         const float* L1 = c->h_lut3[1].empty() ? L0 : c->h_lut3[1].data();
         for (int k = 0; k < FVVDP_LUT_N; ++k)
@@ -691,7 +795,7 @@ static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
                     const size_t s0 = ((size_t)j * FVVDP_LUT_N + (i_lo + i)) * FVVDP_LUT_N + k;       // [Y][rho][ecc]
                     const size_t s1 = ((size_t)j * FVVDP_LUT_N + (i_lo + i + 1)) * FVVDP_LUT_N + k;
                     // slice layout [rho interval i][ecc k][Y j]; rho blend in slope form {v[i], v[i+1] - v[i]}
-                    h[((size_t)i * FVVDP_LUT_N + k) * FVVDP_LUT_N + j] = make_float4(L0[s0], L1[s0], L0[s1] - L0[s0], L1[s1] - L1[s0]);
+                    h[(size_t)i * FOV_PLANE + (size_t)k * FOV_ROW + j] = make_float4(L0[s0], L1[s0], L0[s1] - L0[s0], L1[s1] - L1[s0]);
                 }
         HIP_TRY(hipMemcpy(c->sublut[b], h.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         c->sub_rw[b] = rw;
@@ -736,7 +840,7 @@ static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, hipS
         const dim3 gridf((nblocks + FOV_WPB - 1) / FOV_WPB), blockf(64 * FOV_WPB);
         // dynamic LDS: [LUT slice of the band (mode 1)] + vertical view angle of every band row
         const size_t lds_vy = (size_t)a.h * sizeof(float);
-        const size_t lds_lut = (size_t)FVVDP_LUT_N * FVVDP_LUT_N * a.rw * sizeof(float4);
+        const size_t lds_lut = (size_t)FOV_PLANE * a.rw * sizeof(float4);
         if (dbg) hipLaunchKernelGGL((band_kernel<P, true, 2>), gridf, blockf, lds_vy, st, a);
         else if (a.lut_lds && a.rmap && !a.mvx) hipLaunchKernelGGL((band_kernel<P, false, 1>), gridf, blockf, lds_lut + lds_vy, st, a);
         else if (a.lut_lds) hipLaunchKernelGGL((band_kernel<P, false, 3>), gridf, blockf, lds_lut + lds_vy, st, a);
@@ -747,9 +851,39 @@ static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, hipS
     }
 }
 
-extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
-                                   const fvvdp_geom* geom, const fvvdp_band_maps* maps, void* stream) {
+static void fill_pool_args(PoolArgs& a, const float* d_Q, int n_bands, int n_channels, int n_frames, int q_stride,
+                           const fvvdp_pool_params* prm, float* d_jod) {
+    memset(&a, 0, sizeof(a));
+    a.Q = d_Q;
+    a.n_bands = n_bands;
+    a.n_ch = n_channels;
+    a.n_frames = n_frames;
+    a.q_stride = q_stride;
+    a.beta_sch = prm->beta_sch;
+    a.beta_tch = prm->beta_tch;
+    a.beta_t = prm->beta_t;
+    a.w_transient = prm->w_transient;
+    a.jod_a = prm->jod_a;
+    a.beta_jod = prm->beta_jod;
+    a.out = d_jod;
+}
+
+static int check_pool_params(const fvvdp_pool_params* prm) {
+    if (!(prm->beta_sch > 0.0f) || !(prm->beta_tch > 0.0f) || !(prm->beta_t > 0.0f) || !(prm->beta_jod > 0.0f))
+        return fail(FVVDP_EINVAL, "pooling exponents must be positive");
+    return FVVDP_OK;
+}
+
+static int bands_forward_core(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
+                              const fvvdp_geom* geom, const fvvdp_band_maps* maps, const fvvdp_pool_params* pool,
+                              float* d_jod, void* stream) {
     if (!c || !d_Q) return fail(FVVDP_EINVAL, "null argument");
+    if (pool) {
+        if (!d_jod) return fail(FVVDP_EINVAL, "null argument");
+        int rc = check_pool_params(pool);
+        if (rc != FVVDP_OK) return rc;
+    }
+    const bool pool_now = pool && (q_col0 + n == q_stride);      // this call completes the clip
     if (n < 1 || n > c->max_frames) return fail(FVVDP_EINVAL, "n=%d exceeds max_frames=%d", n, c->max_frames);
     if (q_col0 < 0 || q_col0 + n > q_stride) return fail(FVVDP_EINVAL, "Q columns out of range");
     const bool fov = h_fixation != nullptr;
@@ -777,9 +911,26 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
     const char* fuse_env = getenv("FVVDP_BAND_FUSE");
     const int fuse_mode = (fuse_env && (fuse_env[0] == '0' || fuse_env[0] == '1')) ? fuse_env[0] - '0' : -1;   // anything else: automatic
     const bool fuse_ok = !fov && !any_maps && fuse_mode != 0;
+    // The small end of the pyramid, the finalisation and (when asked) the pooling in one launch (band_tail_kernel): plain
+    // evaluation of a batch of frames only -- a workgroup per frame needs frames to run side by side; for a few frames the
+    // per-level launches, which spread ONE frame over the chip, are faster.  FVVDP_BAND_TAIL=0 / 1: never / wherever valid.
+    const char* tail_env = getenv("FVVDP_BAND_TAIL");
+    const int tail_mode = (tail_env && (tail_env[0] == '0' || tail_env[0] == '1')) ? tail_env[0] - '0' : -1;
+    int tail_from = c->n_bands;          // first level of the tail launch (n_bands: no tail)
+    if (!fov && !any_maps && tail_mode != 0 && (n >= 24 || tail_mode == 1)) {
+        while (tail_from > 0 && (long long)c->lw[tail_from - 1] * c->lh[tail_from - 1] <= TAIL_MAX_PX &&
+               c->n_bands - (tail_from - 1) <= TAIL_MAX_LEVELS)
+            --tail_from;
+    }
+    TailArgs* ta = nullptr;
+    std::vector<char> ta_mem;
+    if (tail_from < c->n_bands) {
+        ta_mem.assign(sizeof(TailArgs), 0);
+        ta = reinterpret_cast<TailArgs*>(ta_mem.data());
+    }
     for (int b = 0; b < c->n_bands; ++b) {
         const bool big = (long long)c->lw[b] * c->lh[b] >= 1500000;
-        if (fuse_ok && (big || fuse_mode == 1) && b + 1 < c->n_bands && c->lw[b + 1] >= 4 && c->lh[b + 1] >= 4 &&
+        if (fuse_ok && b + 1 < tail_from && (big || fuse_mode == 1) && b + 1 < c->n_bands && c->lw[b + 1] >= 4 && c->lh[b + 1] >= 4 &&
             c->lw[b + 2] >= 2 && c->lh[b + 2] >= 2) {
             Band2Args a;
             memset(&a, 0, sizeof(a));
@@ -836,7 +987,9 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
         a.wc = c->lw[b + 1];
         a.hc = c->lh[b + 1];
         a.n_strips = band_strips(a.wc);
-        chunking(a.hc, a.n_strips, n, c->wave_capacity, a.n_chunks, a.cr);
+        const bool in_tail = b >= tail_from;
+        if (in_tail) chunking(a.hc, a.n_strips, 1, TAIL_WPT, a.n_chunks, a.cr);      // one frame on the waves of one workgroup
+        else chunking(a.hc, a.n_strips, n, c->wave_capacity, a.n_chunks, a.cr);
         a.band_mul = (b == 0) ? 1.0f : 2.0f;                 // lpyr.get_band, fvvdp_lpyr_dec.py:57-63
         a.csf = c->csf + (size_t)b * FVVDP_LUT_N;
         a.csf_y = c->csf_y;
@@ -904,10 +1057,12 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
         if (nblk > c->max_blk[b]) return fail(FVVDP_ESTATE, "internal: partial buffer too small");
         a.n_items = nblk * n;
         {   // LUT slice in LDS if it fits next to the row table (64 KB of dynamic LDS without opting in to more)
-            const size_t lut_b = (size_t)FVVDP_LUT_N * FVVDP_LUT_N * c->sub_rw[b] * sizeof(float4);
-            a.lut_lds = (fov && lut_b <= 48 * 1024 && lut_b + (size_t)c->lh[b] * sizeof(float) <= 64 * 1024) ? 1 : 0;
+            const size_t lut_b = (size_t)FOV_PLANE * c->sub_rw[b] * sizeof(float4);       // 18.6 KB per rho interval
+            a.lut_lds = (fov && lut_b <= 56 * 1024 && lut_b + (size_t)c->lh[b] * sizeof(float) <= 64 * 1024) ? 1 : 0;
         }
-        {
+        if (in_tail) {
+            ta->band[b - tail_from] = a;
+        } else {
             Timed tm(c, 1 + b, st);
             if (c->P == 4) launch_band<4>(a, nblk * n, dbg, fov, st);
             else launch_band<2>(a, nblk * n, dbg, fov, st);
@@ -924,13 +1079,41 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
     fa.q_col0 = q_col0;
     fa.tc = c->P / 2;
     fa.inv_beta = 1.0f / c->prm.beta;
-    {
-        Timed tm(c, 1 + c->n_bands, st);
-        const int total = c->n_bands * 2 * n;
-        hipLaunchKernelGGL(finalize_kernel, dim3(total), dim3(64), 0, st, fa);
+    if (ta) {
+        ta->n_levels = c->n_bands - tail_from;
+        ta->fin = fa;
+        ta->do_pool = pool_now ? 1 : 0;
+        if (pool_now) fill_pool_args(ta->pool, d_Q, c->n_bands, 2, q_stride, q_stride, pool, d_jod);   // plane 1 of an image is written as 0
+        ta->ticket = c->d_ticket;
+        Timed tm(c, 1 + tail_from, st);      // reported at the first level it covers; finalize reads 0
+        if (c->P == 4) hipLaunchKernelGGL((band_tail_kernel<4>), dim3(n), dim3(64 * TAIL_WPT), 0, st, *ta);
+        else hipLaunchKernelGGL((band_tail_kernel<2>), dim3(n), dim3(64 * TAIL_WPT), 0, st, *ta);
+    } else {
+        {
+            Timed tm(c, 1 + c->n_bands, st);
+            const int total = c->n_bands * 2 * n;
+            hipLaunchKernelGGL(finalize_kernel, dim3(total), dim3(64), 0, st, fa);
+        }
+        if (pool_now) {
+            PoolArgs pa;
+            fill_pool_args(pa, d_Q, c->n_bands, 2, q_stride, q_stride, pool, d_jod);
+            hipLaunchKernelGGL(pool_jod_kernel, dim3(1), dim3(256), 0, st, pa);
+        }
     }
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;
+}
+
+extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
+                                   const fvvdp_geom* geom, const fvvdp_band_maps* maps, void* stream) {
+    return bands_forward_core(c, n, d_Q, q_stride, q_col0, h_fixation, geom, maps, nullptr, nullptr, stream);
+}
+
+extern "C" int fvvdp_bands_forward_pool(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
+                                        const fvvdp_geom* geom, const fvvdp_band_maps* maps, const fvvdp_pool_params* pool,
+                                        float* d_jod, void* stream) {
+    if (!pool) return fail(FVVDP_EINVAL, "null argument");
+    return bands_forward_core(c, n, d_Q, q_stride, q_col0, h_fixation, geom, maps, pool, d_jod, stream);
 }
 
 extern "C" int fvvdp_ctx_set_view_maps(fvvdp_ctx* c, int band, const float* d_view_x, const float* d_view_y,
@@ -960,22 +1143,12 @@ extern "C" int fvvdp_pool_jod(const float* d_Q, int n_bands, int n_channels, int
     if (!d_Q || !prm || !d_jod) return fail(FVVDP_EINVAL, "null argument");
     if (n_bands < 1 || n_frames < 1 || q_stride < n_frames) return fail(FVVDP_EINVAL, "bad Q_per_ch shape");
     if (n_channels != 1 && n_channels != 2) return fail(FVVDP_EINVAL, "n_channels must be 1 (image) or 2 (video)");
-    if (!(prm->beta_sch > 0.0f) || !(prm->beta_tch > 0.0f) || !(prm->beta_t > 0.0f) || !(prm->beta_jod > 0.0f))
-        return fail(FVVDP_EINVAL, "pooling exponents must be positive");
+    {
+        int rc = check_pool_params(prm);
+        if (rc != FVVDP_OK) return rc;
+    }
     PoolArgs a;
-    memset(&a, 0, sizeof(a));
-    a.Q = d_Q;
-    a.n_bands = n_bands;
-    a.n_ch = n_channels;
-    a.n_frames = n_frames;
-    a.q_stride = q_stride;
-    a.beta_sch = prm->beta_sch;
-    a.beta_tch = prm->beta_tch;
-    a.beta_t = prm->beta_t;
-    a.w_transient = prm->w_transient;
-    a.jod_a = prm->jod_a;
-    a.beta_jod = prm->beta_jod;
-    a.out = d_jod;
+    fill_pool_args(a, d_Q, n_bands, n_channels, n_frames, q_stride, prm, d_jod);
     hipLaunchKernelGGL(pool_jod_kernel, dim3(1), dim3(256), 0, reinterpret_cast<hipStream_t>(stream), a);
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;

@@ -593,9 +593,15 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
                 prefetch(FL - 1 + t + TD, nx[u % TD][0], nx[u % TD][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            v2f accS[PX], accT[PX];                  // (test, reference) of the sustained / the transient channel
+            // (test, reference) of the sustained / the transient channel.  With one pixel per lane (64-slot ring) the two sums
+            // would be two dependent chains of 64 multiply-adds each -- latency-bound (an s_nop between every pair); the taps
+            // are split into NS interleaved partial sums per channel there (even / odd taps), added at the end.
+            constexpr int NS = PX == 1 ? 2 : 1;
+            v2f accS[NS][PX], accT[NS][PX];
 #pragma unroll
-            for (int i = 0; i < PX; ++i) accS[i] = accT[i] = v2f{0.0f, 0.0f};
+            for (int q = 0; q < NS; ++q)
+#pragma unroll
+                for (int i = 0; i < PX; ++i) accS[q][i] = accT[q][i] = v2f{0.0f, 0.0f};
             // Taps: TAPC at a time from the kernel-argument segment (scalar cache), oldest first like the reference's sum over the
             // window.  Long filters reload them in every step -- the pointer is laundered so that the loads cannot be hoisted out
             // of the frame loop, where 2*FL scalar values would have to stay alive next to everything else (spills).
@@ -615,14 +621,21 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
                     const int sl = (u - k + 2 * FL) % FL;
                     const v2f f = v2f{tc[2 * kk], tc[2 * kk + 1]};
 #pragma unroll
-                    for (int i = 0; i < PX; ++i) fir_tap(accS[i], accT[i], ring[sl][i], f);
+                    for (int i = 0; i < PX; ++i) fir_tap(accS[k % NS][i], accT[k % NS][i], ring[sl][i], f);
+                }
+            }
+            if constexpr (NS == 2) {
+#pragma unroll
+                for (int i = 0; i < PX; ++i) {
+                    accS[0][i] += accS[1][i];
+                    accT[0][i] += accT[1][i];
                 }
             }
             // transpose through LDS: lane l holds pixels l*PX..l*PX+PX-1, store i writes pixels i*64+l
             wave_lds_order();
 #pragma unroll
             for (int i = 0; i < PX; ++i)
-                s_t[lane * (PX + 1) + i] = make_float4(accS[i].x, accS[i].y, accT[i].x, accT[i].y);
+                s_t[lane * (PX + 1) + i] = make_float4(accS[0][i].x, accS[0][i].y, accT[0][i].x, accT[0][i].y);
             wave_lds_order();
             // the frame number is laundered: otherwise the FL per-step offsets j * HW * 16 (64 bit each) are pre-computed outside
             // the loop and, in the long rings, spilled

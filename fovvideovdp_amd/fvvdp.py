@@ -276,6 +276,9 @@ class fvvdp:
 
         if schedule is None:
             schedule = [min(batch, f1 - b0) for b0 in range(f0, f1, batch)]
+        # pooling + JOD regression (do_pooling_and_jods, fvvdp.py:337-357) ride on the last batch
+        pp = nat.PoolParams(self.beta_sch, self.beta_tch, self.beta_t, self.w_transient, self.jod_a,
+                            float(10.0 ** self.log_jod_exp))
         b0 = f0
         for nb in schedule:
             idx = np.ascontiguousarray(widx[b0:b0 + fl - 1 + nb])          # history + newest frames of this batch
@@ -298,19 +301,18 @@ class fvvdp:
                     self._set_view_maps(ctx, n_bands, width, height)
                     fxa = self._gaze_view_dirs(fxa, width, height)
                 fx = nat.fptr(fxa)
-            nat.check(nat.lib().fvvdp_bands_forward(ctx.handle, nb, C.c_void_p(Q.data_ptr()), n_out, b0 - f0,
-                                                    fx, g, maps_arr, stream))
+            if pool and b0 + nb == f1:               # the batch that completes the clip also pools (one launch fewer)
+                nat.check(nat.lib().fvvdp_bands_forward_pool(ctx.handle, nb, C.c_void_p(Q.data_ptr()), n_out, b0 - f0,
+                                                             fx, g, maps_arr, C.byref(pp), C.c_void_p(res[nq + 1:].data_ptr()),
+                                                             stream))
+            else:
+                nat.check(nat.lib().fvvdp_bands_forward(ctx.handle, nb, C.c_void_p(Q.data_ptr()), n_out, b0 - f0,
+                                                        fx, g, maps_arr, stream))
             if self.do_heatmap:
                 self._heatmap_batch(ctx, nb, dmaps, planes, width, height, stream, heatmap, b0 - f0)
             b0 += nb
 
-        Q_jod = None
-        if pool:                                             # pooling + JOD regression in one small kernel
-            pp = nat.PoolParams(self.beta_sch, self.beta_tch, self.beta_t, self.w_transient, self.jod_a,
-                                float(10.0 ** self.log_jod_exp))
-            nat.check(nat.lib().fvvdp_pool_jod(C.c_void_p(Q.data_ptr()), n_bands, 2, n_out, n_out, C.byref(pp),
-                                               C.c_void_p(res[nq + 1:].data_ptr()), stream))
-            Q_jod = res[nq + 1]
+        Q_jod = res[nq + 1] if pool else None                 # pooled with the last batch (fvvdp_bands_forward_pool)
         stats = {}
         if sync:
             res_h = res.detach().cpu()                       # the one host synchronisation of the call

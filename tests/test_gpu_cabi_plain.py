@@ -85,6 +85,15 @@ def test_video_path_through_the_c_abi_only():
         assert hip.hipMemcpy(Q.ctypes.data_as(C.c_void_p), d_Q, Q.nbytes, D2H) == 0
         assert hip.hipMemcpy(jod.ctypes.data_as(C.c_void_p), d_jod, 4, D2H) == 0
         assert hip.hipMemcpy(flag.ctypes.data_as(C.c_void_p), d_flag, 4, D2H) == 0
+        # the same two stages through the combined entry point: bit-identical JOD and Q
+        assert hip.hipMemset(d_jod, 0, 4) == 0
+        nat.check(lib.fvvdp_bands_forward_pool(ctx, N, d_Q, N, 0, None, None, None, C.byref(pp), d_jod, stream))
+        assert hip.hipStreamSynchronize(stream) == 0
+        Q2 = np.zeros_like(Q)
+        jod2 = np.zeros(1, dtype=np.float32)
+        assert hip.hipMemcpy(Q2.ctypes.data_as(C.c_void_p), d_Q, Q2.nbytes, D2H) == 0
+        assert hip.hipMemcpy(jod2.ctypes.data_as(C.c_void_p), d_jod, 4, D2H) == 0
+        assert np.array_equal(Q2, Q) and jod2[0] == jod[0]
     finally:
         if ctx:
             lib.fvvdp_ctx_destroy(ctx)
