@@ -64,6 +64,7 @@ struct fvvdp_ctx {
     int lw[FVVDP_MAX_BANDS + 1]{}, lh[FVVDP_MAX_BANDS + 1]{};
     float* level[FVVDP_MAX_BANDS + 1]{};
     float* level0_raw = nullptr;  // what dev_alloc returned for level 0 (level[0] may start later, FVVDP_L0_OFFSET_KB)
+    size_t level0_slack = 0;      // floats of extra room behind level 0 (FVVDP_L0_SLACK_MB, placement experiments)
     float* partial = nullptr;
     long long partial_off[FVVDP_MAX_BANDS]{};
     int max_blk[FVVDP_MAX_BANDS]{};
@@ -210,6 +211,15 @@ static void vmm_free_all(fvvdp_ctx* c) {
     c->vmm.clear();
 }
 
+// placement experiments: level 0 starts FVVDP_L0_OFFSET_KB into its allocation (only with FVVDP_L0_SLACK_MB at creation)
+static void place_level0(fvvdp_ctx* c) {
+    if (!c || !c->level0_slack) return;
+    size_t shift = 0;
+    if (const char* e = getenv("FVVDP_L0_OFFSET_KB")) shift = (size_t)atoll(e) * 1024 / sizeof(float);
+    if (shift > c->level0_slack) shift = c->level0_slack;
+    c->level[0] = c->level0_raw + shift;
+}
+
 // strips cover coarse columns [0,62), [62,122), ... (see band_kernel)
 static int band_strips(int wc) { return wc <= 62 ? 1 : 1 + (wc - 62 + STRIP_J - 1) / STRIP_J; }
 
@@ -283,18 +293,18 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
     }
     int rc = FVVDP_OK;
     for (int i = 0; i <= n_bands && rc == FVVDP_OK; ++i) {
-        size_t slack = 0, shift = 0;
+        size_t slack = 0;
         if (i == 0) {
-            // placement experiments (tools/gpu_k1_placement.py): level 0 starts FVVDP_L0_OFFSET_KB into its allocation
-            if (const char* e = getenv("FVVDP_L0_OFFSET_KB")) {
-                shift = (size_t)atoll(e) * 1024 / sizeof(float);
-                slack = shift + 4096;
-            }
+            // placement experiments (tools/gpu_k1_offset_sweep.py): FVVDP_L0_SLACK_MB of extra room behind level 0, inside
+            // which FVVDP_L0_OFFSET_KB (read at every call) moves the start of the level without a new allocation
+            if (const char* e = getenv("FVVDP_L0_SLACK_MB")) slack = (size_t)atoll(e) * (1u << 20) / sizeof(float);
         }
         rc = dev_alloc(c, &c->level[i], (size_t)max_frames * c->lw[i] * c->lh[i] * planes + slack);
         if (rc == FVVDP_OK && i == 0) {
             c->level0_raw = c->level[0];
-            c->level[0] += shift;
+            c->level0_slack = slack;
+            if (getenv("FVVDP_DEBUG_ALLOC")) fprintf(stderr, "fvvdp: level 0 allocation %p, %zu bytes per frame slot\n",
+                                                     (void*)c->level0_raw, (size_t)c->lw[0] * c->lh[0] * planes * 4);
         }
     }
     size_t off = 0;
@@ -464,6 +474,7 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
     if (eotf->kind != FVVDP_EOTF_LUT && dtype == FVVDP_U8) return fail(FVVDP_EINVAL, "uint8 sources need FVVDP_EOTF_LUT (uint16: table or closed form)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int HW = c->W * c->H;
+    place_level0(c);
     Timed tm(c, 0, st);
     // register-ring kernels: up to 32 taps for every sample type, up to 64 taps (129-256 fps) for the cases of k1_ring64_ok()
     // (uint8; 16-bit / float RGB behind an sRGB or PQ display; float luminance frames); the 1-pixel-per-lane ring needs no alignment.  The 64-slot ring is not instantiated
@@ -884,6 +895,7 @@ static int bands_forward_core(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int
         if (rc != FVVDP_OK) return rc;
     }
     const bool pool_now = pool && (q_col0 + n == q_stride);      // this call completes the clip
+    place_level0(c);
     if (n < 1 || n > c->max_frames) return fail(FVVDP_EINVAL, "n=%d exceeds max_frames=%d", n, c->max_frames);
     if (q_col0 < 0 || q_col0 + n > q_stride) return fail(FVVDP_EINVAL, "Q columns out of range");
     const bool fov = h_fixation != nullptr;
@@ -911,13 +923,13 @@ static int bands_forward_core(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int
     const char* fuse_env = getenv("FVVDP_BAND_FUSE");
     const int fuse_mode = (fuse_env && (fuse_env[0] == '0' || fuse_env[0] == '1')) ? fuse_env[0] - '0' : -1;   // anything else: automatic
     const bool fuse_ok = !fov && !any_maps && fuse_mode != 0;
-    // The small end of the pyramid, the finalisation and (when asked) the pooling in one launch (band_tail_kernel): plain
-    // evaluation of a batch of frames only -- a workgroup per frame needs frames to run side by side; for a few frames the
-    // per-level launches, which spread ONE frame over the chip, are faster.  FVVDP_BAND_TAIL=0 / 1: never / wherever valid.
+    // The small end of the pyramid, the finalisation and (when asked) the pooling in ONE launch (band_tail_kernel, one
+    // workgroup per frame): built for VERDICT r2 item 7, measured slower than the per-level launches in every variant (see
+    // tail_kernel.hpp), therefore OFF unless FVVDP_BAND_TAIL=1 (then: every level of <= TAIL_MAX_PX pixels, plain evaluation).
     const char* tail_env = getenv("FVVDP_BAND_TAIL");
-    const int tail_mode = (tail_env && (tail_env[0] == '0' || tail_env[0] == '1')) ? tail_env[0] - '0' : -1;
+    const bool tail_on = tail_env && tail_env[0] == '1';
     int tail_from = c->n_bands;          // first level of the tail launch (n_bands: no tail)
-    if (!fov && !any_maps && tail_mode != 0 && (n >= 24 || tail_mode == 1)) {
+    if (!fov && !any_maps && tail_on) {
         while (tail_from > 0 && (long long)c->lw[tail_from - 1] * c->lh[tail_from - 1] <= TAIL_MAX_PX &&
                c->n_bands - (tail_from - 1) <= TAIL_MAX_LEVELS)
             --tail_from;

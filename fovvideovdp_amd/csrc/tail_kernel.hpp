@@ -1,23 +1,34 @@
 // The small end of the pyramid in ONE launch.  Included by fvvdp_hip.hip after band_kernel.hpp and aux_kernels.hpp.
 #pragma once
 // ------------------------------------------------------------------------------------------------------------
-// band_tail_kernel: pyramid levels whose frames are small (<= TAIL_MAX_PX pixels: at 4K levels 3..6), the pooled-sum
-// finalisation of ALL bands and -- when the caller asks for it and this launch completes the clip -- the band / channel /
-// frame pooling with the JOD regression (do_pooling_and_jods, fvvdp.py:337-357).
+// band_tail_kernel: the pyramid levels whose frames are small (<= TAIL_MAX_PX pixels), the pooled-sum finalisation of ALL
+// bands and -- when the caller asks for it and this launch completes the clip -- the band / channel / frame pooling with the
+// JOD regression (do_pooling_and_jods, fvvdp.py:337-357).  One workgroup of TAIL_WPT waves owns ONE frame and walks its
+// levels in order: level i+1 is written by this workgroup and read back by it after a workgroup barrier (same CU), the
+// frames run side by side on different CUs.  The per-item code is band_kernel's (band_item), so the numbers differ from the
+// per-level launches only through the grouping of the partial sums (different chunk heights).
 //
-// Why: each of these was a launch of its own (4K x60: levels 3-6 42 + 16 + 7 + 6 us, finalize 4 us, pooling 10 us, and a
-// few microseconds of gap between dependent launches): latency-sized kernels that cannot fill the chip.  Here one workgroup
-// of WPT waves owns ONE frame and walks its levels in order -- level i+1 is written by this workgroup and read back by it
-// after a workgroup barrier (same CU: the data goes through its own L1 / the XCD's L2), the frames run side by side on
-// different CUs.  The per-item code is band_kernel's (band_item), so the numbers differ from the per-level launches only
-// through the grouping of the partial sums (different chunk heights).
+// STATUS: an experiment that did NOT pay (VERDICT r2 item 7 asked for it; profiles/r03_tail_launch.md has the numbers), kept
+// behind FVVDP_BAND_TAIL=1 and covered by tests.  The idea was to replace latency-sized launches (4K x60: levels 3-6 42 + 16 +
+// 7 + 6 us, finalize 4 us, pooling 10 us) by one.  What the measurements say:
+//   * levels 3-6 in the tail, 16 waves per frame: 195 us per launch against 88 us for the four per-level launches.  A frame's
+//     levels 3-6 are ~120 us of VALU work for ONE CU, and 60 frames occupy 60 of the 256 CUs; the per-level launches spread
+//     every level over the whole chip.
+//   * levels 5-6 only (120x68, 60x34) + finalize + pooling: 57 us with 16 waves (16 chunks per level: the 8 halo rows of a chunk
+//     dominate), 49 us with 4 waves (one per SIMD: no other wave hides the load latency of the dependent row chain), against
+//     26 us + the 10 us pooling launch.  End to end 4.63-4.68 ms per 4K x60 pair against 4.59-4.62 ms.
+// The small levels are not launch-bound enough: a level is a chain of dependent row steps, and only the per-level launches
+// run all frames' chains of ONE level on all CUs at once.
 //
 // Pooling: every workgroup publishes its frame's Q, then takes a ticket (device-scope atomic after a device-scope release
 // fence); the workgroup that draws the last ticket acquires and pools all frames.  No workgroup waits for another one.
 // ------------------------------------------------------------------------------------------------------------
 #define TAIL_MAX_LEVELS 6
 #define TAIL_MAX_PX 160000
-#define TAIL_WPT 16                     // waves per workgroup (band_item<4, false, 0>: 124 VGPRs -> 4 waves per SIMD)
+#ifndef TAIL_WPT
+#define TAIL_WPT 4                      // waves per workgroup: one per SIMD.  The work of a frame is VALU-bound on ITS CU, so more
+                                        // waves only add halo rows (16 waves, 16 chunks per level: 57 us per 4K x60 launch)
+#endif
 
 struct TailArgs {
     BandArgs band[TAIL_MAX_LEVELS];

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a
         px[i] = ok[i] ? q : a.HW - 1;
     }
     const float w[3] = {a.C == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};
-    bool bad = false;
+    OobMax bad;
     float ring[2][FL][PX];
 #pragma unroll
     for (int u = 0; u < FL; ++u)
@@ -386,11 +386,17 @@ __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a
                     float acc[4][PX];
 #pragma unroll
                     for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
-                    // oldest tap first, like the reference's sum over the window dimension
+                    // oldest tap first, like the reference's sum over the window dimension.  The taps are re-read from the
+                    // kernel-argument segment in every step (laundered pointer): hoisted out of the frame loop, 2*FL scalar values
+                    // stay alive across it and spill
+                    typedef const float __attribute__((address_space(4)))* karg_f_p;
+                    karg_f_p tp = (karg_f_p)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                             offsetof(TemporalArgs, taps2));
+                    asm volatile("" : "+s"(tp));
 #pragma unroll
                     for (int k = FL - 1; k >= 0; --k) {
                         const int sl = (u - k + 2 * FL) % FL;
-                        const float f0 = a.taps2[k][0], f1 = a.taps2[k][1];
+                        const float f0 = tp[2 * k], f1 = tp[2 * k + 1];
 #pragma unroll
                         for (int i = 0; i < PX; ++i) {
                             acc[0][i] = fmaf(ring[0][sl][i], f0, acc[0][i]);
@@ -408,7 +414,7 @@ __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a
             }
         }
     }
-    if (bad && a.oob) atomicOr(a.oob, 1);
+    if (is_oob(bad) && a.oob) atomicOr(a.oob, 1);
 }
 
 // ---- vector variant of the temporally tiled FIR (the fast path) -------------------------------------------------
@@ -593,15 +599,9 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
                 prefetch(FL - 1 + t + TD, nx[u % TD][0], nx[u % TD][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            // (test, reference) of the sustained / the transient channel.  With one pixel per lane (64-slot ring) the two sums
-            // would be two dependent chains of 64 multiply-adds each -- latency-bound (an s_nop between every pair); the taps
-            // are split into NS interleaved partial sums per channel there (even / odd taps), added at the end.
-            constexpr int NS = PX == 1 ? 2 : 1;
-            v2f accS[NS][PX], accT[NS][PX];
+            v2f accS[PX], accT[PX];                  // (test, reference) of the sustained / the transient channel
 #pragma unroll
-            for (int q = 0; q < NS; ++q)
-#pragma unroll
-                for (int i = 0; i < PX; ++i) accS[q][i] = accT[q][i] = v2f{0.0f, 0.0f};
+            for (int i = 0; i < PX; ++i) accS[i] = accT[i] = v2f{0.0f, 0.0f};
             // Taps: TAPC at a time from the kernel-argument segment (scalar cache), oldest first like the reference's sum over the
             // window.  Long filters reload them in every step -- the pointer is laundered so that the loads cannot be hoisted out
             // of the frame loop, where 2*FL scalar values would have to stay alive next to everything else (spills).
@@ -621,21 +621,14 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
                     const int sl = (u - k + 2 * FL) % FL;
                     const v2f f = v2f{tc[2 * kk], tc[2 * kk + 1]};
 #pragma unroll
-                    for (int i = 0; i < PX; ++i) fir_tap(accS[k % NS][i], accT[k % NS][i], ring[sl][i], f);
-                }
-            }
-            if constexpr (NS == 2) {
-#pragma unroll
-                for (int i = 0; i < PX; ++i) {
-                    accS[0][i] += accS[1][i];
-                    accT[0][i] += accT[1][i];
+                    for (int i = 0; i < PX; ++i) fir_tap(accS[i], accT[i], ring[sl][i], f);
                 }
             }
             // transpose through LDS: lane l holds pixels l*PX..l*PX+PX-1, store i writes pixels i*64+l
             wave_lds_order();
 #pragma unroll
             for (int i = 0; i < PX; ++i)
-                s_t[lane * (PX + 1) + i] = make_float4(accS[0][i].x, accS[0][i].y, accT[0][i].x, accT[0][i].y);
+                s_t[lane * (PX + 1) + i] = make_float4(accS[i].x, accS[i].y, accT[i].x, accT[i].y);
             wave_lds_order();
             // the frame number is laundered: otherwise the FL per-step offsets j * HW * 16 (64 bit each) are pre-computed outside
             // the loop and, in the long rings, spilled
@@ -749,8 +742,8 @@ struct YuvArgs {
     int idx[T_MAX_IDX];
 };
 
-template <typename T>
-__device__ __forceinline__ float yuv_lum(const T* __restrict__ f, const YuvArgs& a, int p, bool& bad) {
+template <typename T, typename B>
+__device__ __forceinline__ float yuv_lum(const T* __restrict__ f, const YuvArgs& a, int p, B& bad) {
     const int HW = a.W * a.H;
     const int y = p / a.W, x = p - y * a.W;
     const float Yf = fminf(fmaxf(a.wy * (float)f[p] - (16.0f / 219.0f), 0.0f), 1.0f);
@@ -794,7 +787,7 @@ __global__ __launch_bounds__(256) void temporal_yuv_kernel(const YuvArgs a) {
         ok[i] = q < HW;
         px[i] = ok[i] ? q : HW - 1;
     }
-    bool bad = false;
+    OobMax bad;
     float ring[2][FL][PX];
 #pragma unroll
     for (int u = 0; u < FL; ++u)
@@ -818,10 +811,14 @@ __global__ __launch_bounds__(256) void temporal_yuv_kernel(const YuvArgs a) {
                     float acc[4][PX];
 #pragma unroll
                     for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
+                    typedef const float __attribute__((address_space(4)))* karg_f_p;      // see temporal_ring_kernel
+                    karg_f_p tp = (karg_f_p)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
+                                             offsetof(YuvArgs, taps2));
+                    asm volatile("" : "+s"(tp));
 #pragma unroll
                     for (int k = FL - 1; k >= 0; --k) {
                         const int sl = (u - k + 2 * FL) % FL;
-                        const float t0 = a.taps2[k][0], t1 = a.taps2[k][1];
+                        const float t0 = tp[2 * k], t1 = tp[2 * k + 1];
 #pragma unroll
                         for (int i = 0; i < PX; ++i) {
                             acc[0][i] = fmaf(ring[0][sl][i], t0, acc[0][i]);
@@ -839,7 +836,7 @@ __global__ __launch_bounds__(256) void temporal_yuv_kernel(const YuvArgs a) {
             }
         }
     }
-    if (bad && a.oob) atomicOr(a.oob, 1);
+    if (is_oob(bad) && a.oob) atomicOr(a.oob, 1);
 }
 
 // ---- vector variant of the YUV ingest (the fast path for W % 4 == 0) -----------------------------------------------
@@ -1118,12 +1115,16 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
             for (int i = 0; i < PX; ++i) acc_s[i] = acc_t[i] = splat(0.0f);
             karg_p tp = (karg_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(YuvArgs, taps2);
             if constexpr (FL > 8) asm volatile("" : "+s"(tp));      // reloaded per frame, see temporal_vec_body
+            // two taps per scalar load: this kernel has the colour matrix, the display model and the chroma weights in scalar
+            // registers next to the taps
+            typedef float v4tap __attribute__((ext_vector_type(4), aligned(4)));
+            typedef const v4tap __attribute__((address_space(4)))* karg_tap4_p;
 #pragma unroll
-            for (int c = FL / TAPC - 1; c >= 0; --c) {    // oldest tap first, like the reference's sum over the window
-                const vtapf tc = *(karg_taps_p)(tp + c * (8 * TAPC));
+            for (int c = FL / 2 - 1; c >= 0; --c) {       // oldest tap first, like the reference's sum over the window
+                const v4tap tc = *(karg_tap4_p)(tp + c * 16);
 #pragma unroll
-                for (int kk = TAPC - 1; kk >= 0; --kk) {
-                    const int k = c * TAPC + kk;
+                for (int kk = 1; kk >= 0; --kk) {
+                    const int k = c * 2 + kk;
                     const v2f f = v2f{tc[2 * kk], tc[2 * kk + 1]};
 #pragma unroll
                     for (int i = 0; i < PX; ++i) fir_tap(acc_s[i], acc_t[i], win[FL - 1 - k][i], f);
@@ -1154,20 +1155,16 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
 #ifndef YUV_WAVES16
 #define YUV_WAVES16 2
 #endif
-template <int FL, typename T, bool C420>
-__global__ __launch_bounds__(64, (FL == 8 ? ((sizeof(T) == 2 && !C420) ? 2 : YUV_WAVES8) : YUV_WAVES16))     // 16-bit 4:4:4: 8 raw dwords per frame pair more
+// KIND = display model (compile-time: the host picks the instantiation): one loop body per kernel.  With a switch over the six
+// bodies inside one kernel, scalar values of the prologue stayed alive across all of them and spilled (8 SGPRs in the 16-slot
+// 4:2:0 kernels).
+template <int FL, typename T, bool C420, int KIND>
+__global__ __launch_bounds__(64, (FL == 8 ? (((sizeof(T) == 2 && !C420) || KIND == FVVDP_EOTF_PQ) ? 2 : YUV_WAVES8) : YUV_WAVES16))     // 16-bit 4:4:4: 8 raw dwords per frame pair more; PQ: the longest display model
 void temporal_yuv_vec_kernel(const YuvArgs a_byval) {
     const YuvArgs& a = *(const YuvArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // see temporal_vec_kernel
     (void)a_byval;
     __shared__ float4 s_t[64 * (4 + 1)];
-    switch (a.e.kind) {
-        case FVVDP_EOTF_SRGB: temporal_yuv_vec_body<FL, T, C420, FVVDP_EOTF_SRGB>(a, s_t); break;
-        case FVVDP_EOTF_GAMMA: temporal_yuv_vec_body<FL, T, C420, FVVDP_EOTF_GAMMA>(a, s_t); break;
-        case FVVDP_EOTF_PQ: temporal_yuv_vec_body<FL, T, C420, FVVDP_EOTF_PQ>(a, s_t); break;
-        case FVVDP_EOTF_LINEAR: temporal_yuv_vec_body<FL, T, C420, FVVDP_EOTF_LINEAR>(a, s_t); break;
-        case FVVDP_EOTF_ABSOLUTE: temporal_yuv_vec_body<FL, T, C420, FVVDP_EOTF_ABSOLUTE>(a, s_t); break;
-        default: temporal_yuv_vec_body<FL, T, C420, FVVDP_EOTF_NONE>(a, s_t); break;
-    }
+    temporal_yuv_vec_body<FL, T, C420, KIND>(a, s_t);
 }
 
 // Generic (any fl, any frame size) version: one thread per pixel per output frame, the window is re-read from

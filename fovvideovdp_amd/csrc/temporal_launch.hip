@@ -94,16 +94,28 @@ static void launch_yuv(int bytes, const YuvArgs& a, hipStream_t st) {
     if (bytes == 1) hipLaunchKernelGGL((temporal_yuv_kernel<FL, PX, unsigned char>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((temporal_yuv_kernel<FL, PX, unsigned short>), grid, block, 0, st, a);
 }
+template <int FL, typename T, bool C420>
+static void launch_yuv_vec_kind(const YuvArgs& a, dim3 grid, hipStream_t st) {
+    const dim3 block(64);
+    switch (a.e.kind) {          // the display model is a template constant of the kernel
+        case FVVDP_EOTF_SRGB: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_SRGB>), grid, block, 0, st, a); break;
+        case FVVDP_EOTF_GAMMA: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_GAMMA>), grid, block, 0, st, a); break;
+        case FVVDP_EOTF_PQ: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_PQ>), grid, block, 0, st, a); break;
+        case FVVDP_EOTF_LINEAR: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_LINEAR>), grid, block, 0, st, a); break;
+        case FVVDP_EOTF_ABSOLUTE: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_ABSOLUTE>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_NONE>), grid, block, 0, st, a); break;
+    }
+}
 template <int FL>
 static void launch_yuv_vec(int bytes, bool c420, const YuvArgs& a, hipStream_t st) {
     const int HW = a.W * a.H;
-    dim3 grid((HW / 4 + YUV_QUADS - 1) / YUV_QUADS), block(64);
+    dim3 grid((HW / 4 + YUV_QUADS - 1) / YUV_QUADS);
     if (bytes == 1) {
-        if (c420) hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned char, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned char, false>), grid, block, 0, st, a);
+        if (c420) launch_yuv_vec_kind<FL, unsigned char, true>(a, grid, st);
+        else launch_yuv_vec_kind<FL, unsigned char, false>(a, grid, st);
     } else {
-        if (c420) hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned short, true>), grid, block, 0, st, a);
-        else hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, unsigned short, false>), grid, block, 0, st, a);
+        if (c420) launch_yuv_vec_kind<FL, unsigned short, true>(a, grid, st);
+        else launch_yuv_vec_kind<FL, unsigned short, false>(a, grid, st);
     }
 }
 void k1_launch_yuv_vec(int FL, int bytes, bool c420, const YuvArgs& a, hipStream_t st) {

@@ -168,16 +168,19 @@ def test_tail_launch_on_still_images_and_batches(monkeypatch):
         assert float(qb) == qa, batch
 
 
-def test_default_takes_the_tail_for_long_batches(monkeypatch):
-    """The automatic choice: batches of >= 24 frames take the tail launch for the levels of <= 160000 pixels (here: all of
-    them), shorter ones the per-level launches -- checked through the kernel timing slots (a merged level reports 0)."""
+def test_tail_launch_is_opt_in(monkeypatch):
+    """Default: per-level launches + finalize_kernel + pool_jod_kernel (the tail launch measured slower, tail_kernel.hpp);
+    FVVDP_BAND_TAIL=1 merges the levels of <= 160000 pixels -- checked through the kernel timing slots."""
     import ctypes as C
     import fovvideovdp_amd as fv
     from fovvideovdp_amd import _native as nat
-    monkeypatch.delenv("FVVDP_BAND_TAIL", raising=False)
     monkeypatch.delenv("FVVDP_BAND_FUSE", raising=False)
-    for N, merged in ((30, True), (8, False)):
-        test, ref = _pair(135, 240, 3, N)
+    test, ref = _pair(270, 480, 3, 6)
+    for env, want in ((None, [1, 1, 1, 1, 1, 1, 1]), ("1", [1, 0, 0, 0, 0, 0, 0])):
+        if env is None:
+            monkeypatch.delenv("FVVDP_BAND_TAIL", raising=False)
+        else:
+            monkeypatch.setenv("FVVDP_BAND_TAIL", env)
         m = fv.fvvdp(display_name="standard_fhd")
         m.timing = True
         q, st = m.predict(test, ref, dim_order="FHW", frames_per_second=30)
@@ -185,8 +188,5 @@ def test_default_takes_the_tail_for_long_batches(monkeypatch):
         ms = (C.c_float * 18)()
         cnt = (C.c_int32 * 18)()
         nat.check(nat.lib().fvvdp_ctx_timing_read(m._ctx.handle, ms, cnt, 18, 1))
-        finalize_launches = cnt[nb + 1]
-        assert (finalize_launches == 0) == merged, (N, [cnt[i] for i in range(nb + 2)])
-        q0, Q0, _ = _run_tail(monkeypatch, test, ref, 0, dim_order="FHW", frames_per_second=30)
-        monkeypatch.delenv("FVVDP_BAND_TAIL", raising=False)
-        assert abs(float(q) - q0) < 2e-6
+        launches = [cnt[i] for i in range(1, nb + 2)]              # levels 0 .. nb-1, finalize
+        assert nb == 6 and launches == want, (env, launches)

@@ -848,6 +848,10 @@ def test_raw_yuv_file_source(fv, tmp_path):
     """Raw planar .yuv files (properties encoded in the file name) through the fused ingest: identical to handing the
     same frames over as arrays; frame limit; 10 bit 4:4:4 BT.2020; the resize option goes through torch like the
     reference and agrees with resizing the unpacked RGB frames by hand."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("file_sources", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "file_sources.py"))
+    fs = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fs)
     from fovvideovdp_amd.synth import synth_yuv_pair
     for (N, H, W, bd, css, cs, disp, fps) in ((7, 68, 120, 8, "420", "709", "standard_fhd", 30),
                                              (5, 54, 96, 10, "444", "2020", "standard_hdr_pq", 60)):
@@ -855,12 +859,12 @@ def test_raw_yuv_file_source(fv, tmp_path):
         tn = ty.numpy() if bd == 8 else ty.numpy().astype(np.uint16)
         rn = ry.numpy() if bd == 8 else ry.numpy().astype(np.uint16)
         props = dict(width=W, height=H, bit_depth=bd, color_space=cs, chroma_ss=css, fps=fps)
-        tf = str(tmp_path / fv.create_yuv_fname("test", props))
-        rf = str(tmp_path / fv.create_yuv_fname("ref", props))
+        tf = str(tmp_path / fs.create_yuv_fname("test", props))
+        rf = str(tmp_path / fs.create_yuv_fname("ref", props))
         tn.tofile(tf)
         rn.tofile(rf)
         m = fv.fvvdp(display_name=disp)
-        vs_file = fv.fvvdp_video_source_yuv_file(tf, rf, display_photometry=m.display_photometry)
+        vs_file = fs.fvvdp_video_source_yuv_file(tf, rf, display_photometry=m.display_photometry)
         assert tuple(vs_file.get_video_size()) == (H, W, N) and vs_file.get_frames_per_second() == fps
         q_f, s_f = m.predict_video_source(vs_file)
         vs_arr = fv.fvvdp_video_source_yuv_frames(ty, ry, fps, W, H, bit_depth=bd, chroma_ss=css,
@@ -868,10 +872,10 @@ def test_raw_yuv_file_source(fv, tmp_path):
                                                   display_photometry=m.display_photometry)
         q_a, s_a = m.predict_video_source(vs_arr)
         assert float(q_f) == float(q_a) and np.array_equal(s_f["Q_per_ch"], s_a["Q_per_ch"])
-        vs3 = fv.fvvdp_video_source_yuv_file(tf, rf, display_photometry=m.display_photometry, frames=3)
+        vs3 = fs.fvvdp_video_source_yuv_file(tf, rf, display_photometry=m.display_photometry, frames=3)
         assert vs3.get_video_size()[2] == 3
         # resize to twice the size, bilinear
-        vs_rs = fv.fvvdp_video_source_yuv_file(tf, rf, display_photometry=m.display_photometry, frames=3,
+        vs_rs = fs.fvvdp_video_source_yuv_file(tf, rf, display_photometry=m.display_photometry, frames=3,
                                                full_screen_resize="bilinear", resize_resolution=(2 * W, 2 * H))
         assert tuple(vs_rs.get_video_size()) == (2 * H, 2 * W, 3)
         q_r, _ = m.predict_video_source(vs_rs)
@@ -886,4 +890,4 @@ def test_raw_yuv_file_source(fv, tmp_path):
         q_m, _ = m.predict_video_source(vs_m)
         assert abs(float(q_r) - float(q_m)) < 1e-4
     with pytest.raises(FileNotFoundError):
-        fv.fvvdp_video_source_yuv_file(str(tmp_path / "missing_8x8_8b.yuv"), str(tmp_path / "missing_8x8_8b.yuv"))
+        fs.fvvdp_video_source_yuv_file(str(tmp_path / "missing_8x8_8b.yuv"), str(tmp_path / "missing_8x8_8b.yuv"))

@@ -358,7 +358,9 @@ def test_frame_sharded_call_uploads_only_its_own_frames(fv):
             assert mm.last_h2d_bytes <= 1.2 * share + halo, (pad, rank, mm.last_h2d_bytes, share, halo)
             assert mm.last_h2d_bytes >= share
             Q[:, :, f0:f1] = st["Q_per_ch"]
-        assert np.array_equal(Q, sp["Q_per_ch"]), pad
+        # the same per-pixel work; the chunk heights (grouping of the fp32 partial sums) follow the batch size
+        a, b = Q.astype(np.float64), sp["Q_per_ch"].astype(np.float64)
+        assert np.all(np.abs(a - b) <= 3e-6 * np.abs(b) + 1e-9 * np.max(b)), pad
     oq, ost = orc.Oracle("standard_fhd").predict(test.numpy(), ref.numpy(), frames_per_second=fps, frames=range(0, 10))
     o = ost["Q_per_ch"].astype(np.float64)
     assert np.all(np.abs(s_all["Q_per_ch"][:, :, :10] - o) <= 1e-3 * np.abs(o) + 1e-6 * np.max(o))
