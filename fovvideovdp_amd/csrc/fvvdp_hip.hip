@@ -65,6 +65,13 @@ struct fvvdp_ctx {
     float* level[FVVDP_MAX_BANDS + 1]{};
     float* level0_raw = nullptr;  // what dev_alloc returned for level 0 (level[0] may start later, FVVDP_L0_OFFSET_KB)
     size_t level0_slack = 0;      // floats of extra room behind level 0 (FVVDP_L0_SLACK_MB, placement experiments)
+    size_t level0_floats = 0;     // size of the level-0 allocation
+    int place_phase = 0;          // online placement selection of level 0 (temporal_channels_core): 0 first call, 1 time the
+                                  // incumbent, 2 run + time a candidate, 3 decide, 9 done
+    int place_tries = 0;
+    float* place_alt = nullptr;   // the incumbent buffer while a candidate is being timed
+    hipEvent_t place_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    float place_us[4] = {0, 0, 0, 0};   // (incumbent, candidate) us per frame of each comparison
     float* partial = nullptr;
     long long partial_off[FVVDP_MAX_BANDS]{};
     int max_blk[FVVDP_MAX_BANDS]{};
@@ -303,6 +310,7 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
         if (rc == FVVDP_OK && i == 0) {
             c->level0_raw = c->level[0];
             c->level0_slack = slack;
+            c->level0_floats = (size_t)max_frames * c->lw[i] * c->lh[i] * planes + slack;
             if (getenv("FVVDP_DEBUG_ALLOC")) fprintf(stderr, "fvvdp: level 0 allocation %p, %zu bytes per frame slot\n",
                                                      (void*)c->level0_raw, (size_t)c->lw[0] * c->lh[0] * planes * 4);
         }
@@ -359,6 +367,15 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
 extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     if (!c) return;
     (void)hipDeviceSynchronize();                  // nothing may still read the scratch
+    if (c->place_alt) {                            // a placement comparison was under way: two level-0 buffers exist
+        (void)hipFree(c->level[0]);                // the candidate (always from hipMalloc)
+        dev_free(c, c->place_alt);                 // the incumbent
+        c->level[0] = nullptr;
+        c->level0_raw = nullptr;
+        c->place_alt = nullptr;
+    }
+    for (auto& e : c->place_ev)
+        if (e) (void)hipEventDestroy(e);
     if (c->level0_raw) c->level[0] = c->level0_raw;
     for (int i = 0; i <= FVVDP_MAX_BANDS; ++i)
         dev_free(c, c->level[i]);
@@ -485,45 +502,131 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
     if (ring_ok) {
         const int FL = fl <= 8 ? 8 : (fl <= 16 ? 16 : (fl <= 32 ? 32 : 64));
         const int max_out = T_MAX_IDX - (FL - 1);
-        for (int t0 = 0; t0 < n_out; t0 += max_out) {
-            const int nn = (n_out - t0) < max_out ? (n_out - t0) : max_out;
-            TemporalArgs a;
-            memset(&a, 0, sizeof(a));
-            a.src[0] = d_test;
-            a.src[1] = d_ref;
-            a.chan_stride = chan_stride;
-            a.frame_stride = frame_stride;
-            a.C = C;
-            a.HW = HW;
-            a.e = make_eotf(eotf);
-            if (C == 3) { a.w[0] = h_rgb2y[0]; a.w[1] = h_rgb2y[1]; a.w[2] = h_rgb2y[2]; } else { a.w[0] = 1.0f; }
-            a.n_out = nn;
-            a.fl = fl;
-            a.out = c->level[0] + (size_t)(slot0 + t0) * HW * 4;
-            a.oob = d_oob_flag;
-            for (int k = 0; k < fl; ++k) { a.taps2[k][0] = h_taps[k]; a.taps2[k][1] = h_taps[fl + k]; }
-            // virtual time of h_frame_idx: entry (fl-1+t) is the newest frame of output t; pad older history
-            const int pad = FL - fl;
-            for (int u = 0; u < FL - 1 + nn; ++u) {
-                const int src = t0 + u - pad;         // index into h_frame_idx
-                a.idx[u] = h_frame_idx[src < 0 ? 0 : src];
-                a.idx1[u] = h_frame_idx1 ? h_frame_idx1[src < 0 ? 0 : src] : a.idx[u];
+        // output frames [t_begin, t_end) of this call into the level-0 buffer `level0`
+        auto run = [&](float* level0, int t_begin, int t_end) -> int {
+            for (int t0 = t_begin; t0 < t_end; t0 += max_out) {
+                const int nn = (t_end - t0) < max_out ? (t_end - t0) : max_out;
+                TemporalArgs a;
+                memset(&a, 0, sizeof(a));
+                a.src[0] = d_test;
+                a.src[1] = d_ref;
+                a.chan_stride = chan_stride;
+                a.frame_stride = frame_stride;
+                a.C = C;
+                a.HW = HW;
+                a.e = make_eotf(eotf);
+                if (C == 3) { a.w[0] = h_rgb2y[0]; a.w[1] = h_rgb2y[1]; a.w[2] = h_rgb2y[2]; } else { a.w[0] = 1.0f; }
+                a.n_out = nn;
+                a.fl = fl;
+                a.out = level0 + (size_t)(slot0 + t0) * HW * 4;
+                a.oob = d_oob_flag;
+                for (int k = 0; k < fl; ++k) { a.taps2[k][0] = h_taps[k]; a.taps2[k][1] = h_taps[fl + k]; }
+                // virtual time of h_frame_idx: entry (fl-1+t) is the newest frame of output t; pad older history
+                const int pad = FL - fl;
+                for (int u = 0; u < FL - 1 + nn; ++u) {
+                    const int src = t0 + u - pad;         // index into h_frame_idx
+                    a.idx[u] = h_frame_idx[src < 0 ? 0 : src];
+                    a.idx1[u] = h_frame_idx1 ? h_frame_idx1[src < 0 ? 0 : src] : a.idx[u];
+                }
+                // vector path needs the lane's PX consecutive samples to be naturally aligned
+                const int PXv = k1_px(FL, dtype);        // temporal_launch.hpp
+                const int es = dtype == FVVDP_U8 ? 1 : (dtype == FVVDP_U16 ? 2 : 4);
+                const bool vec_ok = !getenv("FVVDP_TEMPORAL_SCALAR") && (HW % PXv == 0) && (HW >= PXv) &&
+                                    (chan_stride % PXv == 0) && (frame_stride % PXv == 0) &&
+                                    (reinterpret_cast<uintptr_t>(d_test) % (size_t)(es * PXv) == 0) &&
+                                    (reinterpret_cast<uintptr_t>(d_ref) % (size_t)(es * PXv) == 0);
+                if (vec_ok) {
+                    k1_launch_vec(FL, dtype, a, st);
+                } else if (FL == 64) {
+                    // the 64-slot ring exists as the 1-pixel-per-lane vector kernel only; it needs nothing but element alignment
+                    return fail(FVVDP_EINVAL, "source pointers must be aligned to their element size");
+                } else {
+                    k1_launch_ring(FL, dtype, a, st);
+                }
             }
-            // vector path needs the lane's PX consecutive samples to be naturally aligned
-            const int PXv = k1_px(FL, dtype);        // temporal_launch.hpp
-            const int es = dtype == FVVDP_U8 ? 1 : (dtype == FVVDP_U16 ? 2 : 4);
-            const bool vec_ok = !getenv("FVVDP_TEMPORAL_SCALAR") && (HW % PXv == 0) && (HW >= PXv) &&
-                                (chan_stride % PXv == 0) && (frame_stride % PXv == 0) &&
-                                (reinterpret_cast<uintptr_t>(d_test) % (size_t)(es * PXv) == 0) &&
-                                (reinterpret_cast<uintptr_t>(d_ref) % (size_t)(es * PXv) == 0);
-            if (vec_ok) {
-                k1_launch_vec(FL, dtype, a, st);
-            } else if (FL == 64) {
-                // the 64-slot ring exists as the 1-pixel-per-lane vector kernel only; it needs nothing but element alignment
-                return fail(FVVDP_EINVAL, "source pointers must be aligned to their element size");
-            } else {
-                k1_launch_ring(FL, dtype, a, st);
+            return FVVDP_OK;
+        };
+        // Online placement selection of level 0 (OPT-IN: FVVDP_PLACEMENT_PROBE=1; no extra GPU work, a few calls into the life
+        // of a context).  The temporal
+        // kernel runs in one of two modes -- ~31.5 or ~36.5 us per 4K frame -- that are a property of WHERE the level-0
+        // allocation lies physically: stable for an allocation, unchanged by any offset inside it, alternating between
+        // consecutive allocations of the same size, the same with the virtual-memory API (profiles/r03_k1_placement.md).
+        // Short probes do not predict it (12 frames rank the buffers the wrong way round), so the real calls are the
+        // measurement: the 2nd full-batch call of a context is timed on the buffer it has, the 3rd runs on a freshly
+        // allocated one and is timed too, the 4th keeps the faster one and frees the other; if the two were within 5 % of
+        // each other (same mode) one more candidate gets the same treatment.  Results do not depend on the buffer.
+        // Off by default: over 8 contexts it took K1 from 34.1 to 32.9 us per frame on average (there are three modes, 31.5 /
+        // 34.5 / 36.5, and a candidate is as likely to be worse), while the calls that run on a fresh buffer pay its first
+        // touch (41 us per frame) and the context briefly holds level 0 twice -- bench.py gained in 1 of 3 paired runs.
+        bool timed_here = false;
+        if (slot0 == 0 && c->place_phase < 9 && c->level0_slack == 0) {
+            static const bool probe_on = [] { const char* e = getenv("FVVDP_PLACEMENT_PROBE"); return e && e[0] == '1'; }();
+            const size_t bytes = c->level0_floats * sizeof(float);
+            if (!probe_on || bytes < ((size_t)1 << 30) || c->P != 4) {
+                c->place_phase = 9;                        // small scratch (images, short or small clips): nothing to gain
+            } else if (n_out >= 16) {
+                if (c->place_phase == 0) {
+                    c->place_phase = 1;                    // first call: warm-up, not timed
+                } else if (c->place_phase == 1) {
+                    if (!c->place_ev[0] && (hipEventCreate(&c->place_ev[0]) != hipSuccess || hipEventCreate(&c->place_ev[1]) != hipSuccess ||
+                                            hipEventCreate(&c->place_ev[2]) != hipSuccess || hipEventCreate(&c->place_ev[3]) != hipSuccess)) {
+                        c->place_phase = 9;
+                    } else {
+                        (void)hipEventRecord(c->place_ev[0], st);      // the current buffer
+                        timed_here = true;
+                        c->place_phase = 2;
+                    }
+                } else if (c->place_phase == 2) {
+                    void* q = nullptr;
+                    if (hipMalloc(&q, bytes) != hipSuccess) {
+                        (void)hipGetLastError();
+                        c->place_phase = 9;
+                    } else {
+                        c->place_alt = c->level[0];                     // the incumbent waits
+                        c->level[0] = reinterpret_cast<float*>(q);      // this call (temporal kernel AND pyramid) runs on the candidate
+                        (void)hipEventRecord(c->place_ev[2], st);
+                        timed_here = true;
+                        c->place_phase = 3;
+                    }
+                } else if (c->place_phase == 3) {
+                    float t_inc = 0.0f, t_new = 0.0f;
+                    const bool ok = hipEventSynchronize(c->place_ev[3]) == hipSuccess &&
+                                    hipEventElapsedTime(&t_inc, c->place_ev[0], c->place_ev[1]) == hipSuccess &&
+                                    hipEventElapsedTime(&t_new, c->place_ev[2], c->place_ev[3]) == hipSuccess;
+                    float* incumbent = c->place_alt;
+                    float* candidate = c->level[0];
+                    const bool take_new = ok && t_new < 0.95f * t_inc;
+                    float* loser = take_new ? incumbent : candidate;
+                    c->level[0] = take_new ? candidate : incumbent;
+                    c->place_alt = nullptr;
+                    if (loser == c->level0_raw && vmm_owns(c, loser)) {
+                        // (a buffer of the virtual-memory API stays with the context until it is destroyed)
+                    } else {
+                        (void)hipFree(loser);
+                    }
+                    c->level0_raw = c->level[0];
+                    c->place_us[c->place_tries * 2] = t_inc * 1e3f / (float)n_out;
+                    c->place_us[c->place_tries * 2 + 1] = t_new * 1e3f / (float)n_out;
+                    if (getenv("FVVDP_DEBUG_ALLOC"))
+                        fprintf(stderr, "fvvdp: level-0 placement: incumbent %.1f, candidate %.1f us per frame -> %s\n",
+                                t_inc * 1e3f / (float)n_out, t_new * 1e3f / (float)n_out, take_new ? "candidate" : "incumbent");
+                    c->place_tries += 1;
+                    const bool same_mode = ok && t_new > 0.95f * t_inc && t_inc > 0.95f * t_new;
+                    if (same_mode && c->place_tries < 2) {
+                        // re-time the keeper on this call, try one more candidate on the next
+                        (void)hipEventRecord(c->place_ev[0], st);
+                        timed_here = true;
+                        c->place_phase = 2;
+                    } else {
+                        c->place_phase = 9;
+                    }
+                }
             }
+        }
+        {
+            const int rc = run(c->level[0], 0, n_out);
+            if (rc != FVVDP_OK) return rc;
+            if (timed_here) (void)hipEventRecord(c->place_ev[c->place_phase == 3 ? 3 : 1], st);
         }
     } else {
         // images, fl > 32 and frame sizes without 4-sample alignment: one thread per pixel and output frame

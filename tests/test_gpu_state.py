@@ -364,3 +364,36 @@ def test_frame_sharded_call_uploads_only_its_own_frames(fv):
     oq, ost = orc.Oracle("standard_fhd").predict(test.numpy(), ref.numpy(), frames_per_second=fps, frames=range(0, 10))
     o = ost["Q_per_ch"].astype(np.float64)
     assert np.all(np.abs(s_all["Q_per_ch"][:, :, :10] - o) <= 1e-3 * np.abs(o) + 1e-6 * np.max(o))
+
+
+def test_placement_selection_does_not_change_results(tmp_path):
+    """FVVDP_PLACEMENT_PROBE=1 (opt-in, read once per process): during calls 2-6 of a context the level-0 scratch moves between
+    two allocations while they are compared.  Every call must return the same bits as a process without the selection."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import fovvideovdp_amd as fv\n"
+        "from fovvideovdp_amd.synth import synth_video_pair\n"
+        "t, r = synth_video_pair(40, 1080, 1920, device='cuda')\n"         # level 0: 40 x 33 MB = 1.3 GB (>= the 1 GiB threshold)
+        "m = fv.fvvdp(display_name='standard_fhd')\n"
+        "out = []\n"
+        "for k in range(8):\n"
+        "    q, st = m.predict(t, r, frames_per_second=30)\n"
+        "    out.append(np.concatenate([st['Q_per_ch'].reshape(-1), [float(q)]]))\n"
+        "np.save(sys.argv[1], np.stack(out))\n" % root)
+    res = {}
+    for mode in ("1", "0"):
+        f = str(tmp_path / ("sel%s.npy" % mode))
+        env = dict(os.environ, FVVDP_PLACEMENT_PROBE=mode, FVVDP_DEBUG_ALLOC="1")
+        p = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-1500:]
+        res[mode] = (np.load(f), p.stderr)
+    on, log = res["1"]
+    off, _ = res["0"]
+    assert "level-0 placement: incumbent" in log           # the comparison really ran
+    assert all(np.array_equal(on[k], on[0]) for k in range(8))
+    assert np.array_equal(on, off)

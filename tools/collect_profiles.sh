@@ -10,7 +10,7 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 python $R/bench.py > $OUT/bench_plain.json 2> $OUT/bench_plain.err
 rocprofv3 --kernel-trace --stats -d /tmp/kt -o bench -- python $R/bench.py --no-cpu-baseline --no-measure-traffic > $OUT/bench_profiled.json 2> /tmp/kt.err
-python $R/tools/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) --band-levels 7 > $OUT/kernel_trace_bench.md
+python $R/tools/rocpd_summary.py $(find /tmp/kt -name "*.db" | head -1) --band-levels 7 --dispatches band2_kernel > $OUT/kernel_trace_bench.md
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf -o f -- python $R/tools/gpu_bandonly.py > /tmp/pf.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw -o w -- python $R/tools/gpu_bandonly.py > /tmp/pw.log 2>&1
 python $R/tools/pmc_level0.py $(find /tmp/pf -name "*.db" | head -1) $(find /tmp/pw -name "*.db" | head -1) $OUT/pmc_level0.json > /dev/null
@@ -25,12 +25,12 @@ FVVDP_BAND_FUSE=0 python $R/tools/gpu_bandonly_speed.py 12 > $OUT/bandonly_onele
 $R/build_variants/mix > $OUT/mix.txt 2>&1
 python $R/tools/gpu_parity_report.py > $OUT/parity.md 2>/dev/null
 ( python $R/tools/gpu_g9_report.py; python $R/tools/gpu_g10_report.py; python $R/tools/gpu_g11_report.py; python $R/tools/gpu_g12_report.py ) 2>/dev/null | grep -v Warn > $OUT/parity_goldens.txt
-python $R/tools/gpu_fps.py 30:60:u8 60:120:u8 120:120:u8 144:120:u8 240:120:u8 30:60:u16 60:60:u16 144:60:u16 30:60:f32rgb 30:60:f32gray 2>/dev/null | grep -v Warn > $OUT/fps_probe.txt
+python $R/tools/gpu_fps.py 30:60:u8 60:120:u8 120:120:u8 144:120:u8 240:120:u8 30:60:u16 60:60:u16 120:60:u16 144:60:u16 30:60:f32rgb 120:60:f32rgb 30:60:f32gray 2>/dev/null | grep -v Warn > $OUT/fps_probe.txt
 python $R/tools/gpu_k1_ab.py 30:60:u8:5 60:60:u8:5 120:60:u8:5 2>/dev/null | grep -v Warn >> $OUT/fps_probe.txt
 BATCHES=None,60 python $R/tools/gpu_feeder.py 2>/dev/null | cut -c1-110 > $OUT/feeder_probe.txt
 HH=2160 WW=3840 BATCHES=None,60 python $R/tools/gpu_feeder.py 2>/dev/null | cut -c1-110 >> $OUT/feeder_probe.txt
 python $R/bench.py --pairs-per-gpu 8 --no-cpu-baseline --no-h2d > $OUT/bench_pairs8.json 2>/dev/null
-rocprofv3 --kernel-trace --stats -d /tmp/kr -o rates -- python $R/tools/gpu_fps.py 60:120:u8 120:120:u8 30:60:u16 > /dev/null 2> /tmp/kr.err
+rocprofv3 --kernel-trace --stats -d /tmp/kr -o rates -- python $R/tools/gpu_fps.py 60:120:u8 120:120:u8 144:120:u8 240:120:u8 30:60:u16 > /dev/null 2> /tmp/kr.err
 python $R/tools/rocpd_summary.py $(find /tmp/kr -name "*.db" | head -1) --only temporal_vec > $OUT/kernel_trace_rates.md
 # K1 (temporal kernel): HBM traffic per 60-frame launch from the same two counters (algorithmic: 67 frames read x 49.8 MB + 60 x 132.7 MB written)
 STAGE=all REPS=2 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/pf1 -o f -- python $R/tools/gpu_bandonly.py > /tmp/pf1.log 2>&1
@@ -48,4 +48,23 @@ rocprofv3 --kernel-trace --stats -d /tmp/kf -o fov -- python $R/tools/gpu_config
 grep -E "^config4|^Q_per_ch|^kernel us" /tmp/kf.out > $OUT/fov_probe.txt
 python $R/tools/rocpd_summary.py $(find /tmp/kf -name "*.db" | head -1) --band-levels 7 > /tmp/kf.md
 grep -E "kernel \||---|band_kernel<4, false, 1>|temporal_vec" /tmp/kf.md > $OUT/kernel_trace_fov.md
+# SQ / TCC counters of the dominant pyramid kernel and of the foveated kernel: what bounds them
+SQ1="SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
+SQ2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_SALU SQ_ACTIVE_INST_VMEM SQ_LDS_IDX_ACTIVE"
+for T in bandonly fov_bandonly; do
+  rocprofv3 --pmc $SQ1 --kernel-trace -d /tmp/s1_$T -o a -- python $R/tools/gpu_$T.py > /tmp/s1_$T.log 2>&1
+  rocprofv3 --pmc $SQ2 --kernel-trace -d /tmp/s2_$T -o a -- python $R/tools/gpu_$T.py > /tmp/s2_$T.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace -d /tmp/s3_$T -o a -- python $R/tools/gpu_$T.py > /tmp/s3_$T.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/s4_$T -o a -- python $R/tools/gpu_$T.py > /tmp/s4_$T.log 2>&1
+  python $R/tools/pmc_sq_summary.py band $(find /tmp/s1_$T /tmp/s2_$T /tmp/s3_$T /tmp/s4_$T -name "*.db") > $OUT/pmc_sq_$T.md 2>/dev/null
+done
+python $R/tools/codeobj_report.py > $OUT/codeobj.md 2>/dev/null
+rocprofv3 --kernel-trace --stats -d /tmp/ff -o ff -- $R/build_variants/fuse_front 64 14 60 > $OUT/fuse_front.txt 2>/tmp/ff.err
+$R/build_variants/fuse_front 32 14 60 >> $OUT/fuse_front.txt 2>&1
+$R/build_variants/fuse_front 16 14 60 >> $OUT/fuse_front.txt 2>&1
+$R/build_variants/fuse_front 8 14 60 >> $OUT/fuse_front.txt 2>&1
+$R/build_variants/fuse_front 16 0 60 >> $OUT/fuse_front.txt 2>&1
+$R/build_variants/fuse_front 128 14 60 >> $OUT/fuse_front.txt 2>&1
+$R/build_variants/fuse_front 64 0 60 >> $OUT/fuse_front.txt 2>&1
+python $R/tools/rocpd_summary.py $(find /tmp/ff -name "*.db" | head -1) > $OUT/fuse_front_trace.md 2>&1
 ls -la $OUT

@@ -14,7 +14,7 @@ H, W, N = 2160, 3840, 60
 test, ref = synth_video_pair(N, H, W, device="cuda")
 print("src test 0x%x ref 0x%x" % (test.data_ptr(), ref.data_ptr()), flush=True)
 m = fv.fvvdp(display_name="standard_4k"); m.timing = True
-offs = [0, 4, 64, 256, 1024, 2048, 4096, 8192, 16384, 65536, 129600, 262144, 524288, 1048576]
+offs = [int(x) for x in os.environ.get("OFFS", "").split(",") if x] or [0, 4, 64, 256, 1024, 2048, 4096, 8192, 16384, 65536, 129600, 262144, 524288, 1048576]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 for r in range(rounds):
     m._drop_context()                      # a new allocation = a new physical placement
@@ -27,5 +27,5 @@ for r in range(rounds):
         for it in range(3): m.predict(test, ref, frames_per_second=30)
         torch.cuda.synchronize()
         nat.check(nat.lib().fvvdp_ctx_timing_read(m._ctx.handle, ms, cnt, 18, 1))
-        line.append("%d:%.1f" % (off, ms[0] / (3 * N) * 1e3))
-    print("allocation %d  K1 us/frame by offset KB: %s" % (r, "  ".join(line)), flush=True)
+        line.append("%d:%.1f/%.1f" % (off, ms[0] / (3 * N) * 1e3, ms[1] / (3 * N) * 1e3))
+    print("allocation %d  K1/K2b us/frame by offset KB: %s" % (r, "  ".join(line)), flush=True)

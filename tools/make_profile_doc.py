@@ -5,18 +5,24 @@ usage: make_profile_doc.py r02"""
 import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B = os.path.join(ROOT, "gpurun_out", "prof_bundle")
-tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
 rd = lambda n: open(os.path.join(B, n)).read().strip() if os.path.exists(os.path.join(B, n)) else "(not collected)"
 
 
 def kt(name):
     return "\n".join(l for l in rd(name).split("\n")
-                     if ("temporal_" in l or "band_kernel" in l or "band2_kernel" in l or "finalize" in l or "pool_jod" in l
-                         or l.startswith("| kernel") or l.startswith("|---")))
+                     if (l.startswith("|") and ("temporal_" in l or "band_kernel" in l or "band2_kernel" in l or "finalize" in l or "pool_jod" in l
+                                                or "band_tail" in l or l.startswith("| kernel") or l.startswith("|---"))))
+
+
+def dispatch_list(name):
+    txt = rd(name)
+    i = txt.find("dispatches of")
+    return txt[i:] if i >= 0 else "(no dispatch list)"
 
 
 def same_box_table():
-    """rocprof averages next to the HIP-event figures of the SAME profiled process."""
+    """rocprof per-launch figures next to the HIP-event figures of the SAME profiled process."""
     try:
         j = json.loads(rd("bench_profiled.json").split("\n")[-1])
     except Exception:
@@ -24,29 +30,39 @@ def same_box_table():
     rows = {}
     for l in rd("kernel_trace_bench.md").split("\n"):
         c = [x.strip() for x in l.split("|")]
-        if len(c) > 5 and ("band" in c[1] or "finalize" in c[1]):
-            rows[c[1]] = (int(c[2]), float(c[4]), float(c[5]))       # calls, avg us, min us
+        if len(c) > 8 and ("band" in c[1] or "finalize" in c[1]) and c[2].isdigit():
+            rows[c[1]] = (int(c[2]), float(c[4]), float(c[5]), float(c[6]), float(c[7]))       # calls, avg, median, steady median, min
     g = j["graded_pass"]
     n = j["roofline"]["frames_per_launch"]
     alg = g["algorithmic_bytes_per_frame"]
-    out = ["| kernel (rocprofv3 label) | rocprof avg us / launch | rocprof min | per frame (avg) | HIP events, median per frame |", "|---|---|---|---|---|"]
-    tot_avg = tot_min = 0.0
+    out = ["| kernel (rocprofv3 label) | rocprof avg us / launch | rocprof median | steady median (first 3 dropped) | min | per frame (steady median) | HIP events, median per frame |", "|---|---|---|---|---|---|---|"]
+    tot = {"avg": 0.0, "med": 0.0, "steady": 0.0, "min": 0.0}
     ev = list(g["levels_us_per_frame_median"]) + [g["finalize_us_per_frame"]]
-    k = 0
-    for label, (calls, avg, mn) in sorted(rows.items(), key=lambda kv: kv[0].split("[")[-1] if "[" in kv[0] else "z"):
+    for label, (calls, avg, med, steady, mn) in sorted(rows.items(), key=lambda kv: kv[0].split("[")[-1] if "[" in kv[0] else "z"):
         e = ""
         if "levels 0+1" in label: e = "%.2f" % ev[0]
         elif "[level " in label: e = "%.2f" % ev[int(label.split("[level ")[1].split("]")[0])]
         elif "finalize" in label: e = "%.2f" % ev[-1]
-        out.append("| %s | %.1f | %.1f | %.2f | %s |" % (label, avg, mn, avg / n, e))
-        tot_avg += avg / n
-        tot_min += mn / n
-    out.append("| **all pyramid levels + finalize (graded pass)** | | | **%.2f** (min %.2f) | **%.2f** (min %.2f) |" % (
-        tot_avg, tot_min, g["us_per_frame_all_levels"], g["us_per_frame_all_levels_min"]))
+        out.append("| %s | %.1f | %.1f | %.1f | %.1f | %.2f | %s |" % (label, avg, med, steady, mn, steady / n, e))
+        tot["avg"] += avg / n; tot["med"] += med / n; tot["steady"] += steady / n; tot["min"] += mn / n
+    out.append("| **all pyramid levels + finalize (graded pass)** | %.2f / frame | %.2f | **%.2f** | %.2f | | **%.2f** (min %.2f) |" % (
+        tot["avg"], tot["med"], tot["steady"], tot["min"], g["us_per_frame_all_levels"], g["us_per_frame_all_levels_min"]))
     out.append("")
-    out.append("Graded pass against SURVEY 8(d)'s %.1f MB per frame and the 8 TB/s spec peak: **%.3f from the rocprof averages, %.3f "
-               "from the rocprof minima, %.3f from the HIP-event medians** of the same process (target >= 0.60, i.e. <= 46.1 us per frame)." % (
-                   alg / 1e6, alg / (tot_avg * 1e-6) / 8e12, alg / (tot_min * 1e-6) / 8e12, g["hbm_frac_all_levels"]))
+    fr = lambda us: alg / (us * 1e-6) / 8e12
+    out.append("Graded pass against SURVEY 8(d)'s %.1f MB per frame and the 8 TB/s spec peak: **%.3f from the rocprof steady medians, %.3f from "
+               "the rocprof medians over all launches, %.3f from the rocprof averages (they include the cold launches listed below), %.3f from "
+               "the HIP-event medians** of the same process (target >= 0.60, i.e. <= 46.1 us per frame)." % (
+                   alg / 1e6, fr(tot["steady"]), fr(tot["med"]), fr(tot["avg"]), g["hbm_frac_all_levels"]))
+    r = j["roofline"]
+    for label, (calls, avg, med, steady, mn) in rows.items():
+        if "levels 0+1" in label:
+            out.append("")
+            out.append("Dominant kernel (`roofline` of the JSON line): algorithmic %.4f GB per launch / rocprof steady median %.1f us = %.0f GB/s = "
+                       "**%.3f**; / HIP-event median %.1f us = %.0f GB/s = **%.3f** (difference %.1f %%).  With the bytes it really moves "
+                       "(PMC, %s): %.0f GB/s = %.3f of the peak." % (
+                           r["bytes_per_launch"] / 1e9, steady, r["bytes_per_launch"] / steady / 1e3, r["bytes_per_launch"] / steady / 1e3 / 8000.0,
+                           r["median_launch_ms"] * 1e3, r["achieved"], r["frac"], 100.0 * abs(steady - r["median_launch_ms"] * 1e3) / steady,
+                           "live" if r.get("traffic") else "not collected", (r.get("achieved_traffic") or 0.0), (r.get("frac_traffic") or 0.0)))
     return "\n".join(out)
 
 
@@ -60,9 +76,33 @@ level (dispatch order); `band2_kernel` covers two levels per launch.  torch kern
 
 {kt('kernel_trace_bench.md')}
 
+Every launch of the dominant kernel in that process, in order, with the kernel that ran before it.  The launches behind
+`__amd_rocclr_copyBuffer` are the host-array (PCIe-inclusive) calls at the end of bench.py: the GPU idles during the 50 ms
+upload and the kernel starts on cold clocks -- these three and the first two warm-up launches are what separated the rocprof
+AVERAGE from the HIP-event median in round 2 (8 %); the medians agree:
+
+```
+{dispatch_list('kernel_trace_bench.md')}
+```
+
 ## The graded pass on ONE box: rocprof next to the in-library HIP events
 
 {same_box_table()}
+
+## What bounds the dominant kernel: SQ / TCC counters (separate --pmc passes of `tools/gpu_bandonly.py`)
+
+`tools/pmc_sq_summary.py`; shares are of the waves' resident time (SQ_WAVE_CYCLES).  `valu` x 3 waves per SIMD >= 1: the VALU
+pipe is saturated; `wait` (memory / LDS latency not hidden) is 7 %:
+
+{rd('pmc_sq_bandonly.md')}
+
+The foveated kernel (`tools/gpu_fov_bandonly.py`; levels 0 and 1 share a grid size and are averaged in the first block):
+
+{rd('pmc_sq_fov_bandonly.md')}
+
+## Registers, spills, scratch of every kernel in the shipped library (code-object metadata, `tools/codeobj_report.py`)
+
+{rd('codeobj.md')}
 
 bench.py JSON of the SAME profiled process (HIP events on the kernels' stream):
 

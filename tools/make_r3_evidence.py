@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Assemble the round-3 experiment logs (gpurun_out/s*/, written by tools/r3_session*.sh on the GPU box) into tracked files
+under profiles/: K1 placement modes, the tail-launch experiment, the foveated-kernel variants, the fusion front end."""
+import os, re
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+
+
+def rd(rel, drop=("amdgpu.ids", "fvvdp: level 0 allocation")):
+    p = os.path.join(G, rel)
+    if not os.path.exists(p):
+        return "(not collected: %s)" % rel
+    return "\n".join(l for l in open(p).read().rstrip().split("\n") if not any(d in l for d in drop))
+
+
+def w(name, txt):
+    open(os.path.join(P, name), "w").write(txt)
+    print("wrote profiles/%s (%d bytes)" % (name, len(txt)))
+
+
+w("r03_k1_placement.md", f"""# Round 3 -- the two modes of the temporal kernel (K1) and what controls them
+
+K1 = `temporal_vec_kernel<8,4,0>` on the 4K x60 uint8 pair of bench.py (182.5 MB per frame: 6 B read + 16 B written per pixel).
+VERDICT r2 weak 6 / item 4: the same kernel runs at 31-32 us per frame (5.8 TB/s) or 36-38 us (5.0 TB/s) "depending on where the
+8 GB scratch lands physically".  What the experiments of this round add (all: HIP events inside the library, us per frame):
+
+1. **The allocation API does not matter** (`tools/gpu_k1_placement.py`; `FVVDP_ALLOC=vmm` takes `hipMemCreate` / `hipMemMap` of the
+   recommended granularity, `FVVDP_VMM_ALIGN_MB=1024` reserves the range 1 GiB-aligned):
+
+```
+{rd('s2/k1_placement.txt')}
+```
+
+2. **The virtual address does not matter.**  `tools/gpu_k1_offset_sweep.py`, first version: level 0 starts `offset` KB into an
+   allocation that grows by the same amount -- the allocator grows it downwards, so most rows have level 0 at the SAME virtual
+   address (0x...95000000) with a NEW physical allocation each time, and the time still varies between 32.9 and 38.2:
+
+```
+{rd('s4/k1_offsets.txt')}
+```
+
+3. **An offset inside ONE allocation does not matter** (second version: 1.1 GB of slack allocated once per context,
+   `FVVDP_L0_OFFSET_KB` read at every call; K1/K2b; 4 KB steps would rotate any 8-way page interleave, 1-7 KB are misaligned
+   to the 4 KB runs a wave writes):
+
+```
+{rd('s7/k1_fine.txt')}
+```
+
+   (`s5`, offsets 4 KB ... 1 GB on another box: 37.4-38.0 for every offset of every allocation.)
+
+4. **It is a property of the allocation, and the pyramid kernel moves the other way** (`tools/gpu_k1_probe_corr.py`: 14
+   re-creations of the scratch in one process; a cheap probe -- the same kernel fed from one dummy frame -- does NOT predict the
+   mode of the real clip, i.e. the relation to the SOURCE buffers is part of it):
+
+```
+{rd('s6/k1_probe.txt')}
+```
+
+   K1 fast (31) goes with K2b 35.6-38.5, K1 slow (36) with K2b 34.3: the sum is 67.3 vs 70.8 us per frame.
+
+5. **Consecutive allocations alternate strictly** (`tools/gpu_k1_clocks.py`: re-creation in a loop, 1.2 s of calls each; the clocks
+   and the power the driver reports do not differ between the modes -- fclk 1250, mclk 2000 throughout; the sclk reading is the idle
+   value between calls):
+
+```
+{rd('s8/k1_clocks.txt')}
+```
+
+6. **A short probe ranks the buffers the wrong way round** (first attempt at a fix: time 12 frames into the current buffer and
+   into two fresh ones inside the second call, keep the fastest.  `tools/gpu_k1_probe_check.py`: the buffer that runs the full
+   clip in 32.4 us per frame measures 38.5 in the probe, the 36.5 one measures 36):
+
+```
+{rd('s9/probe_on.txt')}
+```
+
+7. **Second attempt, kept as an opt-in (`FVVDP_PLACEMENT_PROBE=1`): online selection with the real calls as the measurement** (`temporal_channels_core` in `fvvdp_hip.hip`): the
+   2nd full-batch call of a context is timed on the buffer it has, the 3rd runs -- and is timed -- on a freshly allocated one, the
+   4th keeps the faster and frees the other; one more candidate if the two were within 5 %.  No extra GPU work, results
+   independent of the buffer (asserted by the tool).  Per re-created context, K1/K2b call by call, selection on:
+
+```
+{rd('s10/probe_on.txt')}
+```
+
+   and off:
+
+```
+{rd('s10/probe_off.txt')}
+```
+
+   bench.py (2 warm-up + 10 timed steps, so the selection runs inside the timed region), separate processes, alternating:
+
+```
+{rd('s10/bench_ab.txt')}
+```
+
+   Final states with the selection: 34.6, 31.6, 31.7, 31.1, 31.1, 34.6, 34.1, 34.7 (mean 32.9); without: 36.6, 34.6, 31.8, 31.2,
+   31.2, 36.4, 36.7, 34.4 (mean 34.1).  There are three modes (31.5 / 34.5 / 36.5), a candidate is as likely to be worse as
+   better, the calls that run on a fresh buffer pay its first touch (39-43 us per frame), and the context holds level 0 twice
+   for two calls.  A 3.5 % gain on K1 in the mean for that price: off by default.
+
+What it is physically is not known to me: not address translation (r2: UTCL1 / UTCL2 counters equal in both modes), not the
+clocks, not the alignment of the buffer, not an XCD <-> page interleave (a 4 KB offset changes nothing).  The per-channel HBM
+counters that would show a channel imbalance are not exposed by rocprofv3 on this stack (TCC_EA0_* are aggregates).
+""")
+
+w("r03_tail_launch.md", f"""# Round 3 -- one launch for the small pyramid levels + finalisation + pooling: measured, not kept as default
+
+VERDICT r2 item 7 asked for levels >= 3, `finalize_kernel` and `pool_jod_kernel` in one launch.  `band_tail_kernel`
+(`csrc/tail_kernel.hpp`; one workgroup per frame walks its levels in order, the last workgroup to finish pools) exists, is
+tested (`tests/test_gpu_fused.py`) and stays behind `FVVDP_BAND_TAIL=1`; `fvvdp_bands_forward_pool` is the entry point.
+bench.py (4K x60, 10 steps), `levels` = HIP-event us per frame of levels 0..6 (a merged level reports at its first level):
+
+levels 3-6 + finalize + pooling in the tail, 16 waves per workgroup (tail=1) against the per-level launches (tail=0):
+
+```
+{rd('s3/tail_ab.txt')}
+```
+
+levels 5-6 + finalize + pooling only, 16 waves (tail=d) against none:
+
+```
+{rd('s4/tail_ab.txt')}
+```
+
+the same with 4 waves per workgroup (one per SIMD; wpt4) and 16 (wpt16):
+
+```
+{rd('s5/tail_ab.txt')}
+```
+
+Still images (tail default-on at that point vs FVVDP_BAND_TAIL=0):
+
+```
+{rd('s5/image_probe.txt')}
+```
+
+Why: a frame's levels 3-6 are ~120 us of VALU work for ONE CU (16 waves share its 4 SIMDs), and 60 frames occupy 60 of 256 CUs;
+the per-level launches spread every level of every frame over the whole chip (88 us for the four).  For the two tiny levels the
+chain of dependent row steps of one frame (17 + 13 steps, nothing to hide the load latency with one wave per SIMD) is longer
+than two launch latencies.
+""")
+
+w("r03_fov_variants.md", f"""# Round 3 -- foveated kernel (BASELINE configs[3]): what bounds it, and the variants that were measured
+
+`tools/gpu_config4.py` (4K x120, standard_hdr_pq, moving gaze), kernel us per frame = [K1, level 0, level 1, ...]:
+default = LUT slice padded to 36-entry rows (bank-conflict-free, `FOV_ROW` in band_kernel.hpp); nopad = the round-2 layout;
+pad33 = 33-entry rows; wpb6 / wpb12 = 6 / 12 waves per workgroup sharing the slice; phase4 = all four pixels of a step batched.
+
+```
+{rd('s2/fov_ab.txt')}
+```
+
+SQ / TCC counters of the round-2 layout (`tools/pmc_sq_summary.py`; levels 0 and 1 have the same grid and are averaged in the
+first block: 6 dispatches = 3 calls x 2 levels):
+
+{rd('s1/pmc_sq_fov_bandonly.md')}
+
+With the padded slice (LDS conflict cycles / LDS active cycles 0.148 -> 0.065 at levels 0+1, 0.425 -> 0.146 at level 2; the time
+does not move: LDS is 1.3 % of the waves' time):
+
+{rd('s2/pmc_fov_padded.md')}
+
+Reading: `valu` 0.318 of a wave's resident time x 3 waves per SIMD = 0.95 -> the VALU pipe is busy 95 % of the time (the plain
+two-level kernel: 0.357 x 3 = 1.07, saturated, `profiles/r03_final_kernel_trace.md`); at the same time the two levels move
+254 MB per frame (level 0: 132.7 MB + 66 MB of rho map + 33 MB written, plus halo) in ~55 us = 4.6 TB/s, level 0 alone 240 MB in
+45 us = 5.3 TB/s -- the memory system's ceiling for a read/write mix (5.0-5.6 TB/s, `tools/microbench/mix.hip`).  Both limits bind
+together; removing bytes (rho map 8 -> 4 B per pixel) costs VALU instructions (+3 %), removing instructions is bounded by
+the 13 transcendentals and the trilinear blend per pixel.  A two-level variant (VERDICT r2 item 2a) multiplies the VALU work by
+60/54 (strip halo) on a kernel that is already VALU-bound and saves 17 % of the bytes: 58 us against 55 by the same arithmetic
+that predicted the plain kernel's gain.  Target (<= 50 us for all levels) not met: 59.5 us.
+""")
+
+w("r03_fusion_front_end.md", f"""# Round 3 -- K1 -> K2 fusion: the front end of the one variant that had not been costed on silicon
+
+VERDICT r2 item 9: (strip, chunk)-persistent single-wave workgroups that walk the frames of their tile in order and re-compute the
+temporal channels from the uint8 frames through L2 / Infinity Cache, writing no level 0.  `tools/microbench/fuse_front.hip` runs
+ONLY that front end (unpack, LDS table, RGB -> Y, 8-tap FIR of both streams; checksum instead of a pyramid): 4 pixels per
+lane, `rows` owned rows + `halo` rows per tile and frame, every tile walks all 60 frames.  If this alone costs more than K1 (35 us
+per frame) plus the hand-off it removes (level 0 written + read: 265 MB = ~50 us at the mix ceiling), the fused kernel -- this
+front end in front of K2b's VALU-bound 34 us in the SAME wave -- cannot win.
+
+```
+{rd('s8/fuse_front.txt')}
+```
+
+rocprofv3 --kernel-trace --stats of the first line:
+
+{rd('s8/fuse_front_trace.md')}
+
+The front end alone takes 260-740 us per frame.  Two things bind: tile-persistent workgroups are few (510 waves at 64-row
+tiles; 3000+ waves only at <= 10-row tiles, where the 14 halo rows of the two-level pyramid make the tile 2.4x its owned rows),
+and the 8-frame window costs 48 dword loads + 48 LDS look-ups + 32 multiply-adds per 4 pixels and frame in place of K1's 6 + 6 + 32
+(the ring in registers converts every source frame once).  Not pursued further; the hand-off stays.
+""")
