@@ -114,7 +114,7 @@ struct fvvdp_ctx {
 
 // Large buffers (the pyramid levels) can come from the virtual-memory API instead of hipMalloc: one physical allocation
 // of the recommended granularity mapped into a reserved range.  FVVDP_ALLOC=vmm selects it (placement experiments:
-// tools/gpu_k1_placement.py; the temporal kernel's speed depends on where the level-0 scratch lands physically).
+// tools/experiments/gpu_k1_placement.py; the temporal kernel's speed depends on where the level-0 scratch lands physically).
 static int vmm_alloc(fvvdp_ctx* c, void** out, size_t bytes);
 static void vmm_free_all(fvvdp_ctx* c);
 
@@ -302,7 +302,7 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
     for (int i = 0; i <= n_bands && rc == FVVDP_OK; ++i) {
         size_t slack = 0;
         if (i == 0) {
-            // placement experiments (tools/gpu_k1_offset_sweep.py): FVVDP_L0_SLACK_MB of extra room behind level 0, inside
+            // placement experiments (tools/experiments/gpu_k1_offset_sweep.py): FVVDP_L0_SLACK_MB of extra room behind level 0, inside
             // which FVVDP_L0_OFFSET_KB (read at every call) moves the start of the level without a new allocation
             if (const char* e = getenv("FVVDP_L0_SLACK_MB")) slack = (size_t)atoll(e) * (1u << 20) / sizeof(float);
         }

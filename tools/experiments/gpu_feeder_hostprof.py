@@ -2,7 +2,7 @@
 """cProfile of predict_video_source on a resident user source (1080p x60): where the host time of the feeder goes."""
 import cProfile, pstats, os, sys, time
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import fovvideovdp_amd as fv
 from fovvideovdp_amd.synth import synth_video_pair
 H, W, N, fps = int(os.environ.get("HH", 1080)), int(os.environ.get("WW", 1920)), 60, 30

@@ -2,7 +2,7 @@
 """Where the host time of one predict() call goes (4K x60 resident pair): cProfile of 20 calls + wall per call."""
 import cProfile, pstats, os, sys, time, io
 import torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import fovvideovdp_amd as fv
 from fovvideovdp_amd.synth import synth_video_pair
 H, W, N = 2160, 3840, 60

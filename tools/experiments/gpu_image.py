@@ -2,7 +2,7 @@
 """Latency of still-image predict() calls (per call; device-resident and host numpy inputs)."""
 import cProfile, pstats, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import fovvideovdp_amd as fv
 from fovvideovdp_amd.synth import synth_video_pair

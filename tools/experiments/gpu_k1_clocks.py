@@ -4,7 +4,7 @@ of the power management rather than two memory placements?  For every re-creatio
 for ~1.2 s while a thread samples the clocks and the power the driver reports in sysfs; prints K1 / K2b next to the medians."""
 import ctypes as C, glob, os, sys, threading, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import fovvideovdp_amd as fv
 from fovvideovdp_amd import _native as nat
 from fovvideovdp_amd.synth import synth_video_pair

@@ -3,7 +3,7 @@
 creation, FVVDP_L0_OFFSET_KB read at every call): separates the virtual / in-allocation offset from the physical placement
 of the allocation (which changes with every hipMalloc).  usage: gpu_k1_offset_sweep.py [rounds]"""
 import ctypes as C, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 os.environ["FVVDP_L0_SLACK_MB"] = "1100"
 os.environ["FVVDP_DEBUG_ALLOC"] = "1"
 import numpy as np, torch

@@ -3,7 +3,7 @@
 the reference clip at (size of the test clip + delta) bytes; K1 us/frame per delta."""
 import ctypes as C, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import fovvideovdp_amd as fv
 from fovvideovdp_amd import _native as nat
 from fovvideovdp_amd.synth import synth_video_pair

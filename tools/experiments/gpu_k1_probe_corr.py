@@ -5,7 +5,7 @@ outputs: the reads stay in cache, the writes go to the scratch) -- if the two co
 scratch lies and can be probed at context creation."""
 import ctypes as C, os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import fovvideovdp_amd as fv
 from fovvideovdp_amd import _native as nat
 from fovvideovdp_amd.synth import synth_video_pair

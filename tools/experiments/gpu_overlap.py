@@ -3,7 +3,7 @@
 the whole clip on one stream?  Two metric objects, two threads, frame_range sharding inside one GPU."""
 import os, sys, time, threading
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import fovvideovdp_amd as fv
 from fovvideovdp_amd.synth import synth_video_pair

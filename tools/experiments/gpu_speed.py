@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
-"""Per-kernel timing probe (HIP events inside the library) for A/B builds: FVVDP_LIB=<variant.so> tools/gpu_speed.py"""
+"""Per-kernel timing probe (HIP events inside the library) for A/B builds: FVVDP_LIB=<variant.so> tools/experiments/gpu_speed.py"""
 import ctypes as C, os, sys, time
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import fovvideovdp_amd as fv
 from fovvideovdp_amd import _native as nat

@@ -3,7 +3,7 @@
 kernels) against the oracle, image and short video."""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import fovvideovdp_amd as fv
 from oracle import fvvdp_oracle as orc
 from fovvideovdp_amd.synth import synth_video_pair

@@ -21,11 +21,11 @@ SQ2="SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_LD
 timeout 300 rocprofv3 --pmc $SQ2 --kernel-trace -d /tmp/q1 -o a -- python $R/tools/gpu_fov_bandonly.py > /tmp/q1.log 2>&1
 python $R/tools/pmc_sq_summary.py band $(find /tmp/q1 -name "*.db") > $OUT/pmc_fov_padded.md 2>&1
 echo "== hipMalloc" > $OUT/k1_placement.txt
-timeout 300 python $R/tools/gpu_k1_placement.py 2>/dev/null | grep ctx >> $OUT/k1_placement.txt
+timeout 300 python $R/tools/experiments/gpu_k1_placement.py 2>/dev/null | grep ctx >> $OUT/k1_placement.txt
 echo "== FVVDP_ALLOC=vmm" >> $OUT/k1_placement.txt
-FVVDP_ALLOC=vmm timeout 300 python $R/tools/gpu_k1_placement.py 2>&1 | grep -E "ctx|rror" >> $OUT/k1_placement.txt
+FVVDP_ALLOC=vmm timeout 300 python $R/tools/experiments/gpu_k1_placement.py 2>&1 | grep -E "ctx|rror" >> $OUT/k1_placement.txt
 echo "== FVVDP_ALLOC=vmm FVVDP_VMM_ALIGN_MB=1024" >> $OUT/k1_placement.txt
-FVVDP_ALLOC=vmm FVVDP_VMM_ALIGN_MB=1024 timeout 300 python $R/tools/gpu_k1_placement.py 2>&1 | grep -E "ctx|rror" >> $OUT/k1_placement.txt
+FVVDP_ALLOC=vmm FVVDP_VMM_ALIGN_MB=1024 timeout 300 python $R/tools/experiments/gpu_k1_placement.py 2>&1 | grep -E "ctx|rror" >> $OUT/k1_placement.txt
 for v in default w64_2; do
   L=$R/build_variants/$v.so; [ $v = default ] && L=$R/fovvideovdp_amd/libfvvdp_hip.so
   FVVDP_LIB=$L timeout 300 python $R/tools/gpu_fps.py 144:120:u8 240:120:u8 144:60:u16 144:60:f32gray 2>/dev/null | grep -v Warn >> $OUT/ring64_ab.txt

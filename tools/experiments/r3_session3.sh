@@ -13,6 +13,6 @@ import json;d=json.load(open('$OUT/bench_tail$t.json'));g=d['graded_pass'];print
 done
 timeout 300 python $R/tools/gpu_fps.py 144:120:u8 240:120:u8 120:120:u8 144:60:u16 2>/dev/null | grep -v Warn > $OUT/fps_probe.txt
 timeout 200 python $R/tools/gpu_config4.py 2>/dev/null | grep -E "^config4|^Q_per|^kernel" | tail -3 > $OUT/fov_probe.txt
-timeout 200 python $R/tools/gpu_image.py > $OUT/image_probe.txt 2>&1
-timeout 600 python $R/tools/gpu_k1_offset_sweep.py > $OUT/k1_offsets.txt 2>&1
+timeout 200 python $R/tools/experiments/gpu_image.py > $OUT/image_probe.txt 2>&1
+timeout 600 python $R/tools/experiments/gpu_k1_offset_sweep.py > $OUT/k1_offsets.txt 2>&1
 ls -la $OUT

@@ -16,7 +16,7 @@ import json;d=json.load(open('$OUT/bench_$t.json'));g=d['graded_pass'];print('ta
 done
 done
 unset FVVDP_BAND_TAIL FVVDP_LIB
-timeout 200 python $R/tools/gpu_image.py 2>&1 | grep image > $OUT/image_probe.txt
-FVVDP_BAND_TAIL=0 timeout 200 python $R/tools/gpu_image.py 2>&1 | grep image | sed 's/^/tail=0 /' >> $OUT/image_probe.txt
-timeout 900 python $R/tools/gpu_k1_offset_sweep.py 5 > $OUT/k1_offsets.txt 2>&1
+timeout 200 python $R/tools/experiments/gpu_image.py 2>&1 | grep image > $OUT/image_probe.txt
+FVVDP_BAND_TAIL=0 timeout 200 python $R/tools/experiments/gpu_image.py 2>&1 | grep image | sed 's/^/tail=0 /' >> $OUT/image_probe.txt
+timeout 900 python $R/tools/experiments/gpu_k1_offset_sweep.py 5 > $OUT/k1_offsets.txt 2>&1
 ls -la $OUT

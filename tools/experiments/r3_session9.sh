@@ -4,8 +4,8 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/s10
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-FVVDP_PLACEMENT_PROBE=1 FVVDP_DEBUG_ALLOC=1 timeout 600 python $R/tools/gpu_k1_probe_check.py 8 > $OUT/probe_on.txt 2>&1
-FVVDP_PLACEMENT_PROBE=0 timeout 600 python $R/tools/gpu_k1_probe_check.py 8 > $OUT/probe_off.txt 2>&1
+FVVDP_PLACEMENT_PROBE=1 FVVDP_DEBUG_ALLOC=1 timeout 600 python $R/tools/experiments/gpu_k1_probe_check.py 8 > $OUT/probe_on.txt 2>&1
+FVVDP_PLACEMENT_PROBE=0 timeout 600 python $R/tools/experiments/gpu_k1_probe_check.py 8 > $OUT/probe_off.txt 2>&1
 for rep in 1 2 3; do
   FVVDP_PLACEMENT_PROBE=1 timeout 300 python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic --warmup 2 --steps 10 > $OUT/b_on$rep.json 2>/dev/null
   FVVDP_PLACEMENT_PROBE=0 timeout 300 python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic --warmup 2 --steps 10 > $OUT/b_off$rep.json 2>/dev/null

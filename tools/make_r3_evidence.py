@@ -25,14 +25,14 @@ K1 = `temporal_vec_kernel<8,4,0>` on the 4K x60 uint8 pair of bench.py (182.5 MB
 VERDICT r2 weak 6 / item 4: the same kernel runs at 31-32 us per frame (5.8 TB/s) or 36-38 us (5.0 TB/s) "depending on where the
 8 GB scratch lands physically".  What the experiments of this round add (all: HIP events inside the library, us per frame):
 
-1. **The allocation API does not matter** (`tools/gpu_k1_placement.py`; `FVVDP_ALLOC=vmm` takes `hipMemCreate` / `hipMemMap` of the
+1. **The allocation API does not matter** (`tools/experiments/gpu_k1_placement.py`; `FVVDP_ALLOC=vmm` takes `hipMemCreate` / `hipMemMap` of the
    recommended granularity, `FVVDP_VMM_ALIGN_MB=1024` reserves the range 1 GiB-aligned):
 
 ```
 {rd('s2/k1_placement.txt')}
 ```
 
-2. **The virtual address does not matter.**  `tools/gpu_k1_offset_sweep.py`, first version: level 0 starts `offset` KB into an
+2. **The virtual address does not matter.**  `tools/experiments/gpu_k1_offset_sweep.py`, first version: level 0 starts `offset` KB into an
    allocation that grows by the same amount -- the allocator grows it downwards, so most rows have level 0 at the SAME virtual
    address (0x...95000000) with a NEW physical allocation each time, and the time still varies between 32.9 and 38.2:
 
@@ -50,7 +50,7 @@ VERDICT r2 weak 6 / item 4: the same kernel runs at 31-32 us per frame (5.8 TB/s
 
    (`s5`, offsets 4 KB ... 1 GB on another box: 37.4-38.0 for every offset of every allocation.)
 
-4. **It is a property of the allocation, and the pyramid kernel moves the other way** (`tools/gpu_k1_probe_corr.py`: 14
+4. **It is a property of the allocation, and the pyramid kernel moves the other way** (`tools/experiments/gpu_k1_probe_corr.py`: 14
    re-creations of the scratch in one process; a cheap probe -- the same kernel fed from one dummy frame -- does NOT predict the
    mode of the real clip, i.e. the relation to the SOURCE buffers is part of it):
 
@@ -60,7 +60,7 @@ VERDICT r2 weak 6 / item 4: the same kernel runs at 31-32 us per frame (5.8 TB/s
 
    K1 fast (31) goes with K2b 35.6-38.5, K1 slow (36) with K2b 34.3: the sum is 67.3 vs 70.8 us per frame.
 
-5. **Consecutive allocations alternate strictly** (`tools/gpu_k1_clocks.py`: re-creation in a loop, 1.2 s of calls each; the clocks
+5. **Consecutive allocations alternate strictly** (`tools/experiments/gpu_k1_clocks.py`: re-creation in a loop, 1.2 s of calls each; the clocks
    and the power the driver reports do not differ between the modes -- fclk 1250, mclk 2000 throughout; the sclk reading is the idle
    value between calls):
 
@@ -69,7 +69,7 @@ VERDICT r2 weak 6 / item 4: the same kernel runs at 31-32 us per frame (5.8 TB/s
 ```
 
 6. **A short probe ranks the buffers the wrong way round** (first attempt at a fix: time 12 frames into the current buffer and
-   into two fresh ones inside the second call, keep the fastest.  `tools/gpu_k1_probe_check.py`: the buffer that runs the full
+   into two fresh ones inside the second call, keep the fastest.  `tools/experiments/gpu_k1_probe_check.py`: the buffer that runs the full
    clip in 32.4 us per frame measures 38.5 in the probe, the 36.5 one measures 36):
 
 ```
