@@ -2,7 +2,7 @@
 (libfvvdp_hip.so) and through the reference-shaped Python API, against (a) golden vectors captured from the real
 reference and (b) the CPU oracle on the same seeded inputs.
 
-Tolerances are <= 3x the errors measured on MI355X (tools/gpu_parity_report.py -> profiles/r02_parity.md, quoted next to
+Tolerances are <= 3x the errors measured on MI355X (tools/gpu_parity_report.py -> profiles/r03_parity.md, quoted next to
 each bound); they are fp32 rounding noise of this algorithm (the contrast is a difference of nearly equal numbers and
 D ~ contrast^2.4).  JOD: north-star bound 1e-3, measured <= 7e-6 against the reference."""
 import os
