@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -98,6 +99,8 @@ struct fvvdp_ctx {
     float* d_fix = nullptr;       // [max_frames][2]
     float* d_taps = nullptr;      // [2][FVVDP_MAX_TAPS]
     int* d_idx = nullptr;         // [max_frames + FVVDP_MAX_TAPS]
+    float* lum_buf = nullptr;     // two-pass temporal path (33..64 taps): fp32 luminance frames [2][lum_frames][HW]
+    size_t lum_floats = 0;
     unsigned int* d_ticket = nullptr;   // band_tail_kernel: workgroups that have published their frame (zero between launches)
     float* heat[FVVDP_MAX_BANDS + 1]{};   // heat-map accumulation images of levels >= 1, allocated on first use
     unsigned int* colour_ws = nullptr;    // colouring workspace per frame: range[2] + hist[1024] + curve[1024], then lin01[1024]
@@ -389,6 +392,7 @@ extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     if (c->d_taps) (void)hipFree(c->d_taps);
     if (c->d_idx) (void)hipFree(c->d_idx);
     if (c->d_ticket) (void)hipFree(c->d_ticket);
+    if (c->lum_buf) (void)hipFree(c->lum_buf);
     if (c->d_axes) (void)hipFree(c->d_axes);
     for (int b = 0; b < FVVDP_MAX_BANDS; ++b) {
         dev_free(c, c->sublut[b]);
@@ -628,8 +632,58 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
             if (rc != FVVDP_OK) return rc;
             if (timed_here) (void)hipEventRecord(c->place_ev[c->place_phase == 3 ? 3 : 1], st);
         }
+    } else if (c->P == 4 && fl > 32 && fl <= 64 && !h_frame_idx1 && !getenv("FVVDP_TEMPORAL_SCALAR") &&
+               fl - 1 + n_out <= T_MAX_IDX && k1_ring64_ok(FVVDP_F32, 1, FVVDP_EOTF_NONE)) {
+        // 33..64 taps (129-256 fps) for a sample type / display model the 64-slot ring is not instantiated for: two passes.
+        // Every source frame of the window -> fp32 luminance once (luminance_frames_kernel), then the 64-slot ring on those
+        // frames.  The generic kernel below would evaluate the display model fl times per pixel and output frame.
+        const int total = fl - 1 + n_out;
+        std::vector<int> uniq(h_frame_idx, h_frame_idx + total);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        const int nu = (int)uniq.size();
+        const size_t need = (size_t)2 * nu * HW;
+        if (c->lum_floats < need) {
+            HIP_TRY(hipStreamSynchronize(st));                       // earlier calls may still read the old buffer
+            if (c->lum_buf) (void)hipFree(c->lum_buf);
+            c->lum_buf = nullptr;
+            c->lum_floats = 0;
+            void* q = nullptr;
+            if (hipMalloc(&q, need * sizeof(float)) != hipSuccess)
+                return fail(FVVDP_ENOMEM, "hipMalloc(%zu bytes) for the luminance frames of a %d-tap filter failed", need * sizeof(float), fl);
+            c->lum_buf = reinterpret_cast<float*>(q);
+            c->lum_floats = need;
+            c->scratch += need * sizeof(float);
+        }
+        LumArgs la;
+        memset(&la, 0, sizeof(la));
+        la.src[0] = d_test;
+        la.src[1] = d_ref;
+        la.chan_stride = chan_stride;
+        la.frame_stride = frame_stride;
+        la.C = C;
+        la.HW = HW;
+        la.e = make_eotf(eotf);
+        if (C == 3) { la.w[0] = h_rgb2y[0]; la.w[1] = h_rgb2y[1]; la.w[2] = h_rgb2y[2]; } else { la.w[0] = 1.0f; }
+        la.n_frames = nu;
+        la.out = c->lum_buf;
+        la.oob = d_oob_flag;
+        for (int k = 0; k < nu; ++k) la.fr[k] = uniq[k];
+        k1_launch_luminance(dtype, la, st);
+        std::vector<int32_t> pos(total);
+        for (int u = 0; u < total; ++u) pos[u] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), h_frame_idx[u]) - uniq.begin());
+        fvvdp_eotf none;
+        memset(&none, 0, sizeof(none));
+        none.kind = FVVDP_EOTF_NONE;
+        HIP_TRY(hipGetLastError());
+        const bool timing = c->timing;
+        c->timing = false;                  // the events of this call (both passes) belong to the outer timer
+        const int rc2 = temporal_channels_core(c, c->lum_buf, c->lum_buf + (size_t)nu * HW, FVVDP_F32, 1, 0, (size_t)HW, &none, nullptr,
+                                               pos.data(), nullptr, h_taps, fl, n_out, slot0, d_oob_flag, stream);
+        c->timing = timing;
+        return rc2;
     } else {
-        // images, fl > 32 and frame sizes without 4-sample alignment: one thread per pixel and output frame
+        // images, more than 64 taps and frame sizes without 4-sample alignment: one thread per pixel and output frame
         if (h_frame_idx1) return fail(FVVDP_EINVAL, "per-frame source pointers are supported for video with fl <= 32 (uint8: 64) only");
         if (fl - 1 + n_out > c->max_frames + FVVDP_MAX_TAPS) return fail(FVVDP_EINVAL, "too many frames for one call");
         GenericArgs a;

@@ -1236,6 +1236,54 @@ __global__ __launch_bounds__(256) void temporal_generic_kernel(const GenericArgs
     if (bad && a.oob) atomicOr(a.oob, 1);
 }
 
+// ---- luminance frames (first pass of the two-pass path for 33..64 taps) ------------------------------------------------
+// Sample types / display models for which the 64-slot ring is not instantiated (k1_ring64_ok) used to take
+// temporal_generic_kernel, which evaluates the display model fl times per pixel and output frame (float gray behind sRGB at
+// 144 fps: 1126 us per 4K frame).  Instead: every source frame of the window is converted ONCE to fp32 luminance
+// (L_test, L_ref: the same Sampler code, so the same values), and the 64-slot ring runs on those frames as it does for a
+// user source's luminance frames.  One thread per pixel and frame; memory-bound.
+struct LumArgs {
+    const void* src[2];
+    size_t chan_stride, frame_stride;
+    int C, HW;
+    EotfDev e;
+    float w[3];
+    int n_frames;
+    float* out;              // [2 streams][n_frames][HW]
+    int* oob;
+    int fr[T_MAX_IDX];       // source frame of every output frame of this pass
+};
+
+template <int SRC>
+__global__ __launch_bounds__(256) void luminance_frames_kernel(const LumArgs a) {
+    __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
+    if constexpr (SRC == SRC_U8) {
+        build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 256);
+        __syncthreads();
+    }
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (p >= a.HW) return;
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        Sampler<SRC, 1> S;
+        S.base = a.src[s];
+        S.chan_stride = a.chan_stride;
+        S.C = a.C;
+        S.lutw = lutw;
+        S.lut16 = a.e.lut;
+        S.w0 = a.C == 3 ? a.w[0] : 1.0f;
+        S.w1 = a.w[1];
+        S.w2 = a.w[2];
+        S.e = a.e;
+        float l[1];
+        S.lum((size_t)a.fr[k] * a.frame_stride + p, l, bad);
+        a.out[((size_t)s * a.n_frames + k) * a.HW + p] = l[0];
+    }
+    if (bad && a.oob) atomicOr(a.oob, 1);
+}
+
 // planar [n][P][HW] <-> interleaved [n][HW][P]
 template <int P>
 __global__ void interleave_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int to_interleaved) {

@@ -58,6 +58,10 @@ void K1_NAME(k1_generic)(int planes, const GenericArgs& a, hipStream_t st) {
     if (planes == 2) launch_generic<2>(a, st);
     else launch_generic<4>(a, st);
 }
+void K1_NAME(k1_luminance)(const LumArgs& a, hipStream_t st) {
+    dim3 grid((a.HW + 255) / 256, a.n_frames), block(256);
+    hipLaunchKernelGGL((luminance_frames_kernel<SRC>), grid, block, 0, st, a);
+}
 #endif
 
 #if K1_PART == 3
@@ -70,6 +74,9 @@ void k1_ring_f32(int, const TemporalArgs&, hipStream_t);
 void k1_generic_u8(int, const GenericArgs&, hipStream_t);
 void k1_generic_u16(int, const GenericArgs&, hipStream_t);
 void k1_generic_f32(int, const GenericArgs&, hipStream_t);
+void k1_luminance_u8(const LumArgs&, hipStream_t);
+void k1_luminance_u16(const LumArgs&, hipStream_t);
+void k1_luminance_f32(const LumArgs&, hipStream_t);
 
 void k1_launch_vec(int FL, int dtype, const TemporalArgs& a, hipStream_t st) {
     if (dtype == FVVDP_U8) k1_vec_u8(FL, a, st);
@@ -80,6 +87,11 @@ void k1_launch_ring(int FL, int dtype, const TemporalArgs& a, hipStream_t st) {
     if (dtype == FVVDP_U8) k1_ring_u8(FL, a, st);
     else if (dtype == FVVDP_U16) k1_ring_u16(FL, a, st);
     else k1_ring_f32(FL, a, st);
+}
+void k1_launch_luminance(int dtype, const LumArgs& a, hipStream_t st) {
+    if (dtype == FVVDP_U8) k1_luminance_u8(a, st);
+    else if (dtype == FVVDP_U16) k1_luminance_u16(a, st);
+    else k1_luminance_f32(a, st);
 }
 void k1_launch_generic(int planes, int dtype, const GenericArgs& a, hipStream_t st) {
     if (dtype == FVVDP_U8) k1_generic_u8(planes, a, st);

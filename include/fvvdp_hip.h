@@ -156,9 +156,11 @@ int fvvdp_ctx_set_view_maps(fvvdp_ctx* ctx, int band, const float* d_view_x, con
  *   d_oob_flag      optional int: set to 1 if a float sample was outside [0,1] (the caller re-emits the
  *                   reference's warning "Pixel outside the valid range 0-1")
  * Asynchronous.  Filters of up to 32 taps (64 taps, i.e. up to 256 fps, for uint8 sources, 16-bit / float RGB behind an sRGB or
- * PQ display model and float luminance) run on the register-ring kernels;
- * longer ones take a generic kernel that re-reads the window per output frame (an order of magnitude slower) and, like
- * more than 320 window entries in a still-image context, synchronises the stream for two small table uploads.   */
+ * PQ display model and float luminance) run on the register-ring kernels in one pass; the other sample types / display models
+ * with 33..64 taps take two passes (every source frame of the window -> fp32 luminance once, into a context-owned buffer that is
+ * allocated on first use, then the 64-slot ring on those frames); more than 64 taps (above 256 fps) take a generic kernel that
+ * re-reads the window per output frame (an order of magnitude slower) and, like more than 320 window entries in a still-image
+ * context, synchronises the stream for two small table uploads.                                                   */
 int fvvdp_temporal_channels(fvvdp_ctx* ctx, const void* d_test, const void* d_ref, int dtype, int C,
                             size_t chan_stride, size_t frame_stride, const fvvdp_eotf* eotf,
                             const float* h_rgb2y, const int32_t* h_frame_idx, const float* h_taps, int fl,

@@ -891,3 +891,40 @@ def test_raw_yuv_file_source(fv, tmp_path):
         assert abs(float(q_r) - float(q_m)) < 1e-4
     with pytest.raises(FileNotFoundError):
         fs.fvvdp_video_source_yuv_file(str(tmp_path / "missing_8x8_8b.yuv"), str(tmp_path / "missing_8x8_8b.yuv"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fps", [144, 240])
+def test_two_pass_temporal_path_for_the_other_high_frame_rate_inputs(fv, fps, monkeypatch):
+    """33..64 taps for sample types / display models without a 64-slot ring instantiation (gray float behind sRGB, float RGB
+    behind a linear HDR display, 16-bit gray behind PQ, the exact 16-bit table): every source frame -> luminance once, then the
+    64-slot ring on the luminance frames (r3; before: the generic kernel, the display model fl times per pixel and frame).
+    Same values, same summation order: bit-identical to the generic kernel (FVVDP_TEMPORAL_SCALAR=1), and against the oracle."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    N, H, W = 70, 36, 64
+    test, ref = synth_video_pair(N, H, W)
+    g1, r1 = test[:, 1:2].float() / 255, ref[:, 1:2].float() / 255
+    f3, rf3 = test.float() / 255, ref.float() / 255
+    u16 = lambda a: a.numpy().astype(np.uint16) * 257
+    cases = [("f32 gray sRGB", "standard_fhd", g1, r1, {}),
+             ("f32 rgb linear", "standard_hdr_linear", f3 * 900.0, rf3 * 900.0, {}),
+             ("u16 gray PQ", "standard_hdr_pq", u16(test[:, 1:2]), u16(ref[:, 1:2]), {}),
+             ("u16 rgb table", "standard_fhd", u16(test), u16(ref), {"exact_uint16": True})]
+    for name, disp, t, r, attrs in cases:
+        monkeypatch.delenv("FVVDP_TEMPORAL_SCALAR", raising=False)
+        m = fv.fvvdp(display_name=disp)
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        q, st = m.predict(t, r, frames_per_second=fps)
+        monkeypatch.setenv("FVVDP_TEMPORAL_SCALAR", "1")
+        mg = fv.fvvdp(display_name=disp)
+        for k, v in attrs.items():
+            setattr(mg, k, v)
+        qg, sg = mg.predict(t, r, frames_per_second=fps)
+        monkeypatch.delenv("FVVDP_TEMPORAL_SCALAR", raising=False)
+        assert float(q) == float(qg) and np.array_equal(st["Q_per_ch"], sg["Q_per_ch"]), name
+        tn, rn = (t, r) if isinstance(t, np.ndarray) else (t.numpy(), r.numpy())
+        oq, ost = orc.Oracle(disp).predict(tn, rn, frames_per_second=fps)
+        assert abs(float(q) - float(oq)) < 1e-4, (name, float(q), float(oq))
+        check_q(st["Q_per_ch"], ost["Q_per_ch"], coarse=4e-3, fine=4e-3)      # 36x64 frame: every band is tiny (as test_other_frame_rates_vs_oracle)
