@@ -479,6 +479,22 @@ static EotfDev make_eotf(const fvvdp_eotf* e) {
     return d;
 }
 
+// context-owned buffer of fp32 luminance frames for the two-pass temporal paths (33..64 taps), grown on demand
+static int grow_lum_buf(fvvdp_ctx* c, size_t need_floats, int fl, hipStream_t st) {
+    if (c->lum_floats >= need_floats) return FVVDP_OK;
+    HIP_TRY(hipStreamSynchronize(st));                       // earlier calls may still read the old buffer
+    if (c->lum_buf) (void)hipFree(c->lum_buf);
+    c->lum_buf = nullptr;
+    c->lum_floats = 0;
+    void* q = nullptr;
+    if (hipMalloc(&q, need_floats * sizeof(float)) != hipSuccess)
+        return fail(FVVDP_ENOMEM, "hipMalloc(%zu bytes) for the luminance frames of a %d-tap filter failed", need_floats * sizeof(float), fl);
+    c->lum_buf = reinterpret_cast<float*>(q);
+    c->lum_floats = need_floats;
+    c->scratch += need_floats * sizeof(float);
+    return FVVDP_OK;
+}
+
 // h_frame_idx1: per-stream frame indices of the reference stream, or nullptr = the same as h_frame_idx
 static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* d_ref, int dtype, int C,
                                   size_t chan_stride, size_t frame_stride, const fvvdp_eotf* eotf,
@@ -642,18 +658,9 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
         std::sort(uniq.begin(), uniq.end());
         uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
         const int nu = (int)uniq.size();
-        const size_t need = (size_t)2 * nu * HW;
-        if (c->lum_floats < need) {
-            HIP_TRY(hipStreamSynchronize(st));                       // earlier calls may still read the old buffer
-            if (c->lum_buf) (void)hipFree(c->lum_buf);
-            c->lum_buf = nullptr;
-            c->lum_floats = 0;
-            void* q = nullptr;
-            if (hipMalloc(&q, need * sizeof(float)) != hipSuccess)
-                return fail(FVVDP_ENOMEM, "hipMalloc(%zu bytes) for the luminance frames of a %d-tap filter failed", need * sizeof(float), fl);
-            c->lum_buf = reinterpret_cast<float*>(q);
-            c->lum_floats = need;
-            c->scratch += need * sizeof(float);
+        {
+            const int rc = grow_lum_buf(c, (size_t)2 * nu * HW, fl, st);
+            if (rc != FVVDP_OK) return rc;
         }
         LumArgs la;
         memset(&la, 0, sizeof(la));
@@ -782,11 +789,60 @@ extern "C" int fvvdp_temporal_channels_yuv(fvvdp_ctx* c, const void* d_test, con
     if (c->P != 4) return fail(FVVDP_EINVAL, "YUV ingest is for video contexts (planes == 4)");
     if (fmt->bit_depth < 8 || fmt->bit_depth > 16) return fail(FVVDP_EINVAL, "bit depth %d not supported", fmt->bit_depth);
     if (fmt->chroma_420 && ((c->W | c->H) & 1)) return fail(FVVDP_EINVAL, "4:2:0 needs even frame dimensions");
-    if (fl < 1 || fl > 32) return fail(FVVDP_EINVAL, "filter length %d out of range for the YUV path (1..32)", fl);
+    if (fl < 1 || fl > 64) return fail(FVVDP_EINVAL, "filter length %d out of range for the YUV path (1..64)", fl);
     if (n_out < 1 || slot0 < 0 || slot0 + n_out > c->max_frames) return fail(FVVDP_EINVAL, "slots out of range");
     if (eotf->kind == FVVDP_EOTF_LUT) return fail(FVVDP_EINVAL, "YUV sources need a closed-form display model (RGB is fractional after the matrix)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     Timed tm(c, 0, st);
+    if (fl > 32) {
+        // 33..64 taps (129-256 fps): every source frame of the window -> fp32 luminance once, then the 64-slot ring on the
+        // luminance frames (see temporal_channels_core)
+        const int total = fl - 1 + n_out;
+        if (total > T_MAX_IDX) return fail(FVVDP_EINVAL, "too many frames for one call");
+        const int HW = c->W * c->H;
+        std::vector<int> uniq(h_frame_idx, h_frame_idx + total);
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        const int nu = (int)uniq.size();
+        {
+            const int rc = grow_lum_buf(c, (size_t)2 * nu * HW, fl, st);
+            if (rc != FVVDP_OK) return rc;
+        }
+        YuvLumArgs la;
+        memset(&la, 0, sizeof(la));
+        YuvArgs& a = la.y;
+        a.src[0] = d_test;
+        a.src[1] = d_ref;
+        a.frame_stride = frame_stride;
+        a.W = c->W;
+        a.H = c->H;
+        a.chroma420 = fmt->chroma_420 ? 1 : 0;
+        a.uvw = fmt->chroma_420 ? c->W / 2 : c->W;
+        a.uvh = fmt->chroma_420 ? c->H / 2 : c->H;
+        const float scale = (float)(1 << (fmt->bit_depth - 8));
+        a.wy = 1.0f / (scale * 219.0f);
+        a.wc = 1.0f / (scale * 224.0f);
+        for (int i = 0; i < 9; ++i) a.m[i] = fmt->ycbcr2rgb[i];
+        a.e = make_eotf(eotf);
+        a.w[0] = h_rgb2y[0]; a.w[1] = h_rgb2y[1]; a.w[2] = h_rgb2y[2];
+        a.oob = d_oob_flag;
+        la.n_frames = nu;
+        la.out = c->lum_buf;
+        for (int k = 0; k < nu; ++k) la.fr[k] = uniq[k];
+        k1_launch_yuv_luminance(fmt->bit_depth > 8 ? 2 : 1, la, st);
+        HIP_TRY(hipGetLastError());
+        std::vector<int32_t> pos(total);
+        for (int u = 0; u < total; ++u) pos[u] = (int32_t)(std::lower_bound(uniq.begin(), uniq.end(), h_frame_idx[u]) - uniq.begin());
+        fvvdp_eotf none;
+        memset(&none, 0, sizeof(none));
+        none.kind = FVVDP_EOTF_NONE;
+        const bool timing = c->timing;
+        c->timing = false;
+        const int rc2 = temporal_channels_core(c, c->lum_buf, c->lum_buf + (size_t)nu * HW, FVVDP_F32, 1, 0, (size_t)HW, &none, nullptr,
+                                               pos.data(), nullptr, h_taps, fl, n_out, slot0, d_oob_flag, stream);
+        c->timing = timing;
+        return rc2;
+    }
     const int FL = fl <= 8 ? 8 : (fl <= 16 ? 16 : 32);
     const int max_out = T_MAX_IDX - (FL - 1);
     for (int t0 = 0; t0 < n_out; t0 += max_out) {

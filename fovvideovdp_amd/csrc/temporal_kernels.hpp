@@ -1284,6 +1284,31 @@ __global__ __launch_bounds__(256) void luminance_frames_kernel(const LumArgs a) 
     if (bad && a.oob) atomicOr(a.oob, 1);
 }
 
+// the same first pass for planar YUV sources (33..64 taps): unpack, chroma upsampling, colour matrix, display model and
+// luminance of every source frame of the window, once (yuv_lum above); the 64-slot ring then runs on the luminance frames
+struct YuvLumArgs {
+    YuvArgs y;               // src, frame_stride, geometry, conversion constants, display model (taps / idx unused)
+    int n_frames;
+    float* out;              // [2 streams][n_frames][HW]
+    int fr[T_MAX_IDX];
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void yuv_luminance_frames_kernel(const YuvLumArgs a) {
+    const int HW = a.y.W * a.y.H;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    const int k = blockIdx.y;
+    if (p >= HW) return;
+    bool bad = false;
+    const size_t off = (size_t)a.fr[k] * a.y.frame_stride;
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const T* f = reinterpret_cast<const T*>(a.y.src[s]) + off;
+        a.out[((size_t)s * a.n_frames + k) * HW + p] = yuv_lum<T>(f, a.y, p, bad);
+    }
+    if (bad && a.y.oob) atomicOr(a.y.oob, 1);
+}
+
 // planar [n][P][HW] <-> interleaved [n][HW][P]
 template <int P>
 __global__ void interleave_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int to_interleaved) {

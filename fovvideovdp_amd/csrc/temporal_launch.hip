@@ -134,6 +134,11 @@ void k1_launch_yuv_vec(int FL, int bytes, bool c420, const YuvArgs& a, hipStream
     if (FL == 8) launch_yuv_vec<8>(bytes, c420, a, st);
     else launch_yuv_vec<16>(bytes, c420, a, st);
 }
+void k1_launch_yuv_luminance(int bytes, const YuvLumArgs& a, hipStream_t st) {
+    dim3 grid((a.y.W * a.y.H + 255) / 256, a.n_frames), block(256);
+    if (bytes == 1) hipLaunchKernelGGL((yuv_luminance_frames_kernel<unsigned char>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((yuv_luminance_frames_kernel<unsigned short>), grid, block, 0, st, a);
+}
 void k1_launch_yuv(int FL, int bytes, const YuvArgs& a, hipStream_t st) {
     if (FL == 8) launch_yuv<8, 2>(bytes, a, st);
     else if (FL == 16) launch_yuv<16, 2>(bytes, a, st);

@@ -671,7 +671,7 @@ class fvvdp:
                 return feed
         if (isinstance(vs, fvvdp_video_source_yuv_frames) and native_eotf(vs.dm_photometry) is not None
                 and not (hasattr(vs, "_resizing") and vs._resizing())
-                and int(np.ceil(250.0 / (1000.0 / max(vs.get_frames_per_second(), 1e-9)))) <= 32):   # > 128 fps: generic path
+                and int(np.ceil(250.0 / (1000.0 / max(vs.get_frames_per_second(), 1e-9)))) <= 64):   # > 256 fps: generic path
             # raw planar YUV: unpacking, chroma upsampling, colour matrix and display model run in the HIP kernel
             test_d = vs.test_yuv.to(self.device).contiguous()
             ref_d = vs.reference_yuv.to(self.device).contiguous()
@@ -691,8 +691,8 @@ class fvvdp:
             w = np.asarray(vs.color_to_luminance, dtype=np.float32)
 
             def feed_yuv(ctx, idx, taps, fl, n_out, oob, stream):
-                if fl > 32:
-                    raise RuntimeError("frame rate too high for the YUV path (temporal filter longer than 32 taps)")
+                if fl > 64:
+                    raise RuntimeError("frame rate too high for the YUV path (temporal filter longer than 64 taps)")
                 nat.check(lib.fvvdp_temporal_channels_yuv(
                     ctx.handle, C.c_void_p(test_d.data_ptr()), C.c_void_p(ref_d.data_ptr()), C.byref(fmt), vs.frame_elems,
                     C.byref(e), nat.fptr(w), idx.ctypes.data_as(C.POINTER(C.c_int32)), nat.fptr(taps), fl, n_out, 0,

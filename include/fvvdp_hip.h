@@ -189,7 +189,8 @@ typedef struct fvvdp_yuv_format {
 /* Replaces video_reader_yuv_pytorch.unpack + _fixed2float_upscale (video_source_file.py:219-276),
  * fvvdp_video_source_video_file._prepare_frame (:355-363) and the temporal filter (fvvdp.py:258-300): like
  * fvvdp_temporal_channels, but the source frames are raw planar YUV.  frame_stride in elements; the display model
- * must be closed-form (kind != FVVDP_EOTF_LUT); full-screen resizing is not supported. */
+ * must be closed-form (kind != FVVDP_EOTF_LUT); full-screen resizing is not supported.  Up to 64 taps (256 fps): 1..32 taps in
+ * one pass, 33..64 in two (YUV frames -> luminance frames once, then the 64-slot ring), FVVDP_EINVAL above. */
 int fvvdp_temporal_channels_yuv(fvvdp_ctx* ctx, const void* d_test, const void* d_ref, const fvvdp_yuv_format* fmt,
                                 size_t frame_stride, const fvvdp_eotf* eotf, const float* h_rgb2y,
                                 const int32_t* h_frame_idx, const float* h_taps, int fl, int n_out, int slot0,

@@ -100,7 +100,8 @@ def test_yuv_vector_kernel_equals_scalar_kernel(H, W, bd, css, fps, monkeypatch)
 
 
 @pytest.mark.parametrize("H,W,bd,css,fps,N", [(40, 72, 8, "420", 120, 34), (36, 66, 10, "420", 25, 9), (30, 50, 8, "444", 50, 14),
-                                              (36, 64, 8, "420", 144, 40)])      # 36 taps: beyond the YUV kernels -> generic feeder
+                                              (36, 64, 8, "420", 144, 40),       # 36 taps: luminance frames + 64-slot ring (two passes)
+                                              (38, 66, 10, "444", 240, 70)])     # 60 taps, 10 bit 4:4:4, width % 4 != 0
 def test_yuv_other_frame_rates_and_widths_vs_oracle(H, W, bd, css, fps, N):
     """YUV sources outside the vector kernel's domain -- 120 fps (30 taps: per-pixel kernel with the 32-slot ring),
     widths that are not a multiple of 4 -- and a zero-padded filter (25 fps: 7 taps in the 8-slot ring), against the
