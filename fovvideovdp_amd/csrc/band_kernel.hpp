@@ -14,7 +14,9 @@
 //   (test, ref) live in adjacent registers and go through packed fp32 math (v_pk_fma_f32), which also makes the
 //   test and reference planes bit-symmetric (identical inputs give exactly D = 0).
 // ------------------------------------------------------------------------------------------------------------
+#ifndef STRIP_J             // (overridable for one timing-only experiment, profiles/r03_fov_variants.md)
 #define STRIP_J 60          // coarse columns produced per wave (64 lanes - 2 halo lanes each side)
+#endif
 
 
 template <int P>

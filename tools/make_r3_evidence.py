@@ -164,12 +164,35 @@ does not move: LDS is 1.3 % of the waves' time):
 
 {rd('s2/pmc_fov_padded.md')}
 
+Two more variants, measured after the first version of this file:
+
+```
+{rd('s14/fov_lane_eff.txt')}
+```
+
+`strip54`: every strip advances by 54 instead of 60 columns (timing only: neighbouring strips overlap, the sums are wrong on
+purpose) -- 12.5 % more waves of unchanged work, the lane efficiency a two-level strip would have.  Levels >= 1 get 10-12 % slower
+(10.1 -> 11.3 us); level 0 does not move, but its wave count changes from 5.0 to 5.6 "rounds" of the chip, so that row is not
+conclusive on its own.  `norhomap` (`FVVDP_FOV_NO_RHOMAP=1`: the rho-axis position recomputed per pixel and frame, no map read):
+56.8 us at level 0 -- the bytes saved do not pay for the instructions.
+
+The rho map at 4 instead of 8 bytes per pixel (interval + fraction in one float, unpacked with floor / sub / mul: +3 VALU
+instructions per pixel, -41 MB per frame at levels 0+1; `tools/experiments/patches/fov_compact_rho_map.patch`, all 157 GPU tests
+green with it), three runs:
+
+```
+{rd('s15/fov_probe.txt')}
+```
+
+45.1-45.9 us at level 0 against 44.3-44.7, 10.5 against 10.1-10.3 at level 1: 14 % fewer bytes at level 0 buy nothing, 3 % more
+instructions cost 1.5 % -- the kernel is bound by its instruction stream, not by the bytes.  Not kept.
+
 Reading: `valu` 0.318 of a wave's resident time x 3 waves per SIMD = 0.95 -> the VALU pipe is busy 95 % of the time (the plain
 two-level kernel: 0.357 x 3 = 1.07, saturated, `profiles/r03_final_kernel_trace.md`); at the same time the two levels move
 254 MB per frame (level 0: 132.7 MB + 66 MB of rho map + 33 MB written, plus halo) in ~55 us = 4.6 TB/s, level 0 alone 240 MB in
-45 us = 5.3 TB/s -- the memory system's ceiling for a read/write mix (5.0-5.6 TB/s, `tools/microbench/mix.hip`).  Both limits bind
-together; removing bytes (rho map 8 -> 4 B per pixel) costs VALU instructions (+3 %), removing instructions is bounded by
-the 13 transcendentals and the trilinear blend per pixel.  A two-level variant (VERDICT r2 item 2a) multiplies the VALU work by
+45 us = 5.3 TB/s -- the memory system's ceiling for a read/write mix (5.0-5.6 TB/s, `tools/microbench/mix.hip`).  Both limits are close, but the
+experiments above decide it: fewer bytes change nothing, more instructions cost time.  Removing instructions is bounded by the 13
+transcendentals and the trilinear blend per pixel.  A two-level variant (VERDICT r2 item 2a) multiplies the VALU work by
 60/54 (strip halo) on a kernel that is already VALU-bound and saves 17 % of the bytes: 58 us against 55 by the same arithmetic
 that predicted the plain kernel's gain.  Target (<= 50 us for all levels) not met: 59.5 us.
 """)
