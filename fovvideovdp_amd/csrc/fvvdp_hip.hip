@@ -53,10 +53,10 @@ extern "C" const char* fvvdp_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------------------
-struct VmmBlock {               // a buffer that came from the virtual-memory API (see dev_alloc)
-    void* ptr;
+struct VmmBlock {               // a buffer that came from the virtual-memory API (see dev_alloc): one reserved range, one or
+    void* ptr;                  // more physical allocations mapped into it
     size_t size;
-    hipMemGenericAllocationHandle_t handle;
+    std::vector<hipMemGenericAllocationHandle_t> handles;
 };
 struct fvvdp_ctx {
     int W = 0, H = 0, n_bands = 0, P = 0, max_frames = 0;
@@ -130,7 +130,16 @@ static int dev_alloc(fvvdp_ctx* c, T** p, size_t count) {
         int rc = vmm_alloc(c, &q, bytes);
         if (rc != FVVDP_OK) return rc;
     } else {
-        hipError_t e = hipMalloc(&q, bytes);
+        // placement experiments: FVVDP_ALLOC_FLAGS=finegrained|uncached|contiguous for the large buffers (hipExtMallocWithFlags)
+        static const unsigned int ext_flags = [] {
+            const char* e = getenv("FVVDP_ALLOC_FLAGS");
+            if (!e) return 0u;
+            if (!strcmp(e, "finegrained")) return (unsigned int)hipDeviceMallocFinegrained;
+            if (!strcmp(e, "uncached")) return (unsigned int)hipDeviceMallocUncached;
+            if (!strcmp(e, "contiguous")) return (unsigned int)hipDeviceMallocContiguous;
+            return 0u;
+        }();
+        hipError_t e = (ext_flags && bytes >= ((size_t)64 << 20)) ? hipExtMallocWithFlags(&q, bytes, ext_flags) : hipMalloc(&q, bytes);
         if (e != hipSuccess) return fail(FVVDP_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
     }
     *p = reinterpret_cast<T*>(q);
@@ -169,31 +178,62 @@ static int vmm_alloc(fvvdp_ctx* c, void** out, size_t bytes) {
     size_t gran = 0;
     HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
     if (gran == 0) gran = (size_t)2 << 20;
+    size_t align = gran;
     if (const char* g = getenv("FVVDP_VMM_ALIGN_MB")) {          // experiment: coarser alignment of the reserved range
         const size_t a = (size_t)atoll(g) << 20;
-        if (a > gran && a % gran == 0) gran = a;
+        if (a > gran && a % gran == 0) align = a;
     }
-    const size_t size = (bytes + gran - 1) / gran * gran;
+    // Placement experiments (profiles/r03_k1_placement.md): the range is backed by physical chunks of FVVDP_VMM_CHUNK_MB
+    // (default: one allocation), created in order and mapped k-way interleaved (FVVDP_VMM_INTERLEAVE=k: consecutive chunks of
+    // the virtual range come from k different parts of the sequence of physical allocations).
+    size_t chunk = 0;
+    if (const char* g = getenv("FVVDP_VMM_CHUNK_MB")) {
+        chunk = (size_t)atoll(g) << 20;
+        chunk = chunk / gran * gran;
+    }
+    int kway = 1;
+    if (const char* g = getenv("FVVDP_VMM_INTERLEAVE")) kway = atoi(g) < 1 ? 1 : atoi(g);
+    const size_t unit = chunk ? chunk : align;
+    const size_t size = (bytes + unit - 1) / unit * unit;
+    if (!chunk) chunk = size;
+    const size_t n = size / chunk;
     VmmBlock b;
     b.size = size;
     b.ptr = nullptr;
-    hipError_t e = hipMemAddressReserve(&b.ptr, size, gran, nullptr, 0);
+    hipError_t e = hipMemAddressReserve(&b.ptr, size, align, nullptr, 0);
     if (e != hipSuccess) return fail(FVVDP_ENOMEM, "hipMemAddressReserve(%zu) failed: %s", size, hipGetErrorString(e));
-    e = hipMemCreate(&b.handle, size, &prop, 0);
-    if (e != hipSuccess) {
+    auto undo = [&]() {
+        (void)hipMemUnmap(b.ptr, size);
+        for (auto h : b.handles) (void)hipMemRelease(h);
         (void)hipMemAddressFree(b.ptr, size);
-        return fail(FVVDP_ENOMEM, "hipMemCreate(%zu) failed: %s", size, hipGetErrorString(e));
+    };
+    for (size_t i = 0; i < n && e == hipSuccess; ++i) {
+        hipMemGenericAllocationHandle_t h;
+        e = hipMemCreate(&h, chunk, &prop, 0);
+        if (e == hipSuccess) b.handles.push_back(h);
     }
-    e = hipMemMap(b.ptr, size, 0, b.handle, 0);
+    if (e != hipSuccess) {
+        for (auto h : b.handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(b.ptr, size);
+        return fail(FVVDP_ENOMEM, "hipMemCreate(%zu x %zu) failed: %s", n, chunk, hipGetErrorString(e));
+    }
+    // slot s of the virtual range <- physical chunk order[s]: round-robin over k consecutive groups of the creation order
+    std::vector<size_t> order;
+    {
+        const size_t m = (n + (size_t)kway - 1) / (size_t)kway;
+        for (size_t j = 0; j < m; ++j)
+            for (size_t g = 0; g < (size_t)kway; ++g)
+                if (g * m + j < n && g * m + j < (g + 1) * m) order.push_back(g * m + j);
+    }
+    for (size_t s2 = 0; s2 < n && e == hipSuccess; ++s2)
+        e = hipMemMap(static_cast<char*>(b.ptr) + s2 * chunk, chunk, 0, b.handles[order[s2]], 0);
     hipMemAccessDesc acc;
     memset(&acc, 0, sizeof(acc));
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
     if (e == hipSuccess) e = hipMemSetAccess(b.ptr, size, &acc, 1);
     if (e != hipSuccess) {
-        (void)hipMemUnmap(b.ptr, size);
-        (void)hipMemRelease(b.handle);
-        (void)hipMemAddressFree(b.ptr, size);
+        undo();
         return fail(FVVDP_ENOMEM, "hipMemMap / hipMemSetAccess(%zu) failed: %s", size, hipGetErrorString(e));
     }
     c->vmm.push_back(b);
@@ -215,7 +255,7 @@ static void dev_free(fvvdp_ctx* c, void* p) {
 static void vmm_free_all(fvvdp_ctx* c) {
     for (VmmBlock& b : c->vmm) {
         (void)hipMemUnmap(b.ptr, b.size);
-        (void)hipMemRelease(b.handle);
+        for (auto h : b.handles) (void)hipMemRelease(h);
         (void)hipMemAddressFree(b.ptr, b.size);
     }
     c->vmm.clear();

@@ -102,6 +102,31 @@ VERDICT r2 weak 6 / item 4: the same kernel runs at 31-32 us per frame (5.8 TB/s
    better, the calls that run on a fresh buffer pay its first touch (39-43 us per frame), and the context holds level 0 twice
    for two calls.  A 3.5 % gain on K1 in the mean for that price: off by default.
 
+8. **It is the physical FRAGMENTATION of the level-0 buffer, and the two kernels want opposite things** (later sessions).
+   `FVVDP_ALLOC_FLAGS=contiguous` (`hipExtMallocWithFlags(hipDeviceMallocContiguous)`) puts K1 in its slow mode every time, the other
+   flags do not decide it:
+
+```
+{rd('s16/alloc_flags.txt')}
+```
+
+   Building the buffer from physical chunks with the virtual-memory API (`FVVDP_ALLOC=vmm FVVDP_VMM_CHUNK_MB=c FVVDP_VMM_INTERLEAVE=k`:
+   chunks created in order, mapped k-way interleaved): 2 MB chunks put K1 in its FAST mode almost every time -- and K2b, which
+   reads the same buffer, at 38 us.  The sum K1 + K2b is 70-71 us per frame at both ends; 67 us (K1 fast AND K2b at 34.5) shows up
+   in about one context in five with large chunks, not reproducibly:
+
+```
+{rd('s17/vmm_layout.txt')}
+```
+
+   A padded frame-slot stride (`tools/experiments/patches/level0_slot_stride_and_vmm_layout.patch`: every kernel that touches level 0
+   takes a slot stride; 135 GPU tests green with a 68 KB pad) on contiguous memory -- is the slow mode a resonance of the
+   132,710,400-byte frame stride?  No:
+
+```
+{rd('s18/slot_pad.txt')}
+```
+
 What it is physically is not known to me: not address translation (r2: UTCL1 / UTCL2 counters equal in both modes), not the
 clocks, not the alignment of the buffer, not an XCD <-> page interleave (a 4 KB offset changes nothing).  The per-channel HBM
 counters that would show a channel imbalance are not exposed by rocprofv3 on this stack (TCC_EA0_* are aggregates).
