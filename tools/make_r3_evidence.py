@@ -127,6 +127,15 @@ VERDICT r2 weak 6 / item 4: the same kernel runs at 31-32 us per frame (5.8 TB/s
 {rd('s18/slot_pad.txt')}
 ```
 
+   Is it the page-table fragment size of the mapping?  Level 0 mapped twice with the virtual-memory API -- the readers use one
+   mapping, K1 stores through a second mapping of the SAME physical allocation shifted by 2 ... 512 MB
+   (`tools/experiments/patches/level0_write_alias.patch`): no change, K1 stays in the slow mode of a single physical allocation
+   (`hipMemAddressReserve` does not honour a 1 GiB alignment request here, so the fragment sizes could not be forced either way):
+
+```
+{rd('s19/alias.txt', drop=("amdgpu.ids", "fvvdp: level 0 at"))}
+```
+
 What it is physically is not known to me: not address translation (r2: UTCL1 / UTCL2 counters equal in both modes), not the
 clocks, not the alignment of the buffer, not an XCD <-> page interleave (a 4 KB offset changes nothing).  The per-channel HBM
 counters that would show a channel imbalance are not exposed by rocprofv3 on this stack (TCC_EA0_* are aggregates).
