@@ -1019,6 +1019,46 @@ __device__ __forceinline__ v2f lum_pair(v2f r, v2f g, v2f b, float w0, float w1,
     return (r * w0 + g * w1) + b * w2;
 }
 
+// Window of the last FL luminance pairs of a lane's 4 pixels, kept in registers WITHOUT moving it: frame v goes to slot
+// v mod FL and the FIR of that frame is one of FL straight-line variants (a wave-uniform switch over v mod FL), each with
+// compile-time slots and taps: age k sits in slot (S - k) mod FL.  (Shifting the window by one slot per frame instead cost
+// FL*8-8 register moves per frame, a quarter of the 16-slot kernel's VALU instructions.)  Oldest tap first, like the
+// reference's sum over the window; two taps per scalar load: this kernel has the colour matrix, the display model and the
+// chroma weights in scalar registers next to the taps.
+template <int FL, int S>
+__device__ __forceinline__ void yuv_window_step(v2f (&win)[FL][4], const v2f (&lum)[4],
+                                                const char __attribute__((address_space(4)))* tp, v2f (&acc_s)[4], v2f (&acc_t)[4]) {
+    typedef float v4tap __attribute__((ext_vector_type(4), aligned(4)));
+    typedef const v4tap __attribute__((address_space(4)))* karg_tap4_p;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) win[S][i] = lum[i];
+#pragma unroll
+    for (int c = FL / 2 - 1; c >= 0; --c) {
+        const v4tap tc = *(karg_tap4_p)(tp + c * 16);
+#pragma unroll
+        for (int kk = 1; kk >= 0; --kk) {
+            const int k = c * 2 + kk;
+            const v2f f = v2f{tc[2 * kk], tc[2 * kk + 1]};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) fir_tap(acc_s[i], acc_t[i], win[(S - k + FL) % FL][i], f);
+        }
+    }
+}
+
+template <int FL>
+__device__ __forceinline__ void yuv_window_dispatch(int slot, v2f (&win)[FL][4], const v2f (&lum)[4],
+                                                    const char __attribute__((address_space(4)))* tp, v2f (&acc_s)[4], v2f (&acc_t)[4]) {
+    static_assert(FL <= 16, "one case per slot below");
+    switch (slot) {
+        default: __builtin_unreachable();
+#define FVVDP_YUV_CASE(N) case N: if constexpr (N < FL) yuv_window_step<FL, (N < FL ? N : 0)>(win, lum, tp, acc_s, acc_t); break;
+        FVVDP_YUV_CASE(0) FVVDP_YUV_CASE(1) FVVDP_YUV_CASE(2) FVVDP_YUV_CASE(3) FVVDP_YUV_CASE(4) FVVDP_YUV_CASE(5)
+        FVVDP_YUV_CASE(6) FVVDP_YUV_CASE(7) FVVDP_YUV_CASE(8) FVVDP_YUV_CASE(9) FVVDP_YUV_CASE(10) FVVDP_YUV_CASE(11)
+        FVVDP_YUV_CASE(12) FVVDP_YUV_CASE(13) FVVDP_YUV_CASE(14) FVVDP_YUV_CASE(15)
+#undef FVVDP_YUV_CASE
+    }
+}
+
 #define YUV_QUADS 62     // pixel quads (4 consecutive pixels) written per wave
 #ifndef YUV_TD8
 #define YUV_TD8 2        // frames of raw samples in flight per lane, 8-slot window
@@ -1027,9 +1067,8 @@ __device__ __forceinline__ v2f lum_pair(v2f r, v2f g, v2f b, float w0, float w1,
 #define YUV_TD16 1       // 16-slot window: 128 registers of window leave room for one frame of raw samples (2 -> 2-11 spilled dwords)
 #endif
 // One rolled loop over the frames, straight-line inside (see temporal_vec_kernel for why: counted waits instead of
-// drains).  The last FL luminance pairs of the lane's 4 pixels sit in a register window that is SHIFTED by one slot per
-// frame (FL*4-4 64-bit moves): the slots the FIR reads are then compile-time constants without unrolling the frame loop
-// FL times -- the conversion of a frame is a few hundred instructions, FL copies of it do not fit the instruction cache.
+// drains).  The conversion of a frame is a few hundred instructions and exists once; the window of the last FL luminance
+// pairs stays where it is (yuv_window_step above) and only the short FIR exists FL times.
 // The FIR also runs during the history frames (its result is dropped by an out-of-range store offset).
 template <int FL, typename T, bool C420, int KIND>
 __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* s_t) {
@@ -1073,7 +1112,7 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
             g.left_own = g.right_own = false;
         }
     }
-    v2f win[FL][PX];                                      // (test, reference) luminance; win[FL-1] = newest frame
+    v2f win[FL][PX];                                      // (test, reference) luminance; frame v of the window in slot v mod FL
 #pragma unroll
     for (int u = 0; u < FL; ++u)
 #pragma unroll
@@ -1104,32 +1143,15 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
             v2f rgb[12];
             yuv_pair_rgb<T, C420>(cur0, cur1, a, g, g_fy, g_gy, g_fx0, g_gx0, rgb);
             eotf_apply_pairs<12, KIND>(rgb, a.e);
+            v2f lum[PX];
 #pragma unroll
-            for (int u = 0; u + 1 < FL; ++u)
-#pragma unroll
-                for (int i = 0; i < PX; ++i) win[u][i] = win[u + 1][i];
-#pragma unroll
-            for (int i = 0; i < PX; ++i) win[FL - 1][i] = lum_pair(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], a.w[0], a.w[1], a.w[2]);
+            for (int i = 0; i < PX; ++i) lum[i] = lum_pair(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], a.w[0], a.w[1], a.w[2]);
             v2f acc_s[PX], acc_t[PX];                     // sustained / transient channel of (test, reference)
 #pragma unroll
             for (int i = 0; i < PX; ++i) acc_s[i] = acc_t[i] = splat(0.0f);
             karg_p tp = (karg_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(YuvArgs, taps2);
             if constexpr (FL > 8) asm volatile("" : "+s"(tp));      // reloaded per frame, see temporal_vec_body
-            // two taps per scalar load: this kernel has the colour matrix, the display model and the chroma weights in scalar
-            // registers next to the taps
-            typedef float v4tap __attribute__((ext_vector_type(4), aligned(4)));
-            typedef const v4tap __attribute__((address_space(4)))* karg_tap4_p;
-#pragma unroll
-            for (int c = FL / 2 - 1; c >= 0; --c) {       // oldest tap first, like the reference's sum over the window
-                const v4tap tc = *(karg_tap4_p)(tp + c * 16);
-#pragma unroll
-                for (int kk = 1; kk >= 0; --kk) {
-                    const int k = c * 2 + kk;
-                    const v2f f = v2f{tc[2 * kk], tc[2 * kk + 1]};
-#pragma unroll
-                    for (int i = 0; i < PX; ++i) fir_tap(acc_s[i], acc_t[i], win[FL - 1 - k][i], f);
-                }
-            }
+            yuv_window_dispatch<FL>(v & (FL - 1), win, lum, tp, acc_s, acc_t);
             wave_lds_order();
 #pragma unroll
             for (int i = 0; i < PX; ++i)

@@ -253,3 +253,34 @@ tiles; 3000+ waves only at <= 10-row tiles, where the 14 halo rows of the two-le
 and the 8-frame window costs 48 dword loads + 48 LDS look-ups + 32 multiply-adds per 4 pixels and frame in place of K1's 6 + 6 + 32
 (the ring in registers converts every source frame once).  Not pursued further; the hand-off stays.
 """)
+
+w("r03_yuv_ingest.md", f"""# Round 3 -- what bounds the planar-YUV ingest kernel (VERDICT r2 item 3: 10-bit 4:2:0 at 60 fps <= 50 us per frame)
+
+`temporal_yuv_vec_kernel<16, uint16, 4:2:0, sRGB>` on a 3840x2160x60 pair at 60 fps (16-tap window), `tools/gpu_yuv.py`.
+
+Round-3 steps, us per 4K frame (rocprof steady median / 60): 65.2 (round 3 start, no spills, 2 waves per SIMD) -> **63.0** with the
+window kept in place (frame v in slot v mod 16, one straight-line FIR per slot behind a wave-uniform switch; before, the 16-slot
+window was shifted by one slot per frame = 120 `v_mov_b32` of 860 VALU instructions per lane and frame).  The 8-slot kernels (30 fps)
+do not change (46 us 4:2:0 8 bit, 37 us 4:4:4 8 bit).
+
+```
+{rd('s20/yuv_probe.txt')}
+```
+
+{rd('s20/kernel_trace_yuv.md')}
+
+SQ counters of the same call (`tools/experiments/r3_session21.sh`: five `--pmc` passes, `tools/pmc_sq_summary.py`):
+
+{rd('s21/pmc_sq_2160_3840_60_10_420_60.md')}
+
+{rd('s21/pmc_sq_2160_3840_60_8_420.md')}
+
+Reading.  16-slot kernel: a wave issues 47.1 k VALU instructions over its 75 frame steps = **628 per step of 4 pixel pairs** (128 of them
+the FIR: 16 taps x 4 pixels x {{sustained, transient}}; ~440 the conversion: 32 integer -> float, the 4:2:0 bilinear blend, the
+colour matrix, 24 `v_log_f32` + 24 `v_exp_f32` of the sRGB curve, the luminance sum with the reference's roundings).  With 2 waves per SIMD
+(the 128-register window leaves no room for a third) the VALU is busy 0.44 x 2 = **0.88** of the time, 0.20 of a wave's time is
+`s_waitcnt` (the tap loads at the head of every FIR variant, the LDS transpose), the rest is the other wave's VALU.  The kernel
+moves 5.7 + 8.0 GB in 3.8 ms = 3.6 TB/s: not the memory system.  50 us would need ~490 VALU instructions per step at the same
+occupancy; the arithmetic of the path (3 transcendental pairs per pixel and stream, 256 multiply-adds of FIR per 4 pixels) does not
+go below ~600 without changing the reference's roundings.  Target not met; the kernel is VALU-bound.
+""")
