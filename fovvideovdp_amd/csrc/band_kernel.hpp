@@ -278,23 +278,29 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
         p1 = ld_px<P>(row + (size_t)xc1 * P);
     };
 
-    Px<P> W[5][2];
+    // The 5-row window of the vertical filter plus the two rows in flight for the next step live in a ring of 8 row slots
+    // that is never moved: fine row r sits in slot (r - (2*ca - 4)) mod 8, and the main loop below is unrolled over the 4
+    // positions the window can take in the ring (a window that is shifted by two rows per step costs 24 64-bit register
+    // moves per step and lane, 6-10 % of the loop's VALU time).
+    Px<P> R[8][2];
+    using std::integral_constant;
 
-    // one coarse row from the current window: vertical 5-tap in registers, horizontal 5-tap across lanes
-    auto coarse_step = [&]() -> Px<P> {
+    // one coarse row from the window that starts in slot S0: vertical 5-tap in registers, horizontal 5-tap across lanes
+    auto coarse_step = [&](auto S0) -> Px<P> {
+        constexpr int s0 = decltype(S0)::value;
         Px<P> c, va, vb;
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
-            v2f a0 = W[0][0].h[k] * K0;
-            a0 = pfma(W[1][0].h[k], K1, a0);
-            a0 = pfma(W[2][0].h[k], K2, a0);
-            a0 = pfma(W[3][0].h[k], K3, a0);
-            va.h[k] = pfma(W[4][0].h[k], K4, a0);
-            v2f b0 = W[0][1].h[k] * K0;
-            b0 = pfma(W[1][1].h[k], K1, b0);
-            b0 = pfma(W[2][1].h[k], K2, b0);
-            b0 = pfma(W[3][1].h[k], K3, b0);
-            vb.h[k] = pfma(W[4][1].h[k], K4, b0);
+            v2f a0 = R[s0][0].h[k] * K0;
+            a0 = pfma(R[(s0 + 1) & 7][0].h[k], K1, a0);
+            a0 = pfma(R[(s0 + 2) & 7][0].h[k], K2, a0);
+            a0 = pfma(R[(s0 + 3) & 7][0].h[k], K3, a0);
+            va.h[k] = pfma(R[(s0 + 4) & 7][0].h[k], K4, a0);
+            v2f b0 = R[s0][1].h[k] * K0;
+            b0 = pfma(R[(s0 + 1) & 7][1].h[k], K1, b0);
+            b0 = pfma(R[(s0 + 2) & 7][1].h[k], K2, b0);
+            b0 = pfma(R[(s0 + 3) & 7][1].h[k], K3, b0);
+            vb.h[k] = pfma(R[(s0 + 4) & 7][1].h[k], K4, b0);
         }
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
@@ -304,34 +310,22 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
         }
         return c;
     };
-    auto shift_window = [&](const Px<P> (&n0)[2], const Px<P> (&n1)[2]) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            W[0][j] = W[2][j];
-            W[1][j] = W[3][j];
-            W[2][j] = W[4][j];
-            W[3][j] = n0[j];
-            W[4][j] = n1[j];
-        }
-    };
 
     // ---- prologue: coarse rows ca-1 and ca --------------------------------------------------------------
     {
-        const int r0 = 2 * (ca - 1) - 2;
+        const int r0 = 2 * (ca - 1) - 2;                              // slot 0
 #pragma unroll
-        for (int k = 0; k < 5; ++k) load_row(r0 + k, W[k][0], W[k][1]);
+        for (int k = 0; k < 5; ++k) load_row(r0 + k, R[k][0], R[k][1]);
     }
-    const Px<P> cA = coarse_step();
-    Px<P> nx0[2], nx1[2];
-    load_row(2 * ca + 1, nx0[0], nx0[1]);
-    load_row(2 * ca + 2, nx1[0], nx1[1]);
-    shift_window(nx0, nx1);
-    const Px<P> cB = coarse_step();
+    const Px<P> cA = coarse_step(integral_constant<int, 0>());
+    load_row(2 * ca + 1, R[5][0], R[5][1]);
+    load_row(2 * ca + 2, R[6][0], R[6][1]);
+    const Px<P> cB = coarse_step(integral_constant<int, 2>());       // rows 2ca-2 .. 2ca+2
     st_px(Gc_rsrc, active ? (unsigned int)(ca * wc + J) * (P * 4u) : FVVDP_NO_STORE, cB);
     Px<P> Gm1 = (ca > 0) ? cA : cB;
     Px<P> G0 = cB;
-    load_row(2 * ca + 3, nx0[0], nx0[1]);
-    load_row(2 * ca + 4, nx1[0], nx1[1]);
+    load_row(2 * ca + 3, R[7][0], R[7][1]);
+    load_row(2 * ca + 4, R[0][0], R[0][1]);
 
     float acc[2] = {0.0f, 0.0f};
 
@@ -512,18 +506,27 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
         }
         q.llb = fast_log2(lb);
         const float yq = __builtin_amdgcn_fmed3f(q.llb, a.ly_lo, a.ly_hi);
+#ifdef FOV_ABLATE_ECC     // timing experiment only: what the eccentricity arithmetic costs (results are wrong)
+        const float eq = vx + vy;
+#else
         const float dx = vx - gx, dy = vy - gy;
         const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
         const float eq = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fmed3f(ecc, a.ecc_lo, a.ecc_hi));
+#endif
         // Y and ecc axes are uniform: interval = floor of the grid position t, fraction = (t - interval) * step/(step+1e-6)
         // (interp.py:11-20 computes (q - knot)/(knot' - knot + 1e-6) from the stored knots: equal to ~2e-6 of an interval,
         // which band_px, the map-writing path, still does).  No LDS look-up, no dependent round trip before the cell reads.
         const float tY = fmaf(yq, a.inv_step[0], a.grid_off[0]);
-        const float tE = fmaf(eq, a.inv_step[2], a.grid_off[2]);
         const float iY = __builtin_amdgcn_fmed3f(floorf(tY), 0.0f, (float)(FVVDP_LUT_N - 2));
-        const float iE = __builtin_amdgcn_fmed3f(floorf(tE), 0.0f, (float)(FVVDP_LUT_N - 2));
         q.fY = (tY - iY) * a.frac_scale[0];
+#ifdef FOV_ABLATE_ECC
+        const float iE = 3.0f;
+        q.fE = eq;
+#else
+        const float tE = fmaf(eq, a.inv_step[2], a.grid_off[2]);
+        const float iE = __builtin_amdgcn_fmed3f(floorf(tE), 0.0f, (float)(FVVDP_LUT_N - 2));
         q.fE = (tE - iE) * a.frac_scale[2];
+#endif
         q.fR = pre_fR;
         // byte offset of the cell (rho plane + ecc * 512 + Y * 16) in float: small integers are exact, one conversion
         const int bo = (int)fmaf(iE, (float)(FOV_ROW * 16), fmaf(iY, 16.0f, pre_kR));
@@ -572,14 +575,42 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
     };
 
     // ---- main loop: band rows 2c, 2c+1 for c in [ca, cb) ------------------------------------------------
-    for (int c = ca; c < cb; ++c) {
-        shift_window(nx0, nx1);               // window = fine rows 2c .. 2c+4
+    auto step = [&](auto PH, const int c) {
+        // window = fine rows 2c .. 2c+4 in slots s0 .. s0+4 (mod 8)
+        constexpr int s0 = (4 + 2 * decltype(PH)::value) & 7;
+        const Px<P> (&W0)[2] = R[s0];
+        const Px<P> (&W1)[2] = R[(s0 + 1) & 7];
         // prefetch the two rows of the next step.  Unconditional (the last step re-reads two rows it does not use; the row
         // index is clamped into the image): with the loads and the store in straight-line code the wait at the top of
         // the next step is vmcnt(1) -- rows landed, store still in flight -- instead of vmcnt(0).
-        load_row(2 * c + 5, nx0[0], nx0[1]);
-        load_row(2 * c + 6, nx1[0], nx1[1]);
-        const Px<P> cN = coarse_step();       // coarse row c+1
+        // foveated, stock geometry: the rho-map records of this step's two rows are requested BEFORE the row prefetch.
+        // Loads return in order (vmcnt): behind the prefetch, the wait for the map was a wait for the two rows just requested
+        // from HBM -- every step, with 3 waves per SIMD to cover it.
+        float4 ra = make_float4(0.0f, -1.0f, 0.0f, -1.0f), rb = ra;      // {f, k} of columns X0, X1 in rows 2c, 2c+1
+        if constexpr (FOV) {
+            if (LEAN || (a.rmap && !a.mvx)) {
+                const int jj = min(max(J, 0), a.rmap_w - 1);
+                ra = a.rmap[(size_t)min(2 * c, h - 1) * a.rmap_w + jj];
+                rb = a.rmap[(size_t)min(2 * c + 1, h - 1) * a.rmap_w + jj];
+            }
+        }
+        float mvx4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, mvy4[4] = {0.0f, 0.0f, 0.0f, 0.0f}, mrm4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
+        if constexpr (FOV && !LEAN) {
+            if (a.mvx) {                      // user geometry: maps evaluated by the caller, requested first for the same reason
+                const int ya = min(2 * c, h - 1), yb = min(2 * c + 1, h - 1);
+                const size_t o[4] = {(size_t)ya * w + xc0, (size_t)ya * w + xc1, (size_t)yb * w + xc0, (size_t)yb * w + xc1};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    mvx4[i] = a.mvx[o[i]];
+                    mvy4[i] = a.mvy[o[i]];
+                    mrm4[i] = a.mrm[o[i]];
+                }
+            }
+        }
+        if constexpr (FOV) __builtin_amdgcn_sched_barrier(0);
+        load_row(2 * c + 5, R[(s0 + 5) & 7][0], R[(s0 + 5) & 7][1]);
+        load_row(2 * c + 6, R[(s0 + 6) & 7][0], R[(s0 + 6) & 7][1]);
+        const Px<P> cN = coarse_step(integral_constant<int, s0>());       // coarse row c+1
         const bool has_next = (c + 1) <= (hc - 1);
         Px<P> Gp1 = has_next ? cN : G0;       // index clamp of the expand (fvvdp_lpyr_dec.py:134,138)
         st_px(Gc_rsrc, (has_next && (c + 1) < cb && active) ? (unsigned int)((c + 1) * wc + J) * (P * 4u) : FVVDP_NO_STORE, cN);
@@ -604,7 +635,7 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
         }
         const bool row1_ok = (2 * c + 1) < h;
 #if defined(BAND_ABLATE) && BAND_ABLATE >= 1      // profiling ablation: no per-pixel tail, keep the data flow alive
-        acc[0] += x00.h[0].x + x01.h[0].x + x10.h[0].x + x11.h[0].x + W[0][0].h[0].x + W[0][1].h[0].x + W[1][0].h[0].x + W[1][1].h[0].x;
+        acc[0] += x00.h[0].x + x01.h[0].x + x10.h[0].x + x11.h[0].x + W0[0].h[0].x + W0[1].h[0].x + W1[0].h[0].x + W1[1].h[0].x;
         if (false)
 #endif
         {
@@ -616,14 +647,12 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
         }
         if constexpr (FOV) {
             float vx4[4] = {vxa, vxb, vxa, vxb}, vy4[4] = {vy0, vy0, vy1, vy1}, rm4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
-            if (!LEAN && a.mvx) {                 // user geometry: maps evaluated by the caller
-                const int ya = min(2 * c, h - 1), yb = min(2 * c + 1, h - 1);
-                const size_t o[4] = {(size_t)ya * w + xc0, (size_t)ya * w + xc1, (size_t)yb * w + xc0, (size_t)yb * w + xc1};
+            if (!LEAN && a.mvx) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    vx4[i] = a.mvx[o[i]];
-                    vy4[i] = a.mvy[o[i]];
-                    rm4[i] = a.mrm[o[i]];
+                    vx4[i] = mvx4[i];
+                    vy4[i] = mvy4[i];
+                    rm4[i] = mrm4[i];
                 }
             } else if (!LEAN && !a.rmap) {
 #pragma unroll
@@ -632,19 +661,13 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
                     rm4[i] = a.cos_delta * fast_rcp(__cosf(va) * __cosf(va + a.delta_rad));
                 }
             }
-            float4 ra = make_float4(0.0f, -1.0f, 0.0f, -1.0f), rb = ra;      // {f, k} of columns X0, X1 in rows 2c, 2c+1
-            if (LEAN || (a.rmap && !a.mvx)) {
-                const int jj = min(max(J, 0), a.rmap_w - 1);
-                ra = a.rmap[(size_t)min(2 * c, h - 1) * a.rmap_w + jj];
-                rb = a.rmap[(size_t)min(2 * c + 1, h - 1) * a.rmap_w + jj];
-            }
             if constexpr (LUT_LDS && !DBG) {
                 if (FOV_PHASE != 0 && (LEAN || (a.rmap && !a.mvx))) {   // stock geometry: phased evaluation (see fov_a / fov_b)
 #if FOV_PHASE == 4
-                    const FovQ q0 = fov_a(W[0][0], x00, vx4[0], vy4[0], ra.x, ra.y);
-                    const FovQ q1 = fov_a(W[0][1], x01, vx4[1], vy4[1], ra.z, ra.w);
-                    const FovQ q2 = fov_a(W[1][0], x10, vx4[2], vy4[2], rb.x, rb.y);
-                    const FovQ q3 = fov_a(W[1][1], x11, vx4[3], vy4[3], rb.z, rb.w);
+                    const FovQ q0 = fov_a(W0[0], x00, vx4[0], vy4[0], ra.x, ra.y);
+                    const FovQ q1 = fov_a(W0[1], x01, vx4[1], vy4[1], ra.z, ra.w);
+                    const FovQ q2 = fov_a(W1[0], x10, vx4[2], vy4[2], rb.x, rb.y);
+                    const FovQ q3 = fov_a(W1[1], x11, vx4[3], vy4[3], rb.z, rb.w);
                     fov_b(q0, active);
                     fov_b(q1, active && col1_ok);
                     fov_b(q2, active && row1_ok);
@@ -652,41 +675,50 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
 #else               // two pixels per phase (default): half the registers in flight; the scheduler may not interleave the phases
                     __builtin_amdgcn_sched_barrier(0);
                     {
-                        const FovQ q0 = fov_a(W[0][0], x00, vx4[0], vy4[0], ra.x, ra.y);
-                        const FovQ q1 = fov_a(W[0][1], x01, vx4[1], vy4[1], ra.z, ra.w);
+                        const FovQ q0 = fov_a(W0[0], x00, vx4[0], vy4[0], ra.x, ra.y);
+                        const FovQ q1 = fov_a(W0[1], x01, vx4[1], vy4[1], ra.z, ra.w);
                         fov_b(q0, active);
                         fov_b(q1, active && col1_ok);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     {
-                        const FovQ q2 = fov_a(W[1][0], x10, vx4[2], vy4[2], rb.x, rb.y);
-                        const FovQ q3 = fov_a(W[1][1], x11, vx4[3], vy4[3], rb.z, rb.w);
+                        const FovQ q2 = fov_a(W1[0], x10, vx4[2], vy4[2], rb.x, rb.y);
+                        const FovQ q3 = fov_a(W1[1], x11, vx4[3], vy4[3], rb.z, rb.w);
                         fov_b(q2, active && row1_ok);
                         fov_b(q3, active && row1_ok && col1_ok);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #endif
                 } else {
-                    band_px(W[0][0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0], ra.x, ra.y);
-                    band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1], ra.z, ra.w);
-                    band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vx4[2], vy4[2], rm4[2], rb.x, rb.y);
-                    band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vx4[3], vy4[3], rm4[3], rb.z, rb.w);
+                    band_px(W0[0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0], ra.x, ra.y);
+                    band_px(W0[1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1], ra.z, ra.w);
+                    band_px(W1[0], x10, active && row1_ok, 2 * c + 1, X0, vx4[2], vy4[2], rm4[2], rb.x, rb.y);
+                    band_px(W1[1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vx4[3], vy4[3], rm4[3], rb.z, rb.w);
                 }
             } else {
-                band_px(W[0][0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0], ra.x, ra.y);
-                band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1], ra.z, ra.w);
-                band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, vx4[2], vy4[2], rm4[2], rb.x, rb.y);
-                band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vx4[3], vy4[3], rm4[3], rb.z, rb.w);
+                band_px(W0[0], x00, active, 2 * c, X0, vx4[0], vy4[0], rm4[0], ra.x, ra.y);
+                band_px(W0[1], x01, active && col1_ok, 2 * c, X1, vx4[1], vy4[1], rm4[1], ra.z, ra.w);
+                band_px(W1[0], x10, active && row1_ok, 2 * c + 1, X0, vx4[2], vy4[2], rm4[2], rb.x, rb.y);
+                band_px(W1[1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, vx4[3], vy4[3], rm4[3], rb.z, rb.w);
             }
         } else {
-            band_px(W[0][0], x00, active, 2 * c, X0, 0.0f, 0.0f, 1.0f);
-            band_px(W[0][1], x01, active && col1_ok, 2 * c, X1, 0.0f, 0.0f, 1.0f);
-            band_px(W[1][0], x10, active && row1_ok, 2 * c + 1, X0, 0.0f, 0.0f, 1.0f);
-            band_px(W[1][1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, 0.0f, 0.0f, 1.0f);
+            band_px(W0[0], x00, active, 2 * c, X0, 0.0f, 0.0f, 1.0f);
+            band_px(W0[1], x01, active && col1_ok, 2 * c, X1, 0.0f, 0.0f, 1.0f);
+            band_px(W1[0], x10, active && row1_ok, 2 * c + 1, X0, 0.0f, 0.0f, 1.0f);
+            band_px(W1[1], x11, active && row1_ok && col1_ok, 2 * c + 1, X1, 0.0f, 0.0f, 1.0f);
         }
         }
         Gm1 = G0;
         G0 = Gp1;
+    };
+    for (int c = ca; c < cb; c += 4) {        // wave-uniform trip count
+        step(integral_constant<int, 0>(), c);
+        if (c + 1 >= cb) break;
+        step(integral_constant<int, 1>(), c + 1);
+        if (c + 2 >= cb) break;
+        step(integral_constant<int, 2>(), c + 2);
+        if (c + 3 >= cb) break;
+        step(integral_constant<int, 3>(), c + 3);
     }
 
     const float s0 = wave_sum(acc[0]);
@@ -731,6 +763,9 @@ __device__ __forceinline__ void band_load_tables(const BandArgs& a, float4* s_cs
 // FOVM: 0 = non-foveated, 1 = foveated with the band's LUT slice in (dynamic) LDS, 2 = foveated, LUT slice in global
 // memory (slice too large, or the map-writing variant).  A compile-time choice: with a run-time flag the compiler
 // merges the two look-ups into one flat load, which is slower than ds_read_b128.
+#ifndef FOV_FRAME_FASTEST
+#define FOV_FRAME_FASTEST 1
+#endif
 template <int P, bool DBG, int FOVM>
 __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_MINW_LEAN : FOV_MINW) : (DBG ? 2 : 4)) void band_kernel(const BandArgs a) {
     constexpr bool FOV = FOVM != 0;
@@ -751,10 +786,21 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
         if constexpr (FOV) bid = bid * WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     }
     const bool wave_has_work = !FOV || bid < a.n_items;
-    const int strip = bid % a.n_strips;
-    bid /= a.n_strips;
-    const int chunk = bid % a.n_chunks;
-    const int frame = bid / a.n_chunks;
+    int strip, chunk, frame;
+    if constexpr (FOVM == 1 && FOV_FRAME_FASTEST) {
+        // frame fastest: an XCD walks all frames of a tile before the next tile, the tile's slice of the (frame-invariant)
+        // rho map stays in that XCD's L2 instead of being fetched once per frame
+        const int n_tiles = a.n_strips * a.n_chunks, n_frames = a.n_items / n_tiles;
+        frame = bid % n_frames;
+        bid /= n_frames;
+        strip = bid % a.n_strips;
+        chunk = bid / a.n_strips;
+    } else {
+        strip = bid % a.n_strips;
+        bid /= a.n_strips;
+        chunk = bid % a.n_chunks;
+        frame = bid / a.n_chunks;
+    }
     band_load_tables<FOVM>(a, s_csf, s_ax, (int)threadIdx.x, 64 * WPB);
     __syncthreads();
     if constexpr (FOV) {
