@@ -155,7 +155,11 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
     auto load_row = [&](int r, Px<P>& p0, Px<P>& p1) {
         int rr = r < 0 ? -1 - r : (r >= h ? 2 * h - 1 - r : r);   // symmetric padding (fvvdp_lpyr_dec.py:190-195)
         rr = min(max(rr, 0), h - 1);
+#if defined(BAND2_ABLATE_MEM)      // profiling ablation: every wave re-reads 8 rows of frame 0 (L2 hits), nothing is stored
+        const float* row = a.Ga + (size_t)(rr & 7) * w * P;
+#else
         const float* row = Ga + (size_t)rr * w * P;
+#endif
         p0 = ld_px<P>(row + (size_t)xc0 * P);
         p1 = ld_px<P>(row + (size_t)xc1 * P);
     };
@@ -358,7 +362,11 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
             v = pfma(R[4].h[q], K4, v);
             Cn.h[q] = dpp_reduce5_pair(v * uq2, v, uq0, uq1, uq3, uq4);
         }
+#if defined(BAND2_ABLATE_MEM)
+        st_px(Gc_rsrc, (k < -1000000) ? 0u : FVVDP_NO_STORE, Cn);
+#else
         st_px(Gc_rsrc, (k >= ka && k < kb && owned && jeven && K < wc) ? (unsigned int)(k * wc + K) * (P * 4u) : FVVDP_NO_STORE, Cn);
+#endif
         CH[0] = CH[1];
         CH[1] = CH[2];
         CH[2] = Cn;

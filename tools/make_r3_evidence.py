@@ -284,3 +284,62 @@ moves 5.7 + 8.0 GB in 3.8 ms = 3.6 TB/s: not the memory system.  50 us would nee
 occupancy; the arithmetic of the path (3 transcendental pairs per pixel and stream, 256 multiply-adds of FIR per 4 pixels) does not
 go below ~600 without changing the reference's roundings.  Target not met; the kernel is VALU-bound.
 """)
+
+w("r03_pyramid_bounds.md", f"""# Round 3 -- what bounds the pyramid kernels: ablation builds, not counters
+
+`tools/experiments/r3_session27.sh`; builds by `tools/build_variant.sh <name> "<flags>"`; us per 4K frame (HIP events inside the
+library, median over the calls of one process; three processes per build, alternating).  The SQ counters of
+`profiles/r03_final_kernel_trace.md` (a wave of `band2_kernel<4>` issues VALU work 0.357 of its resident time, x 3 waves per SIMD
+= 1.07) were read as "VALU-bound" earlier in this round.  The ablations say the kernel is **co-bound**:
+
+## Two-level kernel (`band2_kernel<4>`, levels 0+1 of the bench pair)
+
+```
+{rd('s27/band2_bounds.txt')}
+```
+
+* `default` 35.1-35.6 us (this box; 32.9-34.4 on others).
+* `b2abl` (`-DBAND2_ABLATE=1`: no per-pixel tail -- no contrast, CSF, masking, pooling; loads, both reduce / expand filters and the
+  level-C store stay): 29.2-31.6 us.  That is 153.9 MB per frame (PMC) in 30 us = 5.1 TB/s, the memory system's ceiling for this
+  mix (`tools/microbench/mix.hip`: 5.0-5.6 TB/s) -- the **memory floor**.  4 waves per SIMD instead of 3 (`b2abl4`, 33 % more bytes
+  in flight) do not lower it: 30.0-31.8 us.  More prefetch depth would not either.
+* `b2nomem` (`-DBAND2_ABLATE_MEM`: ALL arithmetic, but every wave re-reads the same 8 L2-resident rows and stores nothing):
+  30.5-30.9 us -- the **arithmetic floor**.
+* Both floors are 30 us; together the kernel takes 33-35.6 us: 10-18 % of imperfect overlap between three waves per SIMD that each
+  alternate between a row wait and ~1600 cycles of arithmetic.  The registers (163 of 168) leave no room for a fourth wave or a
+  second step of prefetch.  Removing arithmetic alone cannot win more than the overlap loss: removing the whole tail (more than half
+  of the instructions) gains 14 %.
+
+## One-level kernels (`band_kernel<4,false,0|1>`)
+
+```
+{rd('s27/band1_bounds.txt')}
+```
+
+```
+{rd('s27/fov_bounds.txt')}
+```
+
+* Non-foveated level 0, one level per launch: 32.3-36.8 us with the tail, 30.2-35.1 us without: the data flow (166 MB per frame at a
+  4:1 read:write mix) is the bound, the arithmetic hides behind it.
+* Foveated level 0 (second number of the `kernel us/frame` lists; first = K1): 40.5-41.8 us with the tail, 30.6-34.8 us without,
+  39.7-41.8 us without the eccentricity arithmetic (`noecc2`: 183 of 1928 VALU instructions of the kernel, all 32 `v_sqrt_f32`): the
+  instruction COUNT is not the bound here either.  What was: every step waited for HBM.  The rho-map records of a step were
+  requested after the two prefetched rows of the next step, and loads return in order (`s_waitcnt vmcnt`), so the wait for the map was
+  a wait for rows requested ~1000 cycles earlier.  Requesting the map first (and walking the frames of a tile back to back so that its
+  map slice stays in the XCD's L2: HBM reads of the level-0 launch 3829 -> 2683 MB per 18 frames, PMC) brought level 0 from 44.7 to
+  40.6 us and the whole foveated pass from 59.3 to 54.4 us per frame:
+
+```
+{rd('s28/ab.txt')}
+```
+(`tools/experiments/r3_session28.sh`: `prev` = the band kernels of commit 005ba66 -- shifted row window, map loads behind the row prefetch,
+strip-fastest work order; `nofirst` = this build with `-DFOV_FRAME_FASTEST=0`; `default` = this build.  Per line: wall time of the
+4K x120 foveated call, then HIP-event medians [K1, level 0, level 1, ...].  The row-window ring alone gave 2 %, the load order 5-6 %,
+the work order nothing measurable in time -- it removes 30 % of the kernel's HBM reads.)
+
+```
+{rd('s26/fov.txt')}
+```
+{rd('s26/pmc.txt')}
+""")
