@@ -1084,7 +1084,11 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
     // chroma columns to lanes 1 and 62 (quads are clamped to the frame: a clamped lane duplicates its neighbour,
     // which then sits at a row start / end and does not look at it)
     const int p0 = blockIdx.x * (YUV_QUADS * PX);
+#ifdef YUV_ABLATE_MEM      // profiling ablation: every wave converts the same 64 quads of source frame 0 (cache hits), nothing is stored
+    const int quad = lane;
+#else
     const int quad = min(max(blockIdx.x * YUV_QUADS - 1 + lane, 0), HW / PX - 1);
+#endif
     const int pl = quad * PX;
     YuvGeom g;
     float g_fy = 0.0f, g_gy = 0.0f;      // vertical bilinear weights
@@ -1119,7 +1123,11 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
         for (int i = 0; i < PX; ++i) win[u][i] = splat(0.0f);
     const int total = FL - 1 + a.n_out;
     auto prefetch = [&](int v, YuvRaw<T, C420>& f0, YuvRaw<T, C420>& f1) {
+#ifdef YUV_ABLATE_MEM
+        const size_t off = (size_t)(idx[min(v, total - 1)] & 0) * a.frame_stride;
+#else
         const size_t off = (size_t)idx[min(v, total - 1)] * a.frame_stride;      // past the end: the last frame again (unused)
+#endif
         f0 = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[0]) + off, g, HW, uvplane);
         f1 = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[1]) + off, g, HW, uvplane);
     };
@@ -1157,7 +1165,11 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
             for (int i = 0; i < PX; ++i)
                 s_t[lane * (PX + 1) + i] = make_float4(acc_s[i].x, acc_s[i].y, acc_t[i].x, acc_t[i].y);
             wave_lds_order();
+#ifdef YUV_ABLATE_MEM
+            const bool live = v < -1000000;
+#else
             const bool live = (v >= FL - 1) && (v < total);
+#endif
             const __amdgpu_buffer_rsrc_t o = level_rsrc(a.out + (size_t)max(v - (FL - 1), 0) * HW * 4, frame_bytes);
 #pragma unroll
             for (int i = 0; i < PX; ++i) {

@@ -283,6 +283,18 @@ colour matrix, 24 `v_log_f32` + 24 `v_exp_f32` of the sRGB curve, the luminance 
 moves 5.7 + 8.0 GB in 3.8 ms = 3.6 TB/s: not the memory system.  50 us would need ~490 VALU instructions per step at the same
 occupancy; the arithmetic of the path (3 transcendental pairs per pixel and stream, 256 multiply-adds of FIR per 4 pixels) does not
 go below ~600 without changing the reference's roundings.  Target not met; the kernel is VALU-bound.
+
+Cross-check by ablation (`-DYUV_ABLATE_MEM`: every wave converts the same 64 pixel quads of source frame 0 and stores nothing;
+`tools/experiments/r3_session29.sh`, us per frame in the last column; JOD 10 = test and reference read the same data):
+
+```
+{rd('s29/yuv_ab.txt')}
+```
+
+The arithmetic alone takes 55 us (16 slots, 10 bit 4:2:0), 39.5 us (8 slots, 4:2:0) and 32 us (8 slots, 4:4:4) of the 63.6 / 46.3 / 37.5 us
+of the full kernels: arithmetic-bound with ~15 % lost to overlap at 2-3 waves per SIMD.  (Also tried: the ten source loads of a frame
+pair in a fixed order, which turns the `s_waitcnt vmcnt(0)` behind the four stores at the top of every step into counted waits:
+63.0-63.2 against 62.8-63.6 us, not kept.)
 """)
 
 w("r03_pyramid_bounds.md", f"""# Round 3 -- what bounds the pyramid kernels: ablation builds, not counters
