@@ -180,6 +180,12 @@ than two launch latencies.
 
 w("r03_fov_variants.md", f"""# Round 3 -- foveated kernel (BASELINE configs[3]): what bounds it, and the variants that were measured
 
+**Superseded reading.**  The "Reading" paragraph at the end was written from the SQ counters and concluded "VALU-bound".  Ablation builds
+made later in the round (`profiles/r03_pyramid_bounds.md`) showed that neither the instruction count nor the byte count bound this
+kernel: every step waited for HBM behind the in-order load queue (map records requested after the row prefetch).  With that fixed the
+kernel runs 40.5-41.3 us at level 0 and 54.4 us over all levels.  The measurements below (all made BEFORE the fix) stand as measurements,
+their flatness is explained by that stall; the counter-based conclusion does not stand.
+
 `tools/gpu_config4.py` (4K x120, standard_hdr_pq, moving gaze), kernel us per frame = [K1, level 0, level 1, ...]:
 default = LUT slice padded to 36-entry rows (bank-conflict-free, `FOV_ROW` in band_kernel.hpp); nopad = the round-2 layout;
 pad33 = 33-entry rows; wpb6 / wpb12 = 6 / 12 waves per workgroup sharing the slice; phase4 = all four pixels of a step batched.
