@@ -176,6 +176,18 @@ Why: a frame's levels 3-6 are ~120 us of VALU work for ONE CU (16 waves share it
 the per-level launches spread every level of every frame over the whole chip (88 us for the four).  For the two tiny levels the
 chain of dependent row steps of one frame (17 + 13 steps, nothing to hide the load latency with one wave per SIMD) is longer
 than two launch latencies.
+
+A last variant at the end of the round: an AUTOMATIC policy -- the tail takes only the levels from which on the pyramid holds at most
+`FVVDP_TAIL_PX` pixels per frame (+ finalize + pooling); `tools/experiments/r3_session30.sh`, `tools/gpu_small_latency.py`, bench.py, 1080p x60:
+
+```
+{rd('s30/tail_auto.txt')}
+```
+
+A 512x512 image: 10 launches -> 4, GPU-side 96.6 -> 81-83 us per call, but `predict()` as the caller sees it (with its host
+synchronisation) 129 -> 128-155 us: the call is bound by the ~100 us of host code between two calls (rocprofv3 time line: kernels of
+4-6 us with 4-6 us gaps, a 30 us tail launch, then > 100 us without any kernel).  The 4K x60 pair and 1080p x60: within noise
+(4.29-4.36 vs 4.35-4.51 / 4.38 / 4.28-4.36 ms; 1.38 vs 1.36-1.39 ms).  Not made the default; the opt-in stays as it was.
 """)
 
 w("r03_fov_variants.md", f"""# Round 3 -- foveated kernel (BASELINE configs[3]): what bounds it, and the variants that were measured
