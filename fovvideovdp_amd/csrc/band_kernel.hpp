@@ -532,10 +532,18 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
         const int bo = (int)fmaf(iE, (float)(FOV_ROW * 16), fmaf(iY, 16.0f, pre_kR));
         const float4* cell = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_lut_dyn) + bo);
         constexpr int sj = 1, sk = FOV_ROW;
+#ifdef FOV_ABLATE_LDS      // timing experiment only: no LUT reads (results are wrong)
+        (void)cell; (void)sj; (void)sk;
+        q.v00 = make_float4(q.fY, q.fE, 0.1f, 0.2f);
+        q.v10 = make_float4(q.fE, q.fY, 0.2f, 0.1f);
+        q.v01 = make_float4(q.fY, q.fY, 0.3f, 0.1f);
+        q.v11 = make_float4(q.fE, q.fE, 0.1f, 0.3f);
+#else
         q.v00 = cell[0];
         q.v10 = cell[sj];
         q.v01 = cell[sk];
         q.v11 = cell[sk + sj];
+#endif
         return q;
     };
     auto fov_b = [&](const FovQ& q, bool valid) {

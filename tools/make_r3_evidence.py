@@ -368,6 +368,15 @@ strip-fastest work order; `nofirst` = this build with `-DFOV_FRAME_FASTEST=0`; `
 4K x120 foveated call, then HIP-event medians [K1, level 0, level 1, ...].  The row-window ring alone gave 2 %, the load order 5-6 %,
 the work order nothing measurable in time -- it removes 30 % of the kernel's HBM reads.)
 
+Where the remaining 5-6 us above the data-flow floor go (`-DFOV_ABLATE_LDS`: the four LUT-cell reads per pixel replaced by constants;
+`abl1` = no per-pixel tail; same box, alternating):
+
+```
+{rd('s31/fov_nolds.txt')}
+```
+
+The LDS reads are worth ~1 us; the rest is the same imperfect overlap of arithmetic and memory as in the two-level kernel.
+
 ```
 {rd('s26/fov.txt')}
 ```
