@@ -74,6 +74,9 @@ def test_config1_crop512(fv):
     check_q(stats["Q_per_ch"][:, 0:1, :], z["Q_per_ch"][:, 0:1, :], coarse=4e-5, fine=4e-5)         # measured 1.1e-5
 
 
+_D_STATS = None        # set to a list by tools/experiments/gpu_dmap_stats.py to collect the measured errors of the D maps
+
+
 def stage_check(maps, exported, z, frames, n_bands, P):
     """maps/exported from the HIP path for the frames in order; z golden npz."""
     TC = P // 2
@@ -98,9 +101,18 @@ def stage_check(maps, exported, z, frames, n_bands, P):
                 if key in z.files:
                     gd, hd = z[key].astype(np.float64), maps[b]["D"][fi, cc].cpu().numpy().astype(np.float64)
                     rel = np.abs(hd - gd) / (np.abs(gd) + 1e-3 * np.max(gd) + 1e-12)
-                    # measured: max 8.7e-3 (single pixels whose contrast is ~1 ulp of the Gaussian levels); mean per map
-                    # <= 4.1e-4 (a 5x8-pixel coarse band; 1.1e-4 at 135x240, 3.8e-5 on average over the maps)
-                    assert np.max(rel) < 2e-2 and np.mean(rel) < 1.2e-3, key
+                    # Per-pixel statement of "difference maps within a stated fp32 tolerance" (tools/experiments/gpu_dmap_stats.py prints
+                    # what is measured).  Maps of >= 4096 pixels: max 4.1e-4, mean 3.8e-5, largest absolute error 3.0e-5 of the
+                    # map's maximum.  The coarse maps (40-144 pixels, five to seven reduce stages deep) carry the outliers:
+                    # max 8.7e-3 on a 5x8-pixel band (contrasts of ~1 ulp of the Gaussian levels), mean 4.1e-4, absolute 7.6e-4 of max.
+                    amax = float(np.max(np.abs(hd - gd)) / np.max(gd))
+                    if gd.size >= 4096:
+                        assert np.max(rel) < 1.5e-3 and np.mean(rel) < 1.5e-4 and amax < 1e-4, key
+                    else:
+                        assert np.max(rel) < 2e-2 and np.mean(rel) < 1.2e-3 and amax < 2.5e-3, key
+                    if _D_STATS is not None:
+                        _D_STATS.append((key, gd.size, float(np.max(np.abs(hd - gd)) / np.max(gd)), float(np.quantile(rel, 0.99)),
+                                         float(np.quantile(rel, 0.999)), float(np.max(rel)), float(np.mean(rel))))
                     assert abs(hd.sum() / gd.sum() - 1) < (6e-5 if gd.size >= 4096 else 4e-4), key  # measured 2.0e-5 / 1.3e-4
         # Gaussian base band = last golden 'band'
         key = f"band_f{ff}_b{n_bands}"
