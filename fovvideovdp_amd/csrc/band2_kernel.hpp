@@ -25,7 +25,7 @@
 // ------------------------------------------------------------------------------------------------------------
 #ifndef F2_PITCH
 #define F2_PITCH 54         // level-B columns owned per wave: lanes 6..59, all the two-level halo leaves valid (the kernel is
-                            // VALU-bound: 54 vs a line-aligned 52 columns measured +3.4 %)
+                            // co-bound -- its arithmetic alone takes as long as its data flow, profiles/r03_pyramid_bounds.md: 54 vs a line-aligned 52 columns measured +3.4 %)
 #define F2_HL 6             // halo lanes on the left (4 on the right); even, so lane parity == column parity
 #endif
 
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
     // Level-A rows live in an 8-slot register ring: row r of the chunk sits in slot r & 7, a step's window is slots
     // base .. base+4 and the two rows of the next step are fetched into slots base+5, base+6.  The base advances by 2 per
     // step, so two stages (4 steps) bring it back: the stage body is instantiated for both phases and nothing is moved
-    // (a 5-row window that is shifted costs 24 v_mov_b64 per stage on a VALU-bound kernel).
+    // (a 5-row window that is shifted costs 24 v_mov_b64 per stage; the kernel's arithmetic is as long as its data flow).
     Px<P> S[8][2];
     auto coarse_step = [&](auto base) -> Px<P> {          // level-B row from the 5-row window of level A at slot `base`
         constexpr int B = decltype(base)::value;

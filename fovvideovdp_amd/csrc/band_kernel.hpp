@@ -57,7 +57,7 @@ __device__ __forceinline__ void st_px(__amdgpu_buffer_rsrc_t r, unsigned int byt
 
 // ---- horizontal taps with the DPP shift folded into the multiply-add (v_fmac_f32_dpp) ------------------------------
 // The compiler keeps `v_mov_b32_dpp` + `v_pk_fma_f32` for update_dpp() followed by fmaf (its DPP combiner does not fold
-// wave shifts on gfx950), i.e. one extra full-rate VALU instruction per neighbour value; the pyramid kernels are VALU-bound, so
+// wave shifts on gfx950), i.e. one extra full-rate VALU instruction per neighbour value; the two-level kernel's arithmetic is as long as its data flow, so
 // the taps are written out.  Hazard: a DPP source operand written by a VALU instruction needs 2 wait states, which the
 // compiler cannot see inside an asm statement -> every block opens with `s_nop 1`, and temporaries produced inside a
 // block are read at least 3 instructions later.  Accumulation order = the order of the fma chain it replaces.
@@ -150,7 +150,7 @@ struct BandArgs {
 // resolution magnification at its view angle (fvvdp.py:424-442, fvvdp_display_model.py:475-526) -- a function of the
 // pixel position only.  Its place on the rho axis of the band's LUT slice (interval and fraction, interp.py:11-20)
 // is evaluated ONCE per geometry here, with exactly the operations band_kernel used per pixel and frame before
-// (4 transcendentals and ~25 VALU instructions per pixel and frame saved in a VALU-bound kernel for 8 B/pixel of reads).
+// (4 transcendentals and ~25 VALU instructions per pixel and frame saved for 8 B/pixel of reads that stay in L2 with the frame-fastest work order).
 struct RhoMapArgs {
     float4* out;            // [h][(w+1)/2] {f(2J), k(2J), f(2J+1), k(2J+1)}, k = (interval - i_lo) * FOV_PLANE * 16 as a float =
                             //   BYTE offset of the interval's (ecc, Y) plane of float4 entries in the band's LUT slice

@@ -1171,7 +1171,7 @@ static int bands_forward_core(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int
     if (maps)
         for (int b = 0; b < c->n_bands; ++b) any_maps = any_maps || maps[b].d_D || maps[b].d_contrast || maps[b].d_lbkg || maps[b].d_S;
     // It pays where the one-level kernel is bound by HBM (large levels: 4K levels 0+1 39 vs 46 us per frame); the
-    // two-level kernel is VALU-bound (its strips own 54 of 64 lanes), so small levels stay on the one-level kernel
+    // two-level kernel's arithmetic takes as long as its data flow (its strips own 54 of 64 lanes), so small levels stay on the one-level kernel
     // (960x540 + 480x270: 3.1 vs 2.95 us).  FVVDP_BAND_FUSE=0 / 1 forces never / wherever valid (tests, A/B runs).
     const char* fuse_env = getenv("FVVDP_BAND_FUSE");
     const int fuse_mode = (fuse_env && (fuse_env[0] == '0' || fuse_env[0] == '1')) ? fuse_env[0] - '0' : -1;   // anything else: automatic
