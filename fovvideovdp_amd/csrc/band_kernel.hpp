@@ -273,7 +273,11 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
     auto load_row = [&](int r, Px<P>& p0, Px<P>& p1) {
         int rr = r < 0 ? -1 - r : (r >= h ? 2 * h - 1 - r : r);   // symmetric padding (fvvdp_lpyr_dec.py:190-195)
         rr = min(max(rr, 0), h - 1);
+#if defined(BAND_ABLATE_MEM)       // profiling ablation: every wave re-reads 8 rows of frame 0 (L2 hits), nothing is stored
+        const float* row = a.Gf + (size_t)(rr & 7) * w * P;
+#else
         const float* row = Gf + (size_t)rr * w * P;
+#endif
         p0 = ld_px<P>(row + (size_t)xc0 * P);
         p1 = ld_px<P>(row + (size_t)xc1 * P);
     };
@@ -621,7 +625,11 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
         const Px<P> cN = coarse_step(integral_constant<int, s0>());       // coarse row c+1
         const bool has_next = (c + 1) <= (hc - 1);
         Px<P> Gp1 = has_next ? cN : G0;       // index clamp of the expand (fvvdp_lpyr_dec.py:134,138)
+#if defined(BAND_ABLATE_MEM)
+        st_px(Gc_rsrc, (c < -1000000) ? 0u : FVVDP_NO_STORE, cN);
+#else
         st_px(Gc_rsrc, (has_next && (c + 1) < cb && active) ? (unsigned int)((c + 1) * wc + J) * (P * 4u) : FVVDP_NO_STORE, cN);
+#endif
         Px<P> x00, x01, x10, x11;             // expanded level at (row 2c|2c+1, col X0|X1)
         Px<P> evE, evO;
 #pragma unroll

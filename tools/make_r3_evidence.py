@@ -377,6 +377,24 @@ Where the remaining 5-6 us above the data-flow floor go (`-DFOV_ABLATE_LDS`: the
 
 The LDS reads are worth ~1 us; the rest is the same imperfect overlap of arithmetic and memory as in the two-level kernel.
 
+The arithmetic floor of the one-level kernels (`-DBAND_ABLATE_MEM`: all arithmetic, rows re-read from 8 L2-resident rows, nothing stored;
+`b1nomem`), next to their data-flow floor (`abl1`), same box, alternating; foveated (second number = level 0), then plain with
+`FVVDP_BAND_FUSE=0` (first number = level 0):
+
+```
+{rd('s33/fov_floors.txt')}
+```
+
+```
+{rd('s33/one_level_floors.txt')}
+```
+
+Foveated level 0: arithmetic alone 33.0-33.2 us, data flow alone 31.4-35.2 us, together 40.4-41.3 us -- co-bound like the two-level
+kernel, with a larger overlap loss (more wait points per step: map, two LDS phases).  A two-level foveated variant would have an
+arithmetic floor of (33 + 8) x 60/54 = 45.6 us for levels 0+1 against 50.1 us for the two launches today: no room for the 8-10 us the
+target needs.  Plain one-level level 0: arithmetic 22.5 us under a data flow of 30 us (32.2 together): memory-bound, which is why
+the two-level kernel pays there.
+
 ```
 {rd('s26/fov.txt')}
 ```
