@@ -89,3 +89,15 @@ def synth_yuv_pair(N, H, W, bit_depth=8, chroma_ss="420", device="cpu", pair=0):
         fr = torch.cat([(Y * sc).reshape(N, -1), (U * sc).reshape(N, -1), (V * sc).reshape(N, -1)], dim=1)
         out.append(fr.to(torch.uint8) if bit_depth == 8 else fr.to(torch.int32))
     return out[0], out[1]
+
+
+def synth_image_pair(H, W, seed):
+    """Gray uint8 test / reference images [H, W] (numpy): seeded noise under a smooth pattern, the test a +-6 code perturbation of the
+    reference.  Used where an input must be reproducible from its size and seed alone (goldens of large frames store only outputs)."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    base = rng.randint(0, 256, (H, W)).astype(np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    ref = np.clip(0.6 * base + 50 + 40 * np.sin(xx / 7.0) * np.cos(yy / 5.0), 0, 255).astype(np.uint8)
+    test = np.clip(ref.astype(np.int32) + rng.randint(-6, 7, (H, W)), 0, 255).astype(np.uint8)
+    return test, ref

@@ -1,8 +1,9 @@
 """GPU: the largest inputs the path is expected to take -- 8K (7680x4320) frames, one pyramid level more than BASELINE's
-4K configurations, and clips long enough to run many batches.  The oracle needs ~45 s for ONE 8K frame, so only the still
-image is compared with it; the 8K video and the long clip are checked through size-independent properties (identical
-pair -> 10 JOD, vector == scalar temporal kernel, two-level == one-level pyramid kernel, a clip == the concatenation of its
-frame ranges)."""
+4K configurations, and clips long enough to run many batches.  Golden g13 holds the REFERENCE's own results for an 8K still
+image and a 4-frame 8K video, plain and foveated (tools/gen_golden.py g13; inputs are seeded synthetic data, only outputs are
+stored).  The oracle needs ~45 s for ONE 8K frame, so only the still image is also compared with it; beyond that the 8K video and
+the long clip are checked through size-independent properties (identical pair -> 10 JOD, vector == scalar temporal kernel,
+two-level == one-level pyramid kernel, a clip == the concatenation of its frame ranges)."""
 import ctypes as C
 
 import numpy as np
@@ -14,25 +15,51 @@ pytestmark = pytest.mark.gpu
 H8, W8 = 4320, 7680
 
 
-def _image_pair(H, W, seed):
-    rng = np.random.RandomState(seed)
-    base = rng.randint(0, 256, (H, W)).astype(np.float32)
-    yy, xx = np.mgrid[0:H, 0:W]
-    ref = np.clip(0.6 * base + 50 + 40 * np.sin(xx / 7.0) * np.cos(yy / 5.0), 0, 255).astype(np.uint8)
-    test = np.clip(ref.astype(np.int32) + rng.randint(-6, 7, (H, W)), 0, 255).astype(np.uint8)
-    return test, ref
+def _golden():
+    import os
+    return np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g13_8k.npz"))
 
 
-def test_8k_image_vs_oracle():
+def _check_q(q, gq, fine, coarse):
+    """Against the reference's golden at 8K: its lp_norm (torch.norm, fp32 accumulation on the CPU) is itself inexact at this size --
+    see tests/test_oracle_golden.py::check_q_large; bound = the usual one + 1.5e-10 per pixel of the band."""
+    q, gq = np.asarray(q, np.float64), np.asarray(gq, np.float64)
+    assert q.shape == gq.shape
+    for b in range(q.shape[0]):
+        tol = (fine if b < 3 else coarse) + 1.5e-10 * (H8 * W8) / 4.0 ** b
+        assert np.all(np.abs(q[b] - gq[b]) <= tol * np.abs(gq[b]) + 1e-6 * np.max(np.abs(gq))), (b, q[b], gq[b])
+
+
+def test_8k_image_vs_reference_golden_and_oracle():
     import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_image_pair
     from oracle import fvvdp_oracle as orc
-    test, ref = _image_pair(H8, W8, 8)
+    z = _golden()
+    test, ref = synth_image_pair(H8, W8, 8)
     q, st = fv.fvvdp(display_name="standard_4k").predict(test, ref, dim_order="HW")
+    assert abs(float(q) - float(z["img_jod"])) < 3e-5, (float(q), float(z["img_jod"]))           # the reference itself (golden g13); measured 1.1e-5
+    _check_q(st["Q_per_ch"][:, 0:1, :], z["img_Q_per_ch"][:, 0:1, :], fine=7e-5, coarse=4e-4)
     oq, ost = orc.Oracle("standard_4k").predict(test, ref, dim_order="HW")
     assert abs(float(q) - float(oq)) < 5e-6, (float(q), float(oq))
     a, b = st["Q_per_ch"][:, 0, 0].astype(np.float64), ost["Q_per_ch"][:, 0, 0].astype(np.float64)
     assert a.shape == b.shape
     assert np.all(np.abs(a - b) <= 3.5e-4 * np.abs(b) + 1e-5 * np.max(b)), (a, b)
+
+
+def test_8k_video_vs_reference_golden():
+    """4 frames of 8K at 30 fps, plain and foveated, against the reference's results (golden g13: outputs only, the clip is the seeded
+    synthetic pair)."""
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair
+    z = _golden()
+    N = int(z["vid_frames"])
+    test, ref = synth_video_pair(N, H8, W8, device="cuda")
+    q, st = fv.fvvdp(display_name="standard_4k").predict(test, ref, frames_per_second=30)
+    assert abs(float(q) - float(z["vid_jod"])) < 5e-5, (float(q), float(z["vid_jod"]))
+    _check_q(st["Q_per_ch"], z["vid_Q_per_ch"], fine=7e-5, coarse=4e-4)
+    qf, sf = fv.fvvdp(display_name="standard_4k", foveated=True).predict(test, ref, frames_per_second=30)
+    assert abs(float(qf) - float(z["fov_jod"])) < 1e-4, (float(qf), float(z["fov_jod"]))
+    _check_q(sf["Q_per_ch"], z["fov_Q_per_ch"], fine=1e-3, coarse=2e-3)
 
 
 def test_8k_video_properties(monkeypatch):

@@ -147,6 +147,34 @@ def test_readme_known_answer_g0():
     assert np.allclose(stats["rho_band"], z["rho_band"], rtol=1e-12)
 
 
+
+def check_q_large(q, gq, H, W):
+    """check_q for frames so large that the REFERENCE's own pooled sums are inexact: lp_norm (fvvdp.py:607) is torch.norm, which
+    accumulates in fp32 on the CPU -- over the 33 M pixels of an 8K band its result is off by -1.2e-3 with 8 threads, -3e-3 with 2,
+    -6.4e-2 with one (measured on uniform data; 4K, 8 threads: -8e-5), in proportion to the pixels per accumulation chain.  The
+    oracle sums in fp64, the HIP path in fp64 over per-wave fp32 partial sums.  Golden g13 was taken with 8 threads: bound = the usual
+    one + 1.5e-10 per pixel of the band."""
+    q, gq = np.asarray(q, np.float64), np.asarray(gq, np.float64)
+    assert q.shape == gq.shape
+    for b in range(q.shape[0]):
+        px = (H * W) / 4.0 ** b
+        tol = (1e-4 if b < 3 else 1e-3) + 1.5e-10 * px
+        assert np.all(np.abs(q[b] - gq[b]) <= tol * np.abs(gq[b]) + 1e-6 * np.max(np.abs(gq))), (b, q[b], gq[b])
+
+
+def test_8k_image_g13():
+    """Maximum size: a 7680x4320 still image (one pyramid level more than the 4K cases) against the reference's own result; the input is
+    rebuilt from size and seed (fovvideovdp_amd.synth.synth_image_pair), the golden holds outputs only."""
+    from fovvideovdp_amd.synth import synth_image_pair
+    z = load("g13_8k")
+    test, ref = synth_image_pair(4320, 7680, 8)
+    jod, stats = orc.Oracle("standard_4k").predict(test, ref, dim_order="HW")
+    assert abs(float(jod) - float(z["img_jod"])) < 3e-5           # measured 1.05e-5: the reference's fp32 accumulation, see check_q_large
+    assert stats["Q_per_ch"].shape[0] == z["img_Q_per_ch"].shape[0] == 7
+    check_q_large(stats["Q_per_ch"][:, 0:1, :], z["img_Q_per_ch"][:, 0:1, :], 4320, 7680)
+    assert np.allclose(stats["rho_band"], z["img_rho_band"], rtol=1e-12)
+
+
 def test_config1_crop512_g1():
     z = load("g1_crop512_blur_fhd")
     z0 = load("g0_wavy_facade_blur_4k")

@@ -542,6 +542,27 @@ def g12(pyfvvdp):
     save("g12_heatmaps_foveated", out)
 
 
+def g13(pyfvvdp):
+    """Maximum sizes: 8K (7680x4320) frames, one pyramid level more than the 4K cases.  Inputs are reproducible from size and seed
+    (fovvideovdp_amd.synth), so only the reference's outputs are stored: a still image, a 4-frame video, the video foveated."""
+    from fovvideovdp_amd.synth import synth_image_pair, synth_video_pair
+    H, W = 4320, 7680
+    out = {}
+    test, ref = synth_image_pair(H, W, 8)
+    r = run_case(pyfvvdp, test, ref, "HW", 0, "standard_4k", keep_maps=False)
+    print("g13 image JOD", r["jod"], "seconds", r["seconds"], flush=True)
+    out.update({"img_jod": r["jod"], "img_Q_per_ch": r["Q_per_ch"], "img_rho_band": r["rho_band"], "img_seconds": r["seconds"]})
+    N = 4
+    test, ref = synth_video_pair(N, H, W)
+    r = run_case(pyfvvdp, test, ref, "BCFHW", 30, "standard_4k", keep_maps=False)
+    print("g13 video JOD", r["jod"], "seconds", r["seconds"], flush=True)
+    out.update({"vid_jod": r["jod"], "vid_Q_per_ch": r["Q_per_ch"], "vid_seconds": r["seconds"], "vid_frames": np.int64(N)})
+    r = run_case(pyfvvdp, test, ref, "BCFHW", 30, "standard_4k", keep_maps=False, foveated=True)
+    print("g13 foveated video JOD", r["jod"], "seconds", r["seconds"], flush=True)
+    out.update({"fov_jod": r["jod"], "fov_Q_per_ch": r["Q_per_ch"], "fov_seconds": r["seconds"]})
+    save("g13_8k", out)
+
+
 def main():
     which = sys.argv[1:] or ["g0", "g1", "g2", "g5"]
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
@@ -578,6 +599,8 @@ def main():
             g11(pyfvvdp)
         elif w == "g12":
             g12(pyfvvdp)
+        elif w == "g13":
+            g13(pyfvvdp)
         else:
             raise SystemExit("unknown case " + w)
         print(w, "done in %.1f s" % (time.time() - t0), flush=True)
