@@ -1,0 +1,85 @@
+#!/usr/bin/env python3
+"""Randomised sweep of the oracle against the REAL reference (build container only: imports /root/reference on torch-CPU, like
+tools/gen_golden.py).  Same case generator as tools/experiments/gpu_stress.py (sizes, frame rates, paddings, dtypes, colour / gray,
+displays, foveated), so that the chain reference -> oracle (here) -> HIP path (gpu_stress.py on the GPU box) is closed on the same
+population of inputs.  Prints one summary line; the output is kept as profiles/rNN_oracle_vs_reference.txt.
+usage: tools/oracle_vs_reference.py [cases] [seed]"""
+import os, sys, types, logging
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import fvvdp_oracle as orc
+from fovvideovdp_amd.synth import synth_video_pair
+
+
+def import_reference():
+    for name in ("imageio", "imageio.v2", "ffmpeg"):
+        if name not in sys.modules:
+            sys.modules[name] = types.ModuleType(name)
+    sys.modules["imageio"].v2 = sys.modules["imageio.v2"]
+    sys.path.insert(0, os.environ.get("FVVDP_REFERENCE", "/root/reference"))
+    import pyfvvdp
+    return pyfvvdp
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    rng = np.random.default_rng(seed)
+    logging.disable(logging.WARNING)
+    pyfvvdp = import_reference()
+    torch.set_num_threads(8)
+    worst, worst_q, fails, both_raise = (0.0, None), (0.0, None), 0, 0
+    for case in range(n_cases):
+        H, W = int(rng.integers(17, 150)), int(rng.integers(17, 260))
+        fps = int(rng.choice([0, 24, 25, 30, 50, 60, 120, 144, 240]))
+        N = 1 if fps == 0 else int(rng.integers(2, 14))
+        pad = str(rng.choice(["replicate", "circular", "pingpong"]))
+        dt = str(rng.choice(["u8", "u16", "f32"]))
+        C_ch = int(rng.choice([1, 3]))
+        disp = str(rng.choice(["standard_4k", "standard_fhd", "standard_hdr_pq", "standard_hmd"]))
+        fov = bool(rng.integers(0, 4) == 0)
+        t, r = synth_video_pair(N, H, W, pair=int(rng.integers(0, 50)))
+        if C_ch == 1:
+            t, r = t[:, 1:2], r[:, 1:2]
+        tn, rn = t.numpy(), r.numpy()
+        if dt == "u16":
+            tn, rn = tn.astype(np.uint16) * 257, rn.astype(np.uint16) * 257
+        elif dt == "f32":
+            tn, rn = tn.astype(np.float32) / np.float32(255), rn.astype(np.float32) / np.float32(255)
+        desc = f"{W}x{H}x{N} fps={fps} pad={pad} {dt} C={C_ch} {disp} fov={fov}"
+        fix = np.array([W * 0.3, H * 0.6]) if fov else None
+        rq = oq = None
+        try:
+            m = pyfvvdp.fvvdp(display_name=disp, temp_padding=pad, foveated=fov, heatmap=None, device=torch.device("cpu"), quiet=True)
+            with torch.no_grad():                # numpy uint16 goes through the reference's own int16 packing (video_source.py:129-137)
+                rq, rst = m.predict(tn, rn, dim_order="BCFHW", frames_per_second=fps,
+                                    fixation_point=None if fix is None else torch.tensor(fix, dtype=torch.float32))
+        except Exception as e:
+            rerr = str(e)[:70]
+        try:
+            oq, ost = orc.Oracle(disp, temp_padding=pad, foveated=fov).predict(tn, rn, "BCFHW", fps, fix)
+        except Exception as e:
+            oerr = str(e)[:70]
+        if rq is None and oq is None:
+            both_raise += 1
+            continue
+        if rq is None or oq is None:
+            print("FAIL (one side raised)", desc, "| reference:", "ok" if rq is not None else rerr, "| oracle:", "ok" if oq is not None else oerr)
+            fails += 1
+            continue
+        dq = abs(float(rq) - float(oq))
+        a = np.asarray(ost["Q_per_ch"], np.float64)
+        b = np.asarray(rst["Q_per_ch"], np.float64)
+        rel = float(np.max(np.abs(a - b) / (np.abs(b) + 1e-5 * b.max() + 1e-12))) if a.shape == b.shape else 1.0
+        if dq > worst[0]: worst = (dq, desc)
+        if rel > worst_q[0]: worst_q = (rel, desc)
+        if dq > 5e-4 or rel > 2e-2:
+            print("FAIL", desc, "dJOD %.2e relQ %.2e" % (dq, rel))
+            fails += 1
+    print("cases", n_cases, "seed", seed, "both raise", both_raise, "fails", fails,
+          "| worst dJOD %.2e (%s) | worst rel Q %.2e (%s)" % (worst[0], worst[1], worst_q[0], worst_q[1]))
+
+
+if __name__ == "__main__":
+    main()
