@@ -3,7 +3,9 @@
 tools/gen_golden.py).  Same case generator as tools/experiments/gpu_stress.py (sizes, frame rates, paddings, dtypes, colour / gray,
 displays, foveated), so that the chain reference -> oracle (here) -> HIP path (gpu_stress.py on the GPU box) is closed on the same
 population of inputs.  Prints one summary line; the output is kept as profiles/rNN_oracle_vs_reference.txt.
-usage: tools/oracle_vs_reference.py [cases] [seed]"""
+usage: tools/oracle_vs_reference.py [cases] [seed]          (RGB / gray arrays, generator of gpu_stress.py)
+       tools/oracle_vs_reference.py yuv [cases] [seed]      (raw planar YUV through the reference's video_reader_yuv_pytorch.unpack,
+                                                             generator of gpu_stress_yuv.py)"""
 import os, sys, types, logging
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -81,5 +83,70 @@ def main():
           "| worst dJOD %.2e (%s) | worst rel Q %.2e (%s)" % (worst[0], worst[1], worst_q[0], worst_q[1]))
 
 
+def main_yuv():
+    from fovvideovdp_amd.synth import synth_yuv_pair
+    n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    rng = np.random.default_rng(seed)
+    logging.disable(logging.WARNING)
+    pyfvvdp = import_reference()
+    import pyfvvdp.video_source_file as vsf
+    from pyfvvdp.video_source import fvvdp_video_source_dm, reshuffle_dims
+    torch.set_num_threads(8)
+    worst, fails = (0.0, None), 0
+    for case in range(n_cases):
+        css = str(rng.choice(["420", "444"]))
+        H, W = int(rng.integers(9, 70)) * 2, int(rng.integers(9, 120)) * 2
+        bd = int(rng.choice([8, 10, 12]))
+        fps = int(rng.choice([24, 30, 50, 60, 120]))
+        N = int(rng.integers(2, 12))
+        cs = str(rng.choice(["bt709", "bt2020nc"]))
+        disp = str(rng.choice(["standard_4k", "standard_fhd", "standard_hdr_pq"]))
+        ty, ry = synth_yuv_pair(N, H, W, bit_depth=bd, chroma_ss=css, pair=int(rng.integers(0, 9)))
+        desc = f"{W}x{H}x{N} {css} {bd}bit {cs} fps={fps} {disp}"
+        tn = ty.numpy() if bd == 8 else ty.numpy().astype(np.uint16)
+        rn = ry.numpy() if bd == 8 else ry.numpy().astype(np.uint16)
+        # the reference's reader object without ffmpeg (as tools/gen_golden.py g7): only unpack() is used (video_source_file.py:219-276)
+        rd = object.__new__(vsf.video_reader_yuv_pytorch)
+        rd.width, rd.height, rd.bit_depth, rd.chroma_ss, rd.color_space = W, H, bd, css, cs
+        rd.y_pixels, rd.y_shape = W * H, (H, W)
+        rd.uv_shape = (H // 2, W // 2) if css == "420" else (H, W)
+        rd.uv_pixels = rd.uv_shape[0] * rd.uv_shape[1]
+        csn = "BT.2020" if cs == "bt2020nc" else "sRGB"
+
+        class Src(fvvdp_video_source_dm):
+            def __init__(self):
+                super().__init__(display_photometry=disp, color_space_name=csn)
+
+            def get_video_size(self):
+                return (H, W, N)
+
+            def get_frames_per_second(self):
+                return fps
+
+            def _fr(self, arr, f, device):
+                t = reshuffle_dims(rd.unpack(arr[f], device), in_dims='HWC', out_dims="BCFHW")
+                L = self.dm_photometry.forward(t)
+                c = self.color_to_luminance
+                return L[:, 0:1] * c[0] + L[:, 1:2] * c[1] + L[:, 2:3] * c[2]
+
+            def get_test_frame(self, f, device):
+                return self._fr(tn, f, device)
+
+            def get_reference_frame(self, f, device):
+                return self._fr(rn, f, device)
+
+        m = pyfvvdp.fvvdp(display_name=disp, heatmap=None, device=torch.device("cpu"), quiet=True)
+        with torch.no_grad():
+            rq, rst = m.predict_video_source(Src())
+        oq, ost = orc.Oracle(disp, color_space=csn).predict_yuv(tn, rn, fps, W, H, bit_depth=bd, chroma_ss=css, color_space=cs)
+        dq = abs(float(rq) - float(oq))
+        if dq > worst[0]: worst = (dq, desc)
+        if dq > 5e-4:
+            print("FAIL", desc, "dJOD %.2e" % dq)
+            fails += 1
+    print("yuv cases", n_cases, "seed", seed, "fails", fails, "| worst dJOD %.2e (%s)" % worst)
+
+
 if __name__ == "__main__":
-    main()
+    main_yuv() if len(sys.argv) > 1 and sys.argv[1] == "yuv" else main()
