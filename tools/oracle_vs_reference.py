@@ -5,7 +5,8 @@ displays, foveated), so that the chain reference -> oracle (here) -> HIP path (g
 population of inputs.  Prints one summary line; the output is kept as profiles/rNN_oracle_vs_reference.txt.
 usage: tools/oracle_vs_reference.py [cases] [seed]          (RGB / gray arrays, generator of gpu_stress.py)
        tools/oracle_vs_reference.py yuv [cases] [seed]      (raw planar YUV through the reference's video_reader_yuv_pytorch.unpack,
-                                                             generator of gpu_stress_yuv.py)"""
+                                                             generator of gpu_stress_yuv.py)
+       tools/oracle_vs_reference.py shapes                  (the extreme frame shapes of gpu_stress_shapes.py, image and 5-frame video)"""
 import os, sys, types, logging
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -148,5 +149,49 @@ def main_yuv():
     print("yuv cases", n_cases, "seed", seed, "fails", fails, "| worst dJOD %.2e (%s)" % worst)
 
 
+def main_shapes():
+    logging.disable(logging.WARNING)
+    pyfvvdp = import_reference()
+    torch.set_num_threads(8)
+    shapes = [(16, 4096), (17, 3001), (2048, 16), (1999, 17), (16, 16), (16, 17), (17, 16), (31, 33), (64, 120), (64, 121), (64, 124),
+              (64, 125), (64, 240), (64, 241), (64, 244), (64, 245), (33, 247), (33, 248), (33, 249), (33, 256), (33, 257), (120, 64),
+              (121, 63), (255, 255), (256, 256), (257, 257), (40, 1024), (41, 1023), (300, 500)]
+    worst, worst_q, fails, both = (0.0, None), (0.0, None), 0, 0
+    for (H, W) in shapes:
+        for (N, fps) in ((1, 0), (5, 30)):
+            t, r = synth_video_pair(N, H, W, pair=3)
+            tn, rn = t.numpy(), r.numpy()
+            desc = f"{W}x{H}x{N}"
+            rq = oq = None
+            try:
+                m = pyfvvdp.fvvdp(display_name="standard_4k", heatmap=None, device=torch.device("cpu"), quiet=True)
+                with torch.no_grad():
+                    rq, rst = m.predict(tn, rn, dim_order="BCFHW", frames_per_second=fps)
+            except Exception as e:
+                rerr = str(e)[:60]
+            try:
+                oq, ost = orc.Oracle("standard_4k").predict(tn, rn, frames_per_second=fps)
+            except Exception as e:
+                oerr = str(e)[:60]
+            if rq is None and oq is None:
+                both += 1
+                continue
+            if rq is None or oq is None:
+                print("one side raised:", desc, "| reference:", "ok" if rq is not None else rerr, "| oracle:", "ok" if oq is not None else oerr)
+                fails += 1
+                continue
+            dq = abs(float(rq) - float(oq))
+            a, b = np.asarray(ost["Q_per_ch"], np.float64), np.asarray(rst["Q_per_ch"], np.float64)
+            rel = float(np.max(np.abs(a - b) / (np.abs(b) + 1e-5 * b.max() + 1e-12))) if a.shape == b.shape else 1.0
+            if dq > worst[0]: worst = (dq, desc)
+            if rel > worst_q[0]: worst_q = (rel, desc)
+            if dq > 5e-4 or rel > 1e-2:
+                print("FAIL", desc, "dJOD %.2e relQ %.2e" % (dq, rel))
+                fails += 1
+    print("shapes", 2 * len(shapes), "both raise", both, "fails", fails,
+          "| worst dJOD %.2e (%s) | worst rel Q %.2e (%s)" % (worst[0], worst[1], worst_q[0], worst_q[1]))
+
+
 if __name__ == "__main__":
-    main_yuv() if len(sys.argv) > 1 and sys.argv[1] == "yuv" else main()
+    mode = sys.argv[1] if len(sys.argv) > 1 else ""
+    main_yuv() if mode == "yuv" else main_shapes() if mode == "shapes" else main()
