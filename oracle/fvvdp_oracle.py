@@ -573,7 +573,10 @@ class Oracle:
     """Mirror of `class fvvdp` restricted to the live branch (local_adapt=gpyr, contrast=weber, pu_dilate=0)."""
 
     def __init__(self, display_name="standard_4k", photometry=None, geometry=None, color_space="sRGB",
-                 foveated=False, temp_padding="replicate"):
+                 foveated=False, temp_padding="replicate", heatmap=None):
+        if heatmap not in (None, "raw"):
+            raise RuntimeError("the oracle restates the 'raw' difference map only (the colouring is a function of it and the context frame)")
+        self.heatmap = heatmap
         d = load_defaults()
         self.prm = d["fvvdp_parameters.json"]
         self.photometry = photometry if photometry is not None else Photometry.load(display_name, d["display_models.json"])
@@ -603,6 +606,7 @@ class Oracle:
         prm = self.prm
         bands, lbkg = contrast_pyr_decompose(R, height)
         Q = np.zeros((height, 2), dtype=_F)
+        dmap_bands = [None] * height
         sens = _F(10.0 ** (prm["sensitivity_correction"] / 20.0))
         for cc in range(temp_ch):
             for bb in range(height):
@@ -626,6 +630,18 @@ class Oracle:
                     self.capture.setdefault("S", []).append(S_raw)
                     self.capture.setdefault("D", []).append(D)
                 Q[bb, cc] = lp_norm(D.ravel(), prm["beta"], 0, True)[0]
+                if self.heatmap is not None:                          # fvvdp.py:458-462 with set_band / get_band, fvvdp_lpyr_dec.py:57-71
+                    if cc == 0:
+                        dmap_bands[bb] = (D / m).astype(_F)
+                    else:
+                        dmap_bands[bb] = ((dmap_bands[bb] * m + _F([1.0, prm["w_transient"]][cc]) * D) / m).astype(_F)
+        if self.heatmap is not None:
+            # heatmap_pyr.reconstruct (fvvdp_lpyr_dec.py:96-103) from the base band of a decomposed zero image, then fvvdp.py:468-470
+            img = np.zeros_like(bands[height][0])
+            for i in reversed(range(height)):
+                img = (gausspyr_expand(img, dmap_bands[i].shape) + dmap_bands[i]).astype(_F)
+            beta_jod = np.float64(10.0) ** prm["log_jod_exp"]
+            self.last_dmap = (np.power(img, _F(beta_jod)) * _F(abs(prm["jod_a"]))).astype(_F).astype(np.float16)
         if self.capture is not None:
             self.capture.setdefault("bands", []).append(bands)
             self.capture.setdefault("L_bkg", []).append(lbkg)
@@ -675,6 +691,7 @@ class Oracle:
 
         out_frames = list(range(N)) if frames is None else list(frames)
         Q_per_ch = np.zeros((height, 2, len(out_frames)), dtype=_F)
+        heat = np.zeros((1, 1, len(out_frames), H, W), dtype=np.float16) if self.heatmap is not None else None
         if is_image:
             temp_ch = 1
         else:
@@ -694,7 +711,11 @@ class Oracle:
                 for key in [k for k in lum_cache if k[1] not in keep]:
                     del lum_cache[key]
             Q_per_ch[:, :, oi] = self.process_frame(ff, R, height, rho_band, temp_ch, fixation_point, (H, W))
+            if heat is not None:
+                heat[0, 0, oi] = self.last_dmap
         jod = do_pooling_and_jods(Q_per_ch, self.prm)
         stats = {"Q_per_ch": Q_per_ch, "rho_band": rho_band, "frames_per_second": frames_per_second,
                  "width": W, "height": H, "N_frames": N, "oob": oob}
+        if heat is not None:
+            stats["heatmap"] = heat                                  # fp16 [1,1,frames,H,W] like the reference's 'raw' mode (fvvdp.py:216-221, 471-472)
         return jod, stats

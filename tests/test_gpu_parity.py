@@ -581,6 +581,34 @@ def test_heatmaps_foveated_golden(fv):
         assert np.mean(d) < 7e-6, tag
 
 
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_heatmaps_raw_vs_oracle_random(fv, seed):
+    """'raw' difference maps of the HIP path against the oracle's restatement (fvvdp.py:458-472) on random small cases: sizes, frame
+    rates, paddings, displays, plain and foveated.  fp16 storage: bound 3 ulp (measured: see tools/experiments/gpu_stress_heat.py)."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    rng = np.random.default_rng(seed)
+    for case in range(6):
+        H, W = int(rng.integers(20, 110)), int(rng.integers(20, 200))
+        fps = int(rng.choice([0, 30, 60]))
+        N = 1 if fps == 0 else int(rng.integers(2, 7))
+        pad = str(rng.choice(["replicate", "circular", "pingpong"]))
+        disp = str(rng.choice(["standard_4k", "standard_fhd", "standard_hdr_pq"]))
+        fov = bool(rng.integers(0, 3) == 0)
+        t, r = synth_video_pair(N, H, W, pair=int(rng.integers(0, 50)))
+        fix = np.array([W * 0.3, H * 0.6]) if fov else None
+        m = fv.fvvdp(display_name=disp, temp_padding=pad, foveated=fov, heatmap="raw")
+        q, st = m.predict(t, r, frames_per_second=fps, fixation_point=fix)
+        oq, ost = orc.Oracle(disp, temp_padding=pad, foveated=fov, heatmap="raw").predict(t.numpy(), r.numpy(), "BCFHW", fps, fix)
+        desc = (H, W, N, fps, pad, disp, fov)
+        assert abs(float(q) - float(oq)) < 2e-5, desc
+        h, g = st["heatmap"].float().numpy().astype(np.float64), ost["heatmap"].astype(np.float64)
+        assert h.shape == g.shape, desc
+        assert np.max(np.abs(h - g) / np.maximum(np.abs(g), 2e-3)) < 3.0 / 1024, desc
+        assert np.mean(np.abs(h - g)) < 7e-5, desc          # measured over 80 cases: <= 2.2e-5 (worst 1.81 fp16 ulp on single values)
+
+
 @pytest.mark.parametrize("tag,H,W,disp", [("fhd", 1080, 1920, "standard_fhd"), ("uhd", 2160, 3840, "standard_4k")])
 def test_full_size_synthetic_video_golden(fv, tag, H, W, disp):
     """BASELINE configs[1] and [2] at full size: 60-frame synthetic uint8 RGB pair against the reference's JOD and

@@ -148,6 +148,38 @@ def test_readme_known_answer_g0():
 
 
 
+
+def _heat_close(h, g):
+    """fp16 maps: equal to 1 ulp of the reference's values (2^-10 relative; across a power of two the step is that of the upper binade:
+    measured 1.05 x 2^-10)."""
+    assert h.dtype == np.float16 and h.shape == g.shape
+    h, g = h.astype(np.float64), g.astype(np.float64)
+    assert np.max(np.abs(h - g) / np.maximum(np.abs(g), 1e-3)) <= 1.1 / 1024
+
+
+def test_heatmaps_raw_g6_g12():
+    """the 'raw' difference map (fvvdp.py:458-472, fvvdp_lpyr_dec.py:65-103) against the reference's maps:
+    plain video and image (g6), foveated with a moving gaze and behind a PQ display (g12)."""
+    from fovvideovdp_amd.synth import synth_gaze
+    z6, z12 = load("g6_heatmaps"), load("g12_heatmaps_foveated")
+    t, r = synth_video_pair(6, 68, 121)
+    q, st = orc.Oracle("standard_fhd", heatmap="raw").predict(t.numpy(), r.numpy(), "BCFHW", 30)
+    assert abs(float(q) - float(z6["video_raw_jod"])) < 1e-5
+    _heat_close(st["heatmap"], z6["video_raw"])
+    t2, r2 = synth_video_pair(1, 135, 240)
+    q, st = orc.Oracle("standard_4k", heatmap="raw").predict(t2.numpy()[0, :, 0], r2.numpy()[0, :, 0], "CHW")
+    assert abs(float(q) - float(z6["image_raw_jod"])) < 1e-5
+    _heat_close(st["heatmap"], z6["image_raw"])
+    gaze = synth_gaze(6, 68, 121).numpy()
+    q, st = orc.Oracle("standard_fhd", heatmap="raw", foveated=True).predict(t.numpy(), r.numpy(), "BCFHW", 30, gaze)
+    assert abs(float(q) - float(z12["video_raw_jod"])) < 2e-5
+    _heat_close(st["heatmap"], z12["video_raw"])
+    q, st = orc.Oracle("standard_hdr_pq", heatmap="raw", foveated=True).predict(t2.numpy()[0, :, 0], r2.numpy()[0, :, 0], "CHW",
+                                                                                  fixation_point=np.array([60, 40]))
+    assert abs(float(q) - float(z12["image_raw_jod"])) < 2e-5
+    _heat_close(st["heatmap"], z12["image_raw"])
+
+
 def check_q_large(q, gq, H, W):
     """check_q for frames so large that the REFERENCE's own pooled sums are inexact: lp_norm (fvvdp.py:607) is torch.norm, which
     accumulates in fp32 on the CPU -- over the 33 M pixels of an 8K band its result is off by -1.2e-3 with 8 threads, -3e-3 with 2,

@@ -6,7 +6,8 @@ population of inputs.  Prints one summary line; the output is kept as profiles/r
 usage: tools/oracle_vs_reference.py [cases] [seed]          (RGB / gray arrays, generator of gpu_stress.py)
        tools/oracle_vs_reference.py yuv [cases] [seed]      (raw planar YUV through the reference's video_reader_yuv_pytorch.unpack,
                                                              generator of gpu_stress_yuv.py)
-       tools/oracle_vs_reference.py shapes                  (the extreme frame shapes of gpu_stress_shapes.py, image and 5-frame video)"""
+       tools/oracle_vs_reference.py shapes                  (the extreme frame shapes of gpu_stress_shapes.py, image and 5-frame video)
+       tools/oracle_vs_reference.py heat [cases] [seed]     ('raw' difference maps, generator of gpu_stress_heat.py)"""
 import os, sys, types, logging
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -192,6 +193,45 @@ def main_shapes():
           "| worst dJOD %.2e (%s) | worst rel Q %.2e (%s)" % (worst[0], worst[1], worst_q[0], worst_q[1]))
 
 
+def main_heat():
+    n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    rng = np.random.default_rng(seed)
+    logging.disable(logging.WARNING)
+    pyfvvdp = import_reference()
+    torch.set_num_threads(8)
+    worst, worst_m, fails = (0.0, None), (0.0, None), 0
+    for case in range(n_cases):
+        H, W = int(rng.integers(17, 150)), int(rng.integers(17, 260))
+        fps = int(rng.choice([0, 24, 30, 60, 120]))
+        N = 1 if fps == 0 else int(rng.integers(2, 9))
+        pad = str(rng.choice(["replicate", "circular", "pingpong"]))
+        disp = str(rng.choice(["standard_4k", "standard_fhd", "standard_hdr_pq", "standard_hmd"]))
+        fov = bool(rng.integers(0, 3) == 0)
+        t, r = synth_video_pair(N, H, W, pair=int(rng.integers(0, 50)))
+        fix = np.array([W * 0.3, H * 0.6]) if fov else None
+        desc = f"{W}x{H}x{N} fps={fps} pad={pad} {disp} fov={fov}"
+        try:
+            m = pyfvvdp.fvvdp(display_name=disp, temp_padding=pad, foveated=fov, heatmap="raw", device=torch.device("cpu"), quiet=True)
+            with torch.no_grad():
+                rq, rst = m.predict(t, r, dim_order="BCFHW", frames_per_second=fps,
+                                    fixation_point=None if fix is None else torch.tensor(fix, dtype=torch.float32))
+            oq, ost = orc.Oracle(disp, temp_padding=pad, foveated=fov, heatmap="raw").predict(t.numpy(), r.numpy(), "BCFHW", fps, fix)
+        except Exception as e:
+            print("raise", desc, str(e)[:80])
+            continue
+        g, h = rst["heatmap"].float().numpy().astype(np.float64), ost["heatmap"].astype(np.float64)
+        rel = float(np.max(np.abs(h - g) / np.maximum(np.abs(g), 2e-3))) * 1024
+        mean = float(np.mean(np.abs(h - g)))
+        if rel > worst[0]: worst = (rel, desc)
+        if mean > worst_m[0]: worst_m = (mean, desc)
+        if rel > 3.0 or abs(float(rq) - float(oq)) > 5e-5:
+            print("FAIL", desc, "ulp %.2f dJOD %.2e" % (rel, abs(float(rq) - float(oq))))
+            fails += 1
+    print("heat cases", n_cases, "seed", seed, "fails", fails,
+          "| worst %.2f fp16 ulp (%s) | worst mean abs %.2e (%s)" % (worst[0], worst[1], worst_m[0], worst_m[1]))
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else ""
-    main_yuv() if mode == "yuv" else main_shapes() if mode == "shapes" else main()
+    main_yuv() if mode == "yuv" else main_shapes() if mode == "shapes" else main_heat() if mode == "heat" else main()
