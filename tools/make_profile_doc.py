@@ -91,8 +91,11 @@ AVERAGE from the HIP-event median in round 2 (8 %); the media
 
 ## What bounds the dominant kernel: SQ / TCC counters (separate --pmc passes of `tools/gpu_bandonly.py`)
 
-`tools/pmc_sq_summary.py`; shares are of the waves' resident time (SQ_WAVE_CYCLES).  `valu` x 3 waves per SIMD >= 1: the VALU
-pipe is saturated; `wait` (memory / LDS latency not hidden) is 7 %:
+`tools/pmc_sq_summary.py`; shares are of the waves' resident time (SQ_WAVE_CYCLES).  `valu` x 3 waves per SIMD >= 1 and `wait`
+(memory / LDS latency not hidden) 7 %: the arithmetic side of a kernel that the ablation builds of `profiles/r03_pyramid_bounds.md` show
+to be CO-bound -- its data flow alone takes 30 us per frame at the memory system's ceiling for the mix, its arithmetic alone 30.5 us,
+together 33-35.6 us.  (Read alone, these counters had been taken for "VALU-bound"; the same reading of the foveated kernel's counters
+was wrong: it waited for HBM every step.)
 
 {rd('pmc_sq_bandonly.md')}
 
