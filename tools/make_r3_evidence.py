@@ -136,6 +136,10 @@ VERDICT r2 weak 6 / item 4: the same kernel runs at 31-32 us per frame (5.8 TB/s
 {rd('s19/alias.txt', drop=("amdgpu.ids", "fvvdp: level 0 at"))}
 ```
 
+   The order in which the XCDs walk the frame?  K1's workgroups take consecutive 1 KB pixel runs, so the eight XCDs (workgroup b runs
+   on XCD b % 8) write interleaved runs; with each XCD on a contiguous eighth of the frame instead (`-DK1_XCD_ORDER=1`, the work order
+   of the pyramid kernels; experiment at the end of the round, not kept): 37.8-38.8 us against 36.5-37.8 us on the same (slow-mode) box.
+
 What it is physically is not known to me: not address translation (r2: UTCL1 / UTCL2 counters equal in both modes), not the
 clocks, not the alignment of the buffer, not an XCD <-> page interleave (a 4 KB offset changes nothing).  The per-channel HBM
 counters that would show a channel imbalance are not exposed by rocprofv3 on this stack (TCC_EA0_* are aggregates).
