@@ -33,11 +33,15 @@ def main():
     logging.disable(logging.WARNING)
     pyfvvdp = import_reference()
     torch.set_num_threads(8)
+    # frame size range as in gpu_stress.py (HLO/HHI/WLO/WHI/NMAX in the environment for mid-size sweeps)
+    HLO, HHI = int(os.environ.get("HLO", 17)), int(os.environ.get("HHI", 150))
+    WLO, WHI = int(os.environ.get("WLO", 17)), int(os.environ.get("WHI", 260))
+    NMAX = int(os.environ.get("NMAX", 14))
     worst, worst_q, fails, both_raise = (0.0, None), (0.0, None), 0, 0
     for case in range(n_cases):
-        H, W = int(rng.integers(17, 150)), int(rng.integers(17, 260))
+        H, W = int(rng.integers(HLO, HHI)), int(rng.integers(WLO, WHI))
         fps = int(rng.choice([0, 24, 25, 30, 50, 60, 120, 144, 240]))
-        N = 1 if fps == 0 else int(rng.integers(2, 14))
+        N = 1 if fps == 0 else int(rng.integers(2, NMAX))
         pad = str(rng.choice(["replicate", "circular", "pingpong"]))
         dt = str(rng.choice(["u8", "u16", "f32"]))
         C_ch = int(rng.choice([1, 3]))
