@@ -46,7 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs-per-gpu", type=int, default=1, help="independent pairs per rank and step (BASELINE configs[4]: 8)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -85,6 +85,22 @@ def main():
         else:
             dist.init_process_group(backend=args.backend)
     assert args.gpus == world, "--gpus must equal the number of launched ranks"
+    comm = None
+    if dist is not None:
+        # what the communicator itself reports, gathered from every rank: the driver can check that N ranks on N devices met
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_rank": local_rank, "device_index": dev.index, "device_name": torch.cuda.get_device_name(dev),
+                "device_uuid": str(getattr(props, "uuid", "")), "pid": os.getpid()}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        ver = None
+        if args.backend == "nccl":
+            try:
+                ver = ".".join(str(v) for v in torch.cuda.nccl.version())
+            except Exception:
+                ver = None
+        comm = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "rccl_version": ver, "ranks": allr,
+                "distinct_devices": len(set((r["device_index"], r["device_uuid"]) for r in allr))}
 
     import fovvideovdp_amd as fv
     from fovvideovdp_amd import _native as nat
@@ -103,7 +119,7 @@ def main():
         # several pairs / ranks: queue every pair without host synchronisation, then the one collective of the path
         # (all-reduce of a zero buffer in which this rank filled its own slots), pooling of all pairs in one call,
         # ONE device -> host copy
-        qs = [m.predict(t, r, dim_order="BCFHW", frames_per_second=fps, sync=False)[1]["Q_per_ch"] for (t, r) in pairs]
+        qs = [st["Q_per_ch"] for (_, st) in m.predict_batch(pairs, dim_order="BCFHW", frames_per_second=fps)]
         allq = gather_pair_results(torch.stack(qs), rank, world)
         return m.do_pooling_and_jods(allq, None).tolist()
 
@@ -117,22 +133,39 @@ def main():
         jods = step()
     fence()
     t0 = time.perf_counter()
+    stamps = [t0]
     for _ in range(args.steps):
         jods = step()
+        stamps.append(time.perf_counter())       # every step ends in its own host synchronisation (the result copy)
     fence()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    # max over ranks of the timed region and of every single step (a step ends in the collective, so the ranks leave it together)
+    tall = torch.tensor([dt] + [b - a for a, b in zip(stamps[:-1], stamps[1:])], dtype=torch.float64, device=dev)
     if dist is not None:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
-    mpix = 2.0 * W * H * N * K * args.steps * world / dt / 1e6
+        dist.all_reduce(tall, op=dist.ReduceOp.MAX)
+    tall = tall.cpu().numpy()
+    dt = float(tall[0])
+    step_s = np.sort(tall[1:])
+    dt_med = float(np.median(step_s))
+    px_step = 2.0 * W * H * N * K * world
+    mpix_mean = px_step * args.steps / dt / 1e6
+    mpix = px_step / dt_med / 1e6                 # the metric is the MEDIAN of >= 10 runs after the warm-ups
 
     # ---- per-kernel timing: HIP events inside the library on the kernels' own stream, one reading per launch ----
     roof = None
     extra = {}
     test, ref = pairs[0]
     if rank == 0:
-        ctx = m._ctx                                  # same context (same HBM scratch) as the timed steps
+        # The timed steps overlap the temporal kernel of one half clip with the pyramid pass of the other on two streams
+        # (fvvdp.pipeline); a kernel's duration under overlap says nothing about the kernel, so the per-kernel leg launches the
+        # same kernels on the same context (same HBM scratch, same placement) strictly one after the other.
+        pipeline_steps = m.pipeline
+        m.pipeline = 0
+        m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
+        ctx = m._ctx
+        extra["level0_alloc"] = ("hipMalloc (FVVDP_ALLOC=malloc)" if os.environ.get("FVVDP_ALLOC") == "malloc" else
+                                 "virtual-memory API, physical chunks of %s MB (profiles/r04_level0_chunks.md)" % os.environ.get("FVVDP_VMM_CHUNK_MB", "32"))
+        extra["pipeline_batches"] = pipeline_steps
         nat.check(nat.lib().fvvdp_ctx_timing_enable(ctx.handle, 1))
         nk = 16 + 2
         ms = (C.c_float * nk)()
@@ -145,6 +178,7 @@ def main():
             nat.check(nat.lib().fvvdp_ctx_timing_read(ctx.handle, ms, cnt, nk, 1))
             rows.append([ms[i] for i in range(n_bands + 2)])          # ms per call: temporal, levels 0.., finalize
         nat.check(nat.lib().fvvdp_ctx_timing_enable(ctx.handle, 0))
+        m.pipeline = pipeline_steps
         t = np.asarray(rows, dtype=np.float64) / N * 1e3              # us per frame
         sizes = level_sizes(W, H, n_bands)
         P = 4
@@ -195,6 +229,29 @@ def main():
                             "frac_traffic: HBM bytes actually moved (PMC) / the same time.  Ablation builds (profiles/r03_pyramid_bounds.md): "
                             "the kernel's data flow alone runs at the memory system's ceiling for this mix (5.1 TB/s real traffic), its "
                             "arithmetic alone takes as long; together 10-18 % above either floor.")
+        # ---- the temporal kernel K1 (unpack + display model + luminance + FIR -> pyramid level 0): its own roofline ----
+        # algorithmic bytes per output frame: every source sample read once (2 streams x C channels x element size) and the
+        # four temporal-channel planes written once (16 B per pixel); fl-1 history frames per launch on top
+        es = pairs[0][0].element_size()
+        Cc = pairs[0][0].shape[1]
+        b_k1 = float(W * H) * (2.0 * Cc * es + 16.0)
+        tk = t[:, 0]
+        medk = float(np.median(tk))
+        roof_k1 = {"bound": "hbm", "kernel": "temporal_vec_kernel<8,4,u8> (unpack + display-model LUT + RGB->Y + 8-tap temporal FIR of both "
+                                            "streams -> pyramid level 0)" if (es, Cc, fps) == (1, 3, 30) else "temporal kernel (K1)",
+                   "achieved": round(b_k1 / (medk * 1e-6) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                   "frac": round(b_k1 / (medk * 1e-6) / 1e9 / HBM_PEAK_GBS, 4), "traffic": None,
+                   "median_launch_ms": round(medk * frames_per_launch * 1e-3, 4), "min_launch_ms": round(float(np.min(tk)) * frames_per_launch * 1e-3, 4),
+                   "max_launch_ms": round(float(np.max(tk)) * frames_per_launch * 1e-3, 4), "launches_timed": len(rows),
+                   "bytes_per_launch": int(b_k1 * frames_per_launch), "frames_per_launch": frames_per_launch,
+                   "bytes_per_pixel_frame": round(b_k1 / (W * H), 2),
+                   "launch_ms_all": [round(float(x) * frames_per_launch * 1e-3, 4) for x in tk],
+                   "note": "reads 6 B and writes 16 B per pixel and frame: nothing to save but the time.  On a physically contiguous "
+                           "level-0 scratch (what hipMalloc returns on a box with free memory) it runs 15 % slower; the context maps "
+                           "the scratch from 32 MB physical chunks instead (profiles/r04_level0_chunks.md)"}
+        extra["roofline_k1"] = roof_k1
+        extra["roofline_pyramid"] = roof
+        extra["longest_kernel"] = "K1 temporal" if medk > med0 else "K2b pyramid levels 0+1"
         # graded pass = all band levels + finalize (B_alg of SURVEY section 8(d): 221.2 MB per 4K frame)
         tot = t[:, 1:].sum(axis=1)
         b_all = float(sum(alg))
@@ -209,6 +266,15 @@ def main():
                                 "hbm_frac_all_levels_at_min": round(b_all / (float(np.min(tot)) * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
                                 "calls_timed": len(rows)}
         extra["batch_frames"] = batch
+        # the whole step against its algorithmic bytes: source samples read once, the four temporal channels written once,
+        # the pyramid by SURVEY 8(d) (K1 + graded pass), on the median step of the timed region (overlap included)
+        b_step = (b_k1 + b_all) * N * K
+        extra["roofline_step"] = {"bound": "hbm", "bytes_per_step": int(b_step), "ms_per_step": round(dt_med * 1e3, 3),
+                                  "achieved": round(b_step / dt_med / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": round(b_step / dt_med / 1e9 / HBM_PEAK_GBS, 4),
+                                  "kernels_back_to_back_ms": round(float(np.median(t.sum(axis=1))) * N * 1e-3, 3),
+                                  "note": "bytes: (2*C*elem + 16) B per pixel and frame for the temporal kernel + SURVEY 8(d)'s pyramid "
+                                          "bytes; kernels_back_to_back_ms: the sum of the isolated kernel medians of one pair"}
 
     # ---- the same call on pageable host arrays (PCIe-inclusive; reported beside `value`, never as `value`) ----
     if rank == 0 and world == 1 and not args.no_h2d:
@@ -278,7 +344,7 @@ def main():
     if rank == 0:
         out = {"metric": "Mpixels/s (test+ref) at 4Kx60f; JOD delta vs reference", "value": round(mpix, 1),
                "unit": "Mpixels/s (test+ref)", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+               "ms_per_step": round(dt_med * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%dx%d x%d-frame synthetic uint8 RGB video pair(s), %d per GPU and step, %s, %d fps, "
                                       "foveated=off (BASELINE.json configs[2]%s)" % (
@@ -286,12 +352,19 @@ def main():
                           "pairs_per_gpu": K,
                           "parallelism": "pair-sharded x%d, %d pair(s) per rank queued without host sync, one all-reduce of "
                                          "Q_per_ch on the device" % (world, K)},
-               "ms_per_pair": round(dt / args.steps / K * 1e3, 3),
+               "ms_per_pair": round(dt_med / K * 1e3, 3),
+               "timing": {"statistic": "median of the %d timed steps (SURVEY 8(d)); value = pixels of a step / ms_per_step" % args.steps,
+                          "ms_per_step_mean": round(dt / args.steps * 1e3, 3), "value_mean": round(mpix_mean, 1),
+                          "ms_per_step_min": round(float(step_s[0]) * 1e3, 3), "ms_per_step_max": round(float(step_s[-1]) * 1e3, 3),
+                          "timed_region_s": round(dt, 4)},
                "jod": [round(j, 6) for j in jods[:8]],
                "jod_delta_vs_reference": None if jod_delta is None else float("%.3g" % jod_delta), "roofline": roof, "cpu_baseline": cpu}
         out.update(extra)
+        if comm is not None:
+            out["communicator"] = comm
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()             # rank 0 ran the per-kernel timing, the PCIe leg and the CPU baseline alone: leave together
         dist.destroy_process_group()
 
 

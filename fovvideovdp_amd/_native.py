@@ -78,6 +78,8 @@ SYMBOLS = {
                                       C.POINTER(Geom), C.POINTER(BandMaps), C.c_void_p]),
     "fvvdp_bands_forward_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
                                            C.POINTER(Geom), C.POINTER(BandMaps), C.POINTER(PoolParams), C.c_void_p, C.c_void_p]),
+    "fvvdp_bands_forward_at": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
+                                         C.POINTER(Geom), C.POINTER(BandMaps), C.POINTER(PoolParams), C.c_void_p, C.c_void_p]),
     "fvvdp_heatmap_reconstruct": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_float, C.c_float, C.c_float,
                                             C.c_void_p, C.c_void_p]),
     "fvvdp_export_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),

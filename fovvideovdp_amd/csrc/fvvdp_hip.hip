@@ -64,15 +64,6 @@ struct fvvdp_ctx {
     double rho_band[FVVDP_MAX_BANDS + 1]{};
     int lw[FVVDP_MAX_BANDS + 1]{}, lh[FVVDP_MAX_BANDS + 1]{};
     float* level[FVVDP_MAX_BANDS + 1]{};
-    float* level0_raw = nullptr;  // what dev_alloc returned for level 0 (level[0] may start later, FVVDP_L0_OFFSET_KB)
-    size_t level0_slack = 0;      // floats of extra room behind level 0 (FVVDP_L0_SLACK_MB, placement experiments)
-    size_t level0_floats = 0;     // size of the level-0 allocation
-    int place_phase = 0;          // online placement selection of level 0 (temporal_channels_core): 0 first call, 1 time the
-                                  // incumbent, 2 run + time a candidate, 3 decide, 9 done
-    int place_tries = 0;
-    float* place_alt = nullptr;   // the incumbent buffer while a candidate is being timed
-    hipEvent_t place_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    float place_us[4] = {0, 0, 0, 0};   // (incumbent, candidate) us per frame of each comparison
     float* partial = nullptr;
     long long partial_off[FVVDP_MAX_BANDS]{};
     int max_blk[FVVDP_MAX_BANDS]{};
@@ -115,9 +106,16 @@ struct fvvdp_ctx {
     int t_cnt[FVVDP_MAX_BANDS + 2]{};
 };
 
-// Large buffers (the pyramid levels) can come from the virtual-memory API instead of hipMalloc: one physical allocation
-// of the recommended granularity mapped into a reserved range.  FVVDP_ALLOC=vmm selects it (placement experiments:
-// tools/experiments/gpu_k1_placement.py; the temporal kernel's speed depends on where the level-0 scratch lands physically).
+// The large pyramid levels are NOT taken from hipMalloc but mapped from physical chunks of 32 MB through the virtual-memory
+// API (hipMemCreate / hipMemMap into one reserved range).  Reason, measured (profiles/r04_level0_chunks.md): on a box whose
+// memory is free, hipMalloc backs the 8 GB of a 4K x 60 level 0 with one physically contiguous range, and on such a range the
+// temporal kernel -- 6 B read, 16 B written per pixel and frame, all of it streaming -- runs at 37.5 us per 4K frame (4.9
+// TB/s); on the same buffer mapped from chunks of 2 ... 128 MB it runs at 32.0-32.6 us (5.7 TB/s), reproducibly, and the
+// pyramid kernels that read the buffer do not change (34.0 us for levels 0+1 either way).  This was the "placement mode" of
+// rounds 2-3: a hipMalloc on a box with fragmented free memory happens to be pieced together the same way.
+// FVVDP_ALLOC=malloc goes back to hipMalloc (A/B runs), FVVDP_VMM_CHUNK_MB overrides the chunk size.
+static const size_t VMM_MIN_BYTES = (size_t)256 << 20;     // buffers below this stay with hipMalloc
+
 static int vmm_alloc(fvvdp_ctx* c, void** out, size_t bytes);
 static void vmm_free_all(fvvdp_ctx* c);
 
@@ -125,21 +123,13 @@ template <typename T>
 static int dev_alloc(fvvdp_ctx* c, T** p, size_t count) {
     void* q = nullptr;
     const size_t bytes = count * sizeof(T);
-    static const bool use_vmm = [] { const char* e = getenv("FVVDP_ALLOC"); return e && strcmp(e, "vmm") == 0; }();
-    if (use_vmm && bytes >= ((size_t)64 << 20)) {
-        int rc = vmm_alloc(c, &q, bytes);
-        if (rc != FVVDP_OK) return rc;
+    static const bool use_vmm = [] { const char* e = getenv("FVVDP_ALLOC"); return !(e && strcmp(e, "malloc") == 0); }();
+    if (use_vmm && bytes >= VMM_MIN_BYTES && vmm_alloc(c, &q, bytes) == FVVDP_OK) {
+        // mapped
     } else {
-        // placement experiments: FVVDP_ALLOC_FLAGS=finegrained|uncached|contiguous for the large buffers (hipExtMallocWithFlags)
-        static const unsigned int ext_flags = [] {
-            const char* e = getenv("FVVDP_ALLOC_FLAGS");
-            if (!e) return 0u;
-            if (!strcmp(e, "finegrained")) return (unsigned int)hipDeviceMallocFinegrained;
-            if (!strcmp(e, "uncached")) return (unsigned int)hipDeviceMallocUncached;
-            if (!strcmp(e, "contiguous")) return (unsigned int)hipDeviceMallocContiguous;
-            return 0u;
-        }();
-        hipError_t e = (ext_flags && bytes >= ((size_t)64 << 20)) ? hipExtMallocWithFlags(&q, bytes, ext_flags) : hipMalloc(&q, bytes);
+        q = nullptr;
+        (void)hipGetLastError();                   // (a device without the virtual-memory API: plain allocation)
+        hipError_t e = hipMalloc(&q, bytes);
         if (e != hipSuccess) return fail(FVVDP_ENOMEM, "hipMalloc(%zu bytes) failed: %s", bytes, hipGetErrorString(e));
     }
     *p = reinterpret_cast<T*>(q);
@@ -178,63 +168,39 @@ static int vmm_alloc(fvvdp_ctx* c, void** out, size_t bytes) {
     size_t gran = 0;
     HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
     if (gran == 0) gran = (size_t)2 << 20;
-    size_t align = gran;
-    if (const char* g = getenv("FVVDP_VMM_ALIGN_MB")) {          // experiment: coarser alignment of the reserved range
-        const size_t a = (size_t)atoll(g) << 20;
-        if (a > gran && a % gran == 0) align = a;
-    }
-    // Placement experiments (profiles/r03_k1_placement.md): the range is backed by physical chunks of FVVDP_VMM_CHUNK_MB
-    // (default: one allocation), created in order and mapped k-way interleaved (FVVDP_VMM_INTERLEAVE=k: consecutive chunks of
-    // the virtual range come from k different parts of the sequence of physical allocations).
-    size_t chunk = 0;
+    size_t chunk = (size_t)32 << 20;
     if (const char* g = getenv("FVVDP_VMM_CHUNK_MB")) {
-        chunk = (size_t)atoll(g) << 20;
-        chunk = chunk / gran * gran;
+        const size_t v = (size_t)atoll(g) << 20;
+        if (v >= gran) chunk = v;
     }
-    int kway = 1;
-    if (const char* g = getenv("FVVDP_VMM_INTERLEAVE")) kway = atoi(g) < 1 ? 1 : atoi(g);
-    const size_t unit = chunk ? chunk : align;
-    const size_t size = (bytes + unit - 1) / unit * unit;
-    if (!chunk) chunk = size;
+    chunk = (chunk + gran - 1) / gran * gran;
+    const size_t size = (bytes + chunk - 1) / chunk * chunk;
     const size_t n = size / chunk;
     VmmBlock b;
     b.size = size;
     b.ptr = nullptr;
-    hipError_t e = hipMemAddressReserve(&b.ptr, size, align, nullptr, 0);
+    hipError_t e = hipMemAddressReserve(&b.ptr, size, gran, nullptr, 0);
     if (e != hipSuccess) return fail(FVVDP_ENOMEM, "hipMemAddressReserve(%zu) failed: %s", size, hipGetErrorString(e));
-    auto undo = [&]() {
-        (void)hipMemUnmap(b.ptr, size);
-        for (auto h : b.handles) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(b.ptr, size);
-    };
     for (size_t i = 0; i < n && e == hipSuccess; ++i) {
         hipMemGenericAllocationHandle_t h;
         e = hipMemCreate(&h, chunk, &prop, 0);
         if (e == hipSuccess) b.handles.push_back(h);
     }
-    if (e != hipSuccess) {
-        for (auto h : b.handles) (void)hipMemRelease(h);
-        (void)hipMemAddressFree(b.ptr, size);
-        return fail(FVVDP_ENOMEM, "hipMemCreate(%zu x %zu) failed: %s", n, chunk, hipGetErrorString(e));
+    size_t mapped = 0;
+    for (size_t i = 0; i < n && e == hipSuccess; ++i) {
+        e = hipMemMap(static_cast<char*>(b.ptr) + i * chunk, chunk, 0, b.handles[i], 0);
+        if (e == hipSuccess) mapped = (i + 1) * chunk;
     }
-    // slot s of the virtual range <- physical chunk order[s]: round-robin over k consecutive groups of the creation order
-    std::vector<size_t> order;
-    {
-        const size_t m = (n + (size_t)kway - 1) / (size_t)kway;
-        for (size_t j = 0; j < m; ++j)
-            for (size_t g = 0; g < (size_t)kway; ++g)
-                if (g * m + j < n && g * m + j < (g + 1) * m) order.push_back(g * m + j);
-    }
-    for (size_t s2 = 0; s2 < n && e == hipSuccess; ++s2)
-        e = hipMemMap(static_cast<char*>(b.ptr) + s2 * chunk, chunk, 0, b.handles[order[s2]], 0);
     hipMemAccessDesc acc;
     memset(&acc, 0, sizeof(acc));
     acc.location = prop.location;
     acc.flags = hipMemAccessFlagsProtReadWrite;
     if (e == hipSuccess) e = hipMemSetAccess(b.ptr, size, &acc, 1);
     if (e != hipSuccess) {
-        undo();
-        return fail(FVVDP_ENOMEM, "hipMemMap / hipMemSetAccess(%zu) failed: %s", size, hipGetErrorString(e));
+        if (mapped) (void)hipMemUnmap(b.ptr, mapped);
+        for (auto h : b.handles) (void)hipMemRelease(h);
+        (void)hipMemAddressFree(b.ptr, size);
+        return fail(FVVDP_ENOMEM, "mapping %zu chunks of %zu bytes failed: %s", n, chunk, hipGetErrorString(e));
     }
     c->vmm.push_back(b);
     *out = b.ptr;
@@ -259,15 +225,6 @@ static void vmm_free_all(fvvdp_ctx* c) {
         (void)hipMemAddressFree(b.ptr, b.size);
     }
     c->vmm.clear();
-}
-
-// placement experiments: level 0 starts FVVDP_L0_OFFSET_KB into its allocation (only with FVVDP_L0_SLACK_MB at creation)
-static void place_level0(fvvdp_ctx* c) {
-    if (!c || !c->level0_slack) return;
-    size_t shift = 0;
-    if (const char* e = getenv("FVVDP_L0_OFFSET_KB")) shift = (size_t)atoll(e) * 1024 / sizeof(float);
-    if (shift > c->level0_slack) shift = c->level0_slack;
-    c->level[0] = c->level0_raw + shift;
 }
 
 // strips cover coarse columns [0,62), [62,122), ... (see band_kernel)
@@ -343,20 +300,7 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
     }
     int rc = FVVDP_OK;
     for (int i = 0; i <= n_bands && rc == FVVDP_OK; ++i) {
-        size_t slack = 0;
-        if (i == 0) {
-            // placement experiments (tools/experiments/gpu_k1_offset_sweep.py): FVVDP_L0_SLACK_MB of extra room behind level 0, inside
-            // which FVVDP_L0_OFFSET_KB (read at every call) moves the start of the level without a new allocation
-            if (const char* e = getenv("FVVDP_L0_SLACK_MB")) slack = (size_t)atoll(e) * (1u << 20) / sizeof(float);
-        }
-        rc = dev_alloc(c, &c->level[i], (size_t)max_frames * c->lw[i] * c->lh[i] * planes + slack);
-        if (rc == FVVDP_OK && i == 0) {
-            c->level0_raw = c->level[0];
-            c->level0_slack = slack;
-            c->level0_floats = (size_t)max_frames * c->lw[i] * c->lh[i] * planes + slack;
-            if (getenv("FVVDP_DEBUG_ALLOC")) fprintf(stderr, "fvvdp: level 0 allocation %p, %zu bytes per frame slot\n",
-                                                     (void*)c->level0_raw, (size_t)c->lw[0] * c->lh[0] * planes * 4);
-        }
+        rc = dev_alloc(c, &c->level[i], (size_t)max_frames * c->lw[i] * c->lh[i] * planes);
     }
     size_t off = 0;
     for (int b = 0; b < n_bands; ++b) {
@@ -410,16 +354,6 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
 extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     if (!c) return;
     (void)hipDeviceSynchronize();                  // nothing may still read the scratch
-    if (c->place_alt) {                            // a placement comparison was under way: two level-0 buffers exist
-        (void)hipFree(c->level[0]);                // the candidate (always from hipMalloc)
-        dev_free(c, c->place_alt);                 // the incumbent
-        c->level[0] = nullptr;
-        c->level0_raw = nullptr;
-        c->place_alt = nullptr;
-    }
-    for (auto& e : c->place_ev)
-        if (e) (void)hipEventDestroy(e);
-    if (c->level0_raw) c->level[0] = c->level0_raw;
     for (int i = 0; i <= FVVDP_MAX_BANDS; ++i)
         dev_free(c, c->level[i]);
     dev_free(c, c->partial);
@@ -551,7 +485,6 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
     if (eotf->kind != FVVDP_EOTF_LUT && dtype == FVVDP_U8) return fail(FVVDP_EINVAL, "uint8 sources need FVVDP_EOTF_LUT (uint16: table or closed form)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int HW = c->W * c->H;
-    place_level0(c);
     Timed tm(c, 0, st);
     // register-ring kernels: up to 32 taps for every sample type, up to 64 taps (129-256 fps) for the cases of k1_ring64_ok()
     // (uint8; 16-bit / float RGB behind an sRGB or PQ display; float luminance frames); the 1-pixel-per-lane ring needs no alignment.  The 64-slot ring is not instantiated
@@ -606,87 +539,9 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
             }
             return FVVDP_OK;
         };
-        // Online placement selection of level 0 (OPT-IN: FVVDP_PLACEMENT_PROBE=1; no extra GPU work, a few calls into the life
-        // of a context).  The temporal
-        // kernel runs in one of two modes -- ~31.5 or ~36.5 us per 4K frame -- that are a property of WHERE the level-0
-        // allocation lies physically: stable for an allocation, unchanged by any offset inside it, alternating between
-        // consecutive allocations of the same size, the same with the virtual-memory API (profiles/r03_k1_placement.md).
-        // Short probes do not predict it (12 frames rank the buffers the wrong way round), so the real calls are the
-        // measurement: the 2nd full-batch call of a context is timed on the buffer it has, the 3rd runs on a freshly
-        // allocated one and is timed too, the 4th keeps the faster one and frees the other; if the two were within 5 % of
-        // each other (same mode) one more candidate gets the same treatment.  Results do not depend on the buffer.
-        // Off by default: over 8 contexts it took K1 from 34.1 to 32.9 us per frame on average (there are three modes, 31.5 /
-        // 34.5 / 36.5, and a candidate is as likely to be worse), while the calls that run on a fresh buffer pay its first
-        // touch (41 us per frame) and the context briefly holds level 0 twice -- bench.py gained in 1 of 3 paired runs.
-        bool timed_here = false;
-        if (slot0 == 0 && c->place_phase < 9 && c->level0_slack == 0) {
-            static const bool probe_on = [] { const char* e = getenv("FVVDP_PLACEMENT_PROBE"); return e && e[0] == '1'; }();
-            const size_t bytes = c->level0_floats * sizeof(float);
-            if (!probe_on || bytes < ((size_t)1 << 30) || c->P != 4) {
-                c->place_phase = 9;                        // small scratch (images, short or small clips): nothing to gain
-            } else if (n_out >= 16) {
-                if (c->place_phase == 0) {
-                    c->place_phase = 1;                    // first call: warm-up, not timed
-                } else if (c->place_phase == 1) {
-                    if (!c->place_ev[0] && (hipEventCreate(&c->place_ev[0]) != hipSuccess || hipEventCreate(&c->place_ev[1]) != hipSuccess ||
-                                            hipEventCreate(&c->place_ev[2]) != hipSuccess || hipEventCreate(&c->place_ev[3]) != hipSuccess)) {
-                        c->place_phase = 9;
-                    } else {
-                        (void)hipEventRecord(c->place_ev[0], st);      // the current buffer
-                        timed_here = true;
-                        c->place_phase = 2;
-                    }
-                } else if (c->place_phase == 2) {
-                    void* q = nullptr;
-                    if (hipMalloc(&q, bytes) != hipSuccess) {
-                        (void)hipGetLastError();
-                        c->place_phase = 9;
-                    } else {
-                        c->place_alt = c->level[0];                     // the incumbent waits
-                        c->level[0] = reinterpret_cast<float*>(q);      // this call (temporal kernel AND pyramid) runs on the candidate
-                        (void)hipEventRecord(c->place_ev[2], st);
-                        timed_here = true;
-                        c->place_phase = 3;
-                    }
-                } else if (c->place_phase == 3) {
-                    float t_inc = 0.0f, t_new = 0.0f;
-                    const bool ok = hipEventSynchronize(c->place_ev[3]) == hipSuccess &&
-                                    hipEventElapsedTime(&t_inc, c->place_ev[0], c->place_ev[1]) == hipSuccess &&
-                                    hipEventElapsedTime(&t_new, c->place_ev[2], c->place_ev[3]) == hipSuccess;
-                    float* incumbent = c->place_alt;
-                    float* candidate = c->level[0];
-                    const bool take_new = ok && t_new < 0.95f * t_inc;
-                    float* loser = take_new ? incumbent : candidate;
-                    c->level[0] = take_new ? candidate : incumbent;
-                    c->place_alt = nullptr;
-                    if (loser == c->level0_raw && vmm_owns(c, loser)) {
-                        // (a buffer of the virtual-memory API stays with the context until it is destroyed)
-                    } else {
-                        (void)hipFree(loser);
-                    }
-                    c->level0_raw = c->level[0];
-                    c->place_us[c->place_tries * 2] = t_inc * 1e3f / (float)n_out;
-                    c->place_us[c->place_tries * 2 + 1] = t_new * 1e3f / (float)n_out;
-                    if (getenv("FVVDP_DEBUG_ALLOC"))
-                        fprintf(stderr, "fvvdp: level-0 placement: incumbent %.1f, candidate %.1f us per frame -> %s\n",
-                                t_inc * 1e3f / (float)n_out, t_new * 1e3f / (float)n_out, take_new ? "candidate" : "incumbent");
-                    c->place_tries += 1;
-                    const bool same_mode = ok && t_new > 0.95f * t_inc && t_inc > 0.95f * t_new;
-                    if (same_mode && c->place_tries < 2) {
-                        // re-time the keeper on this call, try one more candidate on the next
-                        (void)hipEventRecord(c->place_ev[0], st);
-                        timed_here = true;
-                        c->place_phase = 2;
-                    } else {
-                        c->place_phase = 9;
-                    }
-                }
-            }
-        }
         {
             const int rc = run(c->level[0], 0, n_out);
             if (rc != FVVDP_OK) return rc;
-            if (timed_here) (void)hipEventRecord(c->place_ev[c->place_phase == 3 ? 3 : 1], st);
         }
     } else if (c->P == 4 && fl > 32 && fl <= 64 && !h_frame_idx1 && !getenv("FVVDP_TEMPORAL_SCALAR") &&
                fl - 1 + n_out <= T_MAX_IDX && k1_ring64_ok(FVVDP_F32, 1, FVVDP_EOTF_NONE)) {
@@ -1138,17 +993,20 @@ static int check_pool_params(const fvvdp_pool_params* prm) {
     return FVVDP_OK;
 }
 
-static int bands_forward_core(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
+// slot0: first level-0 frame slot of the batch (fvvdp_temporal_channels wrote slots [slot0, slot0 + n)); the levels below are
+// scratch of the pass itself and always use slots [0, n)
+static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
                               const fvvdp_geom* geom, const fvvdp_band_maps* maps, const fvvdp_pool_params* pool,
                               float* d_jod, void* stream) {
     if (!c || !d_Q) return fail(FVVDP_EINVAL, "null argument");
+    if (slot0 < 0 || n < 1 || slot0 + n > c->max_frames) return fail(FVVDP_EINVAL, "slots [%d,%d) exceed max_frames %d", slot0, slot0 + n, c->max_frames);
     if (pool) {
         if (!d_jod) return fail(FVVDP_EINVAL, "null argument");
         int rc = check_pool_params(pool);
         if (rc != FVVDP_OK) return rc;
     }
-    const bool pool_now = pool && (q_col0 + n == q_stride);      // this call completes the clip
-    place_level0(c);
+    const bool last_batch = (q_col0 + n == q_stride);            // this call completes the clip
+    const bool pool_now = pool && last_batch;
     if (n < 1 || n > c->max_frames) return fail(FVVDP_EINVAL, "n=%d exceeds max_frames=%d", n, c->max_frames);
     if (q_col0 < 0 || q_col0 + n > q_stride) return fail(FVVDP_EINVAL, "Q columns out of range");
     const bool fov = h_fixation != nullptr;
@@ -1199,7 +1057,7 @@ static int bands_forward_core(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int
             c->lw[b + 2] >= 2 && c->lh[b + 2] >= 2) {
             Band2Args a;
             memset(&a, 0, sizeof(a));
-            a.Ga = c->level[b];
+            a.Ga = c->level[b] + (b == 0 ? (size_t)slot0 * c->lw[0] * c->lh[0] * c->P : (size_t)0);
             a.Gc = c->level[b + 2];
             a.w = c->lw[b];
             a.h = c->lh[b];
@@ -1245,7 +1103,7 @@ static int bands_forward_core(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int
         }
         BandArgs a;
         memset(&a, 0, sizeof(a));
-        a.Gf = c->level[b];
+        a.Gf = c->level[b] + (b == 0 ? (size_t)slot0 * c->lw[0] * c->lh[0] * c->P : (size_t)0);
         a.Gc = c->level[b + 1];
         a.w = c->lw[b];
         a.h = c->lh[b];
@@ -1371,14 +1229,20 @@ static int bands_forward_core(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int
 
 extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
                                    const fvvdp_geom* geom, const fvvdp_band_maps* maps, void* stream) {
-    return bands_forward_core(c, n, d_Q, q_stride, q_col0, h_fixation, geom, maps, nullptr, nullptr, stream);
+    return bands_forward_core(c, 0, n, d_Q, q_stride, q_col0, h_fixation, geom, maps, nullptr, nullptr, stream);
+}
+
+extern "C" int fvvdp_bands_forward_at(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
+                                      const fvvdp_geom* geom, const fvvdp_band_maps* maps, const fvvdp_pool_params* pool,
+                                      float* d_jod, void* stream) {
+    return bands_forward_core(c, slot0, n, d_Q, q_stride, q_col0, h_fixation, geom, maps, pool, d_jod, stream);
 }
 
 extern "C" int fvvdp_bands_forward_pool(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
                                         const fvvdp_geom* geom, const fvvdp_band_maps* maps, const fvvdp_pool_params* pool,
                                         float* d_jod, void* stream) {
     if (!pool) return fail(FVVDP_EINVAL, "null argument");
-    return bands_forward_core(c, n, d_Q, q_stride, q_col0, h_fixation, geom, maps, pool, d_jod, stream);
+    return bands_forward_core(c, 0, n, d_Q, q_stride, q_col0, h_fixation, geom, maps, pool, d_jod, stream);
 }
 
 extern "C" int fvvdp_ctx_set_view_maps(fvvdp_ctx* c, int band, const float* d_view_x, const float* d_view_y,
@@ -1539,3 +1403,4 @@ extern "C" int fvvdp_ctx_timing_read(fvvdp_ctx* c, float* h_ms, int32_t* h_count
     }
     return FVVDP_OK;
 }
+

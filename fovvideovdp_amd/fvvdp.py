@@ -121,6 +121,18 @@ class fvvdp:
             device = torch.device('cuda:0') if (torch.cuda.is_available() and torch.cuda.device_count() > 0) else torch.device('cpu')
         self.device = torch.device(device)
         self.batch_frames = batch_frames
+        # Stage overlap (extension, OFF by default): with `pipeline` = k >= 2 a clip is cut into k batches whose temporal kernel
+        # runs on one internal stream while the pyramid pass of the previous batch runs on another, the two halves of the level-0
+        # scratch alternating between them.  0 = the strictly sequential order of the reference's frame loop
+        # (pyfvvdp/fvvdp.py:248-311) on the caller's stream.  Built for VERDICT r3 item 1 and measured on MI355X
+        # (profiles/r04_stage_overlap.md): both stages are bound by the same HBM, the two kernels side by side take as long as
+        # one after the other (4K x 60: 4.30-4.34 against 4.12-4.38 ms per pair in a queue of 8 pairs, 4.50-4.68 against
+        # 4.25-4.28 ms for a single pair in two halves), so the sequential order stays the default.  Results are identical up
+        # to the grouping of the fp32 partial sums (the batch size decides the work split of the pooling), <= 3e-6 relative.
+        self.pipeline = int(os.environ.get("FVVDP_PIPELINE", "0"))
+        self._pipe = None
+        self._defer_wait = False
+        self._pending = None
         self._ctx = None
         self._lut_dev = code_value_tables()
         self._chan_w = {}
@@ -142,6 +154,7 @@ class fvvdp:
         self._lut_dev.clear()
         self._chan_w = {}
         self._copy_stream = None
+        self._pipe = None
 
     def _drop_context(self):
         """Everything baked into the native context at creation (band frequencies, CSF tables, model constants,
@@ -209,6 +222,25 @@ class fvvdp:
         with torch.cuda.device(self.device):       # the library launches on the calling thread's current device
             return self._predict_on_device(vid_source, fixation_point, frame_range, pool, sync)
 
+    def predict_batch(self, pairs, dim_order="BCFHW", frames_per_second=0, fixation_point=None):
+        """Extension (BASELINE configs[4]: many independent pairs per GPU): queues every (test, reference) pair of `pairs`
+        without host synchronisation and without making the caller's stream wait between pairs, so that with the stage overlap
+        (`pipeline` >= 2) the temporal kernel of pair p+1 runs against the pyramid pass of pair p.  The caller's stream joins
+        once, after the last pair.  Returns [(Q_JOD, stats)] as `predict(..., sync=False)` does: `stats['Q_per_ch']` are device
+        tensors, `fvvdp.finish(stats)` brings one to the host."""
+        out = []
+        self._defer_wait, self._pending = True, None
+        try:
+            for (t, r) in pairs:
+                out.append(self.predict(t, r, dim_order=dim_order, frames_per_second=frames_per_second,
+                                        fixation_point=fixation_point, sync=False))
+        finally:
+            self._defer_wait = False
+            if self._pending is not None:
+                torch.cuda.current_stream(self.device).wait_event(self._pending)
+                self._pending = None
+        return out
+
     @staticmethod
     def finish(stats):
         """Completes a `sync=False` result in place: device -> host copy of Q_per_ch (one synchronisation) and the
@@ -255,6 +287,15 @@ class fvvdp:
         feeder = self._make_feeder(vid_source, width, height, np.unique(widx[f0:f1 + fl - 1]))
         batch = self._batch_size(width, height, planes, n_out)
         schedule = None
+        # stage overlap: sources the kernels read where they lie (arrays, raw YUV frames), plain evaluation, stock geometry
+        n_pipe = self.pipeline if (self.batch_frames is None and not self.do_heatmap and not is_image and
+                                   getattr(feeder, "takes_slot", False) and
+                                   (not self.foveated or native_geometry(self.display_geometry) is not None)) else 0
+        bank = 0
+        if n_pipe >= 2 and n_out >= 8 * n_pipe:
+            bank = min(-(-n_out // n_pipe), max(8, batch // 2))     # frames per batch = per bank of the level-0 scratch
+            batch = 2 * bank                                          # the context holds two banks
+            schedule = [min(bank, f1 - b) for b in range(f0, f1, bank)]
         if self.batch_frames is None and getattr(feeder, "preferred_batch", None):
             batch = max(1, min(batch, feeder.preferred_batch))
             if not self.do_heatmap:
@@ -280,9 +321,59 @@ class fvvdp:
         pp = nat.PoolParams(self.beta_sch, self.beta_tch, self.beta_t, self.w_transient, self.jod_a,
                             float(10.0 ** self.log_jod_exp))
         b0 = f0
-        for nb in schedule:
+        pipe = self._pipeline_state() if bank else None
+        if pipe is not None:
+            # both internal streams start after everything the caller's stream has queued so far (uploads, the zeroed result
+            # buffer, the caller's own producers of the frames)
+            main = torch.cuda.current_stream(self.device)
+            pipe["ev_in"].record(main)
+            pipe["s1"].wait_event(pipe["ev_in"])
+            pipe["s2"].wait_event(pipe["ev_in"])
+            st1, st2 = C.c_void_p(pipe["s1"].cuda_stream), C.c_void_p(pipe["s2"].cuda_stream)
+        bi = -1
+        while bi + 1 < len(schedule):
+            bi += 1
+            nb = schedule[bi]
             idx = np.ascontiguousarray(widx[b0:b0 + fl - 1 + nb])          # history + newest frames of this batch
-            feeder(ctx, idx, taps, fl, nb, oob, stream)
+            if pipe is not None:
+                k = bi & 1
+                slot0 = k * bank
+                pipe["s1"].wait_event(pipe["ev_k2"][k])       # the pass that last read this bank (also of the previous call)
+                if bi > 0:
+                    # released together with the previous batch's pass, whose first kernel is then dispatched first: the pass
+                    # keeps the wave slots it needs and the temporal kernel fills in (the other order measured 5 % slower)
+                    pipe["s1"].wait_event(pipe["ev_start"])
+                feeder(ctx, idx, taps, fl, nb, oob, st1, slot0)
+                pipe["ev_k1"][k].record(pipe["s1"])
+                pipe["s2"].wait_event(pipe["ev_k1"][k])
+                pipe["ev_start"].record(pipe["s2"])
+                fx, g = None, None
+                if self.foveated:
+                    fx = nat.fptr(np.ascontiguousarray(fix[b0:b0 + nb], dtype=np.float32))
+                    g = C.byref(self._geom_struct())
+                last = pool and b0 + nb == f1
+                nat.check(nat.lib().fvvdp_bands_forward_at(ctx.handle, slot0, nb, C.c_void_p(Q.data_ptr()), n_out, b0 - f0, fx, g, None,
+                                                           C.byref(pp) if last else None,
+                                                           C.c_void_p(res[nq + 1:].data_ptr()) if last else None, st2))
+                pipe["ev_k2"][k].record(pipe["s2"])
+                b0 += nb
+                if b0 == f1:
+                    if self._defer_wait:
+                        self._pending = pipe["ev_k2"][k]      # predict_batch joins once, after the last pair
+                    else:
+                        main.wait_event(pipe["ev_k2"][k])     # the caller's stream continues after the last pass (s2 is in order)
+                continue
+            try:
+                feeder(ctx, idx, taps, fl, nb, oob, stream)
+            except _SourceRecyclesBuffers:
+                # A user source overwrote frames that the kernels of the PREVIOUS batch may still have been reading (it decodes
+                # into buffers it reuses).  The feeder has switched to copying every frame on arrival; the previous batch is
+                # evaluated again from intact frames (its Q columns are simply rewritten, in stream order), then this one.
+                if bi > 0:
+                    bi -= 1
+                    b0 -= schedule[bi]
+                bi -= 1
+                continue
             maps_arr, dmaps = None, None
             if self.do_heatmap:                      # per-band difference maps as extra kernel outputs
                 maps_arr = (nat.BandMaps * n_bands)()
@@ -336,6 +427,15 @@ class fvvdp:
         if hasattr(feeder, "release"):
             feeder.release(synced=sync)
         return (Q_jod, stats)
+
+    def _pipeline_state(self):
+        """The two internal streams of the stage overlap and the events that order them: created once per metric and device."""
+        if self._pipe is None or self._pipe["dev"] != self.device:
+            s1, s2 = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
+            self._pipe = {"dev": self.device, "s1": s1, "s2": s2,
+                          "ev_in": torch.cuda.Event(), "ev_k1": [torch.cuda.Event(), torch.cuda.Event()],
+                          "ev_k2": [torch.cuda.Event(), torch.cuda.Event()], "ev_start": torch.cuda.Event()}
+        return self._pipe
 
     @staticmethod
     def _host_buffer(shape):
@@ -661,13 +761,14 @@ class fvvdp:
                         logging.warning('Pixel values are very low. Perhaps images are not scaled in the absolute units of cd/m^2.')
                 w = np.asarray(vs.color_to_luminance, dtype=np.float32)
 
-                def feed(ctx, idx, taps, fl, n_out, oob, stream):
+                def feed(ctx, idx, taps, fl, n_out, oob, stream, slot0=0):
                     if remap is not None:
                         idx = np.ascontiguousarray(remap[idx])
                     nat.check(lib.fvvdp_temporal_channels(
                         ctx.handle, C.c_void_p(test_d.data_ptr()), C.c_void_p(ref_d.data_ptr()), dtype, C_ch,
                         N * HW, HW, C.byref(e), nat.fptr(w), idx.ctypes.data_as(C.POINTER(C.c_int32)),
-                        nat.fptr(taps), fl, n_out, 0, C.c_void_p(oob.data_ptr()), stream))
+                        nat.fptr(taps), fl, n_out, slot0, C.c_void_p(oob.data_ptr()), stream))
+                feed.takes_slot = True
                 return feed
         if (isinstance(vs, fvvdp_video_source_yuv_frames) and native_eotf(vs.dm_photometry) is not None
                 and not (hasattr(vs, "_resizing") and vs._resizing())
@@ -690,17 +791,23 @@ class fvvdp:
                 fmt.ycbcr2rgb[i] = float(val)
             w = np.asarray(vs.color_to_luminance, dtype=np.float32)
 
-            def feed_yuv(ctx, idx, taps, fl, n_out, oob, stream):
+            def feed_yuv(ctx, idx, taps, fl, n_out, oob, stream, slot0=0):
                 if fl > 64:
                     raise RuntimeError("frame rate too high for the YUV path (temporal filter longer than 64 taps)")
                 nat.check(lib.fvvdp_temporal_channels_yuv(
                     ctx.handle, C.c_void_p(test_d.data_ptr()), C.c_void_p(ref_d.data_ptr()), C.byref(fmt), vs.frame_elems,
-                    C.byref(e), nat.fptr(w), idx.ctypes.data_as(C.POINTER(C.c_int32)), nat.fptr(taps), fl, n_out, 0,
+                    C.byref(e), nat.fptr(w), idx.ctypes.data_as(C.POINTER(C.c_int32)), nat.fptr(taps), fl, n_out, slot0,
                     C.c_void_p(oob.data_ptr()), stream))
+            feed_yuv.takes_slot = True
             return feed_yuv
         # generic sources (user subclasses, custom float photometry): luminance frames come from the source's own
         # get_*_frame (the user's code, run on the device); the kernels take over from the temporal filter on.
         return _PipelinedSourceFeeder(self, vs, width, height)
+
+
+class _SourceRecyclesBuffers(Exception):
+    """Raised by _PipelinedSourceFeeder the moment it sees a source reuse the buffer of a frame that was still in the temporal
+    window (see there); _predict_on_device re-runs the batch whose input may have been overwritten."""
 
 
 class _PipelinedSourceFeeder:
@@ -714,9 +821,13 @@ class _PipelinedSourceFeeder:
     (too far apart in memory, filters longer than 64 taps) go through one stacking copy per stream and batch instead.
 
     Contract for user sources: a tensor returned by `get_*_frame` is read in place for up to filter_len - 1 + batch later
-    frames.  A source that decodes into a buffer it reuses (`return self._buf`) is detected -- a fresh frame arriving at
-    the address of a frame still in the window -- and from then on every frame is copied on arrival (the frames the reuse
-    overwrote are fetched again), which is what the reference does for every source (pyfvvdp/fvvdp.py:289-291).
+    frames, and frames may be asked for again (random access).  A source that decodes into buffers it reuses (`return
+    self._buf`) is noticed AFTER the fact -- a fresh frame arrives at the address of a frame still in the window, or the test and
+    the reference frame of one fetch share an address.  By then the overwritten frames are gone and the kernels of the previous
+    batch, still in flight on the caller's stream, may have read them half-written (the fetches run on a side stream that does
+    not wait for those kernels).  So from that moment every frame is copied on arrival -- what the reference does for every
+    source (pyfvvdp/fvvdp.py:289-291) --, the overwritten frames are fetched again, and _SourceRecyclesBuffers makes the caller
+    evaluate the previous batch again from intact copies (batch k-2 and older had finished before the fetch: back-pressure).
     The fetches run on a side stream that first waits for the caller's current stream, so frames produced asynchronously
     on that stream just before the call (GPU-generated video, non_blocking uploads) are complete when they are read."""
 
@@ -755,6 +866,7 @@ class _PipelinedSourceFeeder:
         self.retired = []                 # tensors of frames that left the window: freed once their last reader has finished
         self.live_ptrs = {}               # address -> source frame, of every tensor in self.frames (aliasing detection)
         self.copy_mode = False            # the source reuses its buffers: clone on arrival
+        self.recycled = False             # set by _buffer_reuse: the batch in flight may have read overwritten frames
         self.waited_main = False
         self.eotf = nat.Eotf()
         self.eotf.kind = nat.EOTF_NONE
@@ -777,20 +889,26 @@ class _PipelinedSourceFeeder:
             r = r.clone()
         tp, rp = t.data_ptr(), r.data_ptr()
         if not self.copy_mode:
-            if tp in self.live_ptrs or rp in self.live_ptrs:
-                return self._buffer_reuse(t, r)
+            if tp == rp or tp in self.live_ptrs or rp in self.live_ptrs:
+                return self._buffer_reuse(f, t, r)
             self.live_ptrs[tp] = f
             self.live_ptrs[rp] = f
         return (t, r, tp, rp)
 
-    def _buffer_reuse(self, t, r):
-        """The source handed out an address that a frame still in the temporal window occupies: it decodes into buffers it
-        reuses.  The new frame is intact right now (copied first); the held frames at the same addresses are not (fetched
-        again and copied); every other held frame is still intact and is copied before a later fetch can overwrite it."""
-        hit = sorted({self.live_ptrs[p] for p in (t.data_ptr(), r.data_ptr()) if p in self.live_ptrs})
+    def _buffer_reuse(self, f, t, r):
+        """The source handed out an address that a frame still in the temporal window occupies (or one address for the test
+        and the reference frame): it decodes into buffers it reuses.  The new frame is intact right now unless its two halves
+        share the buffer (then it is fetched again, copying); the held frames at the same addresses are gone (fetched again
+        and copied); every other held frame is still intact and is copied before a later fetch can overwrite it."""
+        tp, rp = t.data_ptr(), r.data_ptr()
+        hit = sorted({self.live_ptrs[p] for p in (tp, rp) if p in self.live_ptrs})
         self.copy_mode = True
         self.live_ptrs = {}
-        t, r = t.clone(), r.clone()
+        self.recycled = True                             # __call__ raises once the bookkeeping is consistent again
+        if tp == rp:
+            t = r = None                                 # the reference fetch overwrote the test frame
+        else:
+            t, r = t.clone(), r.clone()
         for g in list(self.frames):
             if g not in hit:
                 h = self.frames[g]
@@ -798,6 +916,8 @@ class _PipelinedSourceFeeder:
                 self.frames[g] = (tt, rr, tt.data_ptr(), rr.data_ptr())
         for g in hit:
             self.frames[g] = self._fetch(g)               # copy mode: cloned on arrival
+        if t is None:
+            return self._fetch(f)
         return (t, r, t.data_ptr(), r.data_ptr())
 
     def __call__(self, ctx, idx, taps, fl, n_out, oob, stream):
@@ -821,6 +941,13 @@ class _PipelinedSourceFeeder:
             ready = self.ev_ready
             ready.record(self.side)
         main.wait_event(ready)
+        if self.recycled:
+            # The frames just overwritten may have been inputs of the previous batch, whose kernels are not known to have
+            # finished: hand control back so that batch is evaluated again (every frame held now is a private copy; the
+            # copies were made on the side stream, which the caller's stream has just been made to wait for).
+            self.recycled = False
+            if self.n_batches >= 1:
+                raise _SourceRecyclesBuffers()
         pos = {f: k for k, f in enumerate(uniq)}
         ridx = np.asarray([pos[int(f)] for f in idx], dtype=np.int32)
         held = [self.frames[f] for f in uniq]

@@ -251,6 +251,16 @@ int fvvdp_bands_forward_pool(fvvdp_ctx* ctx, int n, float* d_Q, int q_stride, in
                              const fvvdp_geom* geom, const fvvdp_band_maps* maps, const fvvdp_pool_params* pool,
                              float* d_jod, void* stream);
 
+/* The same pass on the batch in level-0 frame slots [slot0, slot0 + n) (what fvvdp_temporal_channels was given as `slot0`);
+ * `pool` / `d_jod` may be NULL (then as fvvdp_bands_forward).  With two halves ("banks") of the level-0 scratch the temporal
+ * kernel of batch b+1 can fill one bank on one stream while this pass reads the other on a second stream -- the reference's
+ * frame loop is strictly sequential (fvvdp.py:248-311, "TODO: process multiple frames at a time" :360); the only state the two
+ * stages share is level 0, everything below it belongs to this pass and is reused in stream order.  The caller orders the
+ * streams with events: temporal(b) -> pass(b), and pass(b) -> temporal(b+2) for the bank they share.                        */
+int fvvdp_bands_forward_at(fvvdp_ctx* ctx, int slot0, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
+                           const fvvdp_geom* geom, const fvvdp_band_maps* maps, const fvvdp_pool_params* pool,
+                           float* d_jod, void* stream);
+
 /* Colouring of difference maps for heatmap = "threshold" / "supra-threshold" (reference: visualize_diff_map,
  * vis_tonemap, log_luminance in pyfvvdp/visualize_diff_map.py, called at fvvdp.py:474-476): the map d_dmap[n][H][W]
  * (clamped to [0,1]) indexes a colour map (n_knots <= 8 knots h_knots, luminance-normalised colours h_rgb[n_knots][3])
@@ -274,6 +284,7 @@ int fvvdp_export_level(fvvdp_ctx* ctx, int level, int n, float* d_out, void* str
  *   ids: 0 = temporal, 1..n_bands = band kernel of level id-1, n_bands+1 = finalize                       */
 int fvvdp_ctx_timing_enable(fvvdp_ctx* ctx, int on);
 int fvvdp_ctx_timing_read(fvvdp_ctx* ctx, float* h_ms, int32_t* h_count, int capacity, int reset);
+
 
 /* ---- PU21-PSNR side metric ---------------------------------------------------
  * Replaces the per-frame body of pu_psnr.predict_video_source (pyfvvdp/pupsnr.py:64-76): luminance of both streams

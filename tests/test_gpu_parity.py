@@ -968,3 +968,79 @@ def test_two_pass_temporal_path_for_the_other_high_frame_rate_inputs(fv, fps, mo
         oq, ost = orc.Oracle(disp).predict(tn, rn, frames_per_second=fps)
         assert abs(float(q) - float(oq)) < 1e-4, (name, float(q), float(oq))
         check_q(st["Q_per_ch"], ost["Q_per_ch"], coarse=4e-3, fine=4e-3)      # 36x64 frame: every band is tiny (as test_other_frame_rates_vs_oracle)
+
+
+def test_bt2020_rgb_arrays_golden_and_oracle(fv):
+    """Row (a)3's second weight set: color_space='BT.2020' on RGB arrays (video_source.py:204-206, color_spaces.json:19; the
+    weights sum to 1.134).  uint8 (LUT path) and float RGB (closed-form sRGB) video and a uint16 image behind PQ, against the real
+    reference (golden g15) and against the oracle on another size; the temporal channels of two frames against the reference's R."""
+    from lowlevel import Pipeline
+    from fovvideovdp_amd import _native as nat
+    from fovvideovdp_amd.fvvdp import window_frame_indices
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    z = load("g15_bt2020")
+    H, W, N = int(z["H"]), int(z["W"]), int(z["N"])
+    test, ref = synth_video_pair(N, H, W)
+    m = fv.fvvdp(display_name="standard_4k", color_space="BT.2020")
+    for tag, (t, r) in (("u8", (test, ref)), ("f32", (test.float() / 255, ref.float() / 255))):
+        q, stats = m.predict(t, r, frames_per_second=30)
+        assert abs(float(q) - float(z[tag + "_jod"])) < 2e-5, tag
+        check_q(stats["Q_per_ch"], z[tag + "_Q_per_ch"])
+    q_srgb, _ = fv.fvvdp(display_name="standard_4k").predict(test, ref, frames_per_second=30)
+    assert abs(float(q_srgb) - float(z["u8_jod"])) > 1e-3            # the colour space is not ignored
+    # stage 1 through the C ABI with the BT.2020 weights against the reference's R
+    w2020 = orc.load_defaults()["color_spaces.json"]["BT.2020"]["RGB2Y"]
+    pipe = Pipeline(m, W, H, 4, N)
+    fl = orc.filter_len(30)
+    m.filter_len = fl
+    F, _ = m.get_temporal_filters(30)
+    e = nat.Eotf()
+    lut = m._code_lut(m.display_photometry, 8)
+    e.kind, e.d_lut = nat.EOTF_LUT, lut.data_ptr()
+    pipe.temporal(test.cuda(), ref.cuda(), nat.FVVDP_U8, 3, N * H * W, H * W, e, w2020, window_frame_indices(N, fl, "replicate"), F.numpy(), fl, N)
+    R = pipe.export_level(0, N).cpu().numpy()
+    for ff in (0, N - 1):
+        g = z["u8_R_f%d" % ff]
+        assert np.max(np.abs(R[ff] - g)) < 2e-6 * np.max(np.abs(g)), ff
+    # uint16 image behind PQ
+    t16 = test[0, :, 0].permute(1, 2, 0).numpy().astype(np.uint16) * 257
+    r16 = ref[0, :, 0].permute(1, 2, 0).numpy().astype(np.uint16) * 257
+    q, stats = fv.fvvdp(display_name="standard_hdr_pq", color_space="BT.2020").predict(t16, r16, dim_order="HWC")
+    assert abs(float(q) - float(z["img16_pq_jod"])) < 1e-4
+    check_q(stats["Q_per_ch"][:, 0:1], z["img16_pq_Q_per_ch"][:, 0:1])
+    # against the oracle on a size with a misaligned width (scalar temporal kernel) and at 60 fps (16-slot ring)
+    for (Hh, Ww, Nn, fps) in ((90, 161, 7, 30), (96, 160, 18, 60)):
+        t, r = synth_video_pair(Nn, Hh, Ww)
+        oq, ost = orc.Oracle("standard_fhd", color_space="BT.2020").predict(t.numpy(), r.numpy(), frames_per_second=fps)
+        q, stats = fv.fvvdp(display_name="standard_fhd", color_space="BT.2020").predict(t, r, frames_per_second=fps)
+        assert abs(float(q) - float(oq)) < 2e-5, (Hh, Ww)
+        check_q(stats["Q_per_ch"], ost["Q_per_ch"])
+
+
+def test_config5_per_gpu_share_8_pairs_golden(fv):
+    """BASELINE configs[4], one GPU's share: pairs 0..7 of the synthetic 4Kx60 set (seed + 1000*i), queued exactly as
+    bench.py's multi-pair step queues them (predict(sync=False) per pair, gather_pair_results, ONE pooling call, one
+    device->host copy) against the real reference's JOD and Q_per_ch of every pair (golden g3 = pair 0, g14 = pairs 1..7:
+    tools/gen_golden.py, ~3 min of reference CPU time per pair)."""
+    from fovvideovdp_amd.sharding import gather_pair_results
+    from fovvideovdp_amd.synth import synth_video_pair
+    z0, z = load("g3_synth_uhd_60f"), load("g14_config4_pairs")
+    K, N, H, W = 8, 60, 2160, 3840
+    gj = [float(z0["jod"])] + [float(z["jod_p%d" % i]) for i in range(1, K)]
+    gq = [z0["Q_per_ch"]] + [z["Q_per_ch_p%d" % i] for i in range(1, K)]
+    assert min(abs(a - b) for i, a in enumerate(gj) for b in gj[i + 1:]) > 2e-5      # eight different answers: a mixed-up pair order would show
+    pairs = [synth_video_pair(N, H, W, device="cuda", pair=k) for k in range(K)]
+    m = fv.fvvdp(display_name="standard_4k")
+    for rep in range(2):                                      # the second round runs on warm contexts (placement selection done)
+        qs = [m.predict(t, r, dim_order="BCFHW", frames_per_second=30, sync=False)[1]["Q_per_ch"] for (t, r) in pairs]
+        allq = gather_pair_results(torch.stack(qs), 0, 1)
+        jods = m.do_pooling_and_jods(allq, None).tolist()
+        qh = allq.cpu().numpy()
+        for k in range(K):
+            assert abs(jods[k] - gj[k]) < 5e-6, (rep, k, jods[k], gj[k])          # north-star bound 1e-3
+            check_q(qh[k], gq[k], coarse=1.5e-3, fine=1.5e-3)                      # the g3 bound of the full-size test
+    # the synchronous single call gives the same numbers as the queued one
+    q0, st0 = m.predict(pairs[3][0], pairs[3][1], frames_per_second=30)
+    assert abs(float(q0) - jods[3]) < 2e-6
+    assert np.allclose(st0["Q_per_ch"], qh[3], rtol=2e-6, atol=0)

@@ -111,35 +111,67 @@ def test_use_checkpoints_flag_is_accepted_and_gradients_are_refused():
         m.predict(t, ref.to(torch.float32) / 255, frames_per_second=FPS)
 
 
-@pytest.mark.timeout(600)
-def test_bench_multi_rank_step_under_gloo():
-    """bench.py's own multi-rank step (pairs queued with sync=False -> gather_pair_results -> one pooling call), launched the
-    way the driver launches it (torch.distributed.run, one process per rank), here with 2 gloo ranks sharing the GPU.  The
-    nccl (RCCL) run differs by the backend string only.  The JSON line must carry n_gpus 2 and the 4 JODs of the 4 pairs,
-    equal to single-rank calls on the same pairs."""
+def _run_bench_two_ranks(backend):
+    """bench.py launched the way the driver launches it (torch.distributed.run, one process per rank); returns the JSON line."""
     import json
     import subprocess
     import sys
-    import fovvideovdp_amd as fv
-    from fovvideovdp_amd.synth import synth_video_pair
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     W, H, N, K = 960, 540, 20, 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", "gloo",
-           "--pairs-per-gpu", str(K), "--width", str(W), "--height", str(H), "--frames", str(N), "--steps", "2", "--warmup", "1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", backend,
+           "--pairs-per-gpu", str(K), "--width", str(W), "--height", str(H), "--frames", str(N), "--steps", "3", "--warmup", "1",
            "--no-cpu-baseline", "--no-h2d", "--no-measure-traffic"]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
     p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=540)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]                   # ONE JSON line, from rank 0
-    out = json.loads(lines[0])
-    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1 and out["scaling"] == "weak"
+    return json.loads(lines[0]), (W, H, N, K)
+
+
+def _check_bench_line(out, dims, backend):
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair
+    W, H, N, K = dims
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["pairs_per_gpu"] == K and out["value"] > 0 and out["higher_is_better"] is True
     assert out["roofline"] is not None and out["roofline"]["bound"] == "hbm"
+    assert out["roofline_k1"]["bound"] == "hbm" and out["roofline_k1"]["frac"] > 0
+    # value is the median step (SURVEY 8(d)); the mean is carried beside it, and the two are consistent with their times
+    tm = out["timing"]
+    px = 2.0 * W * H * N * K * 2
+    assert abs(out["value"] - px / (out["ms_per_step"] * 1e-3) / 1e6) <= 2e-3 * out["value"]
+    assert abs(tm["value_mean"] - px / (tm["ms_per_step_mean"] * 1e-3) / 1e6) <= 2e-3 * tm["value_mean"]
+    assert tm["ms_per_step_min"] <= out["ms_per_step"] <= tm["ms_per_step_max"]
+    # what the communicator reports: backend, size, one entry per rank
+    cm = out["communicator"]
+    assert cm["backend"] == backend and cm["world_size"] == 2 and [r["rank"] for r in cm["ranks"]] == [0, 1]
+    assert len(set(r["pid"] for r in cm["ranks"])) == 2
+    if backend == "nccl":
+        assert cm["distinct_devices"] == 2 and cm["rccl_version"]
     assert len(out["jod"]) == 2 * K
     m = fv.fvvdp(display_name="standard_4k")
     for pidx in range(2 * K):
         t, r = synth_video_pair(N, H, W, device="cuda", pair=pidx)
         q, _ = m.predict(t, r, frames_per_second=30)
         assert abs(float(q) - out["jod"][pidx]) < 2e-6, (pidx, float(q), out["jod"][pidx])
+
+
+@pytest.mark.timeout(600)
+def test_bench_multi_rank_step_under_gloo():
+    """bench.py's own multi-rank step (pairs queued with sync=False -> gather_pair_results -> one pooling call), launched the
+    way the driver launches it (torch.distributed.run, one process per rank), here with 2 gloo ranks sharing the GPU.  The
+    JSON line must carry n_gpus 2, the communicator's own facts, median and mean timing, and the 4 JODs of the 4 pairs,
+    equal to single-rank calls on the same pairs."""
+    out, dims = _run_bench_two_ranks("gloo")
+    _check_bench_line(out, dims, "gloo")
+
+
+@pytest.mark.timeout(600)
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="the RCCL run needs two GPUs (the driver's multi-GPU box)")
+def test_bench_multi_rank_step_under_rccl():
+    """The same launch with backend nccl (= RCCL over xGMI), one GPU per rank: init with device_id, the all-reduce of the
+    device buffer, the barrier before destroy_process_group.  Skipped on single-GPU boxes."""
+    out, dims = _run_bench_two_ranks("nccl")
+    _check_bench_line(out, dims, "nccl")

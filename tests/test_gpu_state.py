@@ -284,10 +284,54 @@ def test_source_that_reuses_its_output_buffer(fv):
             q1, s1 = mm.predict_video_source(src)
             assert abs(float(q1) - float(oq)) < 2e-5, (k, batch, float(q1), float(oq))
             assert np.array_equal(s1["Q_per_ch"], s0["Q_per_ch"]) or np.allclose(s1["Q_per_ch"], s0["Q_per_ch"], rtol=2e-4, atol=1e-6 * s0["Q_per_ch"].max())
-            assert src.n <= N + k + 1                      # every frame once, plus the ones the reuse overwrote
+            assert src.n <= N + k + 1 + 8 + 7              # every frame once, plus the ones the reuse overwrote and (when the
+                                                           # reuse shows after the first batch) that batch's window again
     q2, s2 = m.predict_video_source(Reuser(1), sync=False)
     fv.fvvdp.finish(s2)
     assert abs(float(q2) - float(q0)) < 5e-6
+
+
+def test_source_whose_buffer_ring_is_shorter_than_window_plus_batch(fv):
+    """a ring of R buffers with 2 < R <= window: the reuse only shows when a later batch is fetched, and the frames it
+    overwrote belong to the PREVIOUS batch, whose kernels may still be reading them on the caller's stream (the fetches run on a
+    side stream).  The feeder must not only repair the batch being fetched but have the previous batch evaluated again.  60 fps
+    (15 taps), default schedule (batches of 8, 16, ...), R = 16 and 20, frames large enough that the previous batch is still
+    running when the source overwrites its input.  Also a source that returns ONE buffer for the test and the reference frame."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    N, H, W, fps = 44, 540, 960, 60
+    test, ref = synth_video_pair(N, H, W, device="cuda")
+    m = fv.fvvdp(display_name="standard_fhd")
+    q0, s0 = m.predict(test, ref, frames_per_second=fps)
+    inner = fv.fvvdp_video_source_array(test, ref, fps, display_photometry=m.display_photometry)
+
+    class Ring(fv.fvvdp_video_source):
+        def __init__(self, k, shared=False):
+            self.k, self.shared = k, shared
+            self.bt = [torch.empty((1, 1, 1, H, W), device="cuda") for _ in range(k)]
+            self.br = self.bt if shared else [torch.empty((1, 1, 1, H, W), device="cuda") for _ in range(k)]
+
+        def get_video_size(self):
+            return (H, W, N)
+
+        def get_frames_per_second(self):
+            return fps
+
+        def get_test_frame(self, frame, device):
+            b = self.bt[frame % self.k]
+            b.copy_(inner.get_test_frame(frame, device))
+            return b
+
+        def get_reference_frame(self, frame, device):
+            b = self.br[frame % self.k]
+            b.copy_(inner.get_reference_frame(frame, device))
+            return b
+
+    for src in (Ring(16), Ring(20), Ring(3), Ring(64, shared=True), Ring(1, shared=True)):
+        for rep in range(3):                                  # a race does not lose every time
+            q1, s1 = fv.fvvdp(display_name="standard_fhd").predict_video_source(src)
+            assert abs(float(q1) - float(q0)) < 5e-6, (src.k, src.shared, rep, float(q1), float(q0))
+            a, b = s1["Q_per_ch"].astype(np.float64), s0["Q_per_ch"].astype(np.float64)
+            assert np.all(np.abs(a - b) <= 2e-4 * np.abs(b) + 1e-6 * np.max(b)), (src.k, src.shared, rep)
 
 
 def test_frames_produced_on_the_callers_stream_just_before_the_call(fv):
@@ -366,9 +410,10 @@ def test_frame_sharded_call_uploads_only_its_own_frames(fv):
     assert np.all(np.abs(s_all["Q_per_ch"][:, :, :10] - o) <= 1e-3 * np.abs(o) + 1e-6 * np.max(o))
 
 
-def test_placement_selection_does_not_change_results(tmp_path):
-    """FVVDP_PLACEMENT_PROBE=1 (opt-in, read once per process): during calls 2-6 of a context the level-0 scratch moves between
-    two allocations while they are compared.  Every call must return the same bits as a process without the selection."""
+def test_chunk_mapped_scratch_gives_the_same_results_as_hipmalloc(tmp_path):
+    """The large pyramid levels are mapped from 32 MB physical chunks through the virtual-memory API (the temporal kernel is 15 %
+    faster than on a physically contiguous hipMalloc range, profiles/r04_level0_chunks.md); FVVDP_ALLOC=malloc (read once per
+    process) goes back to hipMalloc.  Same bits either way, also for another chunk size and across context re-creation."""
     import subprocess
     import sys
     import os
@@ -378,22 +423,83 @@ def test_placement_selection_does_not_change_results(tmp_path):
         "sys.path.insert(0, %r)\n"
         "import fovvideovdp_amd as fv\n"
         "from fovvideovdp_amd.synth import synth_video_pair\n"
-        "t, r = synth_video_pair(40, 1080, 1920, device='cuda')\n"         # level 0: 40 x 33 MB = 1.3 GB (>= the 1 GiB threshold)
-        "m = fv.fvvdp(display_name='standard_fhd')\n"
+        "t, r = synth_video_pair(40, 1080, 1920, device='cuda')\n"         # level 0: 40 x 33 MB = 1.3 GB, level 1 0.33 GB: both mapped
         "out = []\n"
-        "for k in range(8):\n"
-        "    q, st = m.predict(t, r, frames_per_second=30)\n"
-        "    out.append(np.concatenate([st['Q_per_ch'].reshape(-1), [float(q)]]))\n"
+        "for rep in range(2):\n"
+        "    m = fv.fvvdp(display_name='standard_fhd')\n"
+        "    for k in range(2):\n"
+        "        q, st = m.predict(t, r, frames_per_second=30)\n"
+        "        out.append(np.concatenate([st['Q_per_ch'].reshape(-1), [float(q)]]))\n"
+        "    free0 = torch.cuda.mem_get_info()[0]\n"
+        "    del m\n"
+        "    import gc; gc.collect()\n"
+        "    print('FREED', torch.cuda.mem_get_info()[0] - free0)\n"
         "np.save(sys.argv[1], np.stack(out))\n" % root)
     res = {}
-    for mode in ("1", "0"):
-        f = str(tmp_path / ("sel%s.npy" % mode))
-        env = dict(os.environ, FVVDP_PLACEMENT_PROBE=mode, FVVDP_DEBUG_ALLOC="1")
-        p = subprocess.run([sys.executable, "-c", code, f], env=env, capture_output=True, text=True, timeout=300)
+    for mode, env in (("vmm", {}), ("vmm8", {"FVVDP_VMM_CHUNK_MB": "8"}), ("malloc", {"FVVDP_ALLOC": "malloc"})):
+        f = str(tmp_path / ("a_%s.npy" % mode))
+        p = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-1500:]
-        res[mode] = (np.load(f), p.stderr)
-    on, log = res["1"]
-    off, _ = res["0"]
-    assert "level-0 placement: incumbent" in log           # the comparison really ran
-    assert all(np.array_equal(on[k], on[0]) for k in range(8))
-    assert np.array_equal(on, off)
+        res[mode] = np.load(f)
+        freed = [int(l.split()[1]) for l in p.stdout.splitlines() if l.startswith("FREED")]
+        assert len(freed) == 2 and min(freed) > 1.5e9, (mode, freed)      # destroying the context returns the mapped chunks
+    assert all(np.array_equal(res["vmm"][k], res["vmm"][0]) for k in range(4))
+    assert np.array_equal(res["vmm"], res["malloc"]) and np.array_equal(res["vmm"], res["vmm8"])
+
+
+def test_stage_overlap_equals_the_sequential_order():
+    """`pipeline` = k cuts a clip into k batches whose temporal kernel runs on one internal stream against the pyramid pass of
+    the previous batch on another (two banks of the level-0 scratch).  Against the strictly sequential order: equal up to the
+    grouping of the partial sums; against the same batches run sequentially (batch_frames): bit-identical -- the overlap itself
+    changes nothing.  Also with calls queued back to back (sync=False), a frame range, foveated mode and YUV sources."""
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair, synth_gaze, synth_yuv_pair
+    H, W, N = 270, 480, 50
+    pairs = [synth_video_pair(N, H, W, device="cuda", pair=k) for k in range(4)]
+    seq = fv.fvvdp(display_name="standard_fhd")
+    seq.pipeline = 0
+    want = [seq.predict(t, r, frames_per_second=30) for (t, r) in pairs]
+    for k in (2, 3, 5):
+        m = fv.fvvdp(display_name="standard_fhd")
+        m.pipeline = k
+        bank = -(-N // k)
+        same = fv.fvvdp(display_name="standard_fhd", batch_frames=bank)         # the same batches, one after the other
+        same.pipeline = 0
+        for rep in range(2):
+            # queued without host synchronisation: the temporal kernel of pair p+1 starts while pair p's last pass runs
+            st = [m.predict(t, r, frames_per_second=30, sync=False)[1] for (t, r) in pairs]
+            qj = [m.predict(t, r, frames_per_second=30, sync=False)[0] for (t, r) in pairs]
+            for p, s in enumerate(st):
+                fv.fvvdp.finish(s)
+                a, b = s["Q_per_ch"].astype(np.float64), want[p][1]["Q_per_ch"].astype(np.float64)
+                assert np.all(np.abs(a - b) <= 3e-6 * np.abs(b) + 1e-9 * np.max(b)), (k, p)
+                assert abs(float(qj[p]) - float(want[p][0])) < 2e-6
+                qs, ss = same.predict(pairs[p][0], pairs[p][1], frames_per_second=30)
+                assert np.array_equal(s["Q_per_ch"], ss["Q_per_ch"]), (k, p)
+                assert float(qj[p]) == float(qs)
+        # frame range (frame sharding) through the overlap
+        qa, sa = m.predict_video_source(fv.fvvdp_video_source_array(pairs[1][0], pairs[1][1], 30, display_photometry=m.display_photometry),
+                                        frame_range=(7, 47), pool=False)
+        b = want[1][1]["Q_per_ch"][:, :, 7:47].astype(np.float64)
+        assert np.all(np.abs(sa["Q_per_ch"] - b) <= 3e-6 * np.abs(b) + 1e-9 * np.max(b))
+    # foveated with a moving gaze: the gaze rows follow the batches
+    gaze = synth_gaze(N, H, W).numpy()
+    f0 = fv.fvvdp(display_name="standard_hdr_pq", foveated=True)
+    f0.pipeline = 0
+    f2 = fv.fvvdp(display_name="standard_hdr_pq", foveated=True)
+    f2.pipeline = 2
+    q0, s0 = f0.predict(pairs[0][0], pairs[0][1], frames_per_second=30, fixation_point=gaze)
+    q2, s2 = f2.predict(pairs[0][0], pairs[0][1], frames_per_second=30, fixation_point=gaze)
+    assert abs(float(q0) - float(q2)) < 2e-6
+    assert np.all(np.abs(s2["Q_per_ch"] - s0["Q_per_ch"]) <= 3e-6 * np.abs(s0["Q_per_ch"]) + 1e-9 * np.max(s0["Q_per_ch"]))
+    # raw YUV frames
+    ty, ry = synth_yuv_pair(40, 180, 320, 8, "420", device="cuda")
+    res = []
+    for pl in (0, 2):
+        m = fv.fvvdp(display_name="standard_fhd")
+        m.pipeline = pl
+        vs = fv.fvvdp_video_source_yuv_frames(ty, ry, 30, 320, 180, bit_depth=8, chroma_ss="420", display_photometry=m.display_photometry)
+        res.append(m.predict_video_source(vs))
+    assert abs(float(res[0][0]) - float(res[1][0])) < 2e-6
+    a, b = res[1][1]["Q_per_ch"].astype(np.float64), res[0][1]["Q_per_ch"].astype(np.float64)
+    assert np.all(np.abs(a - b) <= 3e-6 * np.abs(b) + 1e-9 * np.max(b))

@@ -258,6 +258,41 @@ def test_f32_gray_and_u16_inputs_g2():
     assert relerr(stats["Q_per_ch"][:, 0, 0], z["Q_per_ch"][:, 0, 0]) < 2e-4
 
 
+def bt2020_inputs():
+    z = load("g15_bt2020")
+    H, W, N = int(z["H"]), int(z["W"]), int(z["N"])
+    test, ref = synth_video_pair(N, H, W)
+    return z, test, ref, N
+
+
+def test_bt2020_rgb_arrays_g15():
+    """colour space BT.2020 on RGB arrays: the second RGB->Y weight set (video_source.py:204-206, color_spaces.json:19 -- it sums
+    to 1.134), uint8 and float video behind sRGB, a uint16 image behind PQ, against the real reference (golden g15)."""
+    z, test, ref, N = bt2020_inputs()
+    o = orc.Oracle("standard_4k", color_space="BT.2020")
+    assert abs(sum(o.rgb2y) - 1.13443) < 1e-4            # NOT the sRGB set
+    for tag, (t, r) in (("u8", (test.numpy(), ref.numpy())),
+                        ("f32", (test.float().numpy() / np.float32(255), ref.float().numpy() / np.float32(255)))):
+        jod, stats = o.predict(t, r, frames_per_second=30)
+        assert abs(float(jod) - float(z[tag + "_jod"])) < 1e-5
+        check_q(stats["Q_per_ch"], z[tag + "_Q_per_ch"])
+        for f in (0, N - 1):                              # the temporal channels of the first and last frame, from their windows
+            fl = orc.filter_len(30)
+            widx = orc.window_frame_indices(N, fl, "replicate")[f]
+            lum = lambda a, j: orc.frame_luminance(orc.reshuffle_dims(a, "BCFHW"), int(j), o.photometry, o.rgb2y)[0]
+            R = orc.temporal_channels(np.stack([lum(t, j) for j in widx]), np.stack([lum(r, j) for j in widx]), o.F)
+            g = z["%s_R_f%d" % (tag, f)]
+            assert np.max(np.abs(R - g)) <= 3e-6 * np.max(np.abs(g))
+    # the sRGB weights give a different answer on the same input: the test would notice a colour space that is ignored
+    jod_srgb, _ = orc.Oracle("standard_4k").predict(test.numpy(), ref.numpy(), frames_per_second=30)
+    assert abs(float(jod_srgb) - float(z["u8_jod"])) > 1e-3
+    t16 = test[0, :, 0].permute(1, 2, 0).numpy().astype(np.uint16) * 257
+    r16 = ref[0, :, 0].permute(1, 2, 0).numpy().astype(np.uint16) * 257
+    jod, stats = orc.Oracle("standard_hdr_pq", color_space="BT.2020").predict(t16, r16, dim_order="HWC")
+    assert abs(float(jod) - float(z["img16_pq_jod"])) < 1e-5
+    check_q(stats["Q_per_ch"][:, :1], z["img16_pq_Q_per_ch"][:, :1])
+
+
 G10_DISPLAYS = ("htc_vive_pro", "ipad_pro_12_9", "iphone_12_pro", "lg_oled_2017_hdr", "lg_oled_2017_sdr", "macbook_pro_16",
                 "sdr_4k_30", "sdr_fhd_24", "standard_hmd", "standard_phone", "standard_hdr_linear")
 

@@ -563,6 +563,60 @@ def g13(pyfvvdp):
     save("g13_8k", out)
 
 
+def g14(pyfvvdp):
+    """BASELINE configs[4], the per-GPU share: pairs 0..7 of the synthetic 4Kx60 set (seeds + 1000*i).  Pair 0 is
+    golden g3_synth_uhd_60f; pairs 1..7 are stored here (outputs only, the inputs are reproducible from the pair index).
+    Written after every pair so that an interrupted run keeps what it has."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    H, W, N = 2160, 3840, 60
+    path = os.path.join(OUT, "g14_config4_pairs.npz")
+    out = dict(np.load(path)) if os.path.exists(path) else {}
+    which = [int(x) for x in os.environ.get("G14_PAIRS", "1,2,3,4,5,6,7").split(",")]
+    for i in which:
+        if ("jod_p%d" % i) in out:
+            continue
+        test, ref = synth_video_pair(N, H, W, pair=i)
+        r = run_case(pyfvvdp, test, ref, "BCFHW", 30, "standard_4k", keep_maps=False)
+        print("g14 pair", i, "JOD", r["jod"], "seconds", r["seconds"], flush=True)
+        out["jod_p%d" % i] = r["jod"]
+        out["Q_per_ch_p%d" % i] = r["Q_per_ch"]
+        out["seconds_p%d" % i] = r["seconds"]
+        out["rho_band"] = r["rho_band"]
+        save("g14_config4_pairs", out)
+
+
+def g15(pyfvvdp):
+    """colour space BT.2020 on RGB arrays (video_source.py:204-206 with color_spaces.json:19, weights summing to 1.134): uint8
+    and float RGB video, and a uint16 image, through the reference with color_space='BT.2020'."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    out = {}
+    H, W, N = 135, 240, 8
+    test, ref = synth_video_pair(N, H, W)
+    for tag, (t, r) in (("u8", (test, ref)), ("f32", (test.float() / 255, ref.float() / 255))):
+        fv = pyfvvdp.fvvdp(display_name="standard_4k", heatmap=None, device=torch.device("cpu"), color_space="BT.2020", quiet=True)
+        cap = Capture(fv, frames=(0, N - 1), keep_maps=True)
+        with torch.no_grad():
+            q, stats = fv.predict(t, r, dim_order="BCFHW", frames_per_second=30)
+        o = {}
+        cap.pack(o)
+        out[tag + "_jod"] = np.float32(q.item())
+        out[tag + "_Q_per_ch"] = stats["Q_per_ch"]
+        for k in o:
+            if k.startswith("R_f"):
+                out[tag + "_" + k] = o[k]
+        print("g15", tag, "JOD", q.item(), flush=True)
+    fv = pyfvvdp.fvvdp(display_name="standard_hdr_pq", heatmap=None, device=torch.device("cpu"), color_space="BT.2020", quiet=True)
+    t16 = (test[0, :, 0].permute(1, 2, 0).numpy().astype(np.uint16) * 257)
+    r16 = (ref[0, :, 0].permute(1, 2, 0).numpy().astype(np.uint16) * 257)
+    with torch.no_grad():
+        q, stats = fv.predict(t16, r16, dim_order="HWC")
+    out["img16_pq_jod"] = np.float32(q.item())
+    out["img16_pq_Q_per_ch"] = stats["Q_per_ch"]
+    print("g15 img16 pq JOD", q.item(), flush=True)
+    out["H"], out["W"], out["N"] = np.int64(H), np.int64(W), np.int64(N)
+    save("g15_bt2020", out)
+
+
 def main():
     which = sys.argv[1:] or ["g0", "g1", "g2", "g5"]
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
@@ -601,6 +655,10 @@ def main():
             g12(pyfvvdp)
         elif w == "g13":
             g13(pyfvvdp)
+        elif w == "g14":
+            g14(pyfvvdp)
+        elif w == "g15":
+            g15(pyfvvdp)
         else:
             raise SystemExit("unknown case " + w)
         print(w, "done in %.1f s" % (time.time() - t0), flush=True)
