@@ -87,7 +87,15 @@ __device__ __forceinline__ v2f dpp_expand2_taps(v2f t, v2f e, float fl, float fr
 #ifndef BAND2_LB
 #define BAND2_LB 3
 #endif
-template <int P>
+// INRANGE: the host has PROVEN from the display model, the RGB->Y weights and the temporal taps (luminance_range,
+// fvvdp_hip.hip) that on these levels  (1) expand(ref sustained) >= lbkg_min, so L_bkg = max(., 0.1) is the identity
+// (fvvdp_lpyr_dec.py:265),  (2) g - e < contrast_max * L_bkg for every plane, so the upper clamp of the contrast never binds
+// (:266),  (3) L_bkg lies strictly inside the Y axis of the CSF table, so neither the clamp of the query (fvvdp.py:530) nor the
+// clamp of the interval index binds.  The four clamps (7 VALU instructions of ~77 per band pixel, all of them min/max/med3 at
+// 3.2-3.8 cycles on a saturated SIMD -- the kernel's arithmetic is as long as its data flow) are then dropped: same bits.
+// Standard-dynamic-range displays qualify (standard_4k: luminances in [0.598, 200], clamp at >= 598 against a range of 253);
+// HDR displays with a black level under 0.1 cd/m^2 and sources without a display model do not and take INRANGE = false.
+template <int P, bool INRANGE = false>
 __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) {
     constexpr int HP = P / 2;
     __shared__ float4 s_csf[2][FVVDP_LUT_N];
@@ -208,18 +216,19 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         (void)band;
         return;
 #endif
-        const float lb = fmaxf(e.h[0].y, a.lbkg_min);
+        const float lb = INRANGE ? e.h[0].y : fmaxf(e.h[0].y, a.lbkg_min);
         const float dcap = a.cmax * lb;
         v2f d[HP];
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
             // component-wise: the expanded level leaves the DPP blocks in single registers (no pair to subtract from)
-            d[k] = v2f{fminf(g.h[k].x - e.h[k].x, dcap), fminf(g.h[k].y - e.h[k].y, dcap)};   // upper clamp only (fvvdp_lpyr_dec.py:266)
+            if constexpr (INRANGE) d[k] = v2f{g.h[k].x - e.h[k].x, g.h[k].y - e.h[k].y};
+            else d[k] = v2f{fminf(g.h[k].x - e.h[k].x, dcap), fminf(g.h[k].y - e.h[k].y, dcap)};   // upper clamp only (fvvdp_lpyr_dec.py:266)
         }
         const float llb = fast_log2(lb);
-        const float yq = __builtin_amdgcn_fmed3f(llb, a.ly_lo, a.ly_hi);
+        const float yq = INRANGE ? llb : __builtin_amdgcn_fmed3f(llb, a.ly_lo, a.ly_hi);
         const float t = fmaf(yq, a.y_inv_step, y_off);                       // (yq - y_first) * y_inv_step
-        const float fi = __builtin_amdgcn_fmed3f(floorf(t), 0.0f, (float)(FVVDP_LUT_N - 2));
+        const float fi = INRANGE ? floorf(t) : __builtin_amdgcn_fmed3f(floorf(t), 0.0f, (float)(FVVDP_LUT_N - 2));
         const float4 r = s_csf[band][(int)fi];
         const float f = t - fi;
         const float slog0 = fmaf(f, r.z, r.x), slog1 = fmaf(f, r.w, r.y);

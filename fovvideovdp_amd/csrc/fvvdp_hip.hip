@@ -64,6 +64,12 @@ struct fvvdp_ctx {
     double rho_band[FVVDP_MAX_BANDS + 1]{};
     int lw[FVVDP_MAX_BANDS + 1]{}, lh[FVVDP_MAX_BANDS + 1]{};
     float* level[FVVDP_MAX_BANDS + 1]{};
+    // what is known about the values in level 0 (luminance_range): sustained planes in [lum_lo, lum_hi], no plane's values
+    // further apart than lum_width; lum_known = false after fvvdp_load_channels_planar or a source without a display model
+    bool lum_known = false;
+    int lum_state = 0;            // 0 nothing written yet, 1 range known, 2 unknown (sticky)
+    int lum_hold = 0;             // > 0: an outer call has set the range, inner calls leave it alone
+    float lum_lo = 0.0f, lum_hi = 0.0f, lum_width = 0.0f;
     float* partial = nullptr;
     long long partial_off[FVVDP_MAX_BANDS]{};
     int max_blk[FVVDP_MAX_BANDS]{};
@@ -342,8 +348,8 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
         if (e != hipSuccess || per_cu < 1) per_cu = 16;
         c->wave_capacity = (long long)per_cu * cus;
         int per_cu2 = 16;
-        e = (planes == 4) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, band2_kernel<4>, 64, 0)
-                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, band2_kernel<2>, 64, 0);
+        e = (planes == 4) ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, band2_kernel<4, false>, 64, 0)
+                          : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu2, band2_kernel<2, false>, 64, 0);
         if (e != hipSuccess || per_cu2 < 1) per_cu2 = 16;
         c->wave_capacity2 = (long long)per_cu2 * cus;
     }
@@ -469,6 +475,75 @@ static int grow_lum_buf(fvvdp_ctx* c, size_t need_floats, int fl, hipStream_t st
     return FVVDP_OK;
 }
 
+// Range of the values the temporal kernels write into level 0, from the display model (every closed-form model clamps its
+// output, eotf_one in temporal_kernels.hpp; a code-value table carries the range of its entries in L_min / L_max), the RGB->Y
+// weights and the filter taps: a filter output lies in [s+ lo + s- hi, s+ hi + s- lo] with s+ / s- the sums of its positive /
+// negative taps.  The pyramid kernels use it to drop clamps that provably never bind (band2_kernel<P, true>).
+// The range of a context only ever WIDENS (slots of level 0 filled by different calls may be evaluated together), and one
+// call of unknown range makes it unknown for good.
+static void luminance_unknown(fvvdp_ctx* c) {
+    c->lum_state = 2;
+}
+static void luminance_range(fvvdp_ctx* c, const fvvdp_eotf* e, int C, const float* h_rgb2y, const float* h_taps, int fl) {
+    if (c->lum_hold || c->lum_state == 2) return;            // (inner pass of the two-pass temporal path: range set by the outer call)
+    luminance_unknown(c);                                    // unless everything below works out
+    const int was = c->lum_known ? 1 : 0;
+    float lo = 0.0f, hi = 0.0f;
+    switch (e->kind) {
+        case FVVDP_EOTF_SRGB: case FVVDP_EOTF_GAMMA: lo = e->Y_black; hi = e->Y_peak; break;
+        case FVVDP_EOTF_PQ: case FVVDP_EOTF_LINEAR: lo = 0.005f + e->Y_black; hi = e->Y_peak + e->Y_black; break;
+        case FVVDP_EOTF_ABSOLUTE: case FVVDP_EOTF_LUT: lo = e->L_min; hi = e->L_max; break;
+        default: return;                                     // FVVDP_EOTF_NONE: the caller's luminance, unknown
+    }
+    if (!(hi > lo) || !(lo >= 0.0f) || !std::isfinite(hi)) return;
+    if (C == 3) {
+        double sw = 0.0;
+        for (int k = 0; k < 3; ++k) {
+            if (!(h_rgb2y[k] >= 0.0f)) return;
+            sw += h_rgb2y[k];
+        }
+        lo = (float)(lo * sw);
+        hi = (float)(hi * sw);
+    }
+    double width = 0.0, lo0 = lo, hi0 = hi;
+    const int n_ch = c->P / 2;
+    for (int ch = 0; ch < n_ch; ++ch) {
+        double sp = 0.0, sn = 0.0;
+        for (int k = 0; k < fl; ++k) {
+            const double t = h_taps[ch * fl + k];
+            if (t > 0) sp += t; else sn += t;
+        }
+        if (c->P == 2) { sp = 1.0; sn = 0.0; }               // still images: the frame itself
+        const double mn = sp * lo + sn * hi, mx = sp * hi + sn * lo;
+        if (ch == 0) { lo0 = mn; hi0 = mx; }
+        if (mx - mn > width) width = mx - mn;
+    }
+    // 1e-3 of slack for the rounding of the table products, the fast log2 / exp2 of the closed-form models and the filters
+    const float nlo = (float)(lo0 * (1.0 - 1e-3)), nhi = (float)(hi0 * (1.0 + 1e-3)), nw = (float)(width * (1.0 + 1e-3));
+    if (!(std::isfinite(nhi) && nlo > 0.0f)) return;
+    c->lum_lo = was ? fminf(c->lum_lo, nlo) : nlo;
+    c->lum_hi = was ? fmaxf(c->lum_hi, nhi) : nhi;
+    c->lum_width = was ? fmaxf(c->lum_width, nw) : nw;
+    c->lum_known = true;
+    c->lum_state = 1;
+}
+
+// May the pyramid pass over levels [b, b + n_levels] drop its clamps (band2_kernel INRANGE)?  Every reduce step on the way
+// must be a convex combination (the reference's right-edge fix-up is not when the row and column parities of a level
+// differ, fvvdp_lpyr_dec.py:198-205: weights summing to 1.25 or 0.75), so that every level and every expanded level stays
+// inside the range of level 0.
+static bool clamps_never_bind(const fvvdp_ctx* c, int b, int n_levels) {
+    if (!c->lum_known || c->lum_state != 1) return false;
+    static const bool off = [] { const char* e = getenv("FVVDP_BAND_INRANGE"); return e && e[0] == '0'; }();   // A/B runs, tests
+    if (off) return false;
+    for (int i = 0; i < b + n_levels; ++i)
+        if ((c->lw[i] & 1) != (c->lh[i] & 1)) return false;
+    const float lo = c->lum_lo, hi = c->lum_hi;
+    return lo >= c->prm.lbkg_min &&                                   // (1) L_bkg = max(., lbkg_min) is the identity
+           c->prm.contrast_max * lo > c->lum_width &&                 // (2) contrast <= contrast_max never binds
+           lo >= 2.0f * c->y_lo && hi <= 0.5f * c->y_hi;             // (3) well inside the Y axis of the CSF table
+}
+
 // h_frame_idx1: per-stream frame indices of the reference stream, or nullptr = the same as h_frame_idx
 static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* d_ref, int dtype, int C,
                                   size_t chan_stride, size_t frame_stride, const fvvdp_eotf* eotf,
@@ -485,6 +560,7 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
     if (eotf->kind != FVVDP_EOTF_LUT && dtype == FVVDP_U8) return fail(FVVDP_EINVAL, "uint8 sources need FVVDP_EOTF_LUT (uint16: table or closed form)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int HW = c->W * c->H;
+    luminance_range(c, eotf, C, h_rgb2y, h_taps, fl);
     Timed tm(c, 0, st);
     // register-ring kernels: up to 32 taps for every sample type, up to 64 taps (129-256 fps) for the cases of k1_ring64_ok()
     // (uint8; 16-bit / float RGB behind an sRGB or PQ display; float luminance frames); the 1-pixel-per-lane ring needs no alignment.  The 64-slot ring is not instantiated
@@ -580,9 +656,11 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
         HIP_TRY(hipGetLastError());
         const bool timing = c->timing;
         c->timing = false;                  // the events of this call (both passes) belong to the outer timer
+        c->lum_hold += 1;                   // ... and so does the luminance range (the inner pass sees plain luminance frames)
         const int rc2 = temporal_channels_core(c, c->lum_buf, c->lum_buf + (size_t)nu * HW, FVVDP_F32, 1, 0, (size_t)HW, &none, nullptr,
                                                pos.data(), nullptr, h_taps, fl, n_out, slot0, d_oob_flag, stream);
         c->timing = timing;
+        c->lum_hold -= 1;
         return rc2;
     } else {
         // images, more than 64 taps and frame sizes without 4-sample alignment: one thread per pixel and output frame
@@ -688,6 +766,7 @@ extern "C" int fvvdp_temporal_channels_yuv(fvvdp_ctx* c, const void* d_test, con
     if (n_out < 1 || slot0 < 0 || slot0 + n_out > c->max_frames) return fail(FVVDP_EINVAL, "slots out of range");
     if (eotf->kind == FVVDP_EOTF_LUT) return fail(FVVDP_EINVAL, "YUV sources need a closed-form display model (RGB is fractional after the matrix)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    luminance_range(c, eotf, 3, h_rgb2y, h_taps, fl);        // (RGB is clamped to [0,1] before the display model)
     Timed tm(c, 0, st);
     if (fl > 32) {
         // 33..64 taps (129-256 fps): every source frame of the window -> fp32 luminance once, then the 64-slot ring on the
@@ -733,9 +812,11 @@ extern "C" int fvvdp_temporal_channels_yuv(fvvdp_ctx* c, const void* d_test, con
         none.kind = FVVDP_EOTF_NONE;
         const bool timing = c->timing;
         c->timing = false;
+        c->lum_hold += 1;
         const int rc2 = temporal_channels_core(c, c->lum_buf, c->lum_buf + (size_t)nu * HW, FVVDP_F32, 1, 0, (size_t)HW, &none, nullptr,
                                                pos.data(), nullptr, h_taps, fl, n_out, slot0, d_oob_flag, stream);
         c->timing = timing;
+        c->lum_hold -= 1;
         return rc2;
     }
     const int FL = fl <= 8 ? 8 : (fl <= 16 ? 16 : 32);
@@ -790,6 +871,7 @@ extern "C" int fvvdp_load_channels_planar(fvvdp_ctx* c, const float* d_R, int n,
     const int HW = c->W * c->H;
     dim3 grid((HW + 255) / 256, n), block(256);
     float* out = c->level[0] + (size_t)slot0 * HW * c->P;
+    luminance_unknown(c);                            // the caller's own temporal channels
     if (c->P == 4) hipLaunchKernelGGL((interleave_kernel<4>), grid, block, 0, st, d_R, out, HW, 1);
     else hipLaunchKernelGGL((interleave_kernel<2>), grid, block, 0, st, d_R, out, HW, 1);
     HIP_TRY(hipGetLastError());
@@ -1090,8 +1172,17 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
             if (nblk > c->max_blk[b] || nblk > c->max_blk[b + 1]) return fail(FVVDP_ESTATE, "internal: partial buffer too small");
             {
                 Timed tm(c, 1 + b, st);
-                if (c->P == 4) hipLaunchKernelGGL((band2_kernel<4>), dim3(nblk * n), dim3(64), 0, st, a);
-                else hipLaunchKernelGGL((band2_kernel<2>), dim3(nblk * n), dim3(64), 0, st, a);
+                const bool inrange = clamps_never_bind(c, b, 2);
+                static const bool say = getenv("FVVDP_DEBUG_VARIANT") != nullptr;       // tests: which variant was launched
+                if (say) fprintf(stderr, "fvvdp: levels %d+%d: band2_kernel<%d, %s>, luminance range %s [%g, %g], widest plane range %g\n",
+                                 b, b + 1, c->P, inrange ? "true" : "false", c->lum_state == 1 ? "known" : "unknown", c->lum_lo, c->lum_hi, c->lum_width);
+                if (c->P == 4) {
+                    if (inrange) hipLaunchKernelGGL((band2_kernel<4, true>), dim3(nblk * n), dim3(64), 0, st, a);
+                    else hipLaunchKernelGGL((band2_kernel<4, false>), dim3(nblk * n), dim3(64), 0, st, a);
+                } else {
+                    if (inrange) hipLaunchKernelGGL((band2_kernel<2, true>), dim3(nblk * n), dim3(64), 0, st, a);
+                    else hipLaunchKernelGGL((band2_kernel<2, false>), dim3(nblk * n), dim3(64), 0, st, a);
+                }
             }
             for (int bb = b; bb <= b + 1; ++bb) {
                 fa.nblk[bb] = nblk;

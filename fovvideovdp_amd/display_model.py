@@ -295,10 +295,23 @@ class code_value_tables:
     def __init__(self):
         self._stock = {}        # (state tuple, nbits) -> device tensor
         self._user = {}         # nbits -> (host table, device tensor)
+        self._range = {}        # data_ptr of a device table -> (smallest, largest entry), from the host copy
 
     def clear(self):
         self._stock.clear()
         self._user.clear()
+        self._range.clear()
+
+    def table_range(self, table):
+        """(smallest, largest) luminance in a table returned by get() -- (0, 0) if unknown or not finite."""
+        return self._range.get(table.data_ptr(), (0.0, 0.0))
+
+    def _note_range(self, host, dev):
+        lo, hi = float(host.min()), float(host.max())
+        if len(self._range) > 4 * self.MAX_ENTRIES:
+            self._range.clear()
+        self._range[dev.data_ptr()] = (lo, hi) if (math.isfinite(lo) and math.isfinite(hi) and hi > lo >= 0.0) else (0.0, 0.0)
+        return dev
 
     @staticmethod
     def _tabulate(photometry, nbits):
@@ -313,12 +326,13 @@ class code_value_tables:
             if key not in self._stock:
                 if len(self._stock) >= self.MAX_ENTRIES:
                     self._stock.clear()
-                self._stock[key] = self._tabulate(photometry, nbits).to(device)
+                host = self._tabulate(photometry, nbits)
+                self._stock[key] = self._note_range(host, host.to(device))
             return self._stock[key]
         host = self._tabulate(photometry, nbits)
         key = (nbits, str(device))
         hit = self._user.get(key)
         if hit is None or not torch.equal(hit[0], host):
-            hit = (host, host.to(device))
+            hit = (host, self._note_range(host, host.to(device)))
             self._user[key] = hit
         return hit[1]

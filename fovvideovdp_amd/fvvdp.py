@@ -750,6 +750,7 @@ class fvvdp:
                 if desc is None:
                     lut = self._code_lut(vs.dm_photometry, nbits)
                     e.kind, e.d_lut = nat.EOTF_LUT, lut.data_ptr()
+                    e.L_min, e.L_max = self._lut_dev.table_range(lut)      # lets the pyramid pass drop clamps that cannot bind
                 else:
                     e.kind = desc[0]
                     e.Y_peak = desc[1].get("Y_peak", 0.0)

@@ -79,7 +79,9 @@ typedef struct fvvdp_eotf {
     float Y_peak;
     float Y_black;
     float gamma;
-    float L_min, L_max;      /* FVVDP_EOTF_ABSOLUTE only */
+    float L_min, L_max;      /* FVVDP_EOTF_ABSOLUTE: the clamp.  FVVDP_EOTF_LUT (optional): smallest / largest entry of the
+                              * table; with it the library can prove that clamps of the pyramid pass never bind on this
+                              * content and drop them (same results); 0, 0 = not stated */
     const float* d_lut;      /* FVVDP_EOTF_LUT: 256 (U8) or 65536 (U16) luminances per code value */
 } fvvdp_eotf;
 

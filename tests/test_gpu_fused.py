@@ -4,6 +4,8 @@ By default the library picks band2_kernel only for large levels (>= 1.5 Mpixel);
 its border logic is valid, =0 disables it, FVVDP_BAND2_KR sets the chunk height (level-C rows), so that strip seams,
 chunk seams and all row/column parities of three consecutive levels are exercised at small sizes.  Both kernels
 evaluate the same per-pixel expressions; only the order in which the per-wave partial sums are added differs."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -190,3 +192,65 @@ def test_tail_launch_is_opt_in(monkeypatch):
         nat.check(nat.lib().fvvdp_ctx_timing_read(m._ctx.handle, ms, cnt, 18, 1))
         launches = [cnt[i] for i in range(1, nb + 2)]              # levels 0 .. nb-1, finalize
         assert nb == 6 and launches == want, (env, launches)
+
+
+def test_clamp_free_variant_is_taken_only_where_proven_and_changes_nothing(tmp_path):
+    """band2_kernel<P, true> drops the four clamps of the per-pixel tail (L_bkg >= 0.1, contrast <= 1000, the two clamps of the
+    CSF table query) when the library has PROVEN from the display model, the RGB->Y weights and the temporal taps that they never
+    bind (luminance_range / clamps_never_bind in fvvdp_hip.hip).  Standard-dynamic-range displays qualify; an HDR display with a
+    black level below 0.1 cd/m^2 does not, nor does a source that hands over its own luminance frames.  Where it is taken the
+    results are bit-identical to FVVDP_BAND_INRANGE=0 (the variable is read once per process)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import fovvideovdp_amd as fv\n"
+        "from fovvideovdp_amd.synth import synth_video_pair\n"
+        "t, r = synth_video_pair(12, 1080, 1920, device='cuda')\n"
+        "out = []\n"
+        "def run(tag, m, *a, **k):\n"
+        "    sys.stderr.write('CASE %%s\\n' %% tag); sys.stderr.flush()\n"
+        "    q, st = m.predict(*a, **k)\n"
+        "    out.append(np.concatenate([st['Q_per_ch'].reshape(-1), [float(q)]]))\n"
+        "run('sdr_u8', fv.fvvdp(display_name='standard_fhd'), t, r, frames_per_second=30)\n"
+        "run('sdr_f32', fv.fvvdp(display_name='standard_fhd'), t.float() / 255, r.float() / 255, frames_per_second=30)\n"
+        "run('sdr_bt2020', fv.fvvdp(display_name='standard_fhd', color_space='BT.2020'), t, r, frames_per_second=30)\n"
+        "run('sdr_img', fv.fvvdp(display_name='standard_4k'), t[0, :, 0].permute(1, 2, 0), r[0, :, 0].permute(1, 2, 0), dim_order='HWC')\n"
+        "run('hdr_pq', fv.fvvdp(display_name='standard_hdr_pq'), t, r, frames_per_second=30)\n"
+        "run('sdr_120fps', fv.fvvdp(display_name='standard_fhd'), t, r, frames_per_second=120)\n"
+        "mm = fv.fvvdp(display_name='standard_fhd')\n"
+        "inner = fv.fvvdp_video_source_array(t, r, 30, display_photometry=mm.display_photometry)\n"
+        "class Src(fv.fvvdp_video_source):\n"
+        "    def get_video_size(self): return inner.get_video_size()\n"
+        "    def get_frames_per_second(self): return 30\n"
+        "    def get_test_frame(self, f, device): return inner.get_test_frame(f, device)\n"
+        "    def get_reference_frame(self, f, device): return inner.get_reference_frame(f, device)\n"
+        "sys.stderr.write('CASE user_src\\n'); sys.stderr.flush()\n"
+        "q, st = mm.predict_video_source(Src())\n"
+        "out.append(np.concatenate([st['Q_per_ch'].reshape(-1), [float(q)]]))\n"
+        "np.save(sys.argv[1], np.stack([np.pad(o, (0, 200 - o.size)) for o in out]))\n" % root)
+    res, logs = {}, {}
+    for mode in ("1", "0"):
+        f = str(tmp_path / ("v%s.npy" % mode))
+        p = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, FVVDP_BAND_INRANGE=mode, FVVDP_DEBUG_VARIANT="1"),
+                           capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-1500:]
+        res[mode], logs[mode] = np.load(f), p.stderr
+    assert np.array_equal(res["1"], res["0"])                     # dropping clamps that cannot bind changes no bit
+    assert "true>" not in logs["0"]
+
+    def variants(log):
+        out, tag = {}, None
+        for line in log.splitlines():
+            if line.startswith("CASE "):
+                tag = line.split()[1]
+            elif "band2_kernel<" in line and tag:
+                out.setdefault(tag, set()).add("true>" in line)
+        return out
+    v = variants(logs["1"])
+    assert v["sdr_u8"] == {True} and v["sdr_f32"] == {True} and v["sdr_bt2020"] == {True} and v["sdr_img"] == {True}
+    assert v["sdr_120fps"] == {True}          # 30 taps: the transient plane's range grows with the sum of |taps|, still far from the clamp
+    assert v["hdr_pq"] == {False}             # black level 0.0174 cd/m^2 < 0.1: max(L_bkg, 0.1) binds, contrast can reach 1000
+    assert v["user_src"] == {False}           # luminance frames from the source's own get_*_frame: range unknown to the library
