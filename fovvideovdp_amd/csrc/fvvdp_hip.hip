@@ -1272,7 +1272,9 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
         a.n_items = nblk * n;
         {   // LUT slice in LDS if it fits next to the row table (64 KB of dynamic LDS without opting in to more)
             const size_t lut_b = (size_t)FOV_PLANE * c->sub_rw[b] * sizeof(float4);       // 18.6 KB per rho interval
-            a.lut_lds = (fov && lut_b <= 56 * 1024 && lut_b + (size_t)c->lh[b] * sizeof(float) <= 64 * 1024) ? 1 : 0;
+            // the kernel's static tables (s_csf 512 B + s_ax 768 B) share the 64 KB with the dynamic part
+            const size_t lds_static = sizeof(float4) * FVVDP_LUT_N + sizeof(float2) * 3 * FVVDP_LUT_N;
+            a.lut_lds = (fov && lut_b <= 56 * 1024 && lut_b + (size_t)c->lh[b] * sizeof(float) + lds_static <= 64 * 1024) ? 1 : 0;
         }
         if (in_tail) {
             ta->band[b - tail_from] = a;

@@ -119,7 +119,7 @@ class fvvdp:
         # forward-only, so the flag is accepted and ignored; asking for gradients is what is refused (predict*)
         if device is None:
             device = torch.device('cuda:0') if (torch.cuda.is_available() and torch.cuda.device_count() > 0) else torch.device('cpu')
-        self.device = torch.device(device)
+        self.device = self._indexed(torch.device(device))
         self.batch_frames = batch_frames
         # Stage overlap (extension, OFF by default): with `pipeline` = k >= 2 a clip is cut into k batches whose temporal kernel
         # runs on one internal stream while the pyramid pass of the previous batch runs on another, the two halves of the level-0
@@ -146,8 +146,16 @@ class fvvdp:
         self.csf_lut = [utils.load_csf_lut(om, self.csf_sigma, self.k_cm, self.csf_cache_dirs) for om in self.omega]
 
     # ---- configuration ------------------------------------------------------------------------------------
+    @staticmethod
+    def _indexed(device):
+        """'cuda' -> 'cuda:<current index>': tensors report an indexed device, comparisons against a bare 'cuda' are never equal
+        (resident arrays were counted as uploads and copied device-to-device)."""
+        if device.type == "cuda" and device.index is None and torch.cuda.is_available():
+            return torch.device("cuda", torch.cuda.current_device())
+        return device
+
     def update_device(self, device):
-        self.device = torch.device(device)
+        self.device = self._indexed(torch.device(device))
         if self._ctx is not None:
             self._ctx.close()
         self._ctx = None
@@ -285,7 +293,7 @@ class fvvdp:
         # the fl-1 frames of temporal halo before them) -- host-resident sources upload these and nothing else
         self.last_h2d_bytes = 0
         feeder = self._make_feeder(vid_source, width, height, np.unique(widx[f0:f1 + fl - 1]))
-        batch = self._batch_size(width, height, planes, n_out)
+        batch = self._batch_size(width, height, planes, n_out, fl)
         schedule = None
         # stage overlap: sources the kernels read where they lie (arrays, raw YUV frames), plain evaluation, stock geometry
         n_pipe = self.pipeline if (self.batch_frames is None and not self.do_heatmap and not is_image and
@@ -607,12 +615,20 @@ class fvvdp:
         self._ctx = ctx
         return ctx
 
-    def _batch_size(self, W, H, planes, n_out):
+    def _batch_size(self, W, H, planes, n_out, fl=1):
+        cap = 128
+        if fl > 32:
+            # 33..64 taps: the two-pass temporal path converts the batch's fl-1+batch source frames to fp32 luminance first
+            # (2 streams x 4 B per pixel, context-owned) and addresses them through a 320-entry index table
+            cap = max(1, min(cap, 320 - (fl - 1)))
         if self.batch_frames is not None:
-            return max(1, min(int(self.batch_frames), n_out))
+            return max(1, min(int(self.batch_frames), n_out, cap if fl > 32 else n_out))
         per_frame = W * H * planes * 4 * 1.34          # all Gaussian levels of one frame
         budget = 24e9                                  # resident pyramid scratch (of 288 GB HBM3E)
-        return max(1, min(n_out, 128, int(budget // per_frame)))
+        if fl > 32:
+            budget -= (fl - 1) * W * H * 8.0           # luminance frames of the temporal window
+            per_frame += W * H * 8.0                   # ... and of every frame of the batch
+        return max(1, min(n_out, cap, int(max(budget, per_frame) // per_frame)))
 
     def _set_view_maps(self, ctx, n_bands, width, height):
         """User geometry model: evaluate its pix2view_direction / get_resolution_magnification once per band on the
@@ -758,7 +774,8 @@ class fvvdp:
                     e.gamma = desc[1].get("gamma", 1.0)
                     e.L_min = desc[1].get("L_min", 0.0)
                     e.L_max = desc[1].get("L_max", 0.0)
-                    if e.kind == nat.EOTF_ABSOLUTE and dtype == nat.FVVDP_F32 and float(torch.maximum(test_d.max(), ref_d.max())) < 1:
+                    # (on the source arrays, not the uploaded subset: a frame-sharded call warns like the unsharded one)
+                    if e.kind == nat.EOTF_ABSOLUTE and dtype == nat.FVVDP_F32 and float(torch.maximum(test.max(), ref.max())) < 1:
                         logging.warning('Pixel values are very low. Perhaps images are not scaled in the absolute units of cd/m^2.')
                 w = np.asarray(vs.color_to_luminance, dtype=np.float32)
 
