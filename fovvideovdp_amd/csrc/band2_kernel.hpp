@@ -160,16 +160,26 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
     float* Gc = a.Gc + (size_t)frame * hc * wc * P;
     const __amdgpu_buffer_rsrc_t Gc_rsrc = level_rsrc(Gc, (unsigned int)(hc * wc * P) * 4u);
 
+    // Level-A rows are read through a buffer resource covering the frame: the row's byte offset is wave-uniform (a scalar
+    // register, computed by the scalar unit), the lane's column offset a loop-invariant vector register -- no vector
+    // instruction goes into addressing (flat loads cost one 64-bit v_lshl_add_u64 each: 16 per loop iteration of a kernel
+    // whose arithmetic is as long as its data flow).
+#if defined(BAND2_ABLATE_MEM)      // profiling ablation: every wave re-reads 8 rows of frame 0 (L2 hits), nothing is stored
+    const __amdgpu_buffer_rsrc_t Ga_rsrc = level_rsrc(const_cast<float*>(a.Ga), (unsigned int)(h * w * P) * 4u);
+#else
+    const __amdgpu_buffer_rsrc_t Ga_rsrc = level_rsrc(const_cast<float*>(Ga), (unsigned int)(h * w * P) * 4u);   // <= 133 MB per frame
+#endif
+    const unsigned int col0_b = (unsigned int)xc0 * (P * 4u), col1_b = (unsigned int)xc1 * (P * 4u);
+    const unsigned int row_b = (unsigned int)w * (P * 4u);
     auto load_row = [&](int r, Px<P>& p0, Px<P>& p1) {
         int rr = r < 0 ? -1 - r : (r >= h ? 2 * h - 1 - r : r);   // symmetric padding (fvvdp_lpyr_dec.py:190-195)
         rr = min(max(rr, 0), h - 1);
-#if defined(BAND2_ABLATE_MEM)      // profiling ablation: every wave re-reads 8 rows of frame 0 (L2 hits), nothing is stored
-        const float* row = a.Ga + (size_t)(rr & 7) * w * P;
-#else
-        const float* row = Ga + (size_t)rr * w * P;
+#if defined(BAND2_ABLATE_MEM)
+        rr &= 7;
 #endif
-        p0 = ld_px<P>(row + (size_t)xc0 * P);
-        p1 = ld_px<P>(row + (size_t)xc1 * P);
+        const unsigned int so = (unsigned int)rr * row_b;
+        p0 = ld_px_buf<P>(Ga_rsrc, col0_b, so);
+        p1 = ld_px_buf<P>(Ga_rsrc, col1_b, so);
     };
 
     // Level-A rows live in an 8-slot register ring: row r of the chunk sits in slot r & 7, a step's window is slots
@@ -228,9 +238,16 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         const float llb = fast_log2(lb);
         const float yq = INRANGE ? llb : __builtin_amdgcn_fmed3f(llb, a.ly_lo, a.ly_hi);
         const float t = fmaf(yq, a.y_inv_step, y_off);                       // (yq - y_first) * y_inv_step
-        const float fi = INRANGE ? floorf(t) : __builtin_amdgcn_fmed3f(floorf(t), 0.0f, (float)(FVVDP_LUT_N - 2));
-        const float4 r = s_csf[band][(int)fi];
-        const float f = t - fi;
+        float4 r;
+        float f;
+        if constexpr (INRANGE) {
+            r = s_csf[band][floor_to_int(t)];          // v_cvt_flr_i32_f32; t lies strictly inside (0, 31)
+            f = __builtin_amdgcn_fractf(t);            // t - floor(t), one instruction
+        } else {
+            const float fi = __builtin_amdgcn_fmed3f(floorf(t), 0.0f, (float)(FVVDP_LUT_N - 2));
+            r = s_csf[band][(int)fi];
+            f = t - fi;
+        }
         const float slog0 = fmaf(f, r.z, r.x), slog1 = fmaf(f, r.w, r.y);
         const float vm = valid ? 1.0f : 0.0f;
         const float lcn = lg_bm[band] - llb;

@@ -41,6 +41,25 @@ __device__ __forceinline__ Px<2> ld_px<2>(const float* p) {
     r.h[0] = v2f{t.x, t.y};
     return r;
 }
+// Loads through a buffer resource: voff = the lane's byte offset (vector register), soff = a wave-uniform byte offset (scalar
+// register) -- the address needs no vector arithmetic.
+template <int P>
+__device__ __forceinline__ Px<P> ld_px_buf(__amdgpu_buffer_rsrc_t r, unsigned int voff, unsigned int soff);
+template <>
+__device__ __forceinline__ Px<4> ld_px_buf<4>(__amdgpu_buffer_rsrc_t r, unsigned int voff, unsigned int soff) {
+    const v4f t = __builtin_bit_cast(v4f, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+    Px<4> p;
+    p.h[0] = v2f{t.x, t.y};
+    p.h[1] = v2f{t.z, t.w};
+    return p;
+}
+template <>
+__device__ __forceinline__ Px<2> ld_px_buf<2>(__amdgpu_buffer_rsrc_t r, unsigned int voff, unsigned int soff) {
+    const v2f t = __builtin_bit_cast(v2f, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+    Px<2> p;
+    p.h[0] = t;
+    return p;
+}
 // The coarse level is written once and only read by the next launch: non-temporal stores (measured +2-3 % on the
 // read+write mix of this kernel, tools/microbench/membw.hip).  The store goes through a buffer resource that covers the
 // frame's coarse level: a lane (or a whole wave) that must not write passes an out-of-range offset, which the hardware
@@ -270,16 +289,24 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
     float* Gc = a.Gc + (size_t)frame * hc * wc * P;
     const __amdgpu_buffer_rsrc_t Gc_rsrc = level_rsrc(Gc, (unsigned int)(hc * wc * P) * 4u);     // <= 33 MB per frame
 
+    // rows of the fine level through a buffer resource: scalar row offset + loop-invariant lane offset, no vector address
+    // arithmetic (see ld_px_buf)
+#if defined(BAND_ABLATE_MEM)       // profiling ablation: every wave re-reads 8 rows of frame 0 (L2 hits), nothing is stored
+    const __amdgpu_buffer_rsrc_t Gf_rsrc = level_rsrc(const_cast<float*>(a.Gf), (unsigned int)(h * w * P) * 4u);
+#else
+    const __amdgpu_buffer_rsrc_t Gf_rsrc = level_rsrc(const_cast<float*>(Gf), (unsigned int)(h * w * P) * 4u);    // <= 133 MB per frame
+#endif
+    const unsigned int col0_b = (unsigned int)xc0 * (P * 4u), col1_b = (unsigned int)xc1 * (P * 4u);
+    const unsigned int row_b = (unsigned int)w * (P * 4u);
     auto load_row = [&](int r, Px<P>& p0, Px<P>& p1) {
         int rr = r < 0 ? -1 - r : (r >= h ? 2 * h - 1 - r : r);   // symmetric padding (fvvdp_lpyr_dec.py:190-195)
         rr = min(max(rr, 0), h - 1);
-#if defined(BAND_ABLATE_MEM)       // profiling ablation: every wave re-reads 8 rows of frame 0 (L2 hits), nothing is stored
-        const float* row = a.Gf + (size_t)(rr & 7) * w * P;
-#else
-        const float* row = Gf + (size_t)rr * w * P;
+#if defined(BAND_ABLATE_MEM)
+        rr &= 7;
 #endif
-        p0 = ld_px<P>(row + (size_t)xc0 * P);
-        p1 = ld_px<P>(row + (size_t)xc1 * P);
+        const unsigned int so = (unsigned int)rr * row_b;
+        p0 = ld_px_buf<P>(Gf_rsrc, col0_b, so);
+        p1 = ld_px_buf<P>(Gf_rsrc, col1_b, so);
     };
 
     // The 5-row window of the vertical filter plus the two rows in flight for the next step live in a ring of 8 row slots
