@@ -95,10 +95,20 @@ __device__ __forceinline__ v2f dpp_expand2_taps(v2f t, v2f e, float fl, float fr
 // 3.2-3.8 cycles on a saturated SIMD -- the kernel's arithmetic is as long as its data flow) are then dropped: same bits.
 // Standard-dynamic-range displays qualify (standard_4k: luminances in [0.598, 200], clamp at >= 598 against a range of 253);
 // HDR displays with a black level under 0.1 cd/m^2 and sources without a display model do not and take INRANGE = false.
+// BAND2_LDS_STAGE: the level-A rows travel HBM -> LDS (LDS-DMA, `buffer_load_dwordx4 ... lds`, no destination registers) two
+// steps ahead of their use and LDS -> registers (ds_read_b128) one step ahead, instead of HBM -> registers one step ahead:
+// twice the time for a request to come back with the same register ring (the rows in flight held 16 registers; the kernel
+// has none to spare for a second step of them).  12 KB of LDS per wave: 3 steps x 4 pieces of 1 KB; 12 waves per CU = 144
+// of 160 KB.  Video (P == 4) only: the DMA moves 16 bytes per lane.
+#ifndef BAND2_LDS_STAGE
+#define BAND2_LDS_STAGE 0
+#endif
 template <int P, bool INRANGE = false>
 __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) {
     constexpr int HP = P / 2;
+    constexpr bool STAGE = (BAND2_LDS_STAGE != 0) && P == 4;
     __shared__ float4 s_csf[2][FVVDP_LUT_N];
+    __shared__ float4 s_stage[STAGE ? 3 * 4 * 64 : 1];
     const int lane = threadIdx.x;
     int bid;
     {   // XCD-aware work order (see band_kernel)
@@ -181,6 +191,65 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         p0 = ld_px_buf<P>(Ga_rsrc, col0_b, so);
         p1 = ld_px_buf<P>(Ga_rsrc, col1_b, so);
     };
+
+    // ---- LDS staging of the rows two steps ahead (BAND2_LDS_STAGE) -----------------------------------------------------------
+    // D(c) = rows 2c+5, 2c+6 (what step c fetches for step c+1).  issue: 4 LDS-DMA pieces (row x pixel of the lane's pair), each
+    // 64 lanes x 16 B = 1 KB at a wave-uniform LDS address in M0.  The compiler does not count these loads: the wait is written
+    // here.  At the top of step c the pieces of D(c) (issued at step c-2) must have landed while those of D(c+1) (issued at
+    // step c-1) may be in flight: vmcnt(4) -- loads return in order; stores issued in between can only make the wait stricter.
+    const unsigned int stage_lds = (unsigned int)(size_t)(&s_stage[0]);          // LDS byte offset (low half of the flat address)
+#if defined(BAND2_ABLATE_MEM)
+    const unsigned long long ga_addr = (unsigned long long)(size_t)a.Ga;
+#else
+    const unsigned long long ga_addr = (unsigned long long)(size_t)Ga;
+#endif
+    // the same buffer resource as Ga_rsrc, as four scalar words for the inline assembly (base, stride 0, bytes, raw dword format)
+    [[maybe_unused]] const v4i Ga_words = v4i{(int)(unsigned int)ga_addr, (int)((unsigned int)(ga_addr >> 32) & 0xFFFFu),
+                                              (int)((unsigned int)(h * w * P) * 4u), 0x00020000};
+    [[maybe_unused]] auto stage_issue = [&](int c, unsigned int slot) {
+        if constexpr (STAGE) {
+            auto off = [&](int r) {
+                int rr = r < 0 ? -1 - r : (r >= h ? 2 * h - 1 - r : r);
+                rr = min(max(rr, 0), h - 1);
+#if defined(BAND2_ABLATE_MEM)
+                rr &= 7;
+#endif
+                return (unsigned int)rr * row_b;
+            };
+            const unsigned int so0 = off(2 * c + 5), so1 = off(2 * c + 6);
+            const unsigned int dst = stage_lds + slot * 4096u;
+            unsigned int keep;
+            asm volatile("s_mov_b32 %[keep], m0\n\t"
+                         "s_mov_b32 m0, %[dst]\n\t"
+                         "s_nop 0\n\t"
+                         "buffer_load_dwordx4 %[v0], %[rs], %[s0] offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t"
+                         "s_nop 0\n\t"
+                         "buffer_load_dwordx4 %[v1], %[rs], %[s0] offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t"
+                         "s_nop 0\n\t"
+                         "buffer_load_dwordx4 %[v0], %[rs], %[s1] offen lds\n\t"
+                         "s_add_u32 m0, m0, 0x400\n\t"
+                         "s_nop 0\n\t"
+                         "buffer_load_dwordx4 %[v1], %[rs], %[s1] offen lds\n\t"
+                         "s_mov_b32 m0, %[keep]"
+                         : [keep] "=&s"(keep)
+                         : [v0] "v"(col0_b), [v1] "v"(col1_b), [rs] "s"(Ga_words), [s0] "s"(so0), [s1] "s"(so1), [dst] "s"(dst)
+                         : "memory", "scc");
+        }
+    };
+    [[maybe_unused]] auto stage_read = [&](unsigned int slot, Px<P> (&r0)[2], Px<P> (&r1)[2]) {
+        if constexpr (STAGE) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            const float4* b = s_stage + slot * 256u + (unsigned int)lane;
+            const float4 t0 = b[0], t1 = b[64], t2 = b[128], t3 = b[192];
+            r0[0].h[0] = v2f{t0.x, t0.y}; r0[0].h[1] = v2f{t0.z, t0.w};
+            r0[1].h[0] = v2f{t1.x, t1.y}; r0[1].h[1] = v2f{t1.z, t1.w};
+            r1[0].h[0] = v2f{t2.x, t2.y}; r1[0].h[1] = v2f{t2.z, t2.w};
+            r1[1].h[0] = v2f{t3.x, t3.y}; r1[1].h[1] = v2f{t3.z, t3.w};
+        }
+    };
+    unsigned int stage_q = 0;        // LDS slot of D(c) at the top of step c
 
     // Level-A rows live in an 8-slot register ring: row r of the chunk sits in slot r & 7, a step's window is slots
     // base .. base+4 and the two rows of the next step are fetched into slots base+5, base+6.  The base advances by 2 per
@@ -327,6 +396,10 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
     CH[0] = CH[1] = CH[2] = R[4];
     load_row(4 * ks + 3, S[3][0], S[3][1]);
     load_row(4 * ks + 4, S[4][0], S[4][1]);
+    if constexpr (STAGE) {
+        stage_issue(2 * ks, 0u);
+        stage_issue(2 * ks + 1, 1u);
+    }
 
     // band B for level-B rows g0 (even), g1 (odd) from the level-C history
     auto band_b_rows = [&](const Px<P>& g0, const Px<P>& g1, int row0) {
@@ -353,16 +426,28 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         Px<P> Be, Bo;
         {   // step c = 2k: level-B row 2k+1
             const int c = 2 * k;
-            load_row(2 * c + 5, S[(BA + 5) & 7][0], S[(BA + 5) & 7][1]);
-            load_row(2 * c + 6, S[(BA + 6) & 7][0], S[(BA + 6) & 7][1]);
+            if constexpr (STAGE) {
+                stage_read(stage_q, S[(BA + 5) & 7], S[(BA + 6) & 7]);
+                stage_issue(c + 2, stage_q >= 1u ? stage_q - 1u : 2u);       // slot (q + 2) % 3
+                stage_q = stage_q >= 2u ? 0u : stage_q + 1u;
+            } else {
+                load_row(2 * c + 5, S[(BA + 5) & 7][0], S[(BA + 5) & 7][1]);
+                load_row(2 * c + 6, S[(BA + 6) & 7][0], S[(BA + 6) & 7][1]);
+            }
             Be = coarse_step(basea);
             if (c + 1 >= hb) Be = R[4];                               // B[hb] = B[hb-1]
             if (c >= ca && c < cb) band_a_rows(basea, c, R[3], R[4], Be);
         }
         {   // step c = 2k+1: level-B row 2k+2
             const int c = 2 * k + 1;
-            load_row(2 * c + 5, S[(BB + 5) & 7][0], S[(BB + 5) & 7][1]);
-            load_row(2 * c + 6, S[(BB + 6) & 7][0], S[(BB + 6) & 7][1]);
+            if constexpr (STAGE) {
+                stage_read(stage_q, S[(BB + 5) & 7], S[(BB + 6) & 7]);
+                stage_issue(c + 2, stage_q >= 1u ? stage_q - 1u : 2u);
+                stage_q = stage_q >= 2u ? 0u : stage_q + 1u;
+            } else {
+                load_row(2 * c + 5, S[(BB + 5) & 7][0], S[(BB + 5) & 7][1]);
+                load_row(2 * c + 6, S[(BB + 6) & 7][0], S[(BB + 6) & 7][1]);
+            }
             Bo = coarse_step(baseb);
             if (c + 1 >= hb) Bo = (c + 1 == hb) ? Be : R[3];          // B[hb] = B[hb-1];  B[hb+1] = B[hb-2]
             if (c >= ca && c < cb) band_a_rows(baseb, c, R[4], Be, Bo);
@@ -416,6 +501,7 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         if (row0 >= ca && row0 < cb) band_b_rows(R[2], R[3], row0);
     }
 
+    if constexpr (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA may outlive the workgroup's LDS
     const float a0 = wave_sum(accA[0]), a1 = wave_sum(accA[1]);
     const float b0 = wave_sum(accB[0]), b1 = wave_sum(accB[1]);
     if (lane == 0) {
