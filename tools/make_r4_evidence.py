@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Round 4: turn the logs of the GPU sessions (gpurun_out/r4s*/, written by tools/experiments/r4_session*.sh; one gpurun call =
+one MI355X box) into the tracked evidence files under profiles/.  Every number in those files is copied from a log."""
+import glob, json, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "gpurun_out")
+P = os.path.join(ROOT, "profiles")
+
+
+def lines(sess, pat):
+    rows = []
+    for f in sorted(glob.glob(os.path.join(G, sess, pat))):
+        try:
+            d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+        except Exception:
+            rows.append((os.path.basename(f), None))
+            continue
+        rows.append((os.path.basename(f), d))
+    return rows
+
+
+def table(rows, extra=()):
+    out = ["| run | ms per pair (median step) | K1 us/frame | levels 0+1 us/frame | all levels + finalize us/frame | JOD |" + "".join(" %s |" % e[0] for e in extra),
+           "|---|---|---|---|---|---|" + "---|" * len(extra)]
+    for name, d in rows:
+        if d is None:
+            out.append("| %s | failed | | | | |" % name)
+            continue
+        g = d.get("graded_pass", {})
+        out.append("| %s | %.3f | %.1f | %.2f | %.2f | %s |" % (name.replace(".json", ""), d["ms_per_pair"], g.get("temporal_us_per_frame_median", 0),
+                                                              g["levels_us_per_frame_median"][0], g.get("us_per_frame_all_levels", 0), d["jod"][0]) +
+                   "".join(" %s |" % e[1](d) for e in extra))
+    return "\n".join(out)
+
+
+def rd(path):
+    p = os.path.join(G, path)
+    return open(p).read().rstrip() if os.path.exists(p) else "(not collected)"
+
+
+def write(name, txt):
+    with open(os.path.join(P, name), "w") as f:
+        f.write(txt.rstrip() + "\n")
+    print("wrote profiles/" + name)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+write("r04_level0_chunks.md", """# Round 4: the level-0 scratch mapped from physical chunks (what the "placement modes" of rounds 2-3 were)
+
+Rounds 2 and 3 found the temporal kernel K1 (unpack + display model + luminance + 8-tap FIR -> pyramid level 0; 6 B read, 16 B written
+per pixel and frame) running in a fast (~31 us per 4K frame) or a slow (~37 us) mode that belonged to the physical allocation of the
+level-0 scratch, and an online selection between two `hipMalloc` buffers that did not help (`profiles/r03_k1_placement.md`).  Round 4:
+
+1. The selection was rebuilt on the SUM temporal + pyramid time with warm candidates (VERDICT r3 item 3) and measured on three boxes
+   (sessions 1 and 3 below): on a box with free memory BOTH `hipMalloc` buffers are in the slow mode (K1 37.4-38.1 us in all 12
+   processes of session 3, with or without the selection) -- there is nothing to select.
+2. What decides the mode is whether the buffer is ONE physically contiguous range.  `hipMalloc` of 8 GB on a fresh box returns one;
+   the same virtual range mapped from physical chunks (`hipMemCreate` x n, `hipMemMap`) of 2 ... 128 MB puts K1 in the fast mode
+   every time, and the pyramid kernel that reads the buffer does not change (session 4; 512 MB chunks: half way).
+3. The library now maps every pyramid level of >= 256 MB from 32 MB chunks (`vmm_alloc` in `csrc/fvvdp_hip.hip`;
+   `FVVDP_ALLOC=malloc` goes back); the selection machinery and its C entry point were removed.  Same-box A/B of the bench line
+   (session 5): 4.57 -> 4.25 ms per 4K x 60 pair, bit-identical results (`test_chunk_mapped_scratch_gives_the_same_results_as_hipmalloc`).
+   Creating the 4K x 60 context (about 330 chunks of 32 MB) and touching it for the first time: 20 ms (session 5, last lines).
+
+## Session 3 (one box): the sum-based selection, `b_s1` = on, `b_s0` = off; `q8_*` = 8 pairs queued per step
+
+`tools/experiments/r4_session3.sh`.  K1 / levels: HIP-event medians of the isolated kernels of the same process.
+
+%s
+
+The selection compared 75.5-76.3 (incumbent) with 74.4-75.0 us per frame (candidate) in every process: both buffers in the same mode.
+
+## Session 4 (another box): the scratch through the virtual-memory API, chunk size; `default` = hipMalloc, `contig` = hipDeviceMallocContiguous
+
+`tools/experiments/r4_session4.sh` (the build of that session still took `FVVDP_ALLOC=vmm FVVDP_VMM_CHUNK_MB=<n>` from the environment).
+
+%s
+
+## Session 5 (a third box): the shipped default (32 MB chunks) against `FVVDP_ALLOC=malloc`; 4K x 60, 8 queued pairs, 1080p x 60
+
+`tools/experiments/r4_session5.sh`; the whole GPU test suite ran first in the same call (167 passed).
+
+%s
+
+## Session 9 (a fourth box): the 120-frame context of configs[3] (16 GB of level 0), `tools/gpu_config4.py`, kernel us per frame [K1, levels 0.., finalize]
+
+```
+%s
+```
+""" % (table(lines("r4s3", "*.json")), table(lines("r4s4", "*.json")), table(lines("r4s5", "*.json")), rd("r4s9/fov_chunks.txt")))
+
+# ---------------------------------------------------------------------------------------------------------------------------
+write("r04_stage_overlap.md", """# Round 4: temporal kernel of batch b+1 against the pyramid pass of batch b on two streams (VERDICT r3 item 1b) -- built, measured, off
+
+Built: `fvvdp_bands_forward_at` (C ABI: the pass on level-0 slots [slot0, slot0 + n)), two banks of the level-0 scratch, two internal
+non-blocking streams with events between them (`fvvdp.pipeline`, `_predict_on_device`), `fvvdp.predict_batch` (a queue of pairs whose
+caller's stream joins once, so that pair p+1's temporal kernel is not held behind pair p's last pass).  Parity:
+`tests/test_gpu_state.py::test_stage_overlap_equals_the_sequential_order` (bit-identical to the same batches run one after the other).
+
+Result: **no gain in the product path** -- a single 4K x 60 pair in two halves 4.50-4.68 ms against 4.25-4.28 ms sequential; a queue of
+8 pairs 4.30-4.34 against 4.12-4.38 ms per pair.  Both stages are bound by the same HBM (K1 moves 182.5 MB, the pass 167 MB per frame:
+~350 MB in 67-70 us = 5.0-5.2 TB/s back to back, which IS what this memory system delivers for such mixes); side by side they take as
+long as one after the other.  The sequential order stays the default (`pipeline = 0`).
+
+## The isolated experiment of round 3, repeated with banks (`tools/experiments/gpu_coexec2.py`, one box)
+
+```
+%s
+```
+
+The "gain" of the two-stream rows is measured against the SUM of two separately synchronised timings, each of which carries its own
+launch + synchronisation cost (~50 us); in the product path the sequential order has no such cost between the stages.  Launch order
+matters: the pass first, the temporal kernel joining, is 3-6 %% better than the other way round (the pass keeps its three waves per
+SIMD); the product path enforces that order with an event.
+
+## Session 1 (one box): `b_p<k>_s<probe>_<rep>` = a single pair cut into k batches (p0 = sequential), natural launch order
+
+%s
+
+## Session 2 (another box): launch order, stream priorities, CU masks (`hipExtStreamCreateWithCUMask`: K1 on k of the 32 CUs of every XCD, the pass on the rest / on all)
+
+`*_q4` = 4 pairs queued per step.  `k2first` = the pass is released first; `prio_k1` / `prio_k2` = that stream has the higher priority;
+`cu<k>` = K1 on k CUs per XCD and the pass on the other 32-k; `cu<k>_all` = the pass on all CUs.
+
+%s
+
+K1 needs the whole chip to reach its bandwidth (on 16 of 32 CUs per XCD the pair takes 5.0 ms): a static partition loses more than
+the overlap could win.
+
+## Session 3 (a third box): queue of 8 pairs through `predict_batch` (the caller's stream joins once), `q8_p0` sequential, `q8_p2` / `q8_p3` two / three batches per pair with the pass released first, `q8_p2nat` natural order
+
+%s
+""" % (rd("r4_coexec2.txt"), table(lines("r4s1", "b_*.json")), table(lines("r4s2", "*.json")), table(lines("r4s3", "q8*.json"))))
+
+# ---------------------------------------------------------------------------------------------------------------------------
+write("r04_pyramid_kernel.md", """# Round 4: the two-level pyramid kernel (levels 0+1 of the bench pair) -- clamp-free variant, floors, address arithmetic, LDS staging
+
+## 1. Clamp-free variant `band2_kernel<P, true>` (kept, default where proven)
+
+The per-pixel tail carried four clamps that can never bind on standard-dynamic-range content: `L_bkg = max(., 0.1)`
+(`fvvdp_lpyr_dec.py:265`), `contrast <= 1000` (`:266`, one `v_min` per plane), the clamp of the CSF query to the table's Y axis
+(`fvvdp.py:530`) and the clamp of the interval index.  The library PROVES it per call from the display model's output range, the
+RGB->Y weights and the filter taps (`luminance_range` / `clamps_never_bind` in `csrc/fvvdp_hip.hip`; standard_4k: luminances in
+[0.598, 200], the contrast clamp would need a difference of 598 where no plane spans more than 253) and launches the variant without
+them: loop body of two stages (20 band pixels per lane, `tools/isa_loop_hist.py`) **1535 -> 1291 VALU instructions** (v_min 160 -> 80,
+v_med3 40 -> 0, v_max 46 -> 6, v_sub 160 -> 80 + packed adds).  Bit-identical results
+(`tests/test_gpu_fused.py::test_clamp_free_variant_is_taken_only_where_proven_and_changes_nothing`); HDR displays with a black level
+below 0.1 cd/m^2 and sources that hand over their own luminance take the variant with the clamps.
+
+Same-box A/B (session 6, `FVVDP_BAND_INRANGE=0` = with clamps):
+
+%s
+
+## 2. Floors after that change (session 7, one box; ablation builds `-DBAND2_ABLATE=1` = no per-pixel tail, `-DBAND2_ABLATE_MEM` = rows from L2, no store)
+
+```
+%s
+```
+
+Clamp-free: arithmetic alone 28.7-28.9 us, data flow alone 32.2-32.3 us, together 35.1-35.6 us on that box (a slow one: the same build
+measures 31.3-31.9 us in session 6 and 33.0-33.1 us in session 8).  With the clamps the arithmetic alone was 31.1-31.8 us.  The data
+flow (153.9 MB per frame at 4.8-5.1 TB/s) is now the longer of the two floors; the kernel sits 9 %% above it.
+
+## 3. Rows through a buffer resource, `v_cvt_flr_i32_f32` / `v_fract_f32` for the table index (kept)
+
+Scalar row offset + loop-invariant lane offset instead of one 64-bit `v_lshl_add_u64` per load; 1291 -> 1275 VALU instructions per loop
+body.  Same-box A/B (session 8; `previous` = the build before the change), pyramid levels us per frame, and the foveated clip of
+configs[3] (level 0: 41.5 -> 40.8 us):
+
+```
+%s
+== foveated, new
+%s
+== foveated, previous
+%s
+```
+
+## 4. LDS-staged row prefetch two steps ahead (VERDICT r3 item 4) -- built, parity green, NOT faster, off (`-DBAND2_LDS_STAGE=1`)
+
+`buffer_load_dwordx4 ... lds` (LDS-DMA, no destination registers) for the rows of step c+2, `s_waitcnt vmcnt(4)` + four `ds_read_b128`
+for the rows of step c+1 at the top of step c, 12 KB of LDS per wave (12 waves per CU = 156 of 160 KB with the CSF tables), the same
+register ring, 157 registers, 3 waves per SIMD.  62 parity tests pass on that build (`FVVDP_LIB=build_variants/r4_stage.so`), the
+pooled sums are bit-identical.  Same-box A/B (session 10):
+
+```
+%s
+```
+
+3-5 %% slower in the pass-only loop, within 1 %% in the bench line.  A request already has a whole step (~2.4 us) to come back and a
+fourth wave per SIMD did not lower the data-flow floor either (round 3): the kernel is not waiting for latency, and the staging
+costs 16 LDS reads and ~10 vector instructions per loop body.
+""" % (table(lines("r4s6", "*.json")), rd("r4s7/floors.txt"), rd("r4s8/ab.txt"), rd("r4s8/fov_new.txt"), rd("r4s8/fov_prev.txt"), rd("r4s10/ab.txt")))
