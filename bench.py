@@ -193,7 +193,8 @@ def main():
         ach = b0 / (med0 * 1e-6) / 1e9
         frames_per_launch = min(N, batch)
         roof = {"bound": "hbm",
-                "kernel": "band2_kernel<4> pyramid levels 0+1 (reduce x2, expand x2, contrast, CSF, masking, pooling)" if fused01
+                "kernel": "band2_kernel<4, true> pyramid levels 0+1 (reduce x2, expand x2, contrast, CSF, masking, pooling; <4, true> = the "
+                          "variant without the clamps the library proved unreachable on this display, <4, false> otherwise)" if fused01
                           else "band_kernel<4> level 0 (pyramid+CSF+masking+pooling)",
                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
                 "traffic": None, "avg_launch_ms": round(float(np.mean(t0f)) * frames_per_launch * 1e-3, 4),
@@ -227,8 +228,8 @@ def main():
             roof["traffic_over_algorithmic"] = round(roof["traffic"] / roof["bytes_per_launch"], 4)
             roof["note"] = ("achieved/frac: algorithmic bytes of levels 0+1 (SURVEY 8(d)) / median launch time; achieved_traffic/"
                             "frac_traffic: HBM bytes actually moved (PMC) / the same time.  Ablation builds (profiles/r03_pyramid_bounds.md): "
-                            "the kernel's data flow alone runs at the memory system's ceiling for this mix (5.1 TB/s real traffic), its "
-                            "arithmetic alone takes as long; together 10-18 % above either floor.")
+                            "the kernel's data flow alone runs at the memory system's ceiling for this mix (4.8-5.1 TB/s real traffic); since round 4 "
+                            "(profiles/r04_pyramid_kernel.md) its arithmetic alone is 10 % shorter than that, together 9 % above the data-flow floor.")
         # ---- the temporal kernel K1 (unpack + display model + luminance + FIR -> pyramid level 0): its own roofline ----
         # algorithmic bytes per output frame: every source sample read once (2 streams x C channels x element size) and the
         # four temporal-channel planes written once (16 B per pixel); fl-1 history frames per launch on top

@@ -59,12 +59,11 @@ for T in bandonly fov_bandonly; do
   python $R/tools/pmc_sq_summary.py band $(find /tmp/s1_$T /tmp/s2_$T /tmp/s3_$T /tmp/s4_$T -name "*.db") > $OUT/pmc_sq_$T.md 2>/dev/null
 done
 python $R/tools/codeobj_report.py > $OUT/codeobj.md 2>/dev/null
-rocprofv3 --kernel-trace --stats -d /tmp/ff -o ff -- $R/build_variants/fuse_front 64 14 60 > $OUT/fuse_front.txt 2>/tmp/ff.err
-$R/build_variants/fuse_front 32 14 60 >> $OUT/fuse_front.txt 2>&1
-$R/build_variants/fuse_front 16 14 60 >> $OUT/fuse_front.txt 2>&1
-$R/build_variants/fuse_front 8 14 60 >> $OUT/fuse_front.txt 2>&1
-$R/build_variants/fuse_front 16 0 60 >> $OUT/fuse_front.txt 2>&1
-$R/build_variants/fuse_front 128 14 60 >> $OUT/fuse_front.txt 2>&1
-$R/build_variants/fuse_front 64 0 60 >> $OUT/fuse_front.txt 2>&1
-python $R/tools/rocpd_summary.py $(find /tmp/ff -name "*.db" | head -1) > $OUT/fuse_front_trace.md 2>&1
+# BASELINE configs[1]: 1920x1080 x60 (standard_fhd, 6 bands): kernel table + the bench line
+rocprofv3 --kernel-trace --stats -d /tmp/kfhd -o fhd -- python $R/bench.py --width 1920 --height 1080 --display standard_fhd --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_fhd.json 2> /tmp/kfhd.err
+python $R/tools/rocpd_summary.py $(find /tmp/kfhd -name "*.db" | head -1) --band-levels 6 > $OUT/kernel_trace_fhd.md
+python $R/bench.py --width 1920 --height 1080 --display standard_fhd --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_fhd_plain.json 2>/dev/null
+# the same allocation A/B as profiles/r04_level0_chunks.md on this box
+FVVDP_ALLOC=malloc python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_malloc.json 2>/dev/null
+FVVDP_BAND_INRANGE=0 python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_clamps.json 2>/dev/null
 ls -la $OUT

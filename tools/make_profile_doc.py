@@ -66,15 +66,69 @@ def same_box_table():
     return "\n".join(out)
 
 
+def quoted_figures():
+    """The derived figures DESIGN.md section 0 quotes, computed here from the files of the bundle so that they are grep-able."""
+    try:
+        jp = json.loads(rd("bench_plain.json").split("\n")[-1])
+        jq = json.loads(rd("bench_profiled.json").split("\n")[-1])
+    except Exception:
+        return "(bench lines not collected)"
+    rows = {}
+    for l in rd("kernel_trace_bench.md").split("\n"):
+        c = [x.strip() for x in l.split("|")]
+        if len(c) > 8 and c[2].isdigit():
+            rows[c[1]] = (int(c[2]), float(c[4]), float(c[5]), float(c[6]))       # calls, avg, median, steady
+    out = []
+    r, k1, g = jp["roofline"], jp["roofline_k1"], jp["graded_pass"]
+    out.append("* unprofiled `bench.py`: %.3f ms per pair = %.1f Gpix/s (test+ref), median of %d steps (mean %.3f, min %.3f, max %.3f); profiled: %.3f ms" % (
+        jp["ms_per_step"], jp["value"] / 1e3, jp["steps"], jp["timing"]["ms_per_step_mean"], jp["timing"]["ms_per_step_min"], jp["timing"]["ms_per_step_max"], jq["ms_per_step"]))
+    for label, (calls, avg, med, steady) in rows.items():
+        if "band2_kernel" in label:
+            b = r["bytes_per_launch"]
+            out.append("* `%s`: %.4f GB algorithmic per launch / rocprof AVERAGE %.1f us = %.2f TB/s = %.3f of 8 TB/s; / steady median %.1f us = %.3f; unprofiled HIP-event median %.1f us = %.4f" % (
+                label.strip("`"), b / 1e9, avg, b / avg / 1e6, b / avg / 1e6 / 8.0, steady, b / steady / 1e6 / 8.0, r["median_launch_ms"] * 1e3, r["frac"]))
+        if "temporal_vec_kernel" in label:
+            b = k1["bytes_per_launch"]
+            n = k1["frames_per_launch"]
+            out.append("* `%s`: %.1f MB per frame; rocprof AVERAGE %.1f us per %d frames = %.1f us per frame = %.2f TB/s = %.3f; unprofiled HIP events %.2f us per frame = %.4f" % (
+                label.strip("`"), b / n / 1e6, avg, n, avg / n, b / avg / 1e6, b / avg / 1e6 / 8.0, g["temporal_us_per_frame_median"], k1["frac"]))
+    if r.get("traffic"):
+        out.append("* real traffic of the dominant kernel: %.2f GB per launch = %.3f of the algorithmic bytes; %.2f TB/s = %.3f of the peak" % (
+            r["traffic"] / 1e9, r["traffic_over_algorithmic"], r["achieved_traffic"] / 1e3, r["frac_traffic"]))
+    out.append("* graded pass, unprofiled: %.1f us per frame = %.3f; profiled HIP events %.2f us = %.3f" % (
+        g["us_per_frame_all_levels"], g["hbm_frac_all_levels"], jq["graded_pass"]["us_per_frame_all_levels"], jq["graded_pass"]["hbm_frac_all_levels"]))
+    rs = jp["roofline_step"]
+    out.append("* whole step: %.2f GB per pair, %.2f TB/s = %.3f; kernels back to back %.3f ms of %.3f ms" % (
+        rs["bytes_per_step"] / 1e9, rs["achieved"] / 1e3, rs["frac"], rs["kernels_back_to_back_ms"], rs["ms_per_step"]))
+    for name in ("bench_malloc.json", "bench_clamps.json", "bench_pairs8.json", "bench_fhd.json", "bench_fhd_plain.json"):
+        try:
+            j = json.loads(rd(name).split("\n")[-1])
+            gg = j["graded_pass"]
+            out.append("* `%s`: %.3f ms per pair = %.1f Gpix/s; K1 %.2f us, levels 0+1 %.2f us, all levels %.2f us per frame" % (
+                name, j["ms_per_pair"], j["value"] / 1e3, gg["temporal_us_per_frame_median"], gg["levels_us_per_frame_median"][0], gg["us_per_frame_all_levels"]))
+        except Exception:
+            pass
+    cb = jp.get("cpu_baseline") or {}
+    if cb:
+        out.append("* CPU baseline: %.2f Mpix/s on %d cores; reference %.1f s per pair = %.2f Mpix/s; PCIe-inclusive %.1f Gpix/s" % (
+            cb["value"], cb["cores"], cb.get("reference_torch_cpu_seconds_build_container", 0), cb.get("reference_torch_cpu_mpix_s_build_container", 0),
+            jp.get("value_h2d_inclusive", 0) / 1e3))
+    return "\n".join(out)
+
+
 doc = f"""# Round {tag[1:]} -- rocprofv3 --kernel-trace --stats of `python bench.py --no-cpu-baseline` (final build of the round)
 
 Produced by `tools/collect_profiles.sh` in ONE gpurun call (one box) and formatted by `tools/make_profile_doc.py`.
-Workload: 3840x2160 x60 uint8 RGB pair, standard_4k, 30 fps (8 taps), non-foveated; 2 warm-up + 5 timed steps + the
-in-library HIP-event timing pass (>= 10 further calls) + the host-array call.  band_kernel rows are labelled by pyramid
+Workload: 3840x2160 x60 uint8 RGB pair, standard_4k, 30 fps (8 taps), non-foveated; 5 warm-up + 10 timed steps + the
+in-library HIP-event timing pass (>= 10 further calls, kernels strictly one after the other) + the host-array call.  band_kernel rows are labelled by pyramid
 level (dispatch order); `band2_kernel` covers two levels per launch.  torch kernels of the synthetic input generator
 (setup, untimed) are omitted.
 
 {kt('kernel_trace_bench.md')}
+
+Figures derived from this bundle (quoted in DESIGN.md section 0):
+
+{quoted_figures()}
 
 Every launch of the dominant kernel in that process, in order, with the kernel that ran before it.  The launches behind
 `__amd_rocclr_copyBuffer` are the host-array (PCIe-inclusive) calls at the end of bench.py: the GPU idles during the 50 ms
@@ -91,11 +145,9 @@ AVERAGE from the HIP-event median in round 2 (8 %); the media
 
 ## What bounds the dominant kernel: SQ / TCC counters (separate --pmc passes of `tools/gpu_bandonly.py`)
 
-`tools/pmc_sq_summary.py`; shares are of the waves' resident time (SQ_WAVE_CYCLES).  `valu` x 3 waves per SIMD >= 1 and `wait`
-(memory / LDS latency not hidden) 7 %: the arithmetic side of a kernel that the ablation builds of `profiles/r03_pyramid_bounds.md` show
-to be CO-bound -- its data flow alone takes 30 us per frame at the memory system's ceiling for the mix, its arithmetic alone 30.5 us,
-together 33-35.6 us.  (Read alone, these counters had been taken for "VALU-bound"; the same reading of the foveated kernel's counters
-was wrong: it waited for HBM every step.)
+`tools/pmc_sq_summary.py`; shares are of the waves' resident time (SQ_WAVE_CYCLES).  Read together with the ablation builds
+(`profiles/r04_pyramid_kernel.md`: arithmetic alone 28.7-28.9 us per frame, data flow alone 32.2-32.3 us, together 35.1-35.6 us on one box):
+the kernel is co-bound, since round 4 (clamp-free variant) with the data flow as the longer of the two floors.
 
 {rd('pmc_sq_bandonly.md')}
 
@@ -124,6 +176,32 @@ bench.py JSON of the unprofiled run on the same box, right before:
 ```
 {rd('bench_pairs8.json')}
 ```
+
+Same box, the two switches of round 4 turned back: `FVVDP_ALLOC=malloc` (level 0 from hipMalloc instead of 32 MB chunks,
+`profiles/r04_level0_chunks.md`) and `FVVDP_BAND_INRANGE=0` (the pyramid kernel with its clamps, `profiles/r04_pyramid_kernel.md`):
+
+```
+{rd('bench_malloc.json')}
+{rd('bench_clamps.json')}
+```
+
+## BASELINE configs[1]: 1920x1080 x60, standard_fhd (6 bands) -- kernel table of `bench.py --width 1920 --height 1080 --display standard_fhd`
+
+{kt('kernel_trace_fhd.md')}
+
+The profiled line and the unprofiled one of the same box:
+
+```
+{rd('bench_fhd.json')}
+{rd('bench_fhd_plain.json')}
+```
+
+Per pixel the 1080p pair is slower than the 4K pair ONLY in the pyramid pass (the temporal kernel scales with the pixel count:
+compare its us per frame x 4 with the 4K table).  The two-level kernel covers a 1080p frame with 18 strips x 8 chunks of 34 level-C rows
+(cost model of `chunking2`): 8640 single-wave workgroups for 60 frames = 2.8 rounds of the 3072 resident waves, and every chunk
+pays 9 halo steps on top of its 68 (13 %; 4K: 78-row chunks, 9 on 156 = 6 %, 4.9 rounds); the launch lasts 0.6 ms, so ramp-up and
+drain (~25 us) weigh 4 % where they weigh 1 % at 4K; the small levels (2..5) and the finalisation are launch-latency-sized at both
+resolutions and therefore four times as heavy per pixel at 1080p.
 
 ## A/B on the same box: two levels per pass (band2_kernel) vs one level per pass (FVVDP_BAND_FUSE=0)
 
