@@ -67,11 +67,14 @@ __device__ __forceinline__ Px<2> ld_px_buf<2>(__amdgpu_buffer_rsrc_t r, unsigned
 // top of the next step (loads and stores share one in-order counter on gfx9), i.e. every step would wait for the
 // previous step's store to be acknowledged before its own prefetched rows are usable.
 // (level_rsrc / FVVDP_NO_STORE: device_common.hpp)
+#ifndef BAND_STORE_AUX
+#define BAND_STORE_AUX 2    // cache policy bits of the coarse-level stores: 2 = nt (streaming)
+#endif
 __device__ __forceinline__ void st_px(__amdgpu_buffer_rsrc_t r, unsigned int byte_off, const Px<4>& a) {
-    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{a.h[0].x, a.h[0].y, a.h[1].x, a.h[1].y}), r, byte_off, 0, 2 /*nt*/);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{a.h[0].x, a.h[0].y, a.h[1].x, a.h[1].y}), r, byte_off, 0, BAND_STORE_AUX);
 }
 __device__ __forceinline__ void st_px(__amdgpu_buffer_rsrc_t r, unsigned int byte_off, const Px<2>& a) {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, a.h[0]), r, byte_off, 0, 2 /*nt*/);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2i, a.h[0]), r, byte_off, 0, BAND_STORE_AUX);
 }
 
 // ---- horizontal taps with the DPP shift folded into the multiply-add (v_fmac_f32_dpp) ------------------------------

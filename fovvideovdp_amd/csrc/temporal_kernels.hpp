@@ -327,6 +327,25 @@ __device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lu
     for (int i = 0; i < PX; ++i) L[i] = (C == 3) ? __fadd_rn(__fadd_rn(v[0][i], v[1][i]), v[2][i]) : v[0][i];
 }
 
+// One filter tap on one pixel: accS += x * f.x, accT += x * f.y for the (test, reference) pair x.  The tap pair f = {sustained,
+// transient} sits in ONE scalar register pair and is broadcast by the operand selects of the packed instruction.  Written out
+// because the compiler materialises a splat {f, f} pair per tap and channel instead: 4 scalar registers per tap, 256 for a
+// 64-tap filter -- they spilled into vector-register lanes and every multiply-add came with ~1.4 v_readlane (r2: 777-4619
+// spilled SGPRs in the 32- and 64-slot rings).
+__device__ __forceinline__ void fir_tap(v2f& accS, v2f& accT, v2f x, v2f f) {
+    asm("v_pk_fma_f32 %0, %2, %3, %0 op_sel_hi:[1,0,1]\n\t"
+        "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
+        : "+v"(accS), "+v"(accT) : "v"(x), "s"(f));
+}
+// TAPC taps = 2*TAPC floats of TemporalArgs::taps2 / YuvArgs::taps2, read from the kernel-argument segment with one scalar load
+#ifndef K1_TAPC
+#define K1_TAPC 4
+#endif
+constexpr int TAPC = K1_TAPC;
+typedef float vtapf __attribute__((ext_vector_type(2 * K1_TAPC)));
+typedef vtapf vtapf_a4 __attribute__((aligned(4)));
+typedef const vtapf_a4 __attribute__((address_space(4)))* karg_taps_p;
+
 // Temporally tiled FIR: one thread owns PX pixels for the whole launch and keeps the last FL luminance values of
 // both streams in registers (ring with compile-time slot indices), so every source frame is read exactly once and
 // every output pixel is written once as one float4 (test-sust, ref-sust, test-trans, ref-trans).  The raw samples
@@ -352,19 +371,23 @@ __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a
     }
     const float w[3] = {a.C == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};
     OobMax bad;
-    float ring[2][FL][PX];
-#pragma unroll
-    for (int u = 0; u < FL; ++u)
-#pragma unroll
-        for (int i = 0; i < PX; ++i) ring[0][u][i] = ring[1][u][i] = 0.0f;
+    // .x = test, .y = reference (one register pair per ring value, one v_pk_fma per tap and channel: fir_tap).  Not initialised:
+    // every slot is written before its first read (history: slots 0..FL-2, first output step: slot FL-1).
+    v2f ring[FL][PX];
     // virtual time v = 0 .. FL-2 is the history, v = FL-1+t the newest frame of output t; ring slot = v % FL.
     // The same pipelined loop fills the history and produces the outputs, so at most one frame is in flight.
     const int total = FL - 1 + a.n_out;
+    // window index lists and taps straight from the kernel-argument segment (scalar loads), as in temporal_vec_body
+    typedef const int __attribute__((address_space(4)))* karg_int_p;
+    typedef const char __attribute__((address_space(4)))* karg_p;
+    const karg_p ka = (karg_p)__builtin_amdgcn_kernarg_segment_ptr();
+    const karg_int_p idx0 = (karg_int_p)(ka + offsetof(TemporalArgs, idx));
+    const karg_int_p idx1 = (karg_int_p)(ka + offsetof(TemporalArgs, idx1));
     RawFrame<SRC, PX> nx[TDIST][2];           // raw samples of the next TDIST frames, in flight
 #pragma unroll
     for (int d = 0; d < TDIST; ++d) {
-        const size_t off = (size_t)a.idx[d < total ? d : total - 1] * a.frame_stride;
-        const size_t off1 = (size_t)a.idx1[d < total ? d : total - 1] * a.frame_stride;
+        const size_t off = (size_t)idx0[d < total ? d : total - 1] * a.frame_stride;
+        const size_t off1 = (size_t)idx1[d < total ? d : total - 1] * a.frame_stride;
         nx[d][0] = fetch_frame<SRC, PX>(a.src[0], off, a.chan_stride, a.C, px);
         nx[d][1] = fetch_frame<SRC, PX>(a.src[1], off1, a.chan_stride, a.C, px);
     }
@@ -375,41 +398,50 @@ __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a
             if (v < total) {
                 const RawFrame<SRC, PX> cur0 = nx[u % TDIST][0], cur1 = nx[u % TDIST][1];
                 if (v + TDIST < total) {
-                    const size_t off = (size_t)a.idx[v + TDIST] * a.frame_stride;
-                    const size_t off1 = (size_t)a.idx1[v + TDIST] * a.frame_stride;
+                    const size_t off = (size_t)idx0[v + TDIST] * a.frame_stride;
+                    const size_t off1 = (size_t)idx1[v + TDIST] * a.frame_stride;
                     nx[u % TDIST][0] = fetch_frame<SRC, PX>(a.src[0], off, a.chan_stride, a.C, px);
                     nx[u % TDIST][1] = fetch_frame<SRC, PX>(a.src[1], off1, a.chan_stride, a.C, px);
                 }
-                frame_lum<SRC, PX, RawFrame<SRC, PX>>(cur0, a.C, lutw, a.e.lut, w, a.e, ring[0][u], bad);
-                frame_lum<SRC, PX, RawFrame<SRC, PX>>(cur1, a.C, lutw, a.e.lut, w, a.e, ring[1][u], bad);
-                if (v >= FL - 1) {
-                    float acc[4][PX];
+                {
+                    float L0[PX], L1[PX];
+                    frame_lum<SRC, PX, RawFrame<SRC, PX>>(cur0, a.C, lutw, a.e.lut, w, a.e, L0, bad);
+                    frame_lum<SRC, PX, RawFrame<SRC, PX>>(cur1, a.C, lutw, a.e.lut, w, a.e, L1, bad);
 #pragma unroll
-                    for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
-                    // oldest tap first, like the reference's sum over the window dimension.  The taps are re-read from the
-                    // kernel-argument segment in every step (laundered pointer): hoisted out of the frame loop, 2*FL scalar values
-                    // stay alive across it and spill
-                    typedef const float __attribute__((address_space(4)))* karg_f_p;
-                    karg_f_p tp = (karg_f_p)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
-                                             offsetof(TemporalArgs, taps2));
+                    for (int i = 0; i < PX; ++i) {
+                        ring[u][i] = v2f{L0[i], L1[i]};
+                        asm volatile("" : "+v"(ring[u][i]));       // pinned where it is produced (see temporal_vec_body::push)
+                    }
+                }
+                if (v >= FL - 1) {
+                    v2f accS[PX], accT[PX];                  // (test, reference) of the sustained / the transient channel
+#pragma unroll
+                    for (int i = 0; i < PX; ++i) accS[i] = accT[i] = v2f{0.0f, 0.0f};
+                    // oldest tap first, like the reference's sum over the window dimension.  TAPC taps per scalar load, re-read
+                    // in every step through a laundered pointer: hoisted out of the frame loop (or loaded all at once), 2*FL
+                    // scalar values stay alive and spill into vector-register lanes (round 3: 1210-1241 spilled SGPRs at FL = 32)
+                    karg_p tp = ka + offsetof(TemporalArgs, taps2);
                     asm volatile("" : "+s"(tp));
 #pragma unroll
-                    for (int k = FL - 1; k >= 0; --k) {
-                        const int sl = (u - k + 2 * FL) % FL;
-                        const float f0 = tp[2 * k], f1 = tp[2 * k + 1];
+                    for (int c = FL / TAPC - 1; c >= 0; --c) {
+                        const vtapf tc = *(karg_taps_p)(tp + c * (8 * TAPC));
 #pragma unroll
-                        for (int i = 0; i < PX; ++i) {
-                            acc[0][i] = fmaf(ring[0][sl][i], f0, acc[0][i]);
-                            acc[1][i] = fmaf(ring[1][sl][i], f0, acc[1][i]);
-                            acc[2][i] = fmaf(ring[0][sl][i], f1, acc[2][i]);
-                            acc[3][i] = fmaf(ring[1][sl][i], f1, acc[3][i]);
+                        for (int kk = TAPC - 1; kk >= 0; --kk) {
+                            const int k = c * TAPC + kk;
+                            const int sl = (u - k + 2 * FL) % FL;
+                            const v2f f = v2f{tc[2 * kk], tc[2 * kk + 1]};
+#pragma unroll
+                            for (int i = 0; i < PX; ++i) fir_tap(accS[i], accT[i], ring[sl][i], f);
                         }
+                        if constexpr (FL > 16) __builtin_amdgcn_sched_barrier(0);     // one chunk of taps in scalar registers at a time
                     }
-                    float* o = a.out + (size_t)(v - (FL - 1)) * a.HW * 4;
+                    int t_opaque = v - (FL - 1);              // laundered: no per-step 64-bit offsets pre-computed outside the loop
+                    asm volatile("" : "+s"(t_opaque));
+                    float* o = a.out + (size_t)t_opaque * a.HW * 4;
 #pragma unroll
                     for (int i = 0; i < PX; ++i)
                         if (ok[i])
-                            *reinterpret_cast<float4*>(o + (size_t)px[i] * 4) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+                            *reinterpret_cast<float4*>(o + (size_t)px[i] * 4) = make_float4(accS[i].x, accS[i].y, accT[i].x, accT[i].y);
                 }
             }
         }
@@ -495,25 +527,6 @@ __device__ __forceinline__ void wave_lds_order() {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-
-// One filter tap on one pixel: accS += x * f.x, accT += x * f.y for the (test, reference) pair x.  The tap pair f = {sustained,
-// transient} sits in ONE scalar register pair and is broadcast by the operand selects of the packed instruction.  Written out
-// because the compiler materialises a splat {f, f} pair per tap and channel instead: 4 scalar registers per tap, 256 for a
-// 64-tap filter -- they spilled into vector-register lanes and every multiply-add came with ~1.4 v_readlane (r2: 777-4619
-// spilled SGPRs in the 32- and 64-slot rings).
-__device__ __forceinline__ void fir_tap(v2f& accS, v2f& accT, v2f x, v2f f) {
-    asm("v_pk_fma_f32 %0, %2, %3, %0 op_sel_hi:[1,0,1]\n\t"
-        "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
-        : "+v"(accS), "+v"(accT) : "v"(x), "s"(f));
-}
-// TAPC taps = 2*TAPC floats of TemporalArgs::taps2 / YuvArgs::taps2, read from the kernel-argument segment with one scalar load
-#ifndef K1_TAPC
-#define K1_TAPC 4
-#endif
-constexpr int TAPC = K1_TAPC;
-typedef float vtapf __attribute__((ext_vector_type(2 * K1_TAPC)));
-typedef vtapf vtapf_a4 __attribute__((aligned(4)));
-typedef const vtapf_a4 __attribute__((address_space(4)))* karg_taps_p;
 
 // CC = number of colour channels as a compile-time constant (3 or 1): with a run-time `C == 3` around the loads and the
 // table look-ups, every step has control-flow joins and the compiler falls back to s_waitcnt vmcnt(0).
@@ -788,50 +801,52 @@ __global__ __launch_bounds__(256) void temporal_yuv_kernel(const YuvArgs a) {
         px[i] = ok[i] ? q : HW - 1;
     }
     OobMax bad;
-    float ring[2][FL][PX];
-#pragma unroll
-    for (int u = 0; u < FL; ++u)
-#pragma unroll
-        for (int i = 0; i < PX; ++i) ring[0][u][i] = ring[1][u][i] = 0.0f;
+    v2f ring[FL][PX];               // .x = test, .y = reference; every slot is written before its first read
     const int total = FL - 1 + a.n_out;
+    typedef const int __attribute__((address_space(4)))* karg_int_p;
+    typedef const char __attribute__((address_space(4)))* karg_p;
+    const karg_p ka = (karg_p)__builtin_amdgcn_kernarg_segment_ptr();
+    const karg_int_p idx0 = (karg_int_p)(ka + offsetof(YuvArgs, idx));
     for (int v0 = 0; v0 < total; v0 += FL) {
 #pragma unroll
         for (int u = 0; u < FL; ++u) {
             const int v = v0 + u;
             if (v < total) {
-                const size_t off = (size_t)a.idx[v] * a.frame_stride;
+                const size_t off = (size_t)idx0[v] * a.frame_stride;
                 const T* f0 = reinterpret_cast<const T*>(a.src[0]) + off;
                 const T* f1 = reinterpret_cast<const T*>(a.src[1]) + off;
 #pragma unroll
                 for (int i = 0; i < PX; ++i) {
-                    ring[0][u][i] = yuv_lum<T>(f0, a, px[i], bad);
-                    ring[1][u][i] = yuv_lum<T>(f1, a, px[i], bad);
+                    ring[u][i] = v2f{yuv_lum<T>(f0, a, px[i], bad), yuv_lum<T>(f1, a, px[i], bad)};
+                    asm volatile("" : "+v"(ring[u][i]));
                 }
                 if (v >= FL - 1) {
-                    float acc[4][PX];
+                    v2f accS[PX], accT[PX];
 #pragma unroll
-                    for (int i = 0; i < PX; ++i) acc[0][i] = acc[1][i] = acc[2][i] = acc[3][i] = 0.0f;
-                    typedef const float __attribute__((address_space(4)))* karg_f_p;      // see temporal_ring_kernel
-                    karg_f_p tp = (karg_f_p)((const char __attribute__((address_space(4)))*)__builtin_amdgcn_kernarg_segment_ptr() +
-                                             offsetof(YuvArgs, taps2));
+                    for (int i = 0; i < PX; ++i) accS[i] = accT[i] = v2f{0.0f, 0.0f};
+                    // taps: TAPC per scalar load, laundered pointer, one chunk alive at a time (see temporal_ring_kernel)
+                    karg_p tp = ka + offsetof(YuvArgs, taps2);
                     asm volatile("" : "+s"(tp));
 #pragma unroll
-                    for (int k = FL - 1; k >= 0; --k) {
-                        const int sl = (u - k + 2 * FL) % FL;
-                        const float t0 = tp[2 * k], t1 = tp[2 * k + 1];
+                    for (int c = FL / TAPC - 1; c >= 0; --c) {
+                        const vtapf tc = *(karg_taps_p)(tp + c * (8 * TAPC));
 #pragma unroll
-                        for (int i = 0; i < PX; ++i) {
-                            acc[0][i] = fmaf(ring[0][sl][i], t0, acc[0][i]);
-                            acc[1][i] = fmaf(ring[1][sl][i], t0, acc[1][i]);
-                            acc[2][i] = fmaf(ring[0][sl][i], t1, acc[2][i]);
-                            acc[3][i] = fmaf(ring[1][sl][i], t1, acc[3][i]);
+                        for (int kk = TAPC - 1; kk >= 0; --kk) {
+                            const int k = c * TAPC + kk;
+                            const int sl = (u - k + 2 * FL) % FL;
+                            const v2f f = v2f{tc[2 * kk], tc[2 * kk + 1]};
+#pragma unroll
+                            for (int i = 0; i < PX; ++i) fir_tap(accS[i], accT[i], ring[sl][i], f);
                         }
+                        if constexpr (FL > 16) __builtin_amdgcn_sched_barrier(0);
                     }
-                    float* o = a.out + (size_t)(v - (FL - 1)) * HW * 4;
+                    int t_opaque = v - (FL - 1);
+                    asm volatile("" : "+s"(t_opaque));
+                    float* o = a.out + (size_t)t_opaque * HW * 4;
 #pragma unroll
                     for (int i = 0; i < PX; ++i)
                         if (ok[i])
-                            *reinterpret_cast<float4*>(o + (size_t)px[i] * 4) = make_float4(acc[0][i], acc[1][i], acc[2][i], acc[3][i]);
+                            *reinterpret_cast<float4*>(o + (size_t)px[i] * 4) = make_float4(accS[i].x, accS[i].y, accT[i].x, accT[i].y);
                 }
             }
         }
