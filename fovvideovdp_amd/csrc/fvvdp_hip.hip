@@ -47,7 +47,6 @@ extern "C" const char* fvvdp_last_error(void) { return g_err; }
 #include "band_kernel.hpp"
 #include "band2_kernel.hpp"
 #include "aux_kernels.hpp"
-#include "tail_kernel.hpp"
 #include "psnr_kernel.hpp"
 
 // ------------------------------------------------------------------------------------------------------------
@@ -98,7 +97,6 @@ struct fvvdp_ctx {
     int* d_idx = nullptr;         // [max_frames + FVVDP_MAX_TAPS]
     float* lum_buf = nullptr;     // two-pass temporal path (33..64 taps): fp32 luminance frames [2][lum_frames][HW]
     size_t lum_floats = 0;
-    unsigned int* d_ticket = nullptr;   // band_tail_kernel: workgroups that have published their frame (zero between launches)
     float* heat[FVVDP_MAX_BANDS + 1]{};   // heat-map accumulation images of levels >= 1, allocated on first use
     unsigned int* colour_ws = nullptr;    // colouring workspace per frame: range[2] + hist[1024] + curve[1024], then lin01[1024]
     size_t scratch = 0;
@@ -330,8 +328,6 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_fix, (size_t)max_frames * 2);
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_taps, (size_t)2 * FVVDP_MAX_TAPS);
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_idx, (size_t)max_frames + FVVDP_MAX_TAPS);
-    if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_ticket, (size_t)1);
-    if (rc == FVVDP_OK && hipMemset(c->d_ticket, 0, sizeof(unsigned int)) != hipSuccess) rc = fail(FVVDP_EHIP, "hipMemset failed");
     if (rc != FVVDP_OK) {
         fvvdp_ctx_destroy(c);
         return rc;
@@ -371,7 +367,6 @@ extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     if (c->d_fix) (void)hipFree(c->d_fix);
     if (c->d_taps) (void)hipFree(c->d_taps);
     if (c->d_idx) (void)hipFree(c->d_idx);
-    if (c->d_ticket) (void)hipFree(c->d_ticket);
     if (c->lum_buf) (void)hipFree(c->lum_buf);
     if (c->d_axes) (void)hipFree(c->d_axes);
     for (int b = 0; b < FVVDP_MAX_BANDS; ++b) {
@@ -1116,26 +1111,9 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
     const char* fuse_env = getenv("FVVDP_BAND_FUSE");
     const int fuse_mode = (fuse_env && (fuse_env[0] == '0' || fuse_env[0] == '1')) ? fuse_env[0] - '0' : -1;   // anything else: automatic
     const bool fuse_ok = !fov && !any_maps && fuse_mode != 0;
-    // The small end of the pyramid, the finalisation and (when asked) the pooling in ONE launch (band_tail_kernel, one
-    // workgroup per frame): built for VERDICT r2 item 7, measured slower than the per-level launches in every variant (see
-    // tail_kernel.hpp), therefore OFF unless FVVDP_BAND_TAIL=1 (then: every level of <= TAIL_MAX_PX pixels, plain evaluation).
-    const char* tail_env = getenv("FVVDP_BAND_TAIL");
-    const bool tail_on = tail_env && tail_env[0] == '1';
-    int tail_from = c->n_bands;          // first level of the tail launch (n_bands: no tail)
-    if (!fov && !any_maps && tail_on) {
-        while (tail_from > 0 && (long long)c->lw[tail_from - 1] * c->lh[tail_from - 1] <= TAIL_MAX_PX &&
-               c->n_bands - (tail_from - 1) <= TAIL_MAX_LEVELS)
-            --tail_from;
-    }
-    TailArgs* ta = nullptr;
-    std::vector<char> ta_mem;
-    if (tail_from < c->n_bands) {
-        ta_mem.assign(sizeof(TailArgs), 0);
-        ta = reinterpret_cast<TailArgs*>(ta_mem.data());
-    }
     for (int b = 0; b < c->n_bands; ++b) {
         const bool big = (long long)c->lw[b] * c->lh[b] >= 1500000;
-        if (fuse_ok && b + 1 < tail_from && (big || fuse_mode == 1) && b + 1 < c->n_bands && c->lw[b + 1] >= 4 && c->lh[b + 1] >= 4 &&
+        if (fuse_ok && (big || fuse_mode == 1) && b + 1 < c->n_bands && c->lw[b + 1] >= 4 && c->lh[b + 1] >= 4 &&
             c->lw[b + 2] >= 2 && c->lh[b + 2] >= 2) {
             Band2Args a;
             memset(&a, 0, sizeof(a));
@@ -1201,9 +1179,7 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
         a.wc = c->lw[b + 1];
         a.hc = c->lh[b + 1];
         a.n_strips = band_strips(a.wc);
-        const bool in_tail = b >= tail_from;
-        if (in_tail) chunking(a.hc, a.n_strips, 1, TAIL_WPT, a.n_chunks, a.cr);      // one frame on the waves of one workgroup
-        else chunking(a.hc, a.n_strips, n, c->wave_capacity, a.n_chunks, a.cr);
+        chunking(a.hc, a.n_strips, n, c->wave_capacity, a.n_chunks, a.cr);
         a.band_mul = (b == 0) ? 1.0f : 2.0f;                 // lpyr.get_band, fvvdp_lpyr_dec.py:57-63
         a.csf = c->csf + (size_t)b * FVVDP_LUT_N;
         a.csf_y = c->csf_y;
@@ -1276,9 +1252,7 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
             const size_t lds_static = sizeof(float4) * FVVDP_LUT_N + sizeof(float2) * 3 * FVVDP_LUT_N;
             a.lut_lds = (fov && lut_b <= 56 * 1024 && lut_b + (size_t)c->lh[b] * sizeof(float) + lds_static <= 64 * 1024) ? 1 : 0;
         }
-        if (in_tail) {
-            ta->band[b - tail_from] = a;
-        } else {
+        {
             Timed tm(c, 1 + b, st);
             if (c->P == 4) launch_band<4>(a, nblk * n, dbg, fov, st);
             else launch_band<2>(a, nblk * n, dbg, fov, st);
@@ -1295,26 +1269,15 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
     fa.q_col0 = q_col0;
     fa.tc = c->P / 2;
     fa.inv_beta = 1.0f / c->prm.beta;
-    if (ta) {
-        ta->n_levels = c->n_bands - tail_from;
-        ta->fin = fa;
-        ta->do_pool = pool_now ? 1 : 0;
-        if (pool_now) fill_pool_args(ta->pool, d_Q, c->n_bands, 2, q_stride, q_stride, pool, d_jod);   // plane 1 of an image is written as 0
-        ta->ticket = c->d_ticket;
-        Timed tm(c, 1 + tail_from, st);      // reported at the first level it covers; finalize reads 0
-        if (c->P == 4) hipLaunchKernelGGL((band_tail_kernel<4>), dim3(n), dim3(64 * TAIL_WPT), 0, st, *ta);
-        else hipLaunchKernelGGL((band_tail_kernel<2>), dim3(n), dim3(64 * TAIL_WPT), 0, st, *ta);
-    } else {
-        {
-            Timed tm(c, 1 + c->n_bands, st);
-            const int total = c->n_bands * 2 * n;
-            hipLaunchKernelGGL(finalize_kernel, dim3(total), dim3(64), 0, st, fa);
-        }
-        if (pool_now) {
-            PoolArgs pa;
-            fill_pool_args(pa, d_Q, c->n_bands, 2, q_stride, q_stride, pool, d_jod);
-            hipLaunchKernelGGL(pool_jod_kernel, dim3(1), dim3(256), 0, st, pa);
-        }
+    {
+        Timed tm(c, 1 + c->n_bands, st);
+        const int total = c->n_bands * 2 * n;
+        hipLaunchKernelGGL(finalize_kernel, dim3(total), dim3(64), 0, st, fa);
+    }
+    if (pool_now) {
+        PoolArgs pa;
+        fill_pool_args(pa, d_Q, c->n_bands, 2, q_stride, q_stride, pool, d_jod);
+        hipLaunchKernelGGL(pool_jod_kernel, dim3(1), dim3(256), 0, st, pa);
     }
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;

@@ -245,10 +245,8 @@ int fvvdp_pool_jod(const float* d_Q, int n_bands, int n_channels, int n_frames, 
 
 /* fvvdp_bands_forward (process_block_of_frames, fvvdp.py:359-478) and, when this batch completes the clip (q_col0 + n ==
  * q_stride), fvvdp_pool_jod (do_pooling_and_jods, fvvdp.py:337-357) over all q_stride frames of d_Q in the same call:
- * the result in d_jod[0] is bit-identical to the two separate calls.  For batches of many frames (plain evaluation) the
- * small pyramid levels, the pooled-sum finalisation and this pooling share ONE launch (a workgroup per frame; the
- * workgroup that finishes last pools) instead of seven latency-sized ones.  Earlier batches of the clip (q_col0 + n <
- * q_stride) only run the bands.                                                                                   */
+ * the result in d_jod[0] is bit-identical to the two separate calls (one launch and no host round trip more than
+ * fvvdp_bands_forward).  Earlier batches of the clip (q_col0 + n < q_stride) only run the bands.                    */
 int fvvdp_bands_forward_pool(fvvdp_ctx* ctx, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
                              const fvvdp_geom* geom, const fvvdp_band_maps* maps, const fvvdp_pool_params* pool,
                              float* d_jod, void* stream);

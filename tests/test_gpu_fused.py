@@ -104,96 +104,6 @@ def test_large_still_image_takes_the_two_level_kernel(monkeypatch):
     assert np.array_equal(sd["Q_per_ch"][:2], Q1[:2].astype(np.float32))       # default == forced for levels 0+1
 
 
-# ---- band_tail_kernel: the small pyramid levels + finalisation + pooling of a batch of frames in one launch ---------------
-def _run_tail(monkeypatch, test, ref, tail, disp="standard_fhd", **kw):
-    import fovvideovdp_amd as fv
-    monkeypatch.delenv("FVVDP_BAND_FUSE", raising=False)
-    monkeypatch.delenv("FVVDP_BAND2_KR", raising=False)
-    if tail is None:
-        monkeypatch.delenv("FVVDP_BAND_TAIL", raising=False)
-    else:
-        monkeypatch.setenv("FVVDP_BAND_TAIL", str(tail))
-    m = fv.fvvdp(display_name=disp)
-    q, st = m.predict(test, ref, **kw)
-    return float(q), st["Q_per_ch"].astype(np.float64), m
-
-
-@pytest.mark.parametrize("H,W,N", [(34, 108, 5), (37, 217, 7), (131, 220, 30), (135, 240, 26), (270, 480, 24), (301, 531, 9)])
-def test_tail_launch_equals_the_per_level_launches_and_the_oracle(monkeypatch, H, W, N):
-    """FVVDP_BAND_TAIL=1 runs every level of these small frames, the finalisation and the pooling in band_tail_kernel (one
-    workgroup per frame); =0 takes the per-level launches + finalize_kernel + pool_jod_kernel.  Same per-pixel code: Q differs
-    by the grouping of the partial sums only (measured <= 6e-7); the pooled JOD of the tail equals fvvdp_pool_jod on its own Q."""
-    import ctypes as C
-    import fovvideovdp_amd as fv
-    from fovvideovdp_amd import _native as nat
-    from oracle import fvvdp_oracle as orc
-    test, ref = _pair(H, W, 7 * H + W, N)
-    kw = dict(dim_order="FHW", frames_per_second=30)
-    q0, Q0, _ = _run_tail(monkeypatch, test, ref, 0, **kw)
-    q1, Q1, m = _run_tail(monkeypatch, test, ref, 1, **kw)
-    assert abs(q1 - q0) < 2e-6, (q1, q0)
-    _close(Q1, Q0)
-    # the in-kernel pooling (last workgroup) against the separate pooling kernel on the same Q: bit-identical
-    Qd = torch.as_tensor(Q1.astype(np.float32), device="cuda").contiguous()
-    jd = torch.zeros(1, device="cuda")
-    pp = nat.PoolParams(m.beta_sch, m.beta_tch, m.beta_t, m.w_transient, m.jod_a, float(10.0 ** m.log_jod_exp))
-    nat.check(nat.lib().fvvdp_pool_jod(C.c_void_p(Qd.data_ptr()), Q1.shape[0], 2, N, N, C.byref(pp), C.c_void_p(jd.data_ptr()),
-                                       C.c_void_p(torch.cuda.current_stream().cuda_stream)))
-    assert float(jd[0]) == np.float32(q1)
-    if N <= 9:
-        oq, ost = orc.Oracle("standard_fhd").predict(test, ref, dim_order="FHW", frames_per_second=30)
-        assert abs(q1 - float(oq)) < 1e-4
-        b = ost["Q_per_ch"].astype(np.float64)
-        assert np.all(np.abs(Q1 - b) <= 1e-3 * np.abs(b) + 1e-5 * np.max(b))
-    # run-to-run bit-identical (fixed summation order, whichever workgroup pools)
-    for _ in range(3):
-        q2, Q2, _m = _run_tail(monkeypatch, test, ref, 1, **kw)
-        assert q2 == q1 and np.array_equal(Q2, Q1)
-
-
-def test_tail_launch_on_still_images_and_batches(monkeypatch):
-    """Images (2 planes, one frame: tail only when forced) and a clip evaluated in several batches: only the batch that
-    completes the clip pools, over ALL frames."""
-    import fovvideovdp_amd as fv
-    test, ref = _pair(131, 324, 5)
-    q0, Q0, _ = _run_tail(monkeypatch, test, ref, 0, disp="standard_4k", dim_order="HW")
-    q1, Q1, _ = _run_tail(monkeypatch, test, ref, 1, disp="standard_4k", dim_order="HW")
-    assert abs(q1 - q0) < 2e-6
-    _close(Q1, Q0)
-    tv, rv = _pair(72, 130, 11, 50)
-    qa, Qa, _ = _run_tail(monkeypatch, tv, rv, 1, dim_order="FHW", frames_per_second=30)
-    for batch in (7, 24, 49):
-        monkeypatch.setenv("FVVDP_BAND_TAIL", "1")
-        m = fv.fvvdp(display_name="standard_fhd", batch_frames=batch)
-        qb, sb = m.predict(tv, rv, dim_order="FHW", frames_per_second=30)
-        assert np.array_equal(sb["Q_per_ch"].astype(np.float64), Qa), batch      # per-frame work is batch-independent
-        assert float(qb) == qa, batch
-
-
-def test_tail_launch_is_opt_in(monkeypatch):
-    """Default: per-level launches + finalize_kernel + pool_jod_kernel (the tail launch measured slower, tail_kernel.hpp);
-    FVVDP_BAND_TAIL=1 merges the levels of <= 160000 pixels -- checked through the kernel timing slots."""
-    import ctypes as C
-    import fovvideovdp_amd as fv
-    from fovvideovdp_amd import _native as nat
-    monkeypatch.delenv("FVVDP_BAND_FUSE", raising=False)
-    test, ref = _pair(270, 480, 3, 6)
-    for env, want in ((None, [1, 1, 1, 1, 1, 1, 1]), ("1", [1, 0, 0, 0, 0, 0, 0])):
-        if env is None:
-            monkeypatch.delenv("FVVDP_BAND_TAIL", raising=False)
-        else:
-            monkeypatch.setenv("FVVDP_BAND_TAIL", env)
-        m = fv.fvvdp(display_name="standard_fhd")
-        m.timing = True
-        q, st = m.predict(test, ref, dim_order="FHW", frames_per_second=30)
-        nb = st["Q_per_ch"].shape[0]
-        ms = (C.c_float * 18)()
-        cnt = (C.c_int32 * 18)()
-        nat.check(nat.lib().fvvdp_ctx_timing_read(m._ctx.handle, ms, cnt, 18, 1))
-        launches = [cnt[i] for i in range(1, nb + 2)]              # levels 0 .. nb-1, finalize
-        assert nb == 6 and launches == want, (env, launches)
-
-
 def test_clamp_free_variant_is_taken_only_where_proven_and_changes_nothing(tmp_path):
     """band2_kernel<P, true> drops the four clamps of the per-pixel tail (L_bkg >= 0.1, contrast <= 1000, the two clamps of the
     CSF table query) when the library has PROVEN from the display model, the RGB->Y weights and the temporal taps that they never
