@@ -41,6 +41,19 @@ struct Band2Args {
     float lg_gain, lg_k, p, q0, q1, beta, lbkg_min, cmax, lg_dmax;
     float* partialA;        // [n][n_strips*n_chunks][2]
     float* partialB;
+    // ---- foveated mode (band2_fov_kernel; stock geometry only) ------------------------------------------------------------
+    const float4* lut2;     // both bands' slices of the CSF table, band A's rwA rho planes then band B's rwB: plane = n_e ecc rows of
+                            //   FOV_ROW entries (+8), i.e. trimmed to the eccentricities this display can show; records as BandArgs::sublut
+    int lut2_entries;       // float4 entries of lut2 (copied to LDS by every workgroup)
+    int n_items;            // work items (waves) of the launch
+    const float4* rmapA;    // level A, per pixel PAIR {fraction, LDS byte offset of the rho plane} x 2 (fov_rho_map_kernel)
+    int rmapA_w;            //   pairs per row
+    const float2* rmapB;    // level B, per PIXEL {fraction, LDS byte offset of the rho plane}
+    const float* fix;       // device [n][2]: gaze in frame pixels
+    float size_m0, size_m1, dist_m;
+    int frame_w, frame_h;
+    float ecc_lo, ecc_hi;
+    float f_inv_step[2], f_grid_off[2], f_frac_scale[2];    // uniform-grid constants of the Y and the ecc axis (BandArgs::inv_step ...)
 };
 
 // (dpp_reduce_taps / dpp_expand_taps: band_kernel.hpp)
@@ -103,22 +116,21 @@ __device__ __forceinline__ v2f dpp_expand2_taps(v2f t, v2f e, float fl, float fr
 #ifndef BAND2_LDS_STAGE
 #define BAND2_LDS_STAGE 0
 #endif
-template <int P, bool INRANGE = false>
-__global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) {
+// FOV: foveated evaluation of both bands (band2_fov_kernel): the per-pixel tail takes the CSF from the band's slice of the 32^3
+// table in LDS at the pixel's (rho, eccentricity, L_bkg) -- the machinery of band_kernel<P, false, 1> (frame-invariant rho map,
+// row table of vertical view angles, phased LDS reads) for two levels at once, so that level 1 never leaves the chip in
+// foveated mode either (BASELINE configs[3]).
+#ifndef FOV2_PHASE
+#define FOV2_PHASE 2        // pixels whose LUT-cell reads are in flight together in the foveated tail
+#endif
+constexpr bool band2_stage(int P) { return (BAND2_LDS_STAGE != 0) && P == 4; }
+
+template <int P, bool INRANGE, bool FOV>
+__device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, const int chunk, const int frame, const int lane,
+                                           const float4 (*s_csf)[FVVDP_LUT_N], [[maybe_unused]] float4* s_stage) {
     constexpr int HP = P / 2;
-    constexpr bool STAGE = (BAND2_LDS_STAGE != 0) && P == 4;
-    __shared__ float4 s_csf[2][FVVDP_LUT_N];
-    __shared__ float4 s_stage[STAGE ? 3 * 4 * 64 : 1];
-    const int lane = threadIdx.x;
-    int bid;
-    {   // XCD-aware work order (see band_kernel)
-        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
-        bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
-    }
-    const int strip = bid % a.n_strips;
-    bid /= a.n_strips;
-    const int chunk = bid % a.n_chunks;
-    const int frame = bid / a.n_chunks;
+    constexpr bool STAGE = band2_stage(P) && !FOV;
+    static_assert(!(FOV && INRANGE), "the foveated variant keeps its clamps");
     const int blk = chunk * a.n_strips + strip;
 
     const int w = a.w, h = a.h, wb = a.wb, hb = a.hb, wc = a.wc, hc = a.hc;
@@ -131,12 +143,6 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
     const int X0 = 2 * J, X1 = 2 * J + 1;
     const int xc0 = min(max(X0, 0), w - 1), xc1 = min(max(X1, 0), w - 1);
     const bool col1_ok = X1 < w;
-
-    if (lane < FVVDP_LUT_N) {
-        s_csf[0][lane] = a.csfA[lane];
-        s_csf[1][lane] = a.csfB[lane];
-    }
-    __syncthreads();
 
     const float K0 = 0.05f, K1 = 0.25f, K2 = 0.4f, K3 = 0.25f, K4 = 0.05f;
     // ---- per-lane horizontal weights, level A -> B (column J) and B -> C (column K); see band_kernel ----------
@@ -348,8 +354,106 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         }
     };
 
+    // ---- foveated tail: fov_a gathers the query of one pixel (and issues the four LDS reads of its LUT cell), fov_b blends and
+    // pools; pixels are evaluated two at a time so that their LDS reads are in flight together (band_kernel.hpp, fov_a / fov_b:
+    // the same expressions, which differ from band_px by rounding only) ------------------------------------------------------
+    struct FovQ {
+        float4 v00, v10, v01, v11;
+        float fY, fE, fR, llb;
+        v2f d[HP];
+    };
+    float gx = 0.0f, gy = 0.0f, vxa = 0.0f, vxb = 0.0f, vxB = 0.0f;
+    [[maybe_unused]] const float* s_vyA = nullptr;
+    [[maybe_unused]] const float* s_vyB = nullptr;
+    [[maybe_unused]] __amdgpu_buffer_rsrc_t rmA_rsrc, rmB_rsrc;
+    [[maybe_unused]] unsigned int rmA_col = 0, rmB_col = 0;
+    if constexpr (FOV) {
+        // pix2view_direction (fvvdp_display_model.py:498-510) on the grids of level A and level B, pixel centres at +0.5
+        const float kxa = a.size_m0 / (float)w / a.dist_m, kxb = a.size_m0 / (float)wb / a.dist_m;
+        vxa = atanf((((float)X0 + 0.5f) + (-(float)w / 2.0f)) * kxa) * 57.29577951308232f;
+        vxb = atanf((((float)X1 + 0.5f) + (-(float)w / 2.0f)) * kxa) * 57.29577951308232f;
+        vxB = atanf((((float)J + 0.5f) + (-(float)wb / 2.0f)) * kxb) * 57.29577951308232f;
+        const float fxp = a.fix[2 * frame + 0] + 0.5f, fyp = a.fix[2 * frame + 1] + 0.5f;
+        const float gxm = (fxp + (-(float)a.frame_w / 2.0f)) * a.size_m0 / (float)a.frame_w;
+        const float gym = -(fyp + (-(float)a.frame_h / 2.0f)) * a.size_m1 / (float)a.frame_h;
+        gx = atanf(gxm / a.dist_m) * 57.29577951308232f;
+        gy = atanf(gym / a.dist_m) * 57.29577951308232f;
+        s_vyA = reinterpret_cast<const float*>(s_lut_dyn + a.lut2_entries);
+        s_vyB = s_vyA + h;
+        // the rho-map records through buffer resources: scalar row offset, loop-invariant lane offset
+        rmA_rsrc = level_rsrc(reinterpret_cast<float*>(const_cast<float4*>(a.rmapA)), (unsigned int)(h * a.rmapA_w) * 16u);
+        rmB_rsrc = level_rsrc(reinterpret_cast<float*>(const_cast<float2*>(a.rmapB)), (unsigned int)(hb * wb) * 8u);
+        rmA_col = (unsigned int)min(max(J, 0), a.rmapA_w - 1) * 16u;
+        rmB_col = (unsigned int)min(max(J, 0), wb - 1) * 8u;
+    }
+    [[maybe_unused]] auto rmap_a = [&](int row) -> float4 {          // records of level-A row `row`, columns X0, X1
+        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rmA_rsrc, rmA_col, (unsigned int)(min(max(row, 0), h - 1) * a.rmapA_w) * 16u, 0));
+    };
+    [[maybe_unused]] auto rmap_b = [&](int row) -> float2 {          // record of level-B row `row`, column J
+        return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rmB_rsrc, rmB_col, (unsigned int)(min(max(row, 0), hb - 1) * wb) * 8u, 0));
+    };
+    [[maybe_unused]] auto fov_a = [&](const Px<P>& g, const Px<P>& e, float vx, float vy, float pre_fR, float pre_kR) -> FovQ {
+        FovQ q;
+        const float lb = fmaxf(e.h[0].y, a.lbkg_min);
+        const float dcap = a.cmax * lb;
+#pragma unroll
+        for (int k = 0; k < HP; ++k) q.d[k] = v2f{fminf(g.h[k].x - e.h[k].x, dcap), fminf(g.h[k].y - e.h[k].y, dcap)};
+        q.llb = fast_log2(lb);
+        const float yq = __builtin_amdgcn_fmed3f(q.llb, a.ly_lo, a.ly_hi);
+        const float dx = vx - gx, dy = vy - gy;
+        const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
+        const float eq = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fmed3f(ecc, a.ecc_lo, a.ecc_hi));
+        const float tY = fmaf(yq, a.f_inv_step[0], a.f_grid_off[0]);
+        const float iY = __builtin_amdgcn_fmed3f(floorf(tY), 0.0f, (float)(FVVDP_LUT_N - 2));
+        q.fY = (tY - iY) * a.f_frac_scale[0];
+        const float tE = fmaf(eq, a.f_inv_step[1], a.f_grid_off[1]);
+        const float iE = __builtin_amdgcn_fmed3f(floorf(tE), 0.0f, (float)(FVVDP_LUT_N - 2));
+        q.fE = (tE - iE) * a.f_frac_scale[1];
+        q.fR = pre_fR;
+        const int bo = (int)fmaf(iE, (float)(FOV_ROW * 16), fmaf(iY, 16.0f, pre_kR));
+        const float4* cell = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_lut_dyn) + bo);
+        q.v00 = cell[0];
+        q.v10 = cell[1];
+        q.v01 = cell[FOV_ROW];
+        q.v11 = cell[FOV_ROW + 1];
+        return q;
+    };
+    [[maybe_unused]] auto fov_b = [&](const FovQ& q, bool valid, const int band, float (&acc)[2]) {
+        const float fY = q.fY, fE = q.fE, fR = q.fR;
+        auto rho_blend = [&](const float4& v) { return pfma(v2f{v.z, v.w}, fR, v2f{v.x, v.y}); };
+        const v2f r00 = rho_blend(q.v00), r10 = rho_blend(q.v10), r01 = rho_blend(q.v01), r11 = rho_blend(q.v11);
+        const v2f y0 = pfma(r10 - r00, fY, r00), y1 = pfma(r11 - r01, fY, r01);
+        const v2f sl2 = pfma(y1 - y0, fE, y0);
+        const float vm = valid ? 1.0f : 0.0f;
+        const float lcn = lg_bm[band] - q.llb;
+        if constexpr (HP == 2) {
+            const v2f sl = sl2;
+            const v2f A = pfma(sl, pb, splat(fmaf(lcn, pb, pb_base)));
+            const v2f lsm = sl + splat(lcn + lg_mask);
+            const v2f ldiff = v2f{fast_log2(fabsf(q.d[0].x - q.d[0].y)), fast_log2(fabsf(q.d[1].x - q.d[1].y))};
+            const v2f lmin = v2f{fast_log2(fminf(fabsf(q.d[0].x), fabsf(q.d[0].y))), fast_log2(fminf(fabsf(q.d[1].x), fabsf(q.d[1].y)))};
+            const v2f ldb = pfma(ldiff, pb, A);
+            const v2f lm = (lmin + lsm) * v2f{a.q0, a.q1};
+            const v2f one_mq = v2f{fast_exp2(lm.x), fast_exp2(lm.y)} + splat(1.0f);
+            const v2f tb = pfma(v2f{fast_log2(one_mq.x), fast_log2(one_mq.y)}, -a.beta, ldb);
+            const v2f bl = v2f{fminf(tb.x, b_dmax), fminf(tb.y, b_dmax)};
+            const v2f term = v2f{fast_exp2(bl.x), fast_exp2(bl.y)};
+            const v2f av = __builtin_elementwise_fma(term, splat(vm), v2f{acc[0], acc[1]});
+            acc[0] = av.x;
+            acc[1] = av.y;
+        } else {
+            const float dT = q.d[0].x, dR = q.d[0].y;
+            const float ls = sl2.x + lcn;
+            const float ld = a.p * (fast_log2(fabsf(dT - dR)) + (ls + lg_base));
+            const float mq = fast_exp2(a.q0 * (fast_log2(fminf(fabsf(dT), fabsf(dR))) + (ls + lg_mask)));
+            const float ldd = fminf(ld - fast_log2(1.0f + mq), a.lg_dmax);
+            acc[0] = fmaf(fast_exp2(a.beta * ldd), vm, acc[0]);
+        }
+    };
+
     // band A for level-A rows 2c, 2c+1 (window rows 0, 1), expand from level-B rows c-1, c, c+1
-    auto band_a_rows = [&](auto base, int c, const Px<P>& Bm1, const Px<P>& B0, const Px<P>& Bp1) {
+    auto band_a_rows = [&](auto base, int c, const Px<P>& Bm1, const Px<P>& B0, const Px<P>& Bp1,
+                           [[maybe_unused]] const float4 ra = float4{0, 0, 0, 0}, [[maybe_unused]] const float4 rb = float4{0, 0, 0, 0}) {
         constexpr int B = decltype(base)::value;
         Px<P>(&W0)[2] = S[(B + 0) & 7]; Px<P>(&W1)[2] = S[(B + 1) & 7];
         Px<P> x00, x01, x10, x11, evE, evO;
@@ -370,10 +474,39 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
             dpp_expand_taps(evO.h[k], el, er, orr, x10.h[k], x11.h[k]);
         }
         const bool row1_ok = (2 * c + 1) < h;
-        tail(W0[0], x00, owned, 0, accA);
-        tail(W0[1], x01, owned && col1_ok, 0, accA);
-        tail(W1[0], x10, owned && row1_ok, 0, accA);
-        tail(W1[1], x11, owned && row1_ok && col1_ok, 0, accA);
+        if constexpr (FOV) {
+            const float vy0 = s_vyA[min(2 * c, h - 1)], vy1 = s_vyA[min(2 * c + 1, h - 1)];
+            __builtin_amdgcn_sched_barrier(0);
+#if FOV2_PHASE == 1      // one pixel at a time: 24 registers of LUT cell in flight instead of 48
+            { const FovQ q0 = fov_a(W0[0], x00, vxa, vy0, ra.x, ra.y); fov_b(q0, owned, 0, accA); }
+            __builtin_amdgcn_sched_barrier(0);
+            { const FovQ q1 = fov_a(W0[1], x01, vxb, vy0, ra.z, ra.w); fov_b(q1, owned && col1_ok, 0, accA); }
+            __builtin_amdgcn_sched_barrier(0);
+            { const FovQ q2 = fov_a(W1[0], x10, vxa, vy1, rb.x, rb.y); fov_b(q2, owned && row1_ok, 0, accA); }
+            __builtin_amdgcn_sched_barrier(0);
+            { const FovQ q3 = fov_a(W1[1], x11, vxb, vy1, rb.z, rb.w); fov_b(q3, owned && row1_ok && col1_ok, 0, accA); }
+#else
+            {
+                const FovQ q0 = fov_a(W0[0], x00, vxa, vy0, ra.x, ra.y);
+                const FovQ q1 = fov_a(W0[1], x01, vxb, vy0, ra.z, ra.w);
+                fov_b(q0, owned, 0, accA);
+                fov_b(q1, owned && col1_ok, 0, accA);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            {
+                const FovQ q2 = fov_a(W1[0], x10, vxa, vy1, rb.x, rb.y);
+                const FovQ q3 = fov_a(W1[1], x11, vxb, vy1, rb.z, rb.w);
+                fov_b(q2, owned && row1_ok, 0, accA);
+                fov_b(q3, owned && row1_ok && col1_ok, 0, accA);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            tail(W0[0], x00, owned, 0, accA);
+            tail(W0[1], x01, owned && col1_ok, 0, accA);
+            tail(W1[0], x10, owned && row1_ok, 0, accA);
+            tail(W1[1], x11, owned && row1_ok && col1_ok, 0, accA);
+        }
     };
 
     // ---- prologue: level-B row 2*ks and the window of the first step ---------------------------------------
@@ -402,7 +535,8 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
     }
 
     // band B for level-B rows g0 (even), g1 (odd) from the level-C history
-    auto band_b_rows = [&](const Px<P>& g0, const Px<P>& g1, int row0) {
+    auto band_b_rows = [&](const Px<P>& g0, const Px<P>& g1, int row0,
+                           [[maybe_unused]] const float2 qa = float2{0, 0}, [[maybe_unused]] const float2 qb = float2{0, 0}) {
         Px<P> evE, evO, e0, e1;
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
@@ -416,8 +550,24 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
             e0.h[k] = dpp_expand2_taps(evE.h[k] * fc, evE.h[k], fl, fr);
             e1.h[k] = dpp_expand2_taps(evO.h[k] * fc, evO.h[k], fl, fr);
         }
-        tail(g0, e0, owned && row0 < hb, 1, accB);
-        tail(g1, e1, owned && (row0 + 1) < hb, 1, accB);
+        if constexpr (FOV) {
+            const float vy0 = s_vyB[min(max(row0, 0), hb - 1)], vy1 = s_vyB[min(max(row0 + 1, 0), hb - 1)];
+            __builtin_amdgcn_sched_barrier(0);
+#if FOV2_PHASE == 1
+            { const FovQ q0 = fov_a(g0, e0, vxB, vy0, qa.x, qa.y); fov_b(q0, owned && row0 < hb, 1, accB); }
+            __builtin_amdgcn_sched_barrier(0);
+            { const FovQ q1 = fov_a(g1, e1, vxB, vy1, qb.x, qb.y); fov_b(q1, owned && (row0 + 1) < hb, 1, accB); }
+#else
+            const FovQ q0 = fov_a(g0, e0, vxB, vy0, qa.x, qa.y);
+            const FovQ q1 = fov_a(g1, e1, vxB, vy1, qb.x, qb.y);
+            fov_b(q0, owned && row0 < hb, 1, accB);
+            fov_b(q1, owned && (row0 + 1) < hb, 1, accB);
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+        } else {
+            tail(g0, e0, owned && row0 < hb, 1, accB);
+            tail(g1, e1, owned && (row0 + 1) < hb, 1, accB);
+        }
     };
 
     // ---- main loop: stage k = steps c = 2k, 2k+1, then level-C row k and band B of level-B rows 2k-2, 2k-1 ------
@@ -426,6 +576,14 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         Px<P> Be, Bo;
         {   // step c = 2k: level-B row 2k+1
             const int c = 2 * k;
+            // foveated: the rho-map records of this step's rows are requested BEFORE the rows of the next step (loads return in
+            // order: behind the row prefetch, the wait for a record is a wait for HBM, every step -- round 3)
+            float4 ra = float4{0, 0, 0, 0}, rb = ra;
+            if constexpr (FOV) {
+                ra = rmap_a(2 * c);
+                rb = rmap_a(2 * c + 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (STAGE) {
                 stage_read(stage_q, S[(BA + 5) & 7], S[(BA + 6) & 7]);
                 stage_issue(c + 2, stage_q >= 1u ? stage_q - 1u : 2u);       // slot (q + 2) % 3
@@ -436,10 +594,19 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
             }
             Be = coarse_step(basea);
             if (c + 1 >= hb) Be = R[4];                               // B[hb] = B[hb-1]
-            if (c >= ca && c < cb) band_a_rows(basea, c, R[3], R[4], Be);
+            if (c >= ca && c < cb) band_a_rows(basea, c, R[3], R[4], Be, ra, rb);
         }
+        float2 qa = float2{0, 0}, qb = qa;
         {   // step c = 2k+1: level-B row 2k+2
             const int c = 2 * k + 1;
+            float4 ra = float4{0, 0, 0, 0}, rb = ra;
+            if constexpr (FOV) {
+                ra = rmap_a(2 * c);
+                rb = rmap_a(2 * c + 1);
+                qa = rmap_b(2 * k - 2);                  // band B of level-B rows 2k-2, 2k-1 is evaluated at the end of this stage
+                qb = rmap_b(2 * k - 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             if constexpr (STAGE) {
                 stage_read(stage_q, S[(BB + 5) & 7], S[(BB + 6) & 7]);
                 stage_issue(c + 2, stage_q >= 1u ? stage_q - 1u : 2u);
@@ -450,7 +617,7 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
             }
             Bo = coarse_step(baseb);
             if (c + 1 >= hb) Bo = (c + 1 == hb) ? Be : R[3];          // B[hb] = B[hb-1];  B[hb+1] = B[hb-2]
-            if (c >= ca && c < cb) band_a_rows(baseb, c, R[4], Be, Bo);
+            if (c >= ca && c < cb) band_a_rows(baseb, c, R[4], Be, Bo, ra, rb);
         }
         // level-B window of this stage: rows 2k-2 .. 2k+2 (top: rows -2, -1 mirror to 1, 0)
         R[0] = R[2];
@@ -483,7 +650,7 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         CH[2] = Cn;
         if (k == 0) CH[1] = Cn;                                       // C[-1] = C[0] (index clamp of the expand)
         const int row0 = 2 * k - 2;
-        if (row0 >= ca && row0 < cb) band_b_rows(R[0], R[1], row0);
+        if (row0 >= ca && row0 < cb) band_b_rows(R[0], R[1], row0, qa, qb);
     };
     {
         int k = ks;
@@ -498,7 +665,14 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         const int row0 = 2 * hc - 2;
         CH[0] = CH[1];
         CH[1] = CH[2];
-        if (row0 >= ca && row0 < cb) band_b_rows(R[2], R[3], row0);
+        if (row0 >= ca && row0 < cb) {
+            float2 qa = float2{0, 0}, qb = qa;
+            if constexpr (FOV) {
+                qa = rmap_b(row0);
+                qb = rmap_b(row0 + 1);
+            }
+            band_b_rows(R[2], R[3], row0, qa, qb);
+        }
     }
 
     if constexpr (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA may outlive the workgroup's LDS
@@ -511,4 +685,66 @@ __global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) 
         a.partialB[o] = b0;
         a.partialB[o + 1] = b1;
     }
+}
+
+template <int P, bool INRANGE = false>
+__global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) {
+    __shared__ float4 s_csf[2][FVVDP_LUT_N];
+    __shared__ float4 s_stage[band2_stage(P) ? 3 * 4 * 64 : 1];
+    const int lane = threadIdx.x;
+    int bid;
+    {   // XCD-aware work order (see band_kernel)
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
+        bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
+    }
+    const int strip = bid % a.n_strips;
+    bid /= a.n_strips;
+    const int chunk = bid % a.n_chunks;
+    const int frame = bid / a.n_chunks;
+    if (lane < FVVDP_LUT_N) {
+        s_csf[0][lane] = a.csfA[lane];
+        s_csf[1][lane] = a.csfB[lane];
+    }
+    __syncthreads();
+    band2_item<P, INRANGE, false>(a, strip, chunk, frame, lane, s_csf, s_stage);
+}
+
+// Foveated two-level pass: FOV2_WPB independent waves per workgroup share the two bands' LUT slices and the row tables of
+// vertical view angles in dynamic LDS (layout: [lut2_entries float4][h floats][hb floats]); 2 workgroups per CU.
+#ifndef FOV2_WPB
+#define FOV2_WPB 4
+#endif
+#ifndef FOV2_MINB
+#define FOV2_MINB 2
+#endif
+template <int P>
+__global__ __launch_bounds__(64 * FOV2_WPB, FOV2_MINB) void band2_fov_kernel(const Band2Args a) {
+    const int lane = (int)(threadIdx.x & 63);
+    int bid;
+    {
+        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
+        bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
+        bid = bid * FOV2_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    }
+    // tables: LUT slices, then the vertical view angle of every row of level A and of level B (pix2view_direction,
+    // fvvdp_display_model.py:498-510: one atan per row and workgroup)
+    for (int i = (int)threadIdx.x; i < a.lut2_entries; i += 64 * FOV2_WPB) s_lut_dyn[i] = a.lut2[i];
+    float* s_vy = reinterpret_cast<float*>(s_lut_dyn + a.lut2_entries);
+    for (int i = (int)threadIdx.x; i < a.h + a.hb; i += 64 * FOV2_WPB) {
+        const bool lvA = i < a.h;
+        const int r = lvA ? i : i - a.h, hh = lvA ? a.h : a.hb;
+        const float kyb = a.size_m1 / (float)hh / a.dist_m;
+        const float yp = ((float)r + 0.5f) + (-(float)hh / 2.0f);
+        s_vy[i] = atanf(-yp * kyb) * 57.29577951308232f;
+    }
+    __syncthreads();
+    if (bid >= a.n_items) return;
+    // frame fastest: an XCD walks all frames of a tile before the next tile, the tile's slice of the (frame-invariant) rho
+    // maps stays in that XCD's L2
+    const int n_tiles = a.n_strips * a.n_chunks, n_frames = a.n_items / n_tiles;
+    const int frame = bid % n_frames;
+    bid /= n_frames;
+    const int strip = bid % a.n_strips;
+    const int chunk = bid / a.n_strips;
+    band2_item<P, false, true>(a, strip, chunk, frame, lane, nullptr, nullptr);
 }

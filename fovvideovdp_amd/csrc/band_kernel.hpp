@@ -181,6 +181,9 @@ struct RhoMapArgs {
     float rho_band, rho_lo, rho_hi, first, inv_step;
     int i_lo, rw;
     const float* axis;      // [32] rho_log knots
+    int plane_bytes;        // bytes of one rho plane of the slice this map indexes (FOV_PLANE * 16 for the one-level kernels)
+    int base_bytes;         // byte offset of the band's first plane in the kernel's LDS (two-level kernel: band B follows band A)
+    float2* out_px;         // != nullptr: one {f, k} record per PIXEL [h][w] instead of `out` (level B of the two-level kernel)
 };
 __global__ __launch_bounds__(256) void fov_rho_map_kernel(const RhoMapArgs a) {
     const int J = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
@@ -204,9 +207,14 @@ __global__ __launch_bounds__(256) void fov_rho_map_kernel(const RhoMapArgs a) {
         const float x0 = a.axis[k], x1 = a.axis[k + 1 < FVVDP_LUT_N ? k + 1 : k];
         const float f = fmaxf((rq - x0) * (1.0f / (x1 - x0 + 0.000001f)), 0.0f);
         r[2 * i] = f;
-        r[2 * i + 1] = (float)((k - a.i_lo) * (FOV_PLANE * 16));
+        r[2 * i + 1] = (float)((k - a.i_lo) * a.plane_bytes + a.base_bytes);
     }
-    a.out[(size_t)y * pw + J] = make_float4(r[0], r[1], r[2], r[3]);
+    if (a.out_px) {
+        a.out_px[(size_t)y * a.w + 2 * J] = make_float2(r[0], r[1]);
+        if (2 * J + 1 < a.w) a.out_px[(size_t)y * a.w + 2 * J + 1] = make_float2(r[2], r[3]);
+    } else {
+        a.out[(size_t)y * pw + J] = make_float4(r[0], r[1], r[2], r[3]);
+    }
 }
 
 

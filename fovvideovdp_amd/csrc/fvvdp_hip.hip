@@ -83,6 +83,15 @@ struct fvvdp_ctx {
     float4* sublut[FVVDP_MAX_BANDS]{};         // per-band rho slices, rebuilt when the geometry changes
     float4* rmap[FVVDP_MAX_BANDS]{};           // per-band rho-axis coordinates of every pixel pair (stock geometry)
     int sub_rw[FVVDP_MAX_BANDS]{}, sub_ilo[FVVDP_MAX_BANDS]{};
+    // two-level foveated pass over levels 0+1 (band2_fov_kernel): both bands' LUT slices trimmed to the eccentricities the
+    // display can show, the rho maps that index them (level 0 per pixel pair, level 1 per pixel)
+    bool fov2_ok = false;
+    float4* lut2 = nullptr;
+    int lut2_entries = 0;
+    size_t fov2_lds = 0;
+    float4* rmap2A = nullptr;
+    float2* rmap2B = nullptr;
+    long long wave_capacity_fov2 = 2048;
     fvvdp_geom sub_geom{};
     const float* map_vx[FVVDP_MAX_BANDS]{};    // user-geometry maps (owned by the caller)
     const float* map_vy[FVVDP_MAX_BANDS]{};
@@ -373,6 +382,9 @@ extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
         dev_free(c, c->sublut[b]);
         dev_free(c, c->rmap[b]);
     }
+    dev_free(c, c->lut2);
+    dev_free(c, c->rmap2A);
+    dev_free(c, c->rmap2B);
     vmm_free_all(c);
     for (auto& v : c->ev)
         for (auto& pr : v) {
@@ -943,6 +955,105 @@ extern "C" int fvvdp_export_level(fvvdp_ctx* c, int level, int n, float* d_out, 
 // [ecc][Y][rho] of float4 {S0[i], S1[i], S0[i+1], S1[i+1]} so that one aligned 16-byte load returns the two rho
 // corners of both temporal channels (value at knot i and the step to knot i+1: v[i] + f*(v[i+1]-v[i])) and neighbouring
 // pixels (similar ecc, Y) share cache lines.
+// Tables of the two-level foveated pass over levels 0+1 (band2_fov_kernel): stock geometry only.  Both bands' slices must sit
+// in LDS next to the row tables of both levels with two workgroups per CU (80 KB each); they fit because the ecc axis is cut
+// at the largest eccentricity the display can show with the gaze on the screen (twice the view angle of its corner;
+// standard_hdr_pq at 4K: 23 of the 32 ecc rows, 4 planes of 13.4 KB + 13 KB of row tables).
+static int build_fov2(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
+    c->fov2_ok = false;
+    // OFF unless FVVDP_FOV_FUSE=1: built for VERDICT r3 item 2 and measured on configs[3] (profiles/r04_fov_two_level.md): 50.5-51.7
+    // us per 4K frame for levels 0+1 against 49.4-50.4 us for the two one-level launches -- the foveated tail is arithmetic (13
+    // transcendentals, 8 LDS reads and the trilinear blend per pixel), the two-level strips own 54 of 64 lanes where the
+    // one-level strips own 60, and with both slices in LDS and 196-205 registers only 2 waves per SIMD fit.
+    const char* fe = getenv("FVVDP_FOV_FUSE");
+    const bool off = !(fe && fe[0] == '1');
+    if (!g || off || getenv("FVVDP_FOV_NO_RHOMAP") || c->n_bands < 2) return FVVDP_OK;
+    if ((long long)c->lw[0] * c->lh[0] < 1500000 && !getenv("FVVDP_BAND_FUSE")) return FVVDP_OK;     // small frames: one level per launch
+    if (c->lw[1] < 4 || c->lh[1] < 4 || c->lw[2] < 2 || c->lh[2] < 2) return FVVDP_OK;
+    const double ax = atan(0.5 * g->display_size_m[0] / g->distance_m) * 180.0 / M_PI;
+    const double ay = atan(0.5 * g->display_size_m[1] / g->distance_m) * 180.0 / M_PI;
+    const double ecc_max = fmin(2.0 * sqrt(ax * ax + ay * ay) * 1.02, (double)c->ecc_hi);
+    const float* xe = c->h_axes[2];
+    const double e_step = ((double)xe[FVVDP_LUT_N - 1] - (double)xe[0]) / (FVVDP_LUT_N - 1);
+    int n_e = (int)floor((sqrt(ecc_max) - (double)xe[0]) / e_step) + 3;      // rows iE and iE + 1 of every reachable interval, + 1
+    if (const char* e = getenv("FVVDP_FOV2_NE")) n_e = atoi(e);            // debugging: rows of the ecc axis kept in the slices
+    if (n_e > FVVDP_LUT_N) n_e = FVVDP_LUT_N;
+    if (n_e < 2) n_e = 2;
+    const int plane_e = n_e * FOV_ROW + 8;
+    const int rwA = c->sub_rw[0], rwB = c->sub_rw[1];
+    const size_t entries = (size_t)(rwA + rwB) * plane_e;
+    const size_t lds = entries * sizeof(float4) + (size_t)(c->lh[0] + c->lh[1]) * sizeof(float);
+    if (lds > 80 * 1024) return FVVDP_OK;                                   // two workgroups per CU or not at all
+    std::vector<float4> h(entries, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
+    const float* L0 = c->h_lut3[0].data();
+    const float* L1 = c->h_lut3[1].empty() ? L0 : c->h_lut3[1].data();
+    for (int b = 0; b < 2; ++b) {
+        const int base_plane = b == 0 ? 0 : rwA, rw = c->sub_rw[b], i_lo = c->sub_ilo[b];
+        for (int i = 0; i < rw; ++i)
+            for (int k = 0; k < n_e; ++k)
+                for (int j = 0; j < FVVDP_LUT_N; ++j) {
+                    const size_t s0 = ((size_t)j * FVVDP_LUT_N + (i_lo + i)) * FVVDP_LUT_N + k;       // [Y][rho][ecc]
+                    const size_t s1 = ((size_t)j * FVVDP_LUT_N + (i_lo + i + 1)) * FVVDP_LUT_N + k;
+                    h[(size_t)(base_plane + i) * plane_e + (size_t)k * FOV_ROW + j] = make_float4(L0[s0], L1[s0], L0[s1] - L0[s0], L1[s1] - L1[s0]);
+                }
+    }
+    if (c->lut2 && c->lut2_entries != (int)entries) {
+        dev_free(c, c->lut2);
+        c->lut2 = nullptr;
+    }
+    int rc = FVVDP_OK;
+    if (!c->lut2) rc = dev_alloc(c, &c->lut2, entries);
+    if (rc == FVVDP_OK && !c->rmap2A) rc = dev_alloc(c, &c->rmap2A, (size_t)((c->lw[0] + 1) / 2) * c->lh[0]);
+    if (rc == FVVDP_OK && !c->rmap2B) rc = dev_alloc(c, &c->rmap2B, (size_t)c->lw[1] * c->lh[1]);
+    if (rc != FVVDP_OK) return rc;
+    HIP_TRY(hipMemcpy(c->lut2, h.data(), entries * sizeof(float4), hipMemcpyHostToDevice));
+    c->lut2_entries = (int)entries;
+    c->fov2_lds = lds;
+    for (int b = 0; b < 2; ++b) {
+        RhoMapArgs ra;
+        memset(&ra, 0, sizeof(ra));
+        ra.w = c->lw[b];
+        ra.h = c->lh[b];
+        ra.size_m0 = g->display_size_m[0];
+        ra.size_m1 = g->display_size_m[1];
+        ra.dist_m = g->distance_m;
+        const double delta = (1.0 / (double)g->ppd_centre) / 2.0 * M_PI / 180.0;
+        ra.delta_rad = (float)delta;
+        ra.cos_delta = (float)cos(delta);
+        ra.rho_band = (float)c->rho_band[b];
+        ra.rho_lo = c->rho_lo;
+        ra.rho_hi = c->rho_hi;
+        ra.first = c->h_axes[1][0];
+        ra.inv_step = (float)(FVVDP_LUT_N - 1) / (c->h_axes[1][FVVDP_LUT_N - 1] - c->h_axes[1][0]);
+        ra.i_lo = c->sub_ilo[b];
+        ra.rw = c->sub_rw[b];
+        ra.axis = c->d_axes + FVVDP_LUT_N;
+        ra.plane_bytes = plane_e * 16;
+        ra.base_bytes = b == 0 ? 0 : rwA * plane_e * 16;
+        if (b == 0) ra.out = c->rmap2A; else ra.out_px = c->rmap2B;
+        const int pw = (c->lw[b] + 1) / 2;
+        hipLaunchKernelGGL(fov_rho_map_kernel, dim3((pw + 255) / 256, c->lh[b]), dim3(256), 0, st, ra);
+    }
+    {
+        int per_cu = 2, cus = 256, dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
+        hipError_t e;
+        if (c->P == 4) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band2_fov_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, band2_fov_kernel<4>, 64 * FOV2_WPB, lds);
+        } else {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band2_fov_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, band2_fov_kernel<2>, 64 * FOV2_WPB, lds);
+        }
+        if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
+        c->wave_capacity_fov2 = (long long)per_cu * FOV2_WPB * cus;
+    }
+    HIP_TRY(hipGetLastError());
+    c->fov2_ok = true;
+    return FVVDP_OK;
+}
+
 static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
     fvvdp_geom key;
     memset(&key, 0, sizeof(key));
@@ -1021,8 +1132,13 @@ static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
             ra.i_lo = i_lo;
             ra.rw = rw;
             ra.axis = c->d_axes + FVVDP_LUT_N;
+            ra.plane_bytes = FOV_PLANE * 16;
             hipLaunchKernelGGL(fov_rho_map_kernel, dim3((pw + 255) / 256, c->lh[b]), dim3(256), 0, st, ra);
         }
+    }
+    {
+        int rc = build_fov2(c, g, st);
+        if (rc != FVVDP_OK) return rc;
     }
     c->sub_geom = key;
     c->sub_valid = true;
@@ -1111,9 +1227,15 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
     const char* fuse_env = getenv("FVVDP_BAND_FUSE");
     const int fuse_mode = (fuse_env && (fuse_env[0] == '0' || fuse_env[0] == '1')) ? fuse_env[0] - '0' : -1;   // anything else: automatic
     const bool fuse_ok = !fov && !any_maps && fuse_mode != 0;
+    // foveated: levels 0+1 in one pass when the tables of build_fov2 exist and every gaze point lies on the screen (their ecc axis
+    // is cut at the eccentricities such a gaze can produce)
+    bool fov2 = fov && geom && c->fov2_ok && !any_maps && fuse_mode != 0;
+    if (fov2)
+        for (int f = 0; f < n; ++f)
+            if (!(h_fixation[2 * f] >= -0.5f && h_fixation[2 * f] <= (float)c->W && h_fixation[2 * f + 1] >= -0.5f && h_fixation[2 * f + 1] <= (float)c->H)) fov2 = false;
     for (int b = 0; b < c->n_bands; ++b) {
         const bool big = (long long)c->lw[b] * c->lh[b] >= 1500000;
-        if (fuse_ok && (big || fuse_mode == 1) && b + 1 < c->n_bands && c->lw[b + 1] >= 4 && c->lh[b + 1] >= 4 &&
+        if ((fuse_ok || (fov2 && b == 0)) && (big || fuse_mode == 1) && b + 1 < c->n_bands && c->lw[b + 1] >= 4 && c->lh[b + 1] >= 4 &&
             c->lw[b + 2] >= 2 && c->lh[b + 2] >= 2) {
             Band2Args a;
             memset(&a, 0, sizeof(a));
@@ -1126,7 +1248,7 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
             a.wc = c->lw[b + 2];
             a.hc = c->lh[b + 2];
             a.n_strips = band2_strips(a.wb);
-            chunking2(a.hc, a.n_strips, n, c->wave_capacity2, a.n_chunks, a.kr);
+            chunking2(a.hc, a.n_strips, n, fov ? c->wave_capacity_fov2 : c->wave_capacity2, a.n_chunks, a.kr);
             a.mulA = (b == 0) ? 1.0f : 2.0f;
             a.mulB = 2.0f;
             a.csfA = c->csf + (size_t)b * FVVDP_LUT_N;
@@ -1150,9 +1272,37 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
             if (nblk > c->max_blk[b] || nblk > c->max_blk[b + 1]) return fail(FVVDP_ESTATE, "internal: partial buffer too small");
             {
                 Timed tm(c, 1 + b, st);
+                if (fov) {
+                    a.lut2 = c->lut2;
+                    a.lut2_entries = c->lut2_entries;
+                    a.n_items = nblk * n;
+                    a.rmapA = c->rmap2A;
+                    a.rmapA_w = (c->lw[0] + 1) / 2;
+                    a.rmapB = c->rmap2B;
+                    a.fix = c->d_fix;
+                    a.size_m0 = geom->display_size_m[0];
+                    a.size_m1 = geom->display_size_m[1];
+                    a.dist_m = geom->distance_m;
+                    a.frame_w = c->W;
+                    a.frame_h = c->H;
+                    a.ecc_lo = c->ecc_lo;
+                    a.ecc_hi = c->ecc_hi;
+                    for (int ax = 0; ax < 2; ++ax) {
+                        const int src = ax == 0 ? 0 : 2;                       // Y axis, ecc axis
+                        const float first = c->h_axes[src][0];
+                        a.f_inv_step[ax] = (float)(FVVDP_LUT_N - 1) / (c->h_axes[src][FVVDP_LUT_N - 1] - first);
+                        const double step = ((double)c->h_axes[src][FVVDP_LUT_N - 1] - (double)first) / (FVVDP_LUT_N - 1);
+                        a.f_frac_scale[ax] = (float)(step / (step + 1e-6));
+                        a.f_grid_off[ax] = -first * a.f_inv_step[ax];
+                    }
+                    if (getenv("FVVDP_DEBUG_VARIANT")) fprintf(stderr, "fvvdp: levels %d+%d: band2_fov_kernel<%d>, %d waves, %zu bytes of LDS per workgroup\n", b, b + 1, c->P, nblk * n, c->fov2_lds);
+                    const dim3 gridf((nblk * n + FOV2_WPB - 1) / FOV2_WPB), blockf(64 * FOV2_WPB);
+                    if (c->P == 4) hipLaunchKernelGGL((band2_fov_kernel<4>), gridf, blockf, c->fov2_lds, st, a);
+                    else hipLaunchKernelGGL((band2_fov_kernel<2>), gridf, blockf, c->fov2_lds, st, a);
+                } else {
                 const bool inrange = clamps_never_bind(c, b, 2);
-                static const bool say = getenv("FVVDP_DEBUG_VARIANT") != nullptr;       // tests: which variant was launched
-                if (say) fprintf(stderr, "fvvdp: levels %d+%d: band2_kernel<%d, %s>, luminance range %s [%g, %g], widest plane range %g\n",
+                if (getenv("FVVDP_DEBUG_VARIANT"))       // tests: which variant was launched
+                    fprintf(stderr, "fvvdp: levels %d+%d: band2_kernel<%d, %s>, luminance range %s [%g, %g], widest plane range %g\n",
                                  b, b + 1, c->P, inrange ? "true" : "false", c->lum_state == 1 ? "known" : "unknown", c->lum_lo, c->lum_hi, c->lum_width);
                 if (c->P == 4) {
                     if (inrange) hipLaunchKernelGGL((band2_kernel<4, true>), dim3(nblk * n), dim3(64), 0, st, a);
@@ -1160,6 +1310,7 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
                 } else {
                     if (inrange) hipLaunchKernelGGL((band2_kernel<2, true>), dim3(nblk * n), dim3(64), 0, st, a);
                     else hipLaunchKernelGGL((band2_kernel<2, false>), dim3(nblk * n), dim3(64), 0, st, a);
+                }
                 }
             }
             for (int bb = b; bb <= b + 1; ++bb) {
