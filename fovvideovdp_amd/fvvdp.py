@@ -288,11 +288,19 @@ class fvvdp:
         fix = self._fixation(fixation_point, width, height, N_frames) if self.foveated else None
 
         n_out = f1 - f0
-        widx = window_frame_indices(N_frames, fl, self.temp_padding) if not is_image else np.zeros(1, np.int32)
+        wkey = (N_frames, fl, self.temp_padding, f0, f1, is_image)
+        wc = self._filters.get(wkey)
+        if wc is None:
+            widx = window_frame_indices(N_frames, fl, self.temp_padding) if not is_image else np.zeros(1, np.int32)
+            wc = (widx, np.unique(widx[f0:f1 + fl - 1]))
+            if len(self._filters) > 64:
+                self._filters.clear()
+            self._filters[wkey] = wc
+        widx, need = wc
         # source frames this call touches: the windows of output frames [f0, f1) (frame sharding: a rank's own frames plus
         # the fl-1 frames of temporal halo before them) -- host-resident sources upload these and nothing else
         self.last_h2d_bytes = 0
-        feeder = self._make_feeder(vid_source, width, height, np.unique(widx[f0:f1 + fl - 1]))
+        feeder = self._make_feeder(vid_source, width, height, need)
         batch = self._batch_size(width, height, planes, n_out, fl)
         schedule = None
         # stage overlap: sources the kernels read where they lie (arrays, raw YUV frames), plain evaluation, stock geometry
@@ -560,7 +568,11 @@ class fvvdp:
         p = nat.Params()
         p.mask_p = self.mask_p
         p.mask_q[0], p.mask_q[1] = self.mask_q_sust, self.mask_q_trans
-        p.mask_k = float(torch.pow(torch.tensor(10.0), torch.tensor(self.mask_c)))
+        mk = self.__dict__.get("_mask_k")
+        if mk is None or mk[0] != self.mask_c:                  # fp32 power like the reference's (fvvdp.py:585), once per value
+            mk = (self.mask_c, float(torch.pow(torch.tensor(10.0), torch.tensor(self.mask_c))))
+            self._mask_k = mk
+        p.mask_k = mk[1]
         p.beta = self.beta
         p.sens_gain = 10.0 ** (self.sensitivity_correction / 20.0)
         p.lbkg_min, p.contrast_max, p.d_max = 0.1, 1000.0, 1e4

@@ -37,6 +37,8 @@ def reshuffle_dims(T: Tensor, in_dims: str, out_dims: str) -> Tensor:
     """Permute `T` from dimension order `in_dims` (e.g. "HWC") to `out_dims` (e.g. "BCFHW"); dimensions missing
     from `in_dims` become singletons."""
     in_dims, out_dims = in_dims.upper(), out_dims.upper()
+    if in_dims == out_dims:
+        return T                      # already in the requested order (the common call: "BCFHW" tensors)
     present = [d for d in out_dims if d in in_dims]
     T_p = T.permute([in_dims.index(d) for d in present])
     shape = [T_p.shape[present.index(d)] if d in present else 1 for d in out_dims]

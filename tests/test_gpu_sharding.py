@@ -175,3 +175,33 @@ def test_bench_multi_rank_step_under_rccl():
     device buffer, the barrier before destroy_process_group.  Skipped on single-GPU boxes."""
     out, dims = _run_bench_two_ranks("nccl")
     _check_bench_line(out, dims, "nccl")
+
+
+def test_predict_batch_equals_single_calls():
+    """fvvdp.predict_batch (BASELINE configs[4]: many independent pairs per GPU): every pair queued without host synchronisation,
+    the caller's stream joins once.  Same numbers as one synchronous predict() per pair, in the sequential order and with the
+    stage overlap; a failing pair (shape mismatch) does not leave the metric in the deferred state."""
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair
+    pairs = [synth_video_pair(24, 135, 240, device="cuda", pair=k) for k in range(5)]
+    ref = fv.fvvdp(display_name="standard_fhd")
+    want = [ref.predict(t, r, frames_per_second=FPS) for (t, r) in pairs]
+    for pl in (0, 2):
+        m = fv.fvvdp(display_name="standard_fhd")
+        m.pipeline = pl
+        out = m.predict_batch(pairs, frames_per_second=FPS)
+        assert len(out) == len(pairs) and not m._defer_wait and m._pending is None
+        for (q, st), (q0, st0) in zip(out, want):
+            assert st["Q_per_ch"].is_cuda
+            fv.fvvdp.finish(st)
+            if pl == 0:
+                assert float(q) == float(q0) and np.array_equal(st["Q_per_ch"], st0["Q_per_ch"])
+            else:
+                assert abs(float(q) - float(q0)) < 2e-6
+                assert np.allclose(st["Q_per_ch"], st0["Q_per_ch"], rtol=3e-6, atol=1e-9 * st0["Q_per_ch"].max())
+        bad = pairs[:2] + [(pairs[0][0], pairs[1][1][:, :, :5])]
+        with pytest.raises(RuntimeError):
+            m.predict_batch(bad, frames_per_second=FPS)
+        assert not m._defer_wait and m._pending is None
+        q, st = m.predict(pairs[3][0], pairs[3][1], frames_per_second=FPS)          # still usable, synchronous
+        assert abs(float(q) - float(want[3][0])) < 2e-6

