@@ -127,7 +127,11 @@ struct fvvdp_ctx {
 // pyramid kernels that read the buffer do not change (34.0 us for levels 0+1 either way).  This was the "placement mode" of
 // rounds 2-3: a hipMalloc on a box with fragmented free memory happens to be pieced together the same way.
 // FVVDP_ALLOC=malloc goes back to hipMalloc (A/B runs), FVVDP_VMM_CHUNK_MB overrides the chunk size.
-static const size_t VMM_MIN_BYTES = (size_t)256 << 20;     // buffers below this stay with hipMalloc
+// tools/microbench/chunks.hip (profiles/r04_level0_chunks.md): it is the WRITES that a contiguous range slows down -- write only
+// 5.8-6.0 -> 6.9-7.1 TB/s, copy 5.3-5.4 -> 6.0-6.1, reads unchanged at 6.1-6.4 -- so every level that a kernel writes is mapped
+// this way, the smaller ones (16 ... 256 MB) from 4 MB chunks.
+static const size_t VMM_MIN_BYTES = (size_t)16 << 20;      // buffers below this stay with hipMalloc
+static const size_t VMM_BIG_BYTES = (size_t)256 << 20;     // from here on: 32 MB chunks (FVVDP_VMM_CHUNK_MB), below: 4 MB
 
 static int vmm_alloc(fvvdp_ctx* c, void** out, size_t bytes);
 static void vmm_free_all(fvvdp_ctx* c);
@@ -181,10 +185,10 @@ static int vmm_alloc(fvvdp_ctx* c, void** out, size_t bytes) {
     size_t gran = 0;
     HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
     if (gran == 0) gran = (size_t)2 << 20;
-    size_t chunk = (size_t)32 << 20;
+    size_t chunk = bytes >= VMM_BIG_BYTES ? (size_t)32 << 20 : (size_t)4 << 20;
     if (const char* g = getenv("FVVDP_VMM_CHUNK_MB")) {
         const size_t v = (size_t)atoll(g) << 20;
-        if (v >= gran) chunk = v;
+        if (v >= gran && bytes >= VMM_BIG_BYTES) chunk = v;
     }
     chunk = (chunk + gran - 1) / gran * gran;
     const size_t size = (bytes + chunk - 1) / chunk * chunk;

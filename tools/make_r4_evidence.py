@@ -54,10 +54,10 @@ level-0 scratch, and an online selection between two `hipMalloc` buffers that di
 1. The selection was rebuilt on the SUM temporal + pyramid time with warm candidates (VERDICT r3 item 3) and measured on three boxes
    (sessions 1 and 3 below): on a box with free memory BOTH `hipMalloc` buffers are in the slow mode (K1 37.4-38.1 us in all 12
    processes of session 3, with or without the selection) -- there is nothing to select.
-2. What decides the mode is whether the buffer is ONE physically contiguous range.  `hipMalloc` of 8 GB on a fresh box returns one;
+2. What decides the mode on most boxes is whether the buffer is ONE physically contiguous range.  `hipMalloc` of 8 GB on a fresh box returns one;
    the same virtual range mapped from physical chunks (`hipMemCreate` x n, `hipMemMap`) of 2 ... 128 MB puts K1 in the fast mode
-   every time, and the pyramid kernel that reads the buffer does not change (session 4; 512 MB chunks: half way).
-3. The library now maps every pyramid level of >= 256 MB from 32 MB chunks (`vmm_alloc` in `csrc/fvvdp_hip.hip`;
+   on those boxes every time (two of the ~14 boxes of the round stay slow in every allocation mode: last section), and the pyramid kernel that reads the buffer does not change (session 4; 512 MB chunks: half way).
+3. The library now maps every pyramid level of >= 256 MB from 32 MB chunks (>= 16 MB from 4 MB chunks since the microbenchmark of the last section) (`vmm_alloc` in `csrc/fvvdp_hip.hip`;
    `FVVDP_ALLOC=malloc` goes back); the selection machinery and its C entry point were removed.  Same-box A/B of the bench line
    (session 5): 4.57 -> 4.25 ms per 4K x 60 pair, bit-identical results (`test_chunk_mapped_scratch_gives_the_same_results_as_hipmalloc`).
    Creating the 4K x 60 context (about 330 chunks of 32 MB) and touching it for the first time: 20 ms (session 5, last lines).
@@ -87,7 +87,41 @@ The selection compared 75.5-76.3 (incumbent) with 74.4-75.0 us per frame (candid
 ```
 %s
 ```
-""" % (table(lines("r4s3", "*.json")), table(lines("r4s4", "*.json")), table(lines("r4s5", "*.json")), rd("r4s9/fov_chunks.txt")))
+
+## Later sessions (15, 16 and three more boxes): not every box has the fast mode
+
+`tools/experiments/r4_session15.sh` / `r4_session16.sh`; `stride*` = the chunks mapped in a permuted order (virtual slot i <- physical chunk
+i * stride mod n), `linear*` = creation order, the digit = chunk size in MB, `src_expandable` = the SOURCE arrays in chunk-mapped memory as
+well (`PYTORCH_HIP_ALLOC_CONF=expandable_segments:True`), `l0_malloc` = `FVVDP_ALLOC=malloc`.  ms per pair, K1 / levels 0+1 / all levels us per frame.
+
+Session 15 -- a box on which K1 takes 37.4-38.5 us per frame in EVERY allocation mode, although its hipMalloc memory is of the
+fast-write kind (microbenchmark below the table: 7.09 TB/s write-only on hipMalloc).  Neither the mapping order nor 2 MB chunks change it:
+
+```
+%s
+%s
+```
+
+Session 16 (last call) and three further boxes:
+
+```
+%s
+%s
+```
+
+Over the boxes of the round (shipped default, 32 MB chunks): K1 30.6, 31.6, 32.0-32.9, 32.8, 33.3, 33.3, 33.8, 37.1, 37.5 us per frame;
+with hipMalloc: 37.0-38.1 on nine boxes, 35.1-36.0, 32.9, 32.0 on three.  The chunk-mapped scratch is faster on most boxes, equal on some,
+4 %% slower on one, and there are boxes where nothing helps; what those boxes have in common is not known to me (same kernel, pyramid
+kernels and streaming microbenchmarks at their usual rates).  The permuted mapping order was not kept.
+
+`tools/microbench/chunks.hip` on a box whose hipMalloc returns one contiguous range, TB/s -- it is the WRITES that such a range slows down
+(write only 5.8-6.0 -> 6.9-7.1, copy 5.3-5.4 -> 6.0-6.1, reads unchanged); since then every level of >= 16 MB is chunk-mapped:
+
+```
+%s
+```
+""" % (table(lines("r4s3", "*.json")), table(lines("r4s4", "*.json")), table(lines("r4s5", "*.json")), rd("r4s9/fov_chunks.txt"),
+       rd("r4s15/order.txt"), rd("r4s15/chunks_microbench.txt"), rd("r4s16/src.txt"), rd("r4s16/three_more_boxes.txt"), rd("r4_chunks_microbench.txt")))
 
 # ---------------------------------------------------------------------------------------------------------------------------
 write("r04_stage_overlap.md", """# Round 4: temporal kernel of batch b+1 against the pyramid pass of batch b on two streams (VERDICT r3 item 1b) -- built, measured, off

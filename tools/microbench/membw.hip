@@ -3,6 +3,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
+#include <cstring>
+#include <string>
 
 template <int UNROLL>
 __global__ __launch_bounds__(256) void read_f4(const float4* __restrict__ p, size_t n4, float* out) {
@@ -35,18 +38,19 @@ __global__ __launch_bounds__(256) void copy_f4(const float4* __restrict__ p, flo
 // the band kernel's read pattern: single-wave workgroups, each walks down `rows` rows of a [H][W] float4 image,
 // reading 2 x float4 per lane per row (lane l: pixels 2l, 2l+1 of a 128-pixel strip), 2 rows per step, prefetch 1.
 __device__ size_t g_skew = 0;
-template <int ACTIVE, int HALO_L, int NT>
-__global__ __launch_bounds__(64) void read_strips(const float4* __restrict__ img, int W, int H, int n_strips, int chunk_rows,
+template <int ACTIVE, int HALO_L, int NT, int WPB = 1>
+__global__ __launch_bounds__(64 * WPB) void read_strips(const float4* __restrict__ img, int W, int H, int n_strips, int chunk_rows,
                                                   int n_chunks, float4* __restrict__ coarse, float* out) {
     int bid;
     {
         const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
         bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
+        bid = bid * WPB + (int)(threadIdx.x >> 6);        // WPB adjacent strips per workgroup, kept in step by a barrier
     }
     const int strip = bid % n_strips;
     const int chunk = (bid / n_strips) % n_chunks;
     const int frame = bid / (n_strips * n_chunks);
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int x0 = min(max(strip * 2 * ACTIVE + 2 * (lane - HALO_L), 0), W - 2);
     const float4* base = img + (size_t)frame * ((size_t)W * H + g_skew);
     const int r0 = chunk * chunk_rows, r1 = min(r0 + chunk_rows, H);
@@ -60,6 +64,7 @@ __global__ __launch_bounds__(64) void read_strips(const float4* __restrict__ img
     float4 c = LD((size_t)(r0 + 1) * W + x0), d = LD((size_t)(r0 + 1) * W + x0 + 1);
     for (int r = r0; r < r1; r += 2) {
         const float4 a0 = a, b0 = b, c0 = c, d0 = d;
+        if constexpr (WPB > 1) __syncthreads();
         const int rn = min(r + 2, H - 2);
         a = LD((size_t)rn * W + x0); b = LD((size_t)rn * W + x0 + 1);
         c = LD((size_t)(rn + 1) * W + x0); d = LD((size_t)(rn + 1) * W + x0 + 1);
@@ -80,8 +85,32 @@ __global__ __launch_bounds__(64) void read_strips(const float4* __restrict__ img
     if (acc == 123.456f) out[0] = acc;
 }
 
-#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); exit(1); } } while (0)
 
+struct Buf { void* ptr; size_t size; std::vector<hipMemGenericAllocationHandle_t> h; bool vmm; };
+static Buf alloc(size_t bytes, size_t chunk) {
+    Buf b; b.vmm = chunk != 0; b.size = bytes; b.ptr = nullptr;
+    if (!chunk) { CK(hipMalloc(&b.ptr, bytes)); return b; }
+    int dev = 0; CK(hipGetDevice(&dev));
+    hipMemAllocationProp prop; memset(&prop, 0, sizeof(prop));
+    prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+    size_t gran = 0; CK(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
+    chunk = (chunk + gran - 1) / gran * gran;
+    b.size = (bytes + chunk - 1) / chunk * chunk;
+    CK(hipMemAddressReserve(&b.ptr, b.size, gran, nullptr, 0));
+    for (size_t i = 0; i < b.size / chunk; ++i) {
+        hipMemGenericAllocationHandle_t h; CK(hipMemCreate(&h, chunk, &prop, 0)); b.h.push_back(h);
+        CK(hipMemMap((char*)b.ptr + i * chunk, chunk, 0, h, 0));
+    }
+    hipMemAccessDesc acc; memset(&acc, 0, sizeof(acc)); acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+    CK(hipMemSetAccess(b.ptr, b.size, &acc, 1));
+    return b;
+}
+static void release(Buf& b) {
+    if (!b.vmm) { CK(hipFree(b.ptr)); return; }
+    CK(hipMemUnmap(b.ptr, b.size));
+    for (auto h : b.h) CK(hipMemRelease(h));
+    CK(hipMemAddressFree(b.ptr, b.size));
+}
 template <typename F>
 static double timeit(F f, int reps = 5) {
     hipEvent_t e0, e1;
@@ -100,7 +129,11 @@ int main() {
     const int W = 3840, H = 2160, N = 60;
     const size_t n4 = (size_t)W * H * N;            // 7.96 GB
     float4 *p, *q; float* out;
-    CK(hipMalloc(&p, n4 * 16)); CK(hipMalloc(&q, n4 * 16)); CK(hipMalloc(&out, 64));
+    const size_t chunk = getenv("CHUNK_MB") ? ((size_t)atoll(getenv("CHUNK_MB")) << 20) : 0;      // round 4: 0 = hipMalloc, else VMM chunks
+    Buf bp = alloc(n4 * 16, chunk), bq = alloc(n4 * 16, chunk);
+    p = (float4*)bp.ptr; q = (float4*)bq.ptr;
+    printf("buffers: %s\n", chunk ? "mapped from physical chunks (CHUNK_MB)" : "hipMalloc");
+    CK(hipMalloc(&out, 64));
     CK(hipMemset(p, 1, n4 * 16));
     const double gb = n4 * 16 / 1e9;
     for (int blocks : {2048, 4096, 8192, 32768, 131072}) {
@@ -124,6 +157,22 @@ int main() {
             best = t < best ? t : best;
         }
         printf("frame skew %6zu float4: read_strips + nt coarse write: %.2f TB/s alg (59 frames)\n", skew, 1.25 * gb * 59 / 60 / best / 1e3);
+        {
+            double b4 = 1e9, b2 = 1e9;
+            for (int rep = 0; rep < 3; ++rep) {
+                double t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 2, 2>), dim3(grid / 2), dim3(128), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+                b2 = t < b2 ? t : b2;
+                t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 2, 4>), dim3(grid / 4), dim3(256), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, q, out); });
+                b4 = t < b4 ? t : b4;
+            }
+            printf("frame skew %6zu float4: ... 2 / 4 adjacent strips per workgroup in lock-step: %.2f / %.2f TB/s alg\n", skew, 1.25 * gb * 59 / 60 / b2 / 1e3, 1.25 * gb * 59 / 60 / b4 / 1e3);
+        }
+        double best2 = 1e9;
+        for (int rep = 0; rep < 3; ++rep) {
+            double t = timeit([&] { hipLaunchKernelGGL((read_strips<60, 0, 2>), dim3(grid), dim3(64), 0, 0, p, W, H, n_strips, chunk_rows, n_chunks, (float4*)nullptr, out); });
+            best2 = t < best2 ? t : best2;
+        }
+        printf("frame skew %6zu float4: read_strips alone: %.2f TB/s (59 frames)\n", skew, gb * 59 / 60 / best2 / 1e3);
     }
     return 0;
 }
