@@ -68,6 +68,7 @@ struct fvvdp_ctx {
     bool lum_known = false;
     int lum_state = 0;            // 0 nothing written yet, 1 range known, 2 unknown (sticky)
     int lum_hold = 0;             // > 0: an outer call has set the range, inner calls leave it alone
+    int lum_top = 0;              // highest level-0 slot written since the range bookkeeping last started afresh
     float lum_lo = 0.0f, lum_hi = 0.0f, lum_width = 0.0f;
     float* partial = nullptr;
     long long partial_off[FVVDP_MAX_BANDS]{};
@@ -490,8 +491,18 @@ static int grow_lum_buf(fvvdp_ctx* c, size_t need_floats, int fl, hipStream_t st
 // output, eotf_one in temporal_kernels.hpp; a code-value table carries the range of its entries in L_min / L_max), the RGB->Y
 // weights and the filter taps: a filter output lies in [s+ lo + s- hi, s+ hi + s- lo] with s+ / s- the sums of its positive /
 // negative taps.  The pyramid kernels use it to drop clamps that provably never bind (band2_kernel<P, true>).
-// The range of a context only ever WIDENS (slots of level 0 filled by different calls may be evaluated together), and one
-// call of unknown range makes it unknown for good.
+// Slots of level 0 filled by different calls may be evaluated together, so the range of a context only WIDENS, and one call of
+// unknown range makes it unknown -- until a call rewrites every slot written since the last such call (slots [0, n) with n >= the
+// highest slot in use: what every predict() does), which starts the bookkeeping afresh.
+static void luminance_slots(fvvdp_ctx* c, int slot0, int n_out) {
+    if (c->lum_hold) return;
+    if (slot0 == 0 && n_out >= c->lum_top) {
+        c->lum_state = 0;
+        c->lum_known = false;
+        c->lum_top = 0;
+    }
+    if (slot0 + n_out > c->lum_top) c->lum_top = slot0 + n_out;
+}
 static void luminance_unknown(fvvdp_ctx* c) {
     c->lum_state = 2;
 }
@@ -571,6 +582,7 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
     if (eotf->kind != FVVDP_EOTF_LUT && dtype == FVVDP_U8) return fail(FVVDP_EINVAL, "uint8 sources need FVVDP_EOTF_LUT (uint16: table or closed form)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int HW = c->W * c->H;
+    luminance_slots(c, slot0, n_out);
     luminance_range(c, eotf, C, h_rgb2y, h_taps, fl);
     Timed tm(c, 0, st);
     // register-ring kernels: up to 32 taps for every sample type, up to 64 taps (129-256 fps) for the cases of k1_ring64_ok()
@@ -777,6 +789,7 @@ extern "C" int fvvdp_temporal_channels_yuv(fvvdp_ctx* c, const void* d_test, con
     if (n_out < 1 || slot0 < 0 || slot0 + n_out > c->max_frames) return fail(FVVDP_EINVAL, "slots out of range");
     if (eotf->kind == FVVDP_EOTF_LUT) return fail(FVVDP_EINVAL, "YUV sources need a closed-form display model (RGB is fractional after the matrix)");
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    luminance_slots(c, slot0, n_out);
     luminance_range(c, eotf, 3, h_rgb2y, h_taps, fl);        // (RGB is clamped to [0,1] before the display model)
     Timed tm(c, 0, st);
     if (fl > 32) {
@@ -882,6 +895,7 @@ extern "C" int fvvdp_load_channels_planar(fvvdp_ctx* c, const float* d_R, int n,
     const int HW = c->W * c->H;
     dim3 grid((HW + 255) / 256, n), block(256);
     float* out = c->level[0] + (size_t)slot0 * HW * c->P;
+    luminance_slots(c, slot0, n);
     luminance_unknown(c);                            // the caller's own temporal channels
     if (c->P == 4) hipLaunchKernelGGL((interleave_kernel<4>), grid, block, 0, st, d_R, out, HW, 1);
     else hipLaunchKernelGGL((interleave_kernel<2>), grid, block, 0, st, d_R, out, HW, 1);

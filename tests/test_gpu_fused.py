@@ -140,6 +140,12 @@ def test_clamp_free_variant_is_taken_only_where_proven_and_changes_nothing(tmp_p
         "sys.stderr.write('CASE user_src\\n'); sys.stderr.flush()\n"
         "q, st = mm.predict_video_source(Src())\n"
         "out.append(np.concatenate([st['Q_per_ch'].reshape(-1), [float(q)]]))\n"
+        "m2 = fv.fvvdp(display_name='standard_fhd', batch_frames=12)\n"       # one context for a user source and then an array
+        "sys.stderr.write('CASE user_then\\n'); sys.stderr.flush()\n"
+        "m2.predict_video_source(Src())\n"
+        "ctx_a = m2._ctx\n"
+        "run('array_after_user', m2, t, r, frames_per_second=30)\n"
+        "assert m2._ctx is ctx_a\n"
         "np.save(sys.argv[1], np.stack([np.pad(o, (0, 200 - o.size)) for o in out]))\n" % root)
     res, logs = {}, {}
     for mode in ("1", "0"):
@@ -164,6 +170,7 @@ def test_clamp_free_variant_is_taken_only_where_proven_and_changes_nothing(tmp_p
     assert v["sdr_120fps"] == {True}          # 30 taps: the transient plane's range grows with the sum of |taps|, still far from the clamp
     assert v["hdr_pq"] == {False}             # black level 0.0174 cd/m^2 < 0.1: max(L_bkg, 0.1) binds, contrast can reach 1000
     assert v["user_src"] == {False}           # luminance frames from the source's own get_*_frame: range unknown to the library
+    assert v["user_then"] == {False} and v["array_after_user"] == {True}     # a call that rewrites every slot starts the range afresh
 
 
 def _run_fov(monkeypatch, test, ref, fuse, gaze, band_fuse=None, disp="standard_hdr_pq", **kw):
