@@ -46,7 +46,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=8)       # the allocation choice of the context settles in 8 calls
     ap.add_argument("--pairs-per-gpu", type=int, default=1, help="independent pairs per rank and step (BASELINE configs[4]: 8)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -163,8 +163,16 @@ def main():
         m.pipeline = 0
         m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
         ctx = m._ctx
-        extra["level0_alloc"] = ("hipMalloc (FVVDP_ALLOC=malloc)" if os.environ.get("FVVDP_ALLOC") == "malloc" else
-                                 "virtual-memory API, physical chunks of %s MB (profiles/r04_level0_chunks.md)" % os.environ.get("FVVDP_VMM_CHUNK_MB", "32"))
+        st_, cm_, kept_ = C.c_int(0), C.c_int(0), C.c_int(-1)
+        us2_ = (C.c_float * 2)()
+        nat.check(nat.lib().fvvdp_ctx_alloc_info(ctx.handle, C.byref(st_), C.byref(cm_), us2_, C.byref(kept_)))
+        extra["level0_alloc"] = {
+            "in_use": ("virtual-memory API, physical chunks of %s MB" % os.environ.get("FVVDP_VMM_CHUNK_MB", "32")) if cm_.value else "hipMalloc",
+            "start": "hipMalloc (FVVDP_ALLOC=malloc)" if os.environ.get("FVVDP_ALLOC") == "malloc" else "virtual-memory API",
+            # the context timed the temporal kernel + pyramid pass on both kinds during the warm-up steps and kept the faster
+            "compared_us_per_frame": {"first": round(us2_[0], 2), "other_kind": round(us2_[1], 2)} if kept_.value >= 0 else None,
+            "kept": {0: "first", 1: "other_kind"}.get(kept_.value), "state": st_.value,
+            "evidence": "profiles/r04_level0_chunks.md"}
         extra["pipeline_batches"] = pipeline_steps
         nat.check(nat.lib().fvvdp_ctx_timing_enable(ctx.handle, 1))
         nk = 16 + 2

@@ -91,6 +91,7 @@ SYMBOLS = {
                                  C.c_void_p, C.c_void_p]),
     "fvvdp_ctx_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "fvvdp_ctx_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int, C.c_int]),
+    "fvvdp_ctx_alloc_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
 }
 
 _lib = None

@@ -63,6 +63,17 @@ struct fvvdp_ctx {
     double rho_band[FVVDP_MAX_BANDS + 1]{};
     int lw[FVVDP_MAX_BANDS + 1]{}, lh[FVVDP_MAX_BANDS + 1]{};
     float* level[FVVDP_MAX_BANDS + 1]{};
+    // online choice of the level-0 allocation kind (selection_step): calls 0-1 warm up, 2-3 time the buffer in use, 4 switches to
+    // a candidate of the OTHER kind (chunk-mapped <-> hipMalloc; untimed: first touch), 5-6 time the candidate, 7 decides, 9 done
+    int sel_phase = 0;
+    float* sel_other = nullptr;     // the incumbent while the candidate is in use
+    hipEvent_t sel_ev[2] = {nullptr, nullptr};
+    int sel_n = 0;                  // frames of the timed batch
+    int sel_open = 0;               // 1: selection_end still has to record the end event
+    int sel_await = -1;             // whose timing (0 incumbent, 1 candidate) the next step has to read
+    bool sel_bad = false;
+    float sel_us[2] = {0.0f, 0.0f}; // (incumbent, candidate) us per frame, temporal kernel + pyramid pass, smaller of two calls
+    int sel_kept = -1;              // 0 incumbent, 1 candidate, -1 no comparison
     // what is known about the values in level 0 (luminance_range): sustained planes in [lum_lo, lum_hi], no plane's values
     // further apart than lum_width; lum_known = false after fvvdp_load_channels_planar or a source without a display model
     bool lum_known = false;
@@ -236,6 +247,18 @@ static void dev_free(fvvdp_ctx* c, void* p) {
     if (p && !vmm_owns(c, p)) (void)hipFree(p);
 }
 
+static void vmm_free_one(fvvdp_ctx* c, void* p) {
+    for (size_t i = 0; i < c->vmm.size(); ++i)
+        if (c->vmm[i].ptr == p) {
+            VmmBlock& b = c->vmm[i];
+            (void)hipMemUnmap(b.ptr, b.size);
+            for (auto h : b.handles) (void)hipMemRelease(h);
+            (void)hipMemAddressFree(b.ptr, b.size);
+            c->vmm.erase(c->vmm.begin() + (long)i);
+            return;
+        }
+}
+
 static void vmm_free_all(fvvdp_ctx* c) {
     for (VmmBlock& b : c->vmm) {
         (void)hipMemUnmap(b.ptr, b.size);
@@ -370,6 +393,9 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
 extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     if (!c) return;
     (void)hipDeviceSynchronize();                  // nothing may still read the scratch
+    dev_free(c, c->sel_other);                     // a comparison of level-0 allocations was under way
+    for (auto& e : c->sel_ev)
+        if (e) (void)hipEventDestroy(e);
     for (int i = 0; i <= FVVDP_MAX_BANDS; ++i)
         dev_free(c, c->level[i]);
     dev_free(c, c->partial);
@@ -485,6 +511,95 @@ static int grow_lum_buf(fvvdp_ctx* c, size_t need_floats, int fl, hipStream_t st
     c->lum_floats = need_floats;
     c->scratch += need_floats * sizeof(float);
     return FVVDP_OK;
+}
+
+// ---- online choice of the level-0 allocation kind -----------------------------------------------------------------------------
+// The temporal kernel runs at 30.6-33.8 or at 35-38 us per 4K frame depending on where its destination lies physically; on most
+// boxes a range mapped from chunks is the fast one and hipMalloc the slow one, on some it is the other way round, and the pyramid
+// kernels do not care (profiles/r04_level0_chunks.md).  So a context that will be used repeatedly measures: calls 1-2 warm up,
+// calls 3-4 are timed (temporal kernel + pyramid pass of the batch in slot 0, the smaller of the two counts) on the buffer the
+// context has, call 5 runs on a fresh buffer of the OTHER kind untimed (first touch), calls 6-7 are timed on it, call 8 keeps the
+// faster one (the candidate has to win by 3 %) and frees the other.  No extra GPU work; the context holds level 0 twice for four
+// calls.  Results never depend on the buffer.  FVVDP_PLACEMENT_PROBE=0 turns it off.  Only for video contexts whose level 0 holds
+// >= 1 GiB, batches of >= 16 frames, and calls that rewrite every slot in use.
+static void selection_read(fvvdp_ctx* c) {          // the timed call before this one: keep the smaller of the two per buffer
+    if (c->sel_await < 0) return;
+    float ms = 0.0f;
+    const bool ok = !c->sel_open && hipEventSynchronize(c->sel_ev[1]) == hipSuccess &&
+                    hipEventElapsedTime(&ms, c->sel_ev[0], c->sel_ev[1]) == hipSuccess && ms > 0.0f;
+    if (!ok) { (void)hipGetLastError(); c->sel_bad = true; }
+    else {
+        const float us = ms * 1e3f / (float)(c->sel_n > 0 ? c->sel_n : 1);
+        float& slot = c->sel_us[c->sel_await];
+        slot = slot > 0.0f && slot < us ? slot : us;
+    }
+    c->sel_await = -1;
+}
+static void selection_time(fvvdp_ctx* c, int which, int n_out, hipStream_t st) {
+    for (int i = 0; i < 2; ++i)
+        if (!c->sel_ev[i] && hipEventCreate(&c->sel_ev[i]) != hipSuccess) { (void)hipGetLastError(); c->sel_bad = true; return; }
+    (void)hipEventRecord(c->sel_ev[0], st);
+    c->sel_n = n_out;
+    c->sel_open = 1;
+    c->sel_await = which;
+}
+static void selection_step(fvvdp_ctx* c, int n_out, hipStream_t st) {
+    const size_t floats = (size_t)c->max_frames * c->lw[0] * c->lh[0] * c->P;
+    selection_read(c);
+    if (c->sel_bad) {                                            // an event or a call out of order: stay with what is in use
+        if (c->sel_other) { float* cand = c->level[0]; c->level[0] = c->sel_other; c->sel_other = nullptr;
+                            (void)hipStreamSynchronize(st); if (vmm_owns(c, cand)) vmm_free_one(c, cand); else (void)hipFree(cand); }
+        c->sel_phase = 9;
+        return;
+    }
+    switch (c->sel_phase) {
+    case 0: case 1:                                              // warm-up calls
+        c->sel_phase += 1;
+        break;
+    case 2: case 3:                                              // two timed calls on the buffer in use
+        selection_time(c, 0, n_out, st);
+        c->sel_phase += 1;
+        break;
+    case 4: {                                                    // a candidate of the other kind; its first call is not timed
+        void* q = nullptr;
+        const bool inc_vmm = vmm_owns(c, c->level[0]);
+        const bool ok = inc_vmm ? hipMalloc(&q, floats * sizeof(float)) == hipSuccess
+                                : vmm_alloc(c, &q, floats * sizeof(float)) == FVVDP_OK;
+        if (!ok) { (void)hipGetLastError(); c->sel_phase = 9; break; }
+        c->sel_other = c->level[0];
+        c->level[0] = reinterpret_cast<float*>(q);
+        c->sel_phase = 5;
+        break;
+    }
+    case 5: case 6:                                              // two timed calls on the candidate
+        selection_time(c, 1, n_out, st);
+        c->sel_phase += 1;
+        break;
+    case 7: {
+        const float t_inc = c->sel_us[0], t_new = c->sel_us[1];
+        const bool ok = t_inc > 0.0f && t_new > 0.0f;
+        const bool take_new = ok && t_new < 0.97f * t_inc;        // single calls scatter by 1-2 %; real differences are 4-9 %
+        float* loser = take_new ? c->sel_other : c->level[0];
+        if (!take_new) c->level[0] = c->sel_other;
+        c->sel_other = nullptr;
+        (void)hipStreamSynchronize(st);                          // nothing reads the loser any more
+        if (vmm_owns(c, loser)) vmm_free_one(c, loser); else (void)hipFree(loser);
+        c->sel_kept = ok ? (take_new ? 1 : 0) : -1;
+        if (getenv("FVVDP_DEBUG_VARIANT"))
+            fprintf(stderr, "fvvdp: level-0 allocation: in use %.2f, candidate %.2f us per frame (temporal + pyramid) -> kept the %s (%s)\n",
+                    t_inc, t_new, take_new ? "candidate" : "incumbent", vmm_owns(c, c->level[0]) ? "chunk-mapped" : "hipMalloc");
+        c->sel_phase = 9;
+        break;
+    }
+    default:
+        break;
+    }
+}
+static void selection_end(fvvdp_ctx* c, hipStream_t st) {
+    if (c->sel_open) {
+        (void)hipEventRecord(c->sel_ev[1], st);
+        c->sel_open = 0;
+    }
 }
 
 // Range of the values the temporal kernels write into level 0, from the display model (every closed-form model clamps its
@@ -638,6 +753,12 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
             }
             return FVVDP_OK;
         };
+        if (slot0 == 0 && c->sel_phase < 9) {
+            static const bool probe_on = [] { const char* e = getenv("FVVDP_PLACEMENT_PROBE"); return !(e && e[0] == '0'); }();
+            const size_t bytes = (size_t)c->max_frames * c->lw[0] * c->lh[0] * c->P * sizeof(float);
+            if (!probe_on || c->P != 4 || bytes < ((size_t)1 << 30) || c->lum_hold) c->sel_phase = 9;
+            else if (n_out >= 16 && c->lum_top == n_out) selection_step(c, n_out, st);   // this call rewrites every slot in use
+        }
         {
             const int rc = run(c->level[0], 0, n_out);
             if (rc != FVVDP_OK) return rc;
@@ -1448,6 +1569,7 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
         fill_pool_args(pa, d_Q, c->n_bands, 2, q_stride, q_stride, pool, d_jod);
         hipLaunchKernelGGL(pool_jod_kernel, dim3(1), dim3(256), 0, st, pa);
     }
+    if (slot0 == 0) selection_end(c, st);
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;
 }
@@ -1629,3 +1751,13 @@ extern "C" int fvvdp_ctx_timing_read(fvvdp_ctx* c, float* h_ms, int32_t* h_count
     return FVVDP_OK;
 }
 
+
+extern "C" int fvvdp_ctx_alloc_info(const fvvdp_ctx* c, int* state, int* chunk_mapped, float* h_us2, int* kept) {
+    if (!c || !state || !chunk_mapped || !h_us2 || !kept) return fail(FVVDP_EINVAL, "null argument");
+    *state = c->sel_phase;
+    *chunk_mapped = vmm_owns(c, c->level[0]) ? 1 : 0;
+    h_us2[0] = c->sel_us[0];
+    h_us2[1] = c->sel_us[1];
+    *kept = c->sel_kept;
+    return FVVDP_OK;
+}

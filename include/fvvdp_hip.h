@@ -285,6 +285,16 @@ int fvvdp_export_level(fvvdp_ctx* ctx, int level, int n, float* d_out, void* str
 int fvvdp_ctx_timing_enable(fvvdp_ctx* ctx, int on);
 int fvvdp_ctx_timing_read(fvvdp_ctx* ctx, float* h_ms, int32_t* h_count, int capacity, int reset);
 
+/* Where level 0 of the context's scratch lives and how that was decided.  The large scratch levels are mapped from physical
+ * chunks (HIP virtual-memory API) by default; a video context whose level 0 holds >= 1 GiB compares that with a hipMalloc range
+ * on its first eight batches of >= 16 frames (two warm-ups, two timed on the buffer in use, one untimed and two timed on the
+ * other kind, then the faster is kept: the temporal kernel's speed depends on the physical placement of its destination, box by
+ * box; environment FVVDP_PLACEMENT_PROBE=0 turns the comparison off).  Results never depend on it.
+ *   *state: 0..7 = comparison in progress, 9 = finished or not applicable;  *chunk_mapped: 1 = level 0 is chunk-mapped now
+ *   h_us2: {buffer in use, candidate} microseconds per frame (temporal kernel + pyramid pass), 0 = not measured
+ *   *kept: 0 = the first buffer, 1 = the candidate, -1 = no comparison                                                   */
+int fvvdp_ctx_alloc_info(const fvvdp_ctx* ctx, int* state, int* chunk_mapped, float* h_us2, int* kept);
+
 
 /* ---- PU21-PSNR side metric ---------------------------------------------------
  * Replaces the per-frame body of pu_psnr.predict_video_source (pyfvvdp/pupsnr.py:64-76): luminance of both streams

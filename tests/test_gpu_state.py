@@ -447,6 +447,72 @@ def test_chunk_mapped_scratch_gives_the_same_results_as_hipmalloc(tmp_path):
     assert np.array_equal(res["vmm"], res["malloc"]) and np.array_equal(res["vmm"], res["vmm8"])
 
 
+def test_level0_allocation_choice_changes_no_bits_and_settles(tmp_path):
+    """A video context whose level 0 holds >= 1 GiB compares the two allocation kinds of that buffer on its first eight full-size
+    calls (fvvdp_ctx_alloc_info; two warm-ups, two timed, switched, two timed, decided) and keeps the faster.  Every call --
+    before, on the candidate, after -- returns the same bits as a process where the comparison is off; it settles in state 9 with
+    both timings recorded and one level-0 buffer freed again; calls that do not rewrite every slot in use (stage overlap, frame
+    sub-batches at slot > 0) never switch; small contexts and images never start."""
+    import subprocess
+    import sys
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, ctypes as C, numpy as np, torch\n"
+        "sys.path.insert(0, %r)\n"
+        "import fovvideovdp_amd as fv\n"
+        "from fovvideovdp_amd import _native as nat\n"
+        "from fovvideovdp_amd.synth import synth_video_pair\n"
+        "def info(m):\n"
+        "    st, cm, kept = C.c_int(0), C.c_int(0), C.c_int(-1); us = (C.c_float * 2)()\n"
+        "    nat.check(nat.lib().fvvdp_ctx_alloc_info(m._ctx.handle, C.byref(st), C.byref(cm), us, C.byref(kept)))\n"
+        "    return st.value, cm.value, kept.value, us[0], us[1]\n"
+        "t, r = synth_video_pair(40, 1080, 1920, device='cuda')\n"
+        "m = fv.fvvdp(display_name='standard_fhd')\n"
+        "out = []\n"
+        "free = []\n"
+        "for k in range(11):\n"
+        "    if k == 2: m.pipeline = 2\n"                                     # a call in two banks in between: must not advance
+        "    q, st = m.predict(t, r, frames_per_second=30)\n"
+        "    m.pipeline = 0\n"
+        "    out.append(np.concatenate([st['Q_per_ch'].reshape(-1), [float(q)]]))\n"
+        "    print('INFO', k, *info(m))\n"
+        "    free.append(torch.cuda.mem_get_info()[0])\n"
+        "print('FREE', *free)\n"
+        "m2 = fv.fvvdp(display_name='standard_fhd')\n"
+        "t2, r2 = synth_video_pair(20, 270, 480, device='cuda')\n"
+        "for k in range(7): m2.predict(t2, r2, frames_per_second=30)\n"
+        "print('SMALL', *info(m2))\n"
+        "np.save(sys.argv[1], np.stack(out))\n" % root)
+    res, infos = {}, {}
+    for mode, env in (("on", {}), ("off", {"FVVDP_PLACEMENT_PROBE": "0"}), ("on_malloc", {"FVVDP_ALLOC": "malloc"})):
+        f = str(tmp_path / ("s_%s.npy" % mode))
+        p = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=400)
+        assert p.returncode == 0, p.stderr[-1500:]
+        res[mode] = np.load(f)
+        infos[mode] = [l.split()[1:] for l in p.stdout.splitlines() if l.startswith("INFO")]
+        small = [l.split()[1:] for l in p.stdout.splitlines() if l.startswith("SMALL")][0]
+        assert int(small[2]) == -1 and int(small[0]) in (0, 9)                  # a 130 MB level 0 never starts a comparison
+        if mode != "off":
+            free = [int(v) for v in [l for l in p.stdout.splitlines() if l.startswith("FREE")][0].split()[1:]]
+            # (k = 2 ran in two banks and did not count) states after calls 0..10: 1 2 2 3 4 5 6 7 9 9 9
+            assert [int(i[1]) for i in infos[mode]] == [1, 2, 2, 3, 4, 5, 6, 7, 9, 9, 9], infos[mode]
+            kinds = [int(i[2]) for i in infos[mode]]
+            first = 0 if mode == "on_malloc" else 1
+            assert kinds[:5] == [first] * 5 and kinds[5:8] == [1 - first] * 3, kinds      # the candidate is the other kind
+            kept = int(infos[mode][-1][3])
+            assert kept in (0, 1) and kinds[-1] == (first if kept == 0 else 1 - first)
+            assert float(infos[mode][-1][4]) > 0 and float(infos[mode][-1][5]) > 0
+            assert free[5] < free[4] - 1.2e9 and free[10] > free[7] + 1.2e9, free   # held twice for four calls, then freed
+        else:
+            assert all(int(i[1]) == 9 and int(i[3]) == -1 for i in infos[mode][1:])
+    for mode in res:
+        assert all(np.array_equal(res[mode][k], res[mode][0]) for k in (0, 1, 3, 4, 5, 6, 7, 8, 9, 10)), mode
+    # (call 2 ran as two batches: equal up to the grouping of the partial sums, test_stage_overlap_equals_the_sequential_order)
+    assert np.allclose(res["on"][2], res["on"][0], rtol=1e-5)
+    assert np.array_equal(res["on"], res["off"]) and np.array_equal(res["on"], res["on_malloc"])
+
+
 def test_stage_overlap_equals_the_sequential_order():
     """`pipeline` = k cuts a clip into k batches whose temporal kernel runs on one internal stream against the pyramid pass of
     the previous batch on another (two banks of the level-0 scratch).  Against the strictly sequential order: equal up to the

@@ -58,7 +58,8 @@ level-0 scratch, and an online selection between two `hipMalloc` buffers that di
    the same virtual range mapped from physical chunks (`hipMemCreate` x n, `hipMemMap`) of 2 ... 128 MB puts K1 in the fast mode
    on those boxes every time (two of the ~14 boxes of the round stay slow in every allocation mode: last section), and the pyramid kernel that reads the buffer does not change (session 4; 512 MB chunks: half way).
 3. The library now maps every pyramid level of >= 256 MB from 32 MB chunks (>= 16 MB from 4 MB chunks since the microbenchmark of the last section) (`vmm_alloc` in `csrc/fvvdp_hip.hip`;
-   `FVVDP_ALLOC=malloc` goes back); the selection machinery and its C entry point were removed.  Same-box A/B of the bench line
+   `FVVDP_ALLOC=malloc` goes back); the selection between two hipMalloc buffers and its C entry point were removed (a choice between the
+   two KINDS came back at the end of the round: sessions 17-18 below).  Same-box A/B of the bench line
    (session 5): 4.57 -> 4.25 ms per 4K x 60 pair, bit-identical results (`test_chunk_mapped_scratch_gives_the_same_results_as_hipmalloc`).
    Creating the 4K x 60 context (about 330 chunks of 32 MB) and touching it for the first time: 20 ms (session 5, last lines).
 
@@ -114,6 +115,33 @@ with hipMalloc: 37.0-38.1 on nine boxes, 35.1-36.0, 32.9, 32.0 on three.  The ch
 4 %% slower on one, and there are boxes where nothing helps; what those boxes have in common is not known to me (same kernel, pyramid
 kernels and streaming microbenchmarks at their usual rates).  The permuted mapping order was not kept.
 
+## Sessions 17 and 18 (ten boxes): an online choice between the two kinds -- kept, on by default
+
+Since neither kind is the fast one everywhere, a video context whose level 0 holds >= 1 GiB now compares them on its first eight
+full-size calls (`selection_step` in `csrc/fvvdp_hip.hip`, `fvvdp_ctx_alloc_info`; two warm-ups, two timed calls on the buffer it
+has, one untimed and two timed calls on a fresh buffer of the OTHER kind, the smaller of the two timings counts, the candidate has to
+win by 3 %%) and keeps the faster; `FVVDP_PLACEMENT_PROBE=0` turns it off.  The timed quantity is the temporal kernel + the whole
+pyramid pass of the batch (VERDICT r3 item 3).  `choice` = default, `vmm_fixed` / `malloc_fixed` = comparison off, `choice_from_malloc` =
+starting from hipMalloc; ms per pair, K1 and levels 0+1 us per frame (HIP-event medians of the same process), then start -> kept
+and the two timings in us per frame.  `tools/experiments/r4_session17.sh` / `r4_session18.sh`, one gpurun call per box.
+
+First form (one timed call per kind, 1.5 %% margin; boxes 1-7).  It finds the faster kind where the kinds differ (box 4 from hipMalloc:
+4.35 -> 4.04 ms; box 5 from chunks: 4.37-4.46 -> 4.17-4.26), is neutral where they do not (boxes 1, 3, 6), and mis-picked once
+(box 4, first line: 71.27 vs 69.75 us measured, then 3 %% slower than `vmm_fixed`):
+
+```
+%s
+```
+
+Shipped form (two timed calls per kind, 3 %% margin; three more boxes): no mis-pick in 12 processes, gains of 2-4 %% where it switches.
+A candidate allocated late in the life of the process is not always as fast as the same kind allocated first (box 9, `choice_from_malloc`
+first run: 69.83 against 71.94 us is inside the margin, while `vmm_fixed` is 4 %% faster than `malloc_fixed` there) -- the choice removes
+the bad cases, it does not always find the best one:
+
+```
+%s
+```
+
 `tools/microbench/chunks.hip` on a box whose hipMalloc returns one contiguous range, TB/s -- it is the WRITES that such a range slows down
 (write only 5.8-6.0 -> 6.9-7.1, copy 5.3-5.4 -> 6.0-6.1, reads unchanged); since then every level of >= 16 MB is chunk-mapped:
 
@@ -121,7 +149,10 @@ kernels and streaming microbenchmarks at their usual rates).  The permuted mappi
 %s
 ```
 """ % (table(lines("r4s3", "*.json")), table(lines("r4s4", "*.json")), table(lines("r4s5", "*.json")), rd("r4s9/fov_chunks.txt"),
-       rd("r4s15/order.txt"), rd("r4s15/chunks_microbench.txt"), rd("r4s16/src.txt"), rd("r4s16/three_more_boxes.txt"), rd("r4_chunks_microbench.txt")))
+       rd("r4s15/order.txt"), rd("r4s15/chunks_microbench.txt"), rd("r4s16/src.txt"), rd("r4s16/three_more_boxes.txt"),
+       "\n".join("# box %d\n" % i + rd("r4s17/choice_box%d.txt" % i) for i in range(1, 8)),
+       "\n".join("# box %d\n" % (7 + i) + rd("r4s18/choice2_box%d.txt" % i) for i in range(1, 4)),
+       rd("r4_chunks_microbench.txt")))
 
 # ---------------------------------------------------------------------------------------------------------------------------
 write("r04_stage_overlap.md", """# Round 4: temporal kernel of batch b+1 against the pyramid pass of batch b on two streams (VERDICT r3 item 1b) -- built, measured, off
