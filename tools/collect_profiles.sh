@@ -64,6 +64,7 @@ rocprofv3 --kernel-trace --stats -d /tmp/kfhd -o fhd -- python $R/bench.py --wid
 python $R/tools/rocpd_summary.py $(find /tmp/kfhd -name "*.db" | head -1) --band-levels 6 > $OUT/kernel_trace_fhd.md
 python $R/bench.py --width 1920 --height 1080 --display standard_fhd --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_fhd_plain.json 2>/dev/null
 # the same allocation A/B as profiles/r04_level0_chunks.md on this box
-FVVDP_ALLOC=malloc python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_malloc.json 2>/dev/null
+FVVDP_ALLOC=malloc FVVDP_PLACEMENT_PROBE=0 python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_malloc.json 2>/dev/null
+FVVDP_PLACEMENT_PROBE=0 python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_chunks.json 2>/dev/null
 FVVDP_BAND_INRANGE=0 python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_clamps.json 2>/dev/null
 ls -la $OUT

@@ -100,7 +100,7 @@ def quoted_figures():
     rs = jp["roofline_step"]
     out.append("* whole step: %.2f GB per pair, %.2f TB/s = %.3f; kernels back to back %.3f ms of %.3f ms" % (
         rs["bytes_per_step"] / 1e9, rs["achieved"] / 1e3, rs["frac"], rs["kernels_back_to_back_ms"], rs["ms_per_step"]))
-    for name in ("bench_malloc.json", "bench_clamps.json", "bench_pairs8.json", "bench_fhd.json", "bench_fhd_plain.json"):
+    for name in ("bench_malloc.json", "bench_chunks.json", "bench_clamps.json", "bench_pairs8.json", "bench_fhd.json", "bench_fhd_plain.json"):
         try:
             j = json.loads(rd(name).split("\n")[-1])
             gg = j["graded_pass"]
@@ -177,11 +177,13 @@ bench.py JSON of the unprofiled run on the same box, right before:
 {rd('bench_pairs8.json')}
 ```
 
-Same box, the two switches of round 4 turned back: `FVVDP_ALLOC=malloc` (level 0 from hipMalloc instead of 32 MB chunks,
+Same box, the switches of round 4: the level-0 buffer fixed to one kind, comparison off (`FVVDP_ALLOC=malloc FVVDP_PLACEMENT_PROBE=0`,
+then `FVVDP_PLACEMENT_PROBE=0` = 32 MB chunks; the default line above chooses between the two, `level0_alloc` says what it kept;
 `profiles/r04_level0_chunks.md`) and `FVVDP_BAND_INRANGE=0` (the pyramid kernel with its clamps, `profiles/r04_pyramid_kernel.md`):
 
 ```
 {rd('bench_malloc.json')}
+{rd('bench_chunks.json')}
 {rd('bench_clamps.json')}
 ```
 
