@@ -34,6 +34,7 @@ struct Band2Args {
     float* Gc;              // level C [n][hc][wc][P]
     int w, h, wb, hb, wc, hc;
     int n_strips, n_chunks, kr;       // kr = level-C rows per chunk
+    int n_big, kr2, n_frames;         // chunks [0, n_big) have kr rows, chunks [n_big, n_chunks) kr2 rows (dispatched last, all frames)
     float mulA, mulB;       // band multipliers (lpyr.get_band, fvvdp_lpyr_dec.py:57-63)
     const float4* csfA;     // [32] slope-form 1-D CSF records of band A / band B (see BandArgs::csf)
     const float4* csfB;
@@ -127,7 +128,8 @@ constexpr bool band2_stage(int P) { return (BAND2_LDS_STAGE != 0) && P == 4; }
 
 template <int P, bool INRANGE, bool FOV>
 __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, const int chunk, const int frame, const int lane,
-                                           const float4 (*s_csf)[FVVDP_LUT_N], [[maybe_unused]] float4* s_stage) {
+                                           const float4 (*s_csf)[FVVDP_LUT_N], [[maybe_unused]] float4* s_stage,
+                                           [[maybe_unused]] const bool in_step = false) {
     constexpr int HP = P / 2;
     constexpr bool STAGE = band2_stage(P) && !FOV;
     static_assert(!(FOV && INRANGE), "the foveated variant keeps its clamps");
@@ -137,7 +139,9 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
     const int J = strip * F2_PITCH - F2_HL + lane;          // level-B column (may be < 0 or >= wb in halo lanes)
     const int K = J >> 1;                                    // level-C column of the lane pair
     const bool jeven = (lane & 1) == 0;
-    const int ka = chunk * a.kr, kb = min(ka + a.kr, hc);    // owned level-C rows
+    const bool big = chunk < a.n_big;
+    const int ka = big ? chunk * a.kr : a.n_big * a.kr + (chunk - a.n_big) * a.kr2;
+    const int kb = min(ka + (big ? a.kr : a.kr2), hc);       // owned level-C rows
     const int ca = 2 * ka, cb = min(2 * kb, hb);             // owned level-B rows = level-A row pairs
     const bool owned = lane >= F2_HL && lane < F2_HL + F2_PITCH && J < wb;
     const int X0 = 2 * J, X1 = 2 * J + 1;
@@ -574,6 +578,9 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
     auto stage = [&](auto basea, auto baseb, int k) {     // basea / baseb: ring slot of level-A row 4k / 4k+2
         constexpr int BA = decltype(basea)::value, BB = decltype(baseb)::value;
         Px<P> Be, Bo;
+        // the waves of a workgroup walk ADJACENT strips of the same chunk: kept in step, their row requests of a stage cover one
+        // contiguous piece of 4 level-A rows and their halo columns meet in the CU's vector cache (profiles/r04_lockstep.md)
+        if constexpr (!FOV) if (in_step) __builtin_amdgcn_s_barrier();
         {   // step c = 2k: level-B row 2k+1
             const int c = 2 * k;
             // foveated: the rho-map records of this step's rows are requested BEFORE the rows of the next step (loads return in
@@ -687,26 +694,62 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
     }
 }
 
+// waves per workgroup of band2_kernel: 1 .. 4 (adjacent strips of one chunk and frame, one barrier per stage); the launch decides.
+// 8 and 12 waves, or a second barrier per stage, were slower (profiles/r04_lockstep.md).
+#define BAND2_WPB_MAX 4
+#ifdef BAND2_TIMELINE      // profiling build: (start, end) of every workgroup on the 100 MHz wall clock + where it ran (tools/gpu_timeline.py)
+__device__ unsigned long long g_band2_timeline[4 * 65536];
+#endif
+
+// Work distribution of band2_kernel: one workgroup (wpb adjacent strips x one chunk x one frame) per work item, in two phases of
+// block indices -- the tall chunks of all frames, then the short chunks (the bottom rows of every frame, cut finer).  The launch
+// ends when the last item does and the slots that finish earlier idle for up to one item (profiles/r04_lockstep.md: 12 % of the
+// wave-time of a 4K x 60 launch); short items last make that wait short.  Within a phase XCD x (the hardware places workgroup b on
+// XCD b mod 8) walks a contiguous range of (frame, chunk, strip group): neighbouring strips run on one XCD at about the same time
+// and share its L2 (see band_kernel).
+// Resident workgroups that take their items from per-XCD atomic queues and steal from the slowest XCD (the XCDs of one box
+// finish their eighth 5-8 % apart) were built and measured 3.5 % SLOWER than the hardware's dispatch (the loop around the item
+// costs registers: 13-18 scalar spills) -- profiles/r04_lockstep.md, section 5.
 template <int P, bool INRANGE = false>
-__global__ __launch_bounds__(64, BAND2_LB) void band2_kernel(const Band2Args a) {
+__global__ __launch_bounds__(64 * BAND2_WPB_MAX, BAND2_LB) void band2_kernel(const Band2Args a) {
     __shared__ float4 s_csf[2][FVVDP_LUT_N];
     __shared__ float4 s_stage[band2_stage(P) ? 3 * 4 * 64 : 1];
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+#ifdef BAND2_TIMELINE
+    const unsigned long long tl_t0 = wall_clock64();
+#endif
+    const int wpb = (int)(blockDim.x >> 6);
+    const int n_groups = a.n_strips / wpb;                    // (the launch makes wpb divide n_strips)
+    const int first = n_groups * a.n_big * a.n_frames;        // workgroups of the first phase
+    int v = (int)blockIdx.x, nb = first;
+    const bool tall = v < first;
+    if (!tall) { v -= first; nb = (int)gridDim.x - first; }
     int bid;
-    {   // XCD-aware work order (see band_kernel)
-        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
-        bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
+    {   // XCD-aware work order within a phase
+        const int q8 = nb >> 3, r8 = nb & 7, x = v & 7;
+        bid = x * q8 + min(x, r8) + (v >> 3);
     }
-    const int strip = bid % a.n_strips;
-    bid /= a.n_strips;
-    const int chunk = bid % a.n_chunks;
-    const int frame = bid / a.n_chunks;
-    if (lane < FVVDP_LUT_N) {
-        s_csf[0][lane] = a.csfA[lane];
-        s_csf[1][lane] = a.csfB[lane];
+    const int group = bid % n_groups;
+    bid /= n_groups;
+    const int per_frame = tall ? a.n_big : a.n_chunks - a.n_big;
+    const int chunk = (tall ? 0 : a.n_big) + bid % per_frame;
+    const int frame = bid / per_frame;
+    const int strip = group * wpb + (int)(threadIdx.x >> 6);
+    if (threadIdx.x < FVVDP_LUT_N) {
+        s_csf[0][threadIdx.x] = a.csfA[threadIdx.x];
+        s_csf[1][threadIdx.x] = a.csfB[threadIdx.x];
     }
     __syncthreads();
-    band2_item<P, INRANGE, false>(a, strip, chunk, frame, lane, s_csf, s_stage);
+    band2_item<P, INRANGE, false>(a, strip, chunk, frame, lane, s_csf, s_stage, wpb > 1);
+#ifdef BAND2_TIMELINE
+    if (lane == 0 && a.w >= 2560 && blockIdx.x * wpb + (threadIdx.x >> 6) < 65536) {       // (the large launch only)
+        unsigned long long* t = g_band2_timeline + 4 * (size_t)(blockIdx.x * wpb + (threadIdx.x >> 6));
+        t[0] = tl_t0;
+        t[1] = wall_clock64();
+        t[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) << 32) | (unsigned int)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);   // XCC_ID, HW_ID
+        t[3] = ((unsigned long long)frame << 32) | (unsigned int)(chunk * a.n_strips + strip);
+    }
+#endif
 }
 
 // Foveated two-level pass: FOV2_WPB independent waves per workgroup share the two bands' LUT slices and the row tables of

@@ -1373,7 +1373,7 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
         for (int f = 0; f < n; ++f)
             if (!(h_fixation[2 * f] >= -0.5f && h_fixation[2 * f] <= (float)c->W && h_fixation[2 * f + 1] >= -0.5f && h_fixation[2 * f + 1] <= (float)c->H)) fov2 = false;
     for (int b = 0; b < c->n_bands; ++b) {
-        const bool big = (long long)c->lw[b] * c->lh[b] >= 1500000;
+        const bool big = (long long)c->lw[b] * c->lh[b] >= 500000;      // (4K: levels 0+1 and 2+3; 2+3 in one launch: 3.06 -> 2.67 us per frame)
         if ((fuse_ok || (fov2 && b == 0)) && (big || fuse_mode == 1) && b + 1 < c->n_bands && c->lw[b + 1] >= 4 && c->lh[b + 1] >= 4 &&
             c->lw[b + 2] >= 2 && c->lh[b + 2] >= 2) {
             Band2Args a;
@@ -1388,6 +1388,21 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
             a.hc = c->lh[b + 2];
             a.n_strips = band2_strips(a.wb);
             chunking2(a.hc, a.n_strips, n, fov ? c->wave_capacity_fov2 : c->wave_capacity2, a.n_chunks, a.kr);
+            a.n_big = a.n_chunks;
+            a.kr2 = a.kr;
+            a.n_frames = n;
+            if (!fov) {
+                // a launch of several rounds of tall chunks: the last chunk of every frame is cut into four and dispatched after
+                // all tall ones (band2_kernel's two phases)
+                const long long waves = (long long)n * a.n_strips * a.n_chunks;
+                int kr2 = (waves >= 2 * c->wave_capacity2 && a.n_chunks >= 3 && a.kr >= 16) ? (a.kr + 3) / 4 : 0;
+                if (const char* ov = getenv("FVVDP_BAND2_KR2")) kr2 = atoi(ov);       // tuning override; 0 = uniform chunks
+                if (kr2 >= 1 && kr2 < a.kr && a.n_chunks >= 2) {
+                    a.n_big = a.n_chunks - 1;
+                    a.kr2 = kr2;
+                    a.n_chunks = a.n_big + (a.hc - a.n_big * a.kr + kr2 - 1) / kr2;
+                }
+            }
             a.mulA = (b == 0) ? 1.0f : 2.0f;
             a.mulB = 2.0f;
             a.csfA = c->csf + (size_t)b * FVVDP_LUT_N;
@@ -1440,15 +1455,24 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
                     else hipLaunchKernelGGL((band2_fov_kernel<2>), gridf, blockf, c->fov2_lds, st, a);
                 } else {
                 const bool inrange = clamps_never_bind(c, b, 2);
+                // Waves per workgroup: 4 adjacent strips walked in step (one barrier per stage).  Free-running single waves drift
+                // apart over a long launch (items started in the first round of a 4K x 60 launch, all in step, take 316 us, later
+                // ones 390 us); neighbours kept in step meet in the CU's vector cache on their shared halo columns and ask for one
+                // contiguous piece of each row.  Measured (profiles/r04_lockstep.md): -1.5 ... -6 % at 4K on five boxes, -2.6 % at
+                // 8K, 0 ... -3 % at 2560x1440; slower where the strips do not fill whole groups (a workgroup holds its four wave
+                // slots) and below 2560 columns (short launches stay in step by themselves).  Same work items, same partial sums.
+                int wpb = (a.w >= 2560 && a.n_strips % BAND2_WPB_MAX == 0) ? BAND2_WPB_MAX : 1;
+                if (const char* ov = getenv("FVVDP_BAND2_WPB")) { const int v = atoi(ov); if (v >= 1 && v <= BAND2_WPB_MAX && a.n_strips % v == 0) wpb = v; }
+                const dim3 grid2((unsigned int)((a.n_strips / wpb) * a.n_chunks * n)), block2(64 * wpb);
                 if (getenv("FVVDP_DEBUG_VARIANT"))       // tests: which variant was launched
-                    fprintf(stderr, "fvvdp: levels %d+%d: band2_kernel<%d, %s>, luminance range %s [%g, %g], widest plane range %g\n",
-                                 b, b + 1, c->P, inrange ? "true" : "false", c->lum_state == 1 ? "known" : "unknown", c->lum_lo, c->lum_hi, c->lum_width);
+                    fprintf(stderr, "fvvdp: levels %d+%d: band2_kernel<%d, %s>, luminance range %s [%g, %g], widest plane range %g, %d waves per workgroup\n",
+                                 b, b + 1, c->P, inrange ? "true" : "false", c->lum_state == 1 ? "known" : "unknown", c->lum_lo, c->lum_hi, c->lum_width, wpb);
                 if (c->P == 4) {
-                    if (inrange) hipLaunchKernelGGL((band2_kernel<4, true>), dim3(nblk * n), dim3(64), 0, st, a);
-                    else hipLaunchKernelGGL((band2_kernel<4, false>), dim3(nblk * n), dim3(64), 0, st, a);
+                    if (inrange) hipLaunchKernelGGL((band2_kernel<4, true>), grid2, block2, 0, st, a);
+                    else hipLaunchKernelGGL((band2_kernel<4, false>), grid2, block2, 0, st, a);
                 } else {
-                    if (inrange) hipLaunchKernelGGL((band2_kernel<2, true>), dim3(nblk * n), dim3(64), 0, st, a);
-                    else hipLaunchKernelGGL((band2_kernel<2, false>), dim3(nblk * n), dim3(64), 0, st, a);
+                    if (inrange) hipLaunchKernelGGL((band2_kernel<2, true>), grid2, block2, 0, st, a);
+                    else hipLaunchKernelGGL((band2_kernel<2, false>), grid2, block2, 0, st, a);
                 }
                 }
             }
@@ -1761,3 +1785,12 @@ extern "C" int fvvdp_ctx_alloc_info(const fvvdp_ctx* c, int* state, int* chunk_m
     *kept = c->sel_kept;
     return FVVDP_OK;
 }
+
+#ifdef BAND2_TIMELINE      // profiling build only (tools/build_variant.sh timeline "-DBAND2_TIMELINE"): not part of the C ABI
+extern "C" int fvvdp_debug_timeline(unsigned long long* h_out, size_t n_records) {
+    if (n_records > 65536) n_records = 65536;
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_band2_timeline), n_records * 4 * sizeof(unsigned long long)));
+    return FVVDP_OK;
+}
+#endif

@@ -1,6 +1,6 @@
 """GPU: the two-levels-per-pass pyramid kernel (band2_kernel) against the one-level kernel and the CPU oracle.
 
-By default the library picks band2_kernel only for large levels (>= 1.5 Mpixel); FVVDP_BAND_FUSE=1 forces it wherever
+By default the library picks band2_kernel only for large levels (>= 0.5 Mpixel); FVVDP_BAND_FUSE=1 forces it wherever
 its border logic is valid, =0 disables it, FVVDP_BAND2_KR sets the chunk height (level-C rows), so that strip seams,
 chunk seams and all row/column parities of three consecutive levels are exercised at small sizes.  Both kernels
 evaluate the same per-pixel expressions; only the order in which the per-wave partial sums are added differs."""
@@ -102,6 +102,48 @@ def test_large_still_image_takes_the_two_level_kernel(monkeypatch):
     _close(sd["Q_per_ch"].astype(np.float64), Q0)
     _close(Q1, Q0)
     assert np.array_equal(sd["Q_per_ch"][:2], Q1[:2].astype(np.float32))       # default == forced for levels 0+1
+
+
+@pytest.mark.parametrize("H,W,N", [(37, 217, None), (66, 325, 5), (40, 1296, None), (72, 1000, 6), (45, 1290, 4), (131, 433, None)])
+def test_waves_per_workgroup_change_no_bits(monkeypatch, H, W, N):
+    """band2_kernel runs 1, 2, 3 or 4 adjacent strips per workgroup, kept in step by one barrier per stage
+    (FVVDP_BAND2_WPB, honoured where it divides the number of strips; default 4 where a level has >= 2560 columns and its strips
+    fill whole groups, profiles/r04_lockstep.md).  The work items and the order of their partial sums do not depend on it:
+    bit-identical results, also with odd chunk heights.  Sizes: 2, 4, 12, 10, 12 and 5 strips."""
+    test, ref = _pair(H, W, 7 * H + W, N)
+    kw = dict(dim_order="HW") if N is None else dict(dim_order="FHW", frames_per_second=30)
+    for kr in (None, 3):
+        monkeypatch.setenv("FVVDP_BAND2_WPB", "1")
+        q0, Q0 = _run(monkeypatch, test, ref, 1, kr, **kw)
+        for wpb in (2, 3, 4):
+            monkeypatch.setenv("FVVDP_BAND2_WPB", str(wpb))
+            q1, Q1 = _run(monkeypatch, test, ref, 1, kr, **kw)
+            assert q1 == q0 and np.array_equal(Q1, Q0), (H, W, N, kr, wpb)
+
+
+def test_waves_per_workgroup_default_rule_at_full_size(monkeypatch, capfd):
+    """3840x2160 (36 strips at level 1): four waves per workgroup by default; 1920x1080 (18 strips): one.  Same bits as the
+    single-wave launch at both sizes."""
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair
+    monkeypatch.delenv("FVVDP_BAND_FUSE", raising=False)
+    monkeypatch.delenv("FVVDP_BAND2_KR", raising=False)
+    monkeypatch.setenv("FVVDP_DEBUG_VARIANT", "1")
+    for (H, W, disp, want) in ((2160, 3840, "standard_4k", 4), (1080, 1920, "standard_fhd", 1)):
+        t, r = synth_video_pair(6, H, W, device="cuda")
+        out = []
+        for wpb in (None, 1):
+            if wpb is None:
+                monkeypatch.delenv("FVVDP_BAND2_WPB", raising=False)
+            else:
+                monkeypatch.setenv("FVVDP_BAND2_WPB", str(wpb))
+            capfd.readouterr()
+            q, st = fv.fvvdp(display_name=disp).predict(t, r, frames_per_second=30)
+            err = capfd.readouterr().err
+            if wpb is None:
+                assert ("%d waves per workgroup" % want) in err, err[-600:]
+            out.append((float(q), st["Q_per_ch"].copy()))
+        assert out[0][0] == out[1][0] and np.array_equal(out[0][1], out[1][1])
 
 
 def test_clamp_free_variant_is_taken_only_where_proven_and_changes_nothing(tmp_path):

@@ -379,7 +379,7 @@ def test_hot_kernels_do_not_spill():
             seen["temporal_vec"] += 1
         elif "band2_kernel<" in nice or "band2_fov_kernel<" in nice:
             if "fov" in nice:        # opt-in two-level foveated pass: nothing in scratch; a few of its many scalar arguments sit in vector-register lanes
-                assert spills[1:] == (0, 0) and spills[0] <= 8, (nice, spills)
+                assert spills[1:] == (0, 0) and spills[0] <= 16, (nice, spills)
             else:
                 assert spills == (0, 0, 0), (nice, spills)
             seen["band2"] += 1

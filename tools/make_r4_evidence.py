@@ -255,3 +255,116 @@ pooled sums are bit-identical.  Same-box A/B (session 10):
 fourth wave per SIMD did not lower the data-flow floor either (round 3): the kernel is not waiting for latency, and the staging
 costs 16 LDS reads and ~10 vector instructions per loop body.
 """ % (table(lines("r4s6", "*.json")), rd("r4s7/floors.txt"), rd("r4s8/ab.txt"), rd("r4s8/fov_new.txt"), rd("r4s8/fov_prev.txt"), rd("r4s10/ab.txt")))
+
+# ---------------------------------------------------------------------------------------------------------------------------
+write("r04_lockstep.md", """# Round 4: occupancy over ONE launch of the dominant kernel, and adjacent strips walked in step
+
+## 1. Timeline of a launch (`tools/gpu_timeline.py`, profiling build `-DBAND2_TIMELINE`: every workgroup records start / end on the 100 MHz wall clock, XCD and CU)
+
+`band2_kernel<4, true>`, 3840x2160 x60 (15120 single-wave work items, 3072 resident = 3 per SIMD) and 1920x1080 x60, session 19:
+
+```
+%s
+%s
+```
+
+What it shows: (i) the wave slots are full until the last item starts; the last ~390 us (one item) run at falling occupancy: 12 %% of the
+wave-time of the launch is idle, all of it there (4.92 "rounds" of 3072); (ii) the XCDs finish within 8 %% of each other; (iii) **the 3072
+items of the first round, which start together and stay in step, take 316 us, every later item 380-415 us** -- the same work, the same
+occupancy.  Free-running neighbours drift apart; in step they meet in the caches on the 20 of 128 columns they share and ask DRAM for one
+contiguous piece of each row.  At 1920x1080 the whole launch (2.8 rounds of short items) stays in step by itself.
+
+## 2. Adjacent strips in one workgroup, one barrier per stage (`FVVDP_BAND2_WPB`)
+
+Workgroup = w waves = w adjacent strips of one chunk and frame, `s_barrier` at the top of every stage (4 level-A rows).  Same work items,
+same partial sums, bit-identical results (`tests/test_gpu_fused.py::test_waves_per_workgroup_*`).  ms per 4K x 60 pair, K1 / levels 0+1 / all
+levels us per frame (HIP-event medians), one gpurun call = one box per block:
+
+Session 20 (compile-time w; 1920x1080 below):
+
+```
+%s
+```
+
+Timeline of the w = 4 launch on that box (steady items 374 us instead of 390; the first round still 314):
+
+```
+%s
+```
+
+Session 21 (6, 9 and 12 waves: a workgroup of 6 or 9 waves does not spread evenly over the 4 SIMDs; 12 = the whole CU, no gain):
+
+```
+%s
+```
+
+Session 22 (launch-time w; chunk heights; other frame sizes and batch lengths):
+
+```
+%s
+```
+
+Session 24 (a box in the fast K1 mode; 8 waves; a second barrier per stage; widths between 2048 and 3200):
+
+```
+%s
+```
+
+Session 25 (which wave takes which strip rotated with the work item -- no help for partly filled last groups: a workgroup holds its four
+wave slots, so 30 strips in groups of 4 cost the launch the slots of 32):
+
+```
+%s
+```
+
+Shipped rule: 4 waves per workgroup where level A has >= 2560 columns AND the strips fill whole groups (4K: 36 strips, 8K: 72,
+2560x1440: 24), else 1.  4K: -1.5 ... -6 %% on five boxes; 8K -2.6 %%; 2560x1440 0 ... -3 %%; 1920x1080 and 3200x1800 would lose 5-9 %%.
+
+## 3. Short chunks dispatched last (`FVVDP_BAND2_KR2`, session 26) -- kept
+
+The last tall chunk of every frame is cut into four (kr2 = kr / 4 level-C rows) and the short chunks of ALL frames get the highest
+block indices, so they are dispatched after every tall one.  `kr2=0` = uniform chunks; the other values are explicit heights:
+
+```
+%s
+```
+
+Timeline with the short chunks (mean residency 2688 -> 2840 of 3072 waves; what is left of the tail is the XCDs finishing 5-7 %% apart):
+
+```
+%s
+```
+
+Also since session 27: levels of >= 0.5 Mpixel take the two-level kernel (was 1.5): at 4K levels 2+3 in one launch, 3.06 -> 2.67 us per frame:
+
+```
+%s
+```
+
+## 4. Resident workgroups with per-XCD work queues (session 28) -- built, 3.5 %% slower, removed
+
+Grid = resident capacity; every workgroup takes item numbers from the atomic queue of the XCD it runs on (`s_getreg XCC_ID`), the next
+number is requested before the item and looked at after it, an empty queue steals from the others.  The stealing works (2629-2825 items per
+XCD instead of 2700 each), but the loop around the item costs the kernel its register allocation (13-18 scalar spills, 167-168 vector
+registers) and the launch is slower than the hardware's dispatch of one workgroup per item, in the same build and against the previous one:
+
+```
+%s
+```
+
+## 5. The foveated one-level kernel in step (`-DFOV_LOCKSTEP`, session 23) -- no effect, removed
+
+`band_kernel<4, false, 1>` already runs 4 waves per workgroup (4 frames of one tile).  Variant: the 4 waves take adjacent strips of one
+chunk and frame (frame fastest over workgroups, so the rho-map slice stays in L2), one or two barriers per 4 coarse rows.  Parity green
+(13 foveated tests); `tools/gpu_config4.py`, kernel us per frame [K1, level 0, level 1, ...]:
+
+```
+%s
+```
+
+Level 0: 37.7 / 37.7 (base) vs 38.4 / 37.3 (one barrier) vs 38.2 / 37.1 (two): the kernel is bound by its arithmetic, not by where its rows
+come from.  The code was removed again.
+""" % (rd("r4s19/timeline_4k.txt"), rd("r4s19/timeline_fhd.txt"), rd("r4s20/ab.txt"), rd("r4s20/timeline_4k_wpb4.txt"), rd("r4s21/ab.txt"),
+       rd("r4s22/scan.txt"), rd("r4s24/scan.txt"), rd("r4s25/scan.txt"),
+       rd("r4s26/scan.txt"), rd("r4s26/timeline_4k.txt"), rd("r4s27/scan.txt"), rd("r4s28/scan.txt"),
+       "\n".join(l for l in rd("r4s23/fov.txt").split("\n") if l.startswith("==") or l.startswith("kernel us/frame:"))))
