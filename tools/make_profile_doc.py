@@ -83,7 +83,7 @@ def quoted_figures():
     out.append("* unprofiled `bench.py`: %.3f ms per pair = %.1f Gpix/s (test+ref), median of %d steps (mean %.3f, min %.3f, max %.3f); profiled: %.3f ms" % (
         jp["ms_per_step"], jp["value"] / 1e3, jp["steps"], jp["timing"]["ms_per_step_mean"], jp["timing"]["ms_per_step_min"], jp["timing"]["ms_per_step_max"], jq["ms_per_step"]))
     for label, (calls, avg, med, steady) in rows.items():
-        if "band2_kernel" in label:
+        if "band2_kernel" in label and "levels 0+1" in label:
             b = r["bytes_per_launch"]
             out.append("* `%s`: %.4f GB algorithmic per launch / rocprof AVERAGE %.1f us = %.2f TB/s = %.3f of 8 TB/s; / steady median %.1f us = %.3f; unprofiled HIP-event median %.1f us = %.4f" % (
                 label.strip("`"), b / 1e9, avg, b / avg / 1e6, b / avg / 1e6 / 8.0, steady, b / steady / 1e6 / 8.0, r["median_launch_ms"] * 1e3, r["frac"]))

@@ -368,3 +368,28 @@ come from.  The code was removed again.
        rd("r4s22/scan.txt"), rd("r4s24/scan.txt"), rd("r4s25/scan.txt"),
        rd("r4s26/scan.txt"), rd("r4s26/timeline_4k.txt"), rd("r4s27/scan.txt"), rd("r4s28/scan.txt"),
        "\n".join(l for l in rd("r4s23/fov.txt").split("\n") if l.startswith("==") or l.startswith("kernel us/frame:"))))
+
+# ---------------------------------------------------------------------------------------------------------------------------
+write("r04_yuv_counters.md", """# Round 4: what bounds the 10-bit 4:2:0 YUV temporal kernel at 60 fps (VERDICT r3 weak 9)
+
+`temporal_yuv_vec_kernel<16, unsigned short, true, sRGB>` (3840x2160 x60 at 60 fps: 15 taps, 74 source frames per launch) takes 63-65 us per
+output frame = 2.8-2.9 TB/s on its 182.5 MB per frame (0.36 of the peak).  SQ counters of the kernel, two `rocprofv3 --pmc` passes
+(`tools/experiments/r4_session30.sh`, `tools/pmc_sq_summary.py`):
+
+%s
+
+Reading: two waves per SIMD are resident (`__launch_bounds__(64, 2)`, 128 vector registers) and a wave issues vector instructions during
+0.436 of its resident time -- the vector ALU is busy 0.87 of the time, the waves wait for memory 0.22 of theirs, LDS and scalar work are
+noise.  1.575e9 vector instructions / 33 450 waves / 74 frames = **636 per wave and source frame** (4 pixels x 2 streams per lane), of which
+48 are transcendental (quarter rate).  Where they go, from the kernel source (`csrc/temporal_kernels.hpp`, `temporal_yuv_vec_body`):
+unpack + convert 10-bit samples ~64; chroma bilinear x2 ~40; YCbCr matrix ~36; clamp to [0, 1] 32; display model (sRGB: compare, log2, multiply,
+exp2, fused multiply-add, select per value, 24 values as 12 packed pairs) ~170; luminance 12; the two 15-tap filters on packed (test,
+reference) pairs 120; ring bookkeeping ~30; out-of-range flag, stores ~30.  At 4 cycles per instruction and 16 per transcendental that is
+~3100 cycles per wave and frame = 42 us per frame with the ALU never idle -- against 23 us for the bytes.  The reference evaluates the same
+expressions per pixel (float RGB from the upsampled chroma, then the display model: `video_source_file.py:219-276`,
+`fvvdp_display_model.py:147-165`), so a table cannot replace the display model here as it does for 8-bit RGB sources.  Of the 63-65 us,
+14 of 74 processed frames (19 %%) are the filter's warm-up at 60 fps; a 120-frame clip pays 11 %%.
+
+Left as it is: the kernel is bound by arithmetic that the algorithm prescribes; 2 pixels per lane instead of 4 would not change the count
+per pixel.
+""" % rd("r4s30/pmc_sq_yuv.md"))

@@ -16,7 +16,9 @@ def dominant(db, counter):
                        "where (kernel_name like '%band2_kernel%' or kernel_name like '%band_kernel%') and counter_name = ? "
                        "group by dispatch_id order by max(start)", (counter,)).fetchall()
     b2 = [r for r in rows if "band2_kernel" in r[4]]
-    if b2:                      # two-level kernel: at 4K only levels 0+1 take it -> every dispatch is the dominant launch
+    if b2:                      # two-level kernel: at 4K levels 0+1 and levels 2+3 take it -> the large dispatches are the dominant launch
+        mx = max(r[1] for r in b2)
+        b2 = [r for r in b2 if r[1] > 0.5 * mx]
         vals, durs, fused = [r[1] for r in b2], [r[2] for r in b2], True
     else:                       # one-level kernels in level order 0..6 per batch
         n = len(rows) // 7
