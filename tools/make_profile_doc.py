@@ -108,6 +108,19 @@ def quoted_figures():
                 name, j["ms_per_pair"], j["value"] / 1e3, gg["temporal_us_per_frame_median"], gg["levels_us_per_frame_median"][0], gg["us_per_frame_all_levels"]))
         except Exception:
             pass
+    la = jp.get("level0_alloc")
+    if isinstance(la, dict):
+        cmp_ = la.get("compared_us_per_frame")
+        out.append("* level-0 scratch of the unprofiled run: started as %s, in use %s%s" % (la.get("start"), la.get("in_use"),
+                   (" (the context compared %.2f us per frame on the first buffer with %.2f on the other kind, temporal kernel + pyramid pass, and kept the %s)" % (
+                       cmp_["first"], cmp_["other_kind"], {"first": "first", "other_kind": "other kind"}.get(la.get("kept"), "?"))) if cmp_ else ""))
+    out.append("* JOD %s, |delta| to the real reference %.3g (north-star bound 1e-3)" % (jp.get("jod"), jp.get("jod_delta_vs_reference") or 0.0))
+    fov = [l for l in rd("fov_probe.txt").split("\n") if l.startswith("kernel us/frame")]
+    fms = [l.split()[4] for l in rd("fov_probe.txt").split("\n") if l.startswith("config4")]
+    if fov:
+        out.append("* configs[3] (3840x2160 x120 foveated, moving gaze, PQ; `fov_probe.txt`): calls %s ms; %s" % (" / ".join(fms[1:]), fov[0]))
+        if len(fov) > 1:
+            out.append("  %s" % fov[1])
     cb = jp.get("cpu_baseline") or {}
     if cb:
         out.append("* CPU baseline: %.2f Mpix/s on %d cores; reference %.1f s per pair = %.2f Mpix/s; PCIe-inclusive %.1f Gpix/s" % (
@@ -338,3 +351,13 @@ Notes.
 """
     open(os.path.join(ROOT, "profiles", f"{tag}_parity.md"), "w").write(par)
 print("wrote profiles/%s_final_kernel_trace.md (%d bytes)" % (tag, len(doc)))
+# DESIGN.md section 0 quotes exactly these figures: splice them in between the markers
+dpath = os.path.join(ROOT, "DESIGN.md")
+if os.path.exists(dpath):
+    d = open(dpath).read()
+    b, e = "<!-- bundle-figures:begin -->", "<!-- bundle-figures:end -->"
+    if b in d and e in d:
+        d = d[:d.index(b) + len(b)] + "\n" + quoted_figures() + "\n" + d[d.index(e):]
+        open(dpath, "w").write(d)
+        print("updated the figures block of DESIGN.md")
+
