@@ -709,7 +709,7 @@ __device__ unsigned long long g_band2_timeline[4 * 65536];
 // and share its L2 (see band_kernel).
 // Resident workgroups that take their items from per-XCD atomic queues and steal from the slowest XCD (the XCDs of one box
 // finish their eighth 5-8 % apart) were built and measured 3.5 % SLOWER than the hardware's dispatch (the loop around the item
-// costs registers: 13-18 scalar spills) -- profiles/r04_lockstep.md, section 5.
+// costs registers: 13-18 scalar spills) -- profiles/r04_lockstep.md, section 4.
 template <int P, bool INRANGE = false>
 __global__ __launch_bounds__(64 * BAND2_WPB_MAX, BAND2_LB) void band2_kernel(const Band2Args a) {
     __shared__ float4 s_csf[2][FVVDP_LUT_N];

@@ -84,6 +84,7 @@ struct fvvdp_ctx {
     float* partial = nullptr;
     long long partial_off[FVVDP_MAX_BANDS]{};
     int max_blk[FVVDP_MAX_BANDS]{};
+    int* d_ticket = nullptr;      // block counter of the resident temporal kernel (TemporalArgs::ticket), zeroed before every launch
     size_t partial_floats = 0;
     float4* csf = nullptr;        // [n_bands][32] slope-form records of the 1-D tables
     float4* csf_y = nullptr;      // [32] {Y_log[i],0,0,0}
@@ -360,6 +361,11 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
     }
     c->partial_floats = off;
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->partial, off);
+    if (rc == FVVDP_OK) {
+        float* q = nullptr;
+        rc = dev_alloc(c, &q, 16);
+        c->d_ticket = reinterpret_cast<int*>(q);
+    }
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->csf, (size_t)n_bands * FVVDP_LUT_N);
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->csf_y, (size_t)FVVDP_LUT_N);
     if (rc == FVVDP_OK) rc = dev_alloc(c, &c->d_fix, (size_t)max_frames * 2);
@@ -399,6 +405,7 @@ extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     for (int i = 0; i <= FVVDP_MAX_BANDS; ++i)
         dev_free(c, c->level[i]);
     dev_free(c, c->partial);
+    dev_free(c, c->d_ticket);
     if (c->csf) (void)hipFree(c->csf);
     if (c->csf_y) (void)hipFree(c->csf_y);
     for (int i = 0; i <= FVVDP_MAX_BANDS; ++i)
@@ -743,6 +750,14 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
                                     (reinterpret_cast<uintptr_t>(d_test) % (size_t)(es * PXv) == 0) &&
                                     (reinterpret_cast<uintptr_t>(d_ref) % (size_t)(es * PXv) == 0);
                 if (vec_ok) {
+                    // uint8, <= 16 taps: resident workgroups that take their pixel blocks from a counter (temporal_vec_kernel;
+                    // FVVDP_K1_TICKET=0: one workgroup per block).  Measured on three boxes: -4 ... -6 % at 60 fps (16-slot ring),
+                    // -3 ... +1 % at 30 fps (profiles/r04_lockstep.md, section 5).  Same blocks, same arithmetic.
+                    const char* tke = getenv("FVVDP_K1_TICKET");
+                    if (!(tke && tke[0] == '0') && dtype == FVVDP_U8 && FL <= 16 && c->d_ticket) {
+                        if (hipMemsetAsync(c->d_ticket, 0, sizeof(int), st) == hipSuccess) a.ticket = c->d_ticket;
+                        else (void)hipGetLastError();
+                    }
                     k1_launch_vec(FL, dtype, a, st);
                 } else if (FL == 64) {
                     // the 64-slot ring exists as the 1-pixel-per-lane vector kernel only; it needs nothing but element alignment

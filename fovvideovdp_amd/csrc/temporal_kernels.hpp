@@ -195,6 +195,8 @@ struct TemporalArgs {
     int fl;                // true filter length (<= FL)
     float* out;            // level 0 of the first output slot: [n_out][HW][4]
     int* oob;
+    int* ticket;           // nullptr: one workgroup per pixel block; else a zeroed counter -- the grid is the resident capacity and a
+                           // workgroup that has finished a block takes the next one (temporal_vec_kernel)
     float taps2[64][2];    // {sustained, transient} tap k (k frames in the past), zero beyond fl: one scalar register pair per tap
     int idx[T_MAX_IDX];    // [FL-1+n_out], entries before the true history are padded with a valid frame
     int idx1[T_MAX_IDX];   // the same for stream 1 (reference): equal to idx for one array per stream, different when the
@@ -531,7 +533,7 @@ __device__ __forceinline__ void wave_lds_order() {
 // CC = number of colour channels as a compile-time constant (3 or 1): with a run-time `C == 3` around the loads and the
 // table look-ups, every step has control-flow joins and the compiler falls back to s_waitcnt vmcnt(0).
 template <int FL, int PX, int SRC, int TD, int CC, int KIND>
-__device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const float* lutw, float4* s_t) {
+__device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const float* lutw, float4* s_t, const int block = (int)blockIdx.x) {
     // the window index lists are the only dynamically indexed members of the argument block: read them straight from the
     // kernel-argument segment (scalar loads), otherwise the whole 2.9 KB block can end up copied to scratch
     typedef const int __attribute__((address_space(4)))* karg_int_p;
@@ -540,7 +542,7 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
     const karg_int_p idx0 = (karg_int_p)(ka + offsetof(TemporalArgs, idx));
     const karg_int_p idx1 = (karg_int_p)(ka + offsetof(TemporalArgs, idx1));
     const int lane = threadIdx.x;
-    const int p0 = blockIdx.x * (64 * PX);          // first pixel of this wave
+    const int p0 = block * (64 * PX);               // first pixel of this wave
     const int pl = min(p0 + lane * PX, a.HW - PX);  // this lane's PX consecutive pixels (clamped: loads stay in range)
     const float w[3] = {CC == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};
     OobMax bad;
@@ -661,9 +663,9 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
 }
 
 template <int FL, int PX, int SRC, int TD, int KIND>
-__device__ __forceinline__ void temporal_vec_cc(const TemporalArgs& a, const float* lutw, float4* s_t) {
-    if (a.C == 3) temporal_vec_body<FL, PX, SRC, TD, 3, KIND>(a, lutw, s_t);
-    else temporal_vec_body<FL, PX, SRC, TD, 1, KIND>(a, lutw, s_t);
+__device__ __forceinline__ void temporal_vec_cc(const TemporalArgs& a, const float* lutw, float4* s_t, const int block = (int)blockIdx.x) {
+    if (a.C == 3) temporal_vec_body<FL, PX, SRC, TD, 3, KIND>(a, lutw, s_t, block);
+    else temporal_vec_body<FL, PX, SRC, TD, 1, KIND>(a, lutw, s_t, block);
 }
 
 // waves per SIMD the register allocation aims at (uint8: 116 / 128 / 168 VGPRs for the 8 / 16 / 32-slot ring)
@@ -695,9 +697,28 @@ constexpr int k1_waves(int FL, int SRC) {
     return SRC == SRC_U8 ? (FL == 8 ? K1_WAVES8 : (FL == 16 ? K1_WAVES16 : (FL == 32 ? K1_WAVES32 : K1_WAVES64)))
                          : FL == 64 ? K1_WAVES64 : (FL == 8 ? (SRC == SRC_F32 ? K1_WAVESF8 : K1_WAVESX8) : (FL == 16 ? K1_WAVESX16 : K1_WAVESX32));
 }
+#ifdef K1_TIMELINE         // profiling build: (start, end) of every workgroup on the 100 MHz wall clock (tools/gpu_timeline.py k1)
+static __device__ unsigned long long g_k1_timeline[4 * 65536];
+struct K1Clock {
+    unsigned long long t0;
+    __device__ K1Clock() : t0(wall_clock64()) {}
+    __device__ ~K1Clock() {
+        if (threadIdx.x == 0 && blockIdx.x < 65536) {
+            unsigned long long* t = g_k1_timeline + 4 * (size_t)blockIdx.x;
+            t[0] = t0;
+            t[1] = wall_clock64();
+            t[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) << 32) | (unsigned int)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);
+            t[3] = blockIdx.x;
+        }
+    }
+};
+#endif
 template <int FL, int PX, int SRC, int TD = 1>
 __global__ __launch_bounds__(64, k1_waves(FL, SRC))
 void temporal_vec_kernel(const TemporalArgs a_byval) {
+#ifdef K1_TIMELINE
+    K1Clock k1_clock;
+#endif
     // All reads of the argument block go to the kernel-argument segment itself (scalar loads).  Through the by-value
     // parameter the compiler starts from a private copy and, in the largest instantiations, fails to remove it: 2.9 KB of
     // scratch per lane and every filter tap reloaded from it.
@@ -708,7 +729,27 @@ void temporal_vec_kernel(const TemporalArgs a_byval) {
     if constexpr (SRC == SRC_U8) build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 64);
     __syncthreads();
     // colour-channel count and display model as compile-time constants of the loop body (see temporal_vec_body)
-    if constexpr (SRC == SRC_U8) {
+    if constexpr (SRC == SRC_U8 && FL <= 16) {
+        // uint8 at <= 64 fps (the BASELINE configs): with a ticket counter the grid is the resident capacity and a workgroup that
+        // has finished a block of pixels takes the next one -- the XCDs of a box run this memory-bound kernel 5-8 % apart, and the
+        // hardware hands each of them exactly an eighth of the workgroups (profiles/r04_lockstep.md, section 5)
+        typedef const char __attribute__((address_space(4)))* karg_p;
+        int block = (int)blockIdx.x;
+        const int n_blocks = (a.HW + 64 * PX - 1) / (64 * PX);
+        for (;;) {
+            int next = 0x7fffffff;
+            {
+                karg_p ka = (karg_p)__builtin_amdgcn_kernarg_segment_ptr();
+                asm volatile("" : "+s"(ka));
+                int* const tk = *(int* const __attribute__((address_space(4)))*)(ka + offsetof(TemporalArgs, ticket));
+                if (tk && threadIdx.x == 0) next = (int)gridDim.x + atomicAdd(tk, 1);       // asked for now, looked at after the block
+            }
+            temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LUT>(a, lutw, s_t, block);
+            block = __builtin_amdgcn_readfirstlane(next);
+            if (block >= n_blocks) break;
+            wave_lds_order();                        // the transposes of the next block reuse s_t
+        }
+    } else if constexpr (SRC == SRC_U8) {
         temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LUT>(a, lutw, s_t);
     } else if constexpr (FL == 64) {
         // 64-slot ring for 16-bit / float input (k1_ring64_ok() is the host-side list): RGB behind an sRGB or PQ display,

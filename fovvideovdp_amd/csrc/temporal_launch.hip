@@ -22,6 +22,19 @@ static void launch_vec(const TemporalArgs& a, hipStream_t st) {
     constexpr int PX = k1_px(FL, DT);
     constexpr int TD = FL == 8 ? K1_TD8 : (FL == 16 ? K1_TD16 : (FL == 32 ? K1_TD32 : 1));
     dim3 grid((a.HW + 64 * PX - 1) / (64 * PX)), block(64);
+    if (a.ticket) {          // resident workgroups that take their pixel blocks from a.ticket (uint8, FL <= 16; the caller zeroed it)
+        static int resident = 0;
+        if (!resident) {
+            int dev = 0, per_cu = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+                hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, temporal_vec_kernel<FL, PX, SRC, TD>, 64, 0) == hipSuccess && per_cu > 0)
+                resident = per_cu * prop.multiProcessorCount;
+            else { (void)hipGetLastError(); resident = -1; }
+        }
+        if (resident > 0 && (int)grid.x > 2 * resident) grid.x = (unsigned int)resident;
+        else { TemporalArgs b = a; b.ticket = nullptr; hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC, TD>), grid, block, 0, st, b); return; }
+    }
     hipLaunchKernelGGL((temporal_vec_kernel<FL, PX, SRC, TD>), grid, block, 0, st, a);
 }
 template <int FL, int PX>
@@ -41,6 +54,13 @@ static void launch_generic(const GenericArgs& a, hipStream_t st) {
 #define K1_NAME(f) f##_u16
 #else
 #define K1_NAME(f) f##_f32
+#endif
+#if defined(K1_TIMELINE) && K1_PART == 0      // profiling build only: not part of the C ABI
+extern "C" int fvvdp_debug_k1_timeline(unsigned long long* h_out, size_t n_records) {
+    if (n_records > 65536) n_records = 65536;
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    return hipMemcpyFromSymbol(h_out, HIP_SYMBOL(g_k1_timeline), n_records * 4 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
+}
 #endif
 void K1_NAME(k1_vec)(int FL, const TemporalArgs& a, hipStream_t st) {
     if (FL == 8) launch_vec<8>(a, st);

@@ -513,6 +513,30 @@ def test_level0_allocation_choice_changes_no_bits_and_settles(tmp_path):
     assert np.array_equal(res["on"], res["off"]) and np.array_equal(res["on"], res["on_malloc"])
 
 
+def test_ticketed_temporal_kernel_changes_no_bits(monkeypatch):
+    """uint8 sources with <= 16 taps run the temporal kernel as resident workgroups that take their pixel blocks from a counter
+    (more than two rounds of blocks only; FVVDP_K1_TICKET=0 = one workgroup per block).  Same blocks, same arithmetic: level 0 and
+    the results are bit-identical, at 30 and 60 fps, RGB and gray, for a frame whose last block is partial, and call after call
+    (the counter is zeroed before every launch)."""
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair
+    for (N, H, W, fps) in ((12, 2160, 3840, 30), (20, 2160, 3840, 60), (10, 1442, 2564, 30), (9, 1080, 1920, 30)):
+        t, r = synth_video_pair(N, H, W, device="cuda")
+        for gray in (False, True):
+            tt, rr = (t[:, :1], r[:, :1]) if gray else (t, r)
+            out = {}
+            for mode in ("1", "0"):
+                monkeypatch.setenv("FVVDP_K1_TICKET", mode)
+                m = fv.fvvdp(display_name="standard_4k")
+                res = []
+                for rep in range(3):
+                    q, st = m.predict(tt, rr, frames_per_second=fps)
+                    res.append(np.concatenate([st["Q_per_ch"].reshape(-1), [float(q)]]))
+                out[mode] = np.stack(res)
+            assert np.array_equal(out["1"], out["0"]), (N, H, W, fps, gray)
+            assert np.array_equal(out["1"][0], out["1"][2])
+
+
 def test_stage_overlap_equals_the_sequential_order():
     """`pipeline` = k cuts a clip into k batches whose temporal kernel runs on one internal stream against the pyramid pass of
     the previous batch on another (two banks of the level-0 scratch).  Against the strictly sequential order: equal up to the

@@ -22,9 +22,10 @@ for _ in range(3):
     q, st = m.predict(t, r, frames_per_second=30)
 torch.cuda.synchronize()
 lib = C.CDLL(os.environ["FVVDP_LIB"])
-lib.fvvdp_debug_timeline.argtypes = [C.c_void_p, C.c_size_t]
+fn = lib.fvvdp_debug_k1_timeline if os.environ.get("KERNEL", "band2") == "k1" else lib.fvvdp_debug_timeline     # KERNEL=k1: the temporal kernel (-DK1_TIMELINE build)
+fn.argtypes = [C.c_void_p, C.c_size_t]
 buf = np.zeros((65536, 4), dtype=np.uint64)
-assert lib.fvvdp_debug_timeline(buf.ctypes.data, 65536) == 0
+assert fn(buf.ctypes.data, 65536) == 0
 n = int(np.count_nonzero(buf[:, 1]))
 rec = buf[:n]
 if len(sys.argv) > 1:

@@ -352,7 +352,31 @@ registers) and the launch is slower than the hardware's dispatch of one workgrou
 %s
 ```
 
-## 5. The foveated one-level kernel in step (`-DFOV_LOCKSTEP`, session 23) -- no effect, removed
+## 5. The temporal kernel: timeline and pixel blocks from a ticket counter (sessions 31-33) -- kept for uint8, <= 16 taps
+
+`temporal_vec_kernel<8, 4, 0, 1>`, 3840x2160 x60 (32400 single-wave workgroups, 4096 resident), profiling build `-DK1_TIMELINE`:
+
+```
+%s
+```
+
+10 %% of the wave-time idle: the last item's length (items that start when the slots empty run faster -- the kernel is bound by memory),
+and two of the eight XCDs (1 and 5 on that box) finish 6 %% after the others although the hardware hands every XCD exactly 4050 workgroups.
+With a ticket counter (`TemporalArgs::ticket`) the grid is the resident capacity and a workgroup that has finished a block of pixels takes
+the next one; the blocks have no neighbours to share anything with, so any order does.  Same blocks, same arithmetic
+(`test_ticketed_temporal_kernel_changes_no_bits`).  `ticket=0` = one workgroup per block; ms per pair, K1 us per frame; one box per block:
+
+```
+%s
+# second box
+%s
+# third box
+%s
+```
+
+30 fps (8-slot ring): -3 %% ... +1 %%; 60 fps (16-slot ring, 2 pixels per lane, twice the blocks): -4 ... -6 %% on all three boxes.
+
+## 6. The foveated one-level kernel in step (`-DFOV_LOCKSTEP`, session 23) -- no effect, removed
 
 `band_kernel<4, false, 1>` already runs 4 waves per workgroup (4 frames of one tile).  Variant: the 4 waves take adjacent strips of one
 chunk and frame (frame fastest over workgroups, so the rho-map slice stays in L2), one or two barriers per 4 coarse rows.  Parity green
@@ -367,6 +391,7 @@ come from.  The code was removed again.
 """ % (rd("r4s19/timeline_4k.txt"), rd("r4s19/timeline_fhd.txt"), rd("r4s20/ab.txt"), rd("r4s20/timeline_4k_wpb4.txt"), rd("r4s21/ab.txt"),
        rd("r4s22/scan.txt"), rd("r4s24/scan.txt"), rd("r4s25/scan.txt"),
        rd("r4s26/scan.txt"), rd("r4s26/timeline_4k.txt"), rd("r4s27/scan.txt"), rd("r4s28/scan.txt"),
+       rd("r4s31/k1_timeline.txt"), rd("r4s32/scan.txt"), rd("r4s33/scan_box1.txt"), rd("r4s33/scan_box2.txt"),
        "\n".join(l for l in rd("r4s23/fov.txt").split("\n") if l.startswith("==") or l.startswith("kernel us/frame:"))))
 
 # ---------------------------------------------------------------------------------------------------------------------------
