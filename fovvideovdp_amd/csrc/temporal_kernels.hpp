@@ -699,26 +699,20 @@ constexpr int k1_waves(int FL, int SRC) {
 }
 #ifdef K1_TIMELINE         // profiling build: (start, end) of every workgroup on the 100 MHz wall clock (tools/gpu_timeline.py k1)
 static __device__ unsigned long long g_k1_timeline[4 * 65536];
-struct K1Clock {
-    unsigned long long t0;
-    __device__ K1Clock() : t0(wall_clock64()) {}
-    __device__ ~K1Clock() {
-        if (threadIdx.x == 0 && blockIdx.x < 65536) {
-            unsigned long long* t = g_k1_timeline + 4 * (size_t)blockIdx.x;
-            t[0] = t0;
-            t[1] = wall_clock64();
-            t[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) << 32) | (unsigned int)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);
-            t[3] = blockIdx.x;
-        }
+__device__ __forceinline__ void k1_clock_record(int block, unsigned long long t0) {
+    if (threadIdx.x == 0 && block < 65536) {
+        unsigned long long* t = g_k1_timeline + 4 * (size_t)block;
+        t[0] = t0;
+        t[1] = wall_clock64();
+        t[2] = ((unsigned long long)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) << 32) | (unsigned int)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 4);
+        t[3] = (unsigned long long)block;
     }
-};
+}
 #endif
 template <int FL, int PX, int SRC, int TD = 1>
 __global__ __launch_bounds__(64, k1_waves(FL, SRC))
 void temporal_vec_kernel(const TemporalArgs a_byval) {
-#ifdef K1_TIMELINE
-    K1Clock k1_clock;
-#endif
+
     // All reads of the argument block go to the kernel-argument segment itself (scalar loads).  Through the by-value
     // parameter the compiler starts from a private copy and, in the largest instantiations, fails to remove it: 2.9 KB of
     // scratch per lane and every filter tap reloaded from it.
@@ -744,7 +738,13 @@ void temporal_vec_kernel(const TemporalArgs a_byval) {
                 int* const tk = *(int* const __attribute__((address_space(4)))*)(ka + offsetof(TemporalArgs, ticket));
                 if (tk && threadIdx.x == 0) next = (int)gridDim.x + atomicAdd(tk, 1);       // asked for now, looked at after the block
             }
+#ifdef K1_TIMELINE
+            const unsigned long long k1_t0 = wall_clock64();
+#endif
             temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LUT>(a, lutw, s_t, block);
+#ifdef K1_TIMELINE
+            k1_clock_record(block, k1_t0);
+#endif
             block = __builtin_amdgcn_readfirstlane(next);
             if (block >= n_blocks) break;
             wave_lds_order();                        // the transposes of the next block reuse s_t

@@ -376,6 +376,17 @@ the next one; the blocks have no neighbours to share anything with, so any order
 
 30 fps (8-slot ring): -3 %% ... +1 %%; 60 fps (16-slot ring, 2 pixels per lane, twice the blocks): -4 ... -6 %% on all three boxes.
 
+Per-block timelines of both modes on a fourth box (session 35; the profiling build records every block inside the ticket loop).  Without
+tickets XCDs 1 and 5 are again the ones that finish 110 us after the rest (the same two as on the first box: structural, not a box's
+quirk).  With tickets every XCD ends within 55 us of the others and takes 3918-4185 blocks instead of 4050 each -- but the blocks, all
+started within 35 us and never re-placed by the hardware, run in bursts (durations of 120 / 180 / 360 us where the hardware's dispatch
+gives a steady 205), the wave-time per block is 7 %% higher, and the launch is not shorter at 30 fps on this box (1914 vs 1897 us):
+
+```
+%s
+%s
+```
+
 ## 6. The foveated one-level kernel in step (`-DFOV_LOCKSTEP`, session 23) -- no effect, removed
 
 `band_kernel<4, false, 1>` already runs 4 waves per workgroup (4 frames of one tile).  Variant: the 4 waves take adjacent strips of one
@@ -392,6 +403,7 @@ come from.  The code was removed again.
        rd("r4s22/scan.txt"), rd("r4s24/scan.txt"), rd("r4s25/scan.txt"),
        rd("r4s26/scan.txt"), rd("r4s26/timeline_4k.txt"), rd("r4s27/scan.txt"), rd("r4s28/scan.txt"),
        rd("r4s31/k1_timeline.txt"), rd("r4s32/scan.txt"), rd("r4s33/scan_box1.txt"), rd("r4s33/scan_box2.txt"),
+       "# FVVDP_K1_TICKET=1\n" + rd("r4s35/k1_timeline_ticket1.txt"), "# FVVDP_K1_TICKET=0\n" + rd("r4s35/k1_timeline_ticket0.txt"),
        "\n".join(l for l in rd("r4s23/fov.txt").split("\n") if l.startswith("==") or l.startswith("kernel us/frame:"))))
 
 # ---------------------------------------------------------------------------------------------------------------------------
