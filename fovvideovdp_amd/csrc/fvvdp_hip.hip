@@ -750,11 +750,13 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
                                     (reinterpret_cast<uintptr_t>(d_test) % (size_t)(es * PXv) == 0) &&
                                     (reinterpret_cast<uintptr_t>(d_ref) % (size_t)(es * PXv) == 0);
                 if (vec_ok) {
-                    // uint8, <= 16 taps: resident workgroups that take their pixel blocks from a counter (temporal_vec_kernel;
-                    // FVVDP_K1_TICKET=0: one workgroup per block).  Measured on three boxes: -4 ... -6 % at 60 fps (16-slot ring),
-                    // -3 ... +1 % at 30 fps (profiles/r04_lockstep.md, section 5).  Same blocks, same arithmetic.
+                    // uint8, 9..16 taps (33-64 fps): resident workgroups that take their pixel blocks from a counter
+                    // (temporal_vec_kernel).  Measured on five boxes (profiles/r04_lockstep.md, section 5): -2 ... -6 % with the
+                    // 16-slot ring; -3 ... +1.5 % with the 8-slot ring, where it therefore stays off.  FVVDP_K1_TICKET=1 / 0
+                    // forces it on (<= 16 taps) / off.  Same blocks, same arithmetic.
                     const char* tke = getenv("FVVDP_K1_TICKET");
-                    if (!(tke && tke[0] == '0') && dtype == FVVDP_U8 && FL <= 16 && c->d_ticket) {
+                    const bool tickets = tke ? tke[0] != '0' : FL == 16;
+                    if (tickets && dtype == FVVDP_U8 && FL <= 16 && c->d_ticket) {
                         if (hipMemsetAsync(c->d_ticket, 0, sizeof(int), st) == hipSuccess) a.ticket = c->d_ticket;
                         else (void)hipGetLastError();
                     }

@@ -514,8 +514,8 @@ def test_level0_allocation_choice_changes_no_bits_and_settles(tmp_path):
 
 
 def test_ticketed_temporal_kernel_changes_no_bits(monkeypatch):
-    """uint8 sources with <= 16 taps run the temporal kernel as resident workgroups that take their pixel blocks from a counter
-    (more than two rounds of blocks only; FVVDP_K1_TICKET=0 = one workgroup per block).  Same blocks, same arithmetic: level 0 and
+    """uint8 sources with 9..16 taps (and with <= 8 taps under FVVDP_K1_TICKET=1) run the temporal kernel as resident workgroups
+    that take their pixel blocks from a counter (more than two rounds of blocks only; FVVDP_K1_TICKET=0 = one workgroup per block).  Same blocks, same arithmetic: level 0 and
     the results are bit-identical, at 30 and 60 fps, RGB and gray, for a frame whose last block is partial, and call after call
     (the counter is zeroed before every launch)."""
     import fovvideovdp_amd as fv

@@ -352,7 +352,7 @@ registers) and the launch is slower than the hardware's dispatch of one workgrou
 %s
 ```
 
-## 5. The temporal kernel: timeline and pixel blocks from a ticket counter (sessions 31-33) -- kept for uint8, <= 16 taps
+## 5. The temporal kernel: timeline and pixel blocks from a ticket counter (sessions 31-33) -- kept for uint8 with 9..16 taps
 
 `temporal_vec_kernel<8, 4, 0, 1>`, 3840x2160 x60 (32400 single-wave workgroups, 4096 resident), profiling build `-DK1_TIMELINE`:
 
@@ -375,6 +375,15 @@ the next one; the blocks have no neighbours to share anything with, so any order
 ```
 
 30 fps (8-slot ring): -3 %% ... +1 %%; 60 fps (16-slot ring, 2 pixels per lane, twice the blocks): -4 ... -6 %% on all three boxes.
+Two more boxes (session 37, which also tried a STATIC weighting: every k-th workgroup that lands on XCD 1 or 5 idles, `skip=k` -- -2 %% at
+best, +4 %% for one k on one box: dropped): tickets +0.5 / +1.5 %% with the 8-slot ring, -5.5 / -1.7 %% with the 16-slot ring.  Shipped:
+tickets for 9..16 taps (33-64 fps) only.
+
+```
+%s
+# second box
+%s
+```
 
 Per-block timelines of both modes on a fourth box (session 35; the profiling build records every block inside the ticket loop).  Without
 tickets XCDs 1 and 5 are again the ones that finish 110 us after the rest (the same two as on the first box: structural, not a box's
@@ -403,6 +412,7 @@ come from.  The code was removed again.
        rd("r4s22/scan.txt"), rd("r4s24/scan.txt"), rd("r4s25/scan.txt"),
        rd("r4s26/scan.txt"), rd("r4s26/timeline_4k.txt"), rd("r4s27/scan.txt"), rd("r4s28/scan.txt"),
        rd("r4s31/k1_timeline.txt"), rd("r4s32/scan.txt"), rd("r4s33/scan_box1.txt"), rd("r4s33/scan_box2.txt"),
+       rd("r4s37/scan_box1.txt"), rd("r4s37/scan_box2.txt"),
        "# FVVDP_K1_TICKET=1\n" + rd("r4s35/k1_timeline_ticket1.txt"), "# FVVDP_K1_TICKET=0\n" + rd("r4s35/k1_timeline_ticket0.txt"),
        "\n".join(l for l in rd("r4s23/fov.txt").split("\n") if l.startswith("==") or l.startswith("kernel us/frame:"))))
 
