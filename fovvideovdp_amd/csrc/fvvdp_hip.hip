@@ -774,7 +774,12 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
             static const bool probe_on = [] { const char* e = getenv("FVVDP_PLACEMENT_PROBE"); return !(e && e[0] == '0'); }();
             const size_t bytes = (size_t)c->max_frames * c->lw[0] * c->lh[0] * c->P * sizeof(float);
             if (!probe_on || c->P != 4 || bytes < ((size_t)1 << 30) || c->lum_hold) c->sel_phase = 9;
-            else if (n_out >= 16 && c->lum_top == n_out) selection_step(c, n_out, st);   // this call rewrites every slot in use
+            else if (n_out >= 16 && c->lum_top == n_out) {                               // this call rewrites every slot in use
+                // (not while the stream is being captured into a graph: the comparison allocates, frees and reads events)
+                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+                if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
+                if (cap == hipStreamCaptureStatusNone) selection_step(c, n_out, st);
+            }
         }
         {
             const int rc = run(c->level[0], 0, n_out);
