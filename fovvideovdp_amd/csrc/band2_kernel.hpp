@@ -580,6 +580,8 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
         Px<P> Be, Bo;
         // the waves of a workgroup walk ADJACENT strips of the same chunk: kept in step, their row requests of a stage cover one
         // contiguous piece of 4 level-A rows and their halo columns meet in the CU's vector cache (profiles/r04_lockstep.md)
+        // (a soft barrier across the workgroups of a whole row of strips -- a counter in L2, bounded spin -- costs 6 us per use and
+        // slows the launch down at every interval tried: profiles/r04_lockstep.md, section 6)
         if constexpr (!FOV) if (in_step) __builtin_amdgcn_s_barrier();
         {   // step c = 2k: level-B row 2k+1
             const int c = 2 * k;

@@ -396,7 +396,18 @@ gives a steady 205), the wave-time per block is 7 %% higher, and the launch is n
 %s
 ```
 
-## 6. The foveated one-level kernel in step (`-DFOV_LOCKSTEP`, session 23) -- no effect, removed
+## 6. A soft barrier across ALL strip groups of a (frame, chunk) row (session 39) -- far slower, removed
+
+If items in step are 20 %% faster, why stop at 4 strips?  Wider workgroups do not fit the CU's wave slots (section 2), so the nine
+workgroups of a 4K row were made to wait for each other every N stages through a counter in L2 (atomic add, bounded polling; nothing but
+the timing depends on it).  Every use costs about 6 us -- the nine workgroups sit on different CUs with different company and the row runs
+at the pace of its slowest member -- and the launch is slower at every interval (levels 0+1, us per frame; `sync_every=0` = off):
+
+```
+%s
+```
+
+## 7. The foveated one-level kernel in step (`-DFOV_LOCKSTEP`, session 23) -- no effect, removed
 
 `band_kernel<4, false, 1>` already runs 4 waves per workgroup (4 frames of one tile).  Variant: the 4 waves take adjacent strips of one
 chunk and frame (frame fastest over workgroups, so the rho-map slice stays in L2), one or two barriers per 4 coarse rows.  Parity green
@@ -414,6 +425,7 @@ come from.  The code was removed again.
        rd("r4s31/k1_timeline.txt"), rd("r4s32/scan.txt"), rd("r4s33/scan_box1.txt"), rd("r4s33/scan_box2.txt"),
        rd("r4s37/scan_box1.txt"), rd("r4s37/scan_box2.txt"),
        "# FVVDP_K1_TICKET=1\n" + rd("r4s35/k1_timeline_ticket1.txt"), "# FVVDP_K1_TICKET=0\n" + rd("r4s35/k1_timeline_ticket0.txt"),
+       rd("r4s39/scan.txt"),
        "\n".join(l for l in rd("r4s23/fov.txt").split("\n") if l.startswith("==") or l.startswith("kernel us/frame:"))))
 
 # ---------------------------------------------------------------------------------------------------------------------------
