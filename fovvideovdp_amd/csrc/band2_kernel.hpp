@@ -763,7 +763,9 @@ __global__ __launch_bounds__(64 * BAND2_WPB_MAX, BAND2_LB) void band2_kernel(con
 #define FOV2_MINB 2
 #endif
 template <int P>
-__global__ __launch_bounds__(64 * FOV2_WPB, FOV2_MINB) void band2_fov_kernel(const Band2Args a) {
+__global__ __launch_bounds__(64 * FOV2_WPB, FOV2_MINB) void band2_fov_kernel(const Band2Args a_byval) {
+    const Band2Args& a = *(const Band2Args*)__builtin_amdgcn_kernarg_segment_ptr();     // scalar loads where needed (see band_kernel)
+    (void)a_byval;
     const int lane = (int)(threadIdx.x & 63);
     int bid;
     {

@@ -821,7 +821,12 @@ __device__ __forceinline__ void band_load_tables(const BandArgs& a, float4* s_cs
 #define FOV_FRAME_FASTEST 1
 #endif
 template <int P, bool DBG, int FOVM>
-__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_MINW_LEAN : FOV_MINW) : (DBG ? 2 : 4)) void band_kernel(const BandArgs a) {
+__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_MINW_LEAN : FOV_MINW) : (DBG ? 2 : 4)) void band_kernel(const BandArgs a_byval) {
+    // the argument block is read from the kernel-argument segment where it is needed (scalar loads) instead of being held in
+    // scalar registers from the top of the kernel: the variants with many arguments in use (difference maps, caller-built view
+    // maps) otherwise keep 13-48 of them in vector-register lanes
+    const BandArgs& a = *(const BandArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+    (void)a_byval;
     constexpr bool FOV = FOVM != 0;
     constexpr int WPB = FOV ? FOV_WPB : 1;
     __shared__ float4 s_csf[FVVDP_LUT_N];

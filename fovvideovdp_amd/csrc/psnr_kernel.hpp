@@ -29,7 +29,9 @@ __device__ __forceinline__ float pu21_encode(float Y, const Pu21Args& a) {
 // grid (FVVDP_PSNR_SLICES, n_frames): block (slice, f) sums its pixel range of frame f; fixed thread->pixel mapping
 // and fixed reduction order, so the result does not depend on scheduling.
 template <int SRC, int PX>
-__global__ __launch_bounds__(256) void pu21_sse_kernel(const Pu21Args a) {
+__global__ __launch_bounds__(256) void pu21_sse_kernel(const Pu21Args a_byval) {
+    const Pu21Args& a = *(const Pu21Args*)__builtin_amdgcn_kernarg_segment_ptr();      // scalar loads where needed (see band_kernel)
+    (void)a_byval;
     __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
     __shared__ double s_red[4];
     if constexpr (SRC == SRC_U8) {
