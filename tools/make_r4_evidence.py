@@ -407,6 +407,15 @@ at the pace of its slowest member -- and the launch is slower at every interval 
 %s
 ```
 
+Session 42, the other way of keeping the whole chip in step without communication: a metronome -- every wave starts its stages on
+multiples of T ticks of the 100 MHz wall clock (`T=0` = off; a stage takes about 450 ticks free-running, 380 in the first round).
+Slower at every T, and with it even the first-round items take 348 us instead of 314: whatever makes the first round fast, it is not
+that the waves are in phase.
+
+```
+%s
+```
+
 ## 7. The foveated one-level kernel in step (`-DFOV_LOCKSTEP`, session 23) -- no effect, removed
 
 `band_kernel<4, false, 1>` already runs 4 waves per workgroup (4 frames of one tile).  Variant: the 4 waves take adjacent strips of one
@@ -425,7 +434,7 @@ come from.  The code was removed again.
        rd("r4s31/k1_timeline.txt"), rd("r4s32/scan.txt"), rd("r4s33/scan_box1.txt"), rd("r4s33/scan_box2.txt"),
        rd("r4s37/scan_box1.txt"), rd("r4s37/scan_box2.txt"),
        "# FVVDP_K1_TICKET=1\n" + rd("r4s35/k1_timeline_ticket1.txt"), "# FVVDP_K1_TICKET=0\n" + rd("r4s35/k1_timeline_ticket0.txt"),
-       rd("r4s39/scan.txt"),
+       rd("r4s39/scan.txt"), rd("r4s42/scan.txt"),
        "\n".join(l for l in rd("r4s23/fov.txt").split("\n") if l.startswith("==") or l.startswith("kernel us/frame:"))))
 
 # ---------------------------------------------------------------------------------------------------------------------------
