@@ -532,6 +532,10 @@ __device__ __forceinline__ void wave_lds_order() {
 
 // CC = number of colour channels as a compile-time constant (3 or 1): with a run-time `C == 3` around the loads and the
 // table look-ups, every step has control-flow joins and the compiler falls back to s_waitcnt vmcnt(0).
+#ifndef K1_STORE_AUX
+#define K1_STORE_AUX 2     // cache policy of the level-0 stores: 2 = nt.  0 / 1 (sc0) / 16 (sc1) / 18: this kernel within its per-process scatter,
+                           // but the pyramid pass that follows is 2 % slower behind stores that are not nt (tools/experiments/r4_session44.sh)
+#endif
 template <int FL, int PX, int SRC, int TD, int CC, int KIND>
 __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const float* lutw, float4* s_t, const int block = (int)blockIdx.x) {
     // the window index lists are the only dynamically indexed members of the argument block: read them straight from the
@@ -654,7 +658,7 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
             for (int i = 0; i < PX; ++i) {
                 const int q = i * 64 + lane;
                 const float4 val = s_t[(q / PX) * (PX + 1) + (q % PX)];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{val.x, val.y, val.z, val.w}), o, soff[i], 0, 2 /*nt*/);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{val.x, val.y, val.z, val.w}), o, soff[i], 0, K1_STORE_AUX);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
