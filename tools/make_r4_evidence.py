@@ -142,6 +142,21 @@ the bad cases, it does not always find the best one:
 %s
 ```
 
+## Session 45: eight allocations held at once in ONE process -- every allocation is its own draw
+
+`tools/experiments/gpu_alloc_draws.py`: eight contexts (each with its own scratch) alive at the same time, the same 4K x 60 pair through
+each, comparison off; temporal kernel / levels 0+1 us per frame (HIP events, median of 3 calls; two rounds over the contexts):
+
+```
+%s
+```
+
+A context keeps its speed from round to round, and the contexts of one process differ as much as boxes do: K1 31.3-38.3 us per frame
+with either kind of allocation.  The pyramid kernel reading the same buffer tends the OTHER way (the context with the slowest K1, 38.2,
+has the fastest levels 0+1, 28.4), so the sums spread less: 61.2-66.6 us per frame.  The kind of allocation shifts the odds; what decides
+is where the particular buffer landed.  The context's online choice is therefore a best-of-two draw on the sum; a best-of-N over more
+fresh buffers would gain about another 1-2 %% at 3 calls per candidate -- not built.
+
 `tools/microbench/chunks.hip` on a box whose hipMalloc returns one contiguous range, TB/s -- it is the WRITES that such a range slows down
 (write only 5.8-6.0 -> 6.9-7.1, copy 5.3-5.4 -> 6.0-6.1, reads unchanged); since then every level of >= 16 MB is chunk-mapped:
 
@@ -152,6 +167,7 @@ the bad cases, it does not always find the best one:
        rd("r4s15/order.txt"), rd("r4s15/chunks_microbench.txt"), rd("r4s16/src.txt"), rd("r4s16/three_more_boxes.txt"),
        "\n".join("# box %d\n" % i + rd("r4s17/choice_box%d.txt" % i) for i in range(1, 8)),
        "\n".join("# box %d\n" % (7 + i) + rd("r4s18/choice2_box%d.txt" % i) for i in range(1, 4)),
+       rd("r4s45/draws.txt"),
        rd("r4_chunks_microbench.txt")))
 
 # ---------------------------------------------------------------------------------------------------------------------------
