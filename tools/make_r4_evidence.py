@@ -157,6 +157,23 @@ has the fastest levels 0+1, 28.4), so the sums spread less: 61.2-66.6 us per fra
 is where the particular buffer landed.  The context's online choice is therefore a best-of-two draw on the sum; a best-of-N over more
 fresh buffers would gain about another 1-2 %% at 3 calls per candidate -- not built.
 
+## Session 46: fewer resident waves do not cure the slow mode
+
+The temporal kernel's occupancy capped through unused dynamic LDS (experiment build; 16 single-wave workgroups per CU = 4 per SIMD is the
+shipped state), three contexts per process, K1 us per frame; boxes 1 and 2 had every context in the slow mode, box 3 in the fast one:
+
+```
+# box 1
+%s
+# box 2
+%s
+# box 3
+%s
+```
+
+Slow mode: -1.5 %% at 8 per CU, -4 %% at 6 per CU; fast mode: +-0 down to 6 per CU, then steeply worse.  A cap at 8 per CU would be worth
+0.3 us per frame at best; not built.
+
 `tools/microbench/chunks.hip` on a box whose hipMalloc returns one contiguous range, TB/s -- it is the WRITES that such a range slows down
 (write only 5.8-6.0 -> 6.9-7.1, copy 5.3-5.4 -> 6.0-6.1, reads unchanged); since then every level of >= 16 MB is chunk-mapped:
 
@@ -167,7 +184,7 @@ fresh buffers would gain about another 1-2 %% at 3 calls per candidate -- not bu
        rd("r4s15/order.txt"), rd("r4s15/chunks_microbench.txt"), rd("r4s16/src.txt"), rd("r4s16/three_more_boxes.txt"),
        "\n".join("# box %d\n" % i + rd("r4s17/choice_box%d.txt" % i) for i in range(1, 8)),
        "\n".join("# box %d\n" % (7 + i) + rd("r4s18/choice2_box%d.txt" % i) for i in range(1, 4)),
-       rd("r4s45/draws.txt"),
+       rd("r4s45/draws.txt"), rd("r4s46/pads_box1.txt"), rd("r4s46/pads_box2.txt"), rd("r4s46/pads_box3.txt"),
        rd("r4_chunks_microbench.txt")))
 
 # ---------------------------------------------------------------------------------------------------------------------------
