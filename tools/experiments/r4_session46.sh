@@ -1,5 +1,6 @@
 #!/bin/bash
 # round 4, session 46: occupancy of the uint8 temporal kernel capped through unused dynamic LDS (16 / 12 / 10 / 8 / 6 workgroups per CU)
+# (needs the experiment patch of that session: launch_vec passing FVVDP_K1_LDS_PAD bytes of dynamic LDS, -DK1_LDS_PAD_EXPERIMENT; not in the tree)
 R=$(pwd); OUT=$R/gpurun_out/r4s46; mkdir -p $OUT
 cd $R
 export FVVDP_PLACEMENT_PROBE=0 FVVDP_LIB=$R/build_variants/k1pad.so
