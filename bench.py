@@ -4,11 +4,15 @@
 A "step" is one full pass of the hot path over `--pairs-per-gpu` (default 1) synthetic 3840x2160 x 60-frame video pairs
 per GPU (BASELINE.json configs[2]: uint8 RGB, standard_4k, 30 fps -> 8-tap temporal filter, foveated off; configs[4] is
 `--gpus 8 --pairs-per-gpu 8`), inputs already resident in HBM: unpack + sRGB display model + luminance + temporal
-filtering + pyramid + CSF + masking + pooling + JOD regression.  The pairs of a step are queued back to back without
-host synchronisation; with several ranks the per-frame results are combined by ONE all-reduce of the device buffer.
-value = Mpixels/s (test+ref) = 2*W*H*N*pairs*steps*n_gpus / wall seconds.
+filtering + pyramid + CSF + masking + pooling + JOD regression.  ONE step path for every N (`step_path` in the line): the pairs of
+a step are queued back to back without host synchronisation (`predict_batch`; every pair's pooling + JOD regression run in the
+library on the device), the per-pair result rows (Q_per_ch | range flag | JOD) of all ranks are combined by ONE all-reduce of
+the device buffer (a no-op on one rank) and ONE device -> host copy ends the step.  `--shard frames` measures the other
+decomposition of north_star: ONE pair of `--frames` x N frames whose output frames are split across the ranks
+(`predict_frame_sharded`: every rank reads its own fl-1 frames of temporal halo, one all-reduce of Q_per_ch, pooling on every rank).
+value = Mpixels/s (test+ref) = 2*W*H*frames of a step / median step seconds.
 
-  python bench.py [--gpus N --steps K --warmup W --pairs-per-gpu P]       (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W --pairs-per-gpu P --shard pairs|frames]   (N>1: launched by torch.distributed.run)
 
 One JSON line on rank 0.  `roofline`: the dominant kernel (two-level pyramid kernel, levels 0+1), timed per launch
 with HIP events inside the library on the kernels' stream (median/min/max over >= 10 launches); `graded_pass`: all
@@ -46,7 +50,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=8)       # the allocation choice of the context settles in 8 calls
+    ap.add_argument("--warmup", type=int, default=3)       # (the context settles its level-0 buffer at creation, not over calls)
+    ap.add_argument("--shard", default="pairs", choices=["pairs", "frames"], help="pairs: independent pairs per rank (configs[4]); "
+                    "frames: ONE pair of --frames x N frames, output frames split across the ranks (weak scaling in frames)")
     ap.add_argument("--pairs-per-gpu", type=int, default=1, help="independent pairs per rank and step (BASELINE configs[4]: 8)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
@@ -108,20 +114,44 @@ def main():
     from fovvideovdp_amd.sharding import gather_pair_results
 
     W, H, N, fps, K = args.width, args.height, args.frames, args.fps, max(1, args.pairs_per_gpu)
-    # pair sharding: rank r owns pairs r*K .. r*K+K-1, generated on its own GPU (2 x 1.49 GB each at 4K x 60)
-    pairs = [synth_video_pair(N, H, W, device=dev, pair=rank * K + k) for k in range(K)]
+    frames_mode = args.shard == "frames"
+    if frames_mode:
+        K = 1
+    n_clip = N * world if frames_mode else N           # frames of one clip (frame sharding: --frames per rank, weak scaling)
+    # ---- startup guard: what this rank is about to hold in HBM, against what is free (a clear error beats an OOM mid-run) ----
+    es_in = 1                                          # uint8 RGB
+    need = {"source clips": 2.0 * 3 * W * H * n_clip * es_in * K,
+            "pyramid scratch (one batch of <= 128 frames, all levels)": 16.0 * W * H * 1.34 * min(N, 128),
+            "level-0 candidates timed at context creation (one extra level 0) + its synthetic clip": 16.0 * W * H * min(N, 128) + 2.0 * 16 * 3 * W * H,
+            "margin": 2.0 * (1 << 30)}
+    free_b, total_b = torch.cuda.mem_get_info(dev)
+    if sum(need.values()) > free_b:
+        raise SystemExit("bench.py rank %d: needs %.1f GB of HBM on %s (%s) but only %.1f of %.1f GB are free" % (
+            rank, sum(need.values()) / 1e9, dev, ", ".join("%s %.1f GB" % (k, v / 1e9) for k, v in need.items()), free_b / 1e9, total_b / 1e9))
+    # pair sharding: rank r owns pairs r*K .. r*K+K-1, generated on its own GPU (2 x 1.49 GB each at 4K x 60); frame sharding: every
+    # rank holds the whole clip of N*world frames (it reads its own output frames + fl-1 frames of halo) and evaluates its share
+    pairs = [synth_video_pair(n_clip, H, W, device=dev, pair=(0 if frames_mode else rank * K + k)) for k in range(K)]
     m = fv.fvvdp(display_name=args.display, device=dev)
+    step_path = ("predict_frame_sharded: this rank's output frames queued without host sync -> all-reduce of Q_per_ch -> pooling + JOD on every rank"
+                 if frames_mode else
+                 "predict_batch (pairs queued without host sync, pooling + JOD per pair in the library) -> all-reduce of the result rows "
+                 "(no-op on one rank) -> one device-to-host copy")
 
     def step():
-        if world == 1 and K == 1:
-            q, _ = m.predict(pairs[0][0], pairs[0][1], dim_order="BCFHW", frames_per_second=fps)
-            return [float(q)]                                        # the reference's call, incl. its host sync
-        # several pairs / ranks: queue every pair without host synchronisation, then the one collective of the path
-        # (all-reduce of a zero buffer in which this rank filled its own slots), pooling of all pairs in one call,
-        # ONE device -> host copy
-        qs = [st["Q_per_ch"] for (_, st) in m.predict_batch(pairs, dim_order="BCFHW", frames_per_second=fps)]
-        allq = gather_pair_results(torch.stack(qs), rank, world)
-        return m.do_pooling_and_jods(allq, None).tolist()
+        if frames_mode:
+            from fovvideovdp_amd.sharding import predict_frame_sharded
+            vs = fv.fvvdp_video_source_array(pairs[0][0], pairs[0][1], fps, dim_order="BCFHW", display_photometry=m.display_photometry)
+            q, _ = predict_frame_sharded(m, vs, rank, world)
+            return [float(q)]
+        # queue every pair without host synchronisation, then the one collective of the path (all-reduce of a zero buffer in which
+        # this rank filled its own rows; one rank: nothing), ONE device -> host copy of [pairs, Q_per_ch | range flag | JOD]
+        outs = m.predict_batch(pairs, dim_order="BCFHW", frames_per_second=fps)
+        rows = outs[0][1]["result_buffer"].unsqueeze(0) if K == 1 else torch.stack([st["result_buffer"] for (_, st) in outs])
+        return gather_pair_results(rows, rank, world).cpu()[:, -1].tolist()
+
+    def step_reference_call():
+        q, _ = m.predict(pairs[0][0], pairs[0][1], dim_order="BCFHW", frames_per_second=fps)
+        return [float(q)]                                            # the reference's call, incl. its host sync
 
     def fence():
         torch.cuda.synchronize(dev)
@@ -147,7 +177,16 @@ def main():
     dt = float(tall[0])
     step_s = np.sort(tall[1:])
     dt_med = float(np.median(step_s))
-    px_step = 2.0 * W * H * N * K * world
+    px_step = 2.0 * W * H * (n_clip if frames_mode else N * K * world)
+    # the reference-style synchronous call next to the step path, once (one rank, one pair): the same kernels, the same single sync
+    predict_ms = None
+    if world == 1 and K == 1 and not frames_mode:
+        tp = []
+        for _ in range(max(3, args.steps // 2)):
+            t1 = time.perf_counter()
+            step_reference_call()
+            tp.append(time.perf_counter() - t1)
+        predict_ms = float(np.median(tp)) * 1e3
     mpix_mean = px_step * args.steps / dt / 1e6
     mpix = px_step / dt_med / 1e6                 # the metric is the MEDIAN of >= 10 runs after the warm-ups
 
@@ -156,24 +195,22 @@ def main():
     extra = {}
     test, ref = pairs[0]
     if rank == 0:
-        # The timed steps overlap the temporal kernel of one half clip with the pyramid pass of the other on two streams
-        # (fvvdp.pipeline); a kernel's duration under overlap says nothing about the kernel, so the per-kernel leg launches the
-        # same kernels on the same context (same HBM scratch, same placement) strictly one after the other.
-        pipeline_steps = m.pipeline
-        m.pipeline = 0
+        # the per-kernel leg launches the same kernels on the same context (same HBM scratch, same placement) as the timed steps
+        if frames_mode:
+            test, ref = test[:, :, :N], ref[:, :, :N]
         m.predict(test, ref, dim_order="BCFHW", frames_per_second=fps)
         ctx = m._ctx
-        st_, cm_, kept_ = C.c_int(0), C.c_int(0), C.c_int(-1)
-        us2_ = (C.c_float * 2)()
-        nat.check(nat.lib().fvvdp_ctx_alloc_info(ctx.handle, C.byref(st_), C.byref(cm_), us2_, C.byref(kept_)))
+        st_, cm_, nt_, kept_ = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(-1)
+        us_ = (C.c_float * 8)()
+        cs_ = (C.c_int64 * 3)()
+        nat.check(nat.lib().fvvdp_ctx_alloc_info(ctx.handle, C.byref(st_), C.byref(cm_), us_, 8, C.byref(nt_), C.byref(kept_)))
+        nat.check(nat.lib().fvvdp_ctx_call_stats(ctx.handle, cs_))
         extra["level0_alloc"] = {
             "in_use": ("virtual-memory API, physical chunks of %s MB" % os.environ.get("FVVDP_VMM_CHUNK_MB", "32")) if cm_.value else "hipMalloc",
-            "start": "hipMalloc (FVVDP_ALLOC=malloc)" if os.environ.get("FVVDP_ALLOC") == "malloc" else "virtual-memory API",
-            # the context timed the temporal kernel + pyramid pass on both kinds during the warm-up steps and kept the faster
-            "compared_us_per_frame": {"first": round(us2_[0], 2), "other_kind": round(us2_[1], 2)} if kept_.value >= 0 else None,
-            "kept": {0: "first", 1: "other_kind"}.get(kept_.value), "state": st_.value,
-            "evidence": "profiles/r04_level0_chunks.md"}
-        extra["pipeline_batches"] = pipeline_steps
+            # the context timed the temporal kernel + pyramid pass on these candidates inside fvvdp_ctx_create and kept the fastest
+            "candidates_us_per_frame": [round(us_[k], 2) for k in range(nt_.value)], "kept_index": kept_.value, "state": st_.value,
+            "per_frame_calls": {"host_syncs": int(cs_[0]), "allocations": int(cs_[1]), "frees": int(cs_[2])},
+            "evidence": "profiles/r05_k1_mode.md"}
         nat.check(nat.lib().fvvdp_ctx_timing_enable(ctx.handle, 1))
         nk = 16 + 2
         ms = (C.c_float * nk)()
@@ -186,7 +223,6 @@ def main():
             nat.check(nat.lib().fvvdp_ctx_timing_read(ctx.handle, ms, cnt, nk, 1))
             rows.append([ms[i] for i in range(n_bands + 2)])          # ms per call: temporal, levels 0.., finalize
         nat.check(nat.lib().fvvdp_ctx_timing_enable(ctx.handle, 0))
-        m.pipeline = pipeline_steps
         t = np.asarray(rows, dtype=np.float64) / N * 1e3              # us per frame
         sizes = level_sizes(W, H, n_bands)
         P = 4
@@ -219,6 +255,7 @@ def main():
         pmc = sorted(f for f in os.listdir(pdir) if f.endswith("pmc_level0.json")) if os.path.isdir(pdir) else []
         live = measure_traffic_live() if (world == 1 and not args.no_measure_traffic and
                                           (W, H, int(frames_per_launch)) == (3840, 2160, 60)) else None
+        k1_live = live.get("k1") if live else None
         if live is not None and ("band2" in live.get("kernel", "")) == fused01:
             roof["traffic"] = int(live["traffic_bytes"])
             roof["traffic_source"] = "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of tools/gpu_bandonly.py (FETCH_SIZE x2 + WRITE_SIZE)"
@@ -255,9 +292,16 @@ def main():
                    "bytes_per_launch": int(b_k1 * frames_per_launch), "frames_per_launch": frames_per_launch,
                    "bytes_per_pixel_frame": round(b_k1 / (W * H), 2),
                    "launch_ms_all": [round(float(x) * frames_per_launch * 1e-3, 4) for x in tk],
-                   "note": "reads 6 B and writes 16 B per pixel and frame: nothing to save but the time.  On a physically contiguous "
-                           "level-0 scratch (what hipMalloc returns on a box with free memory) it runs 15 % slower; the context maps "
-                           "the scratch from 32 MB physical chunks instead (profiles/r04_level0_chunks.md)"}
+                   "note": "reads 6 B and writes 16 B per pixel and frame: nothing to save but the time.  How fast the 8 GB of level 0 can "
+                           "be WRITTEN depends on where they lie physically (31-33 or 36-38 us per frame; a kernel that only replays the "
+                           "store stream, and a plain streaming write, show the same two speeds on the same buffers; on the slow ones "
+                           "the L2's write requests wait 6-20x longer for DRAM credits): profiles/r05_k1_mode.md.  The context times N "
+                           "candidate buffers at creation and keeps the fastest (level0_alloc)."}
+        if k1_live is not None and (W, H, int(frames_per_launch), es, Cc, fps) == (3840, 2160, 60, 1, 3, 30):
+            roof_k1["traffic"] = int(k1_live["traffic_bytes"])
+            roof_k1["traffic_source"] = ("measured in this run: the same two rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE) of the temporal "
+                                         "kernel; includes the 7 history frames a launch reads before its first output (%.2f GB)" % (k1_live["history_bytes"] / 1e9))
+            roof_k1["traffic_over_algorithmic"] = round(k1_live["traffic_bytes"] / roof_k1["bytes_per_launch"], 4)
         extra["roofline_k1"] = roof_k1
         extra["roofline_pyramid"] = roof
         extra["longest_kernel"] = "K1 temporal" if medk > med0 else "K2b pyramid levels 0+1"
@@ -322,7 +366,9 @@ def main():
                        "sample": "%d output frames (from frame %d on, each incl. its %d-frame temporal window) of the same %dx%d "
                                  "pair, one per process, numpy fp32 oracle, %d processes concurrently (%.1f - %.1f s per frame, "
                                  "%.1f s wall); host has %d cores (%s), of which this container may use %d (affinity / cgroup "
-                                 "cpu.max)" % (args.cpu_procs, fl - 1, fl, W, H, args.cpu_procs, min(per), max(per), wall,
+                                 "cpu.max).  Every process recomputes its frame's whole 8-frame temporal window (display model and "
+                                 "luminance x8 per output frame), which a streaming CPU implementation would do once per frame: the "
+                                 "figure understates what these cores could sustain -- a baseline, not a target" % (args.cpu_procs, fl - 1, fl, W, H, args.cpu_procs, min(per), max(per), wall,
                                                os.cpu_count(), host_cpu_model(), host_cpus_usable())}
                 done = True
             except Exception as e:                      # never let the baseline leg break the benchmark line
@@ -356,12 +402,16 @@ def main():
                "ms_per_step": round(dt_med * 1e3, 3), "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": "%dx%d x%d-frame synthetic uint8 RGB video pair(s), %d per GPU and step, %s, %d fps, "
-                                      "foveated=off (BASELINE.json configs[2]%s)" % (
-                                          W, H, N, K, args.display, fps, "; configs[4]" if (world, K) == (8, 8) else ""),
-                          "pairs_per_gpu": K,
-                          "parallelism": "pair-sharded x%d, %d pair(s) per rank queued without host sync, one all-reduce of "
-                                         "Q_per_ch on the device" % (world, K)},
+                                      "foveated=off (%s)" % (W, H, n_clip, K, args.display, fps, baseline_label(W, H, N, fps, args.display, world, K, frames_mode)),
+                          "pairs_per_gpu": K, "shard": args.shard,
+                          "parallelism": ("frame-sharded x%d: one pair of %d frames, %d output frames per rank (+ fl-1 frames of temporal halo read "
+                                          "by every rank from its own copy), one all-reduce of Q_per_ch on the device" % (world, n_clip, N))
+                                         if frames_mode else
+                                         ("pair-sharded x%d, %d pair(s) per rank queued without host sync, one all-reduce of the "
+                                          "result rows on the device" % (world, K))},
+               "step_path": step_path,
                "ms_per_pair": round(dt_med / K * 1e3, 3),
+               "predict_call_ms": None if predict_ms is None else round(predict_ms, 3),
                "timing": {"statistic": "median of the %d timed steps (SURVEY 8(d)); value = pixels of a step / ms_per_step" % args.steps,
                           "ms_per_step_mean": round(dt / args.steps * 1e3, 3), "value_mean": round(mpix_mean, 1),
                           "ms_per_step_min": round(float(step_s[0]) * 1e3, 3), "ms_per_step_max": round(float(step_s[-1]) * 1e3, 3),
@@ -390,8 +440,8 @@ def measure_traffic_live():
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(d, ctr)
             subprocess.run(["rocprofv3", "--pmc", ctr, "--kernel-trace", "-d", out, "-o", "p", "--", sys.executable,
-                            os.path.join(ROOT, "tools", "gpu_bandonly.py")], check=True, timeout=90, cwd=d,
-                           env=dict(os.environ, TMPDIR=d), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                            os.path.join(ROOT, "tools", "gpu_bandonly.py")], check=True, timeout=120, cwd=d,
+                           env=dict(os.environ, TMPDIR=d, STAGE="all", REPS="3"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             found = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
             if not found:
                 return None
@@ -451,6 +501,18 @@ def host_cpu_model():
     except OSError:
         pass
     return "unknown CPU"
+
+
+def baseline_label(W, H, N, fps, display, world, K, frames_mode):
+    """which BASELINE.json configs[] entry the arguments describe (the label is derived, never assumed)"""
+    if frames_mode:
+        return "frame sharding of one long pair: north_star's frame-parallel decomposition, not a configs[] entry"
+    if (W, H, N, fps, display) == (3840, 2160, 60, 30, "standard_4k"):
+        return "BASELINE.json configs[2]" + ("; configs[4]: 64 pairs over 8 GPUs" if (world, K) == (8, 8) else
+                                            ("; %d of configs[4]'s 64 pairs per step" % (world * K) if world * K > 1 else ""))
+    if (W, H, N, fps, display) == (1920, 1080, 60, 30, "standard_fhd"):
+        return "BASELINE.json configs[1]"
+    return "not a BASELINE.json configuration"
 
 
 def fl_guard(fps):

@@ -78,8 +78,6 @@ SYMBOLS = {
                                       C.POINTER(Geom), C.POINTER(BandMaps), C.c_void_p]),
     "fvvdp_bands_forward_pool": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
                                            C.POINTER(Geom), C.POINTER(BandMaps), C.POINTER(PoolParams), C.c_void_p, C.c_void_p]),
-    "fvvdp_bands_forward_at": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float),
-                                         C.POINTER(Geom), C.POINTER(BandMaps), C.POINTER(PoolParams), C.c_void_p, C.c_void_p]),
     "fvvdp_heatmap_reconstruct": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_float, C.c_float, C.c_float,
                                             C.c_void_p, C.c_void_p]),
     "fvvdp_export_level": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -91,7 +89,9 @@ SYMBOLS = {
                                  C.c_void_p, C.c_void_p]),
     "fvvdp_ctx_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "fvvdp_ctx_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int, C.c_int]),
-    "fvvdp_ctx_alloc_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.POINTER(C.c_int)]),
+    "fvvdp_ctx_alloc_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int,
+                                      C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "fvvdp_ctx_call_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
 }
 
 _lib = None

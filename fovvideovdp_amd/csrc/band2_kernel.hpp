@@ -42,19 +42,6 @@ struct Band2Args {
     float lg_gain, lg_k, p, q0, q1, beta, lbkg_min, cmax, lg_dmax;
     float* partialA;        // [n][n_strips*n_chunks][2]
     float* partialB;
-    // ---- foveated mode (band2_fov_kernel; stock geometry only) ------------------------------------------------------------
-    const float4* lut2;     // both bands' slices of the CSF table, band A's rwA rho planes then band B's rwB: plane = n_e ecc rows of
-                            //   FOV_ROW entries (+8), i.e. trimmed to the eccentricities this display can show; records as BandArgs::sublut
-    int lut2_entries;       // float4 entries of lut2 (copied to LDS by every workgroup)
-    int n_items;            // work items (waves) of the launch
-    const float4* rmapA;    // level A, per pixel PAIR {fraction, LDS byte offset of the rho plane} x 2 (fov_rho_map_kernel)
-    int rmapA_w;            //   pairs per row
-    const float2* rmapB;    // level B, per PIXEL {fraction, LDS byte offset of the rho plane}
-    const float* fix;       // device [n][2]: gaze in frame pixels
-    float size_m0, size_m1, dist_m;
-    int frame_w, frame_h;
-    float ecc_lo, ecc_hi;
-    float f_inv_step[2], f_grid_off[2], f_frac_scale[2];    // uniform-grid constants of the Y and the ecc axis (BandArgs::inv_step ...)
 };
 
 // (dpp_reduce_taps / dpp_expand_taps: band_kernel.hpp)
@@ -109,30 +96,11 @@ __device__ __forceinline__ v2f dpp_expand2_taps(v2f t, v2f e, float fl, float fr
 // 3.2-3.8 cycles on a saturated SIMD -- the kernel's arithmetic is as long as its data flow) are then dropped: same bits.
 // Standard-dynamic-range displays qualify (standard_4k: luminances in [0.598, 200], clamp at >= 598 against a range of 253);
 // HDR displays with a black level under 0.1 cd/m^2 and sources without a display model do not and take INRANGE = false.
-// BAND2_LDS_STAGE: the level-A rows travel HBM -> LDS (LDS-DMA, `buffer_load_dwordx4 ... lds`, no destination registers) two
-// steps ahead of their use and LDS -> registers (ds_read_b128) one step ahead, instead of HBM -> registers one step ahead:
-// twice the time for a request to come back with the same register ring (the rows in flight held 16 registers; the kernel
-// has none to spare for a second step of them).  12 KB of LDS per wave: 3 steps x 4 pieces of 1 KB; 12 waves per CU = 144
-// of 160 KB.  Video (P == 4) only: the DMA moves 16 bytes per lane.
-#ifndef BAND2_LDS_STAGE
-#define BAND2_LDS_STAGE 0
-#endif
-// FOV: foveated evaluation of both bands (band2_fov_kernel): the per-pixel tail takes the CSF from the band's slice of the 32^3
-// table in LDS at the pixel's (rho, eccentricity, L_bkg) -- the machinery of band_kernel<P, false, 1> (frame-invariant rho map,
-// row table of vertical view angles, phased LDS reads) for two levels at once, so that level 1 never leaves the chip in
-// foveated mode either (BASELINE configs[3]).
-#ifndef FOV2_PHASE
-#define FOV2_PHASE 2        // pixels whose LUT-cell reads are in flight together in the foveated tail
-#endif
-constexpr bool band2_stage(int P) { return (BAND2_LDS_STAGE != 0) && P == 4; }
 
-template <int P, bool INRANGE, bool FOV>
+template <int P, bool INRANGE>
 __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, const int chunk, const int frame, const int lane,
-                                           const float4 (*s_csf)[FVVDP_LUT_N], [[maybe_unused]] float4* s_stage,
-                                           [[maybe_unused]] const bool in_step = false) {
+                                           const float4 (*s_csf)[FVVDP_LUT_N], const bool in_step = false) {
     constexpr int HP = P / 2;
-    constexpr bool STAGE = band2_stage(P) && !FOV;
-    static_assert(!(FOV && INRANGE), "the foveated variant keeps its clamps");
     const int blk = chunk * a.n_strips + strip;
 
     const int w = a.w, h = a.h, wb = a.wb, hb = a.hb, wc = a.wc, hc = a.hc;
@@ -202,64 +170,6 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
         p1 = ld_px_buf<P>(Ga_rsrc, col1_b, so);
     };
 
-    // ---- LDS staging of the rows two steps ahead (BAND2_LDS_STAGE) -----------------------------------------------------------
-    // D(c) = rows 2c+5, 2c+6 (what step c fetches for step c+1).  issue: 4 LDS-DMA pieces (row x pixel of the lane's pair), each
-    // 64 lanes x 16 B = 1 KB at a wave-uniform LDS address in M0.  The compiler does not count these loads: the wait is written
-    // here.  At the top of step c the pieces of D(c) (issued at step c-2) must have landed while those of D(c+1) (issued at
-    // step c-1) may be in flight: vmcnt(4) -- loads return in order; stores issued in between can only make the wait stricter.
-    const unsigned int stage_lds = (unsigned int)(size_t)(&s_stage[0]);          // LDS byte offset (low half of the flat address)
-#if defined(BAND2_ABLATE_MEM)
-    const unsigned long long ga_addr = (unsigned long long)(size_t)a.Ga;
-#else
-    const unsigned long long ga_addr = (unsigned long long)(size_t)Ga;
-#endif
-    // the same buffer resource as Ga_rsrc, as four scalar words for the inline assembly (base, stride 0, bytes, raw dword format)
-    [[maybe_unused]] const v4i Ga_words = v4i{(int)(unsigned int)ga_addr, (int)((unsigned int)(ga_addr >> 32) & 0xFFFFu),
-                                              (int)((unsigned int)(h * w * P) * 4u), 0x00020000};
-    [[maybe_unused]] auto stage_issue = [&](int c, unsigned int slot) {
-        if constexpr (STAGE) {
-            auto off = [&](int r) {
-                int rr = r < 0 ? -1 - r : (r >= h ? 2 * h - 1 - r : r);
-                rr = min(max(rr, 0), h - 1);
-#if defined(BAND2_ABLATE_MEM)
-                rr &= 7;
-#endif
-                return (unsigned int)rr * row_b;
-            };
-            const unsigned int so0 = off(2 * c + 5), so1 = off(2 * c + 6);
-            const unsigned int dst = stage_lds + slot * 4096u;
-            unsigned int keep;
-            asm volatile("s_mov_b32 %[keep], m0\n\t"
-                         "s_mov_b32 m0, %[dst]\n\t"
-                         "s_nop 0\n\t"
-                         "buffer_load_dwordx4 %[v0], %[rs], %[s0] offen lds\n\t"
-                         "s_add_u32 m0, m0, 0x400\n\t"
-                         "s_nop 0\n\t"
-                         "buffer_load_dwordx4 %[v1], %[rs], %[s0] offen lds\n\t"
-                         "s_add_u32 m0, m0, 0x400\n\t"
-                         "s_nop 0\n\t"
-                         "buffer_load_dwordx4 %[v0], %[rs], %[s1] offen lds\n\t"
-                         "s_add_u32 m0, m0, 0x400\n\t"
-                         "s_nop 0\n\t"
-                         "buffer_load_dwordx4 %[v1], %[rs], %[s1] offen lds\n\t"
-                         "s_mov_b32 m0, %[keep]"
-                         : [keep] "=&s"(keep)
-                         : [v0] "v"(col0_b), [v1] "v"(col1_b), [rs] "s"(Ga_words), [s0] "s"(so0), [s1] "s"(so1), [dst] "s"(dst)
-                         : "memory", "scc");
-        }
-    };
-    [[maybe_unused]] auto stage_read = [&](unsigned int slot, Px<P> (&r0)[2], Px<P> (&r1)[2]) {
-        if constexpr (STAGE) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            const float4* b = s_stage + slot * 256u + (unsigned int)lane;
-            const float4 t0 = b[0], t1 = b[64], t2 = b[128], t3 = b[192];
-            r0[0].h[0] = v2f{t0.x, t0.y}; r0[0].h[1] = v2f{t0.z, t0.w};
-            r0[1].h[0] = v2f{t1.x, t1.y}; r0[1].h[1] = v2f{t1.z, t1.w};
-            r1[0].h[0] = v2f{t2.x, t2.y}; r1[0].h[1] = v2f{t2.z, t2.w};
-            r1[1].h[0] = v2f{t3.x, t3.y}; r1[1].h[1] = v2f{t3.z, t3.w};
-        }
-    };
-    unsigned int stage_q = 0;        // LDS slot of D(c) at the top of step c
 
     // Level-A rows live in an 8-slot register ring: row r of the chunk sits in slot r & 7, a step's window is slots
     // base .. base+4 and the two rows of the next step are fetched into slots base+5, base+6.  The base advances by 2 per
@@ -358,106 +268,8 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
         }
     };
 
-    // ---- foveated tail: fov_a gathers the query of one pixel (and issues the four LDS reads of its LUT cell), fov_b blends and
-    // pools; pixels are evaluated two at a time so that their LDS reads are in flight together (band_kernel.hpp, fov_a / fov_b:
-    // the same expressions, which differ from band_px by rounding only) ------------------------------------------------------
-    struct FovQ {
-        float4 v00, v10, v01, v11;
-        float fY, fE, fR, llb;
-        v2f d[HP];
-    };
-    float gx = 0.0f, gy = 0.0f, vxa = 0.0f, vxb = 0.0f, vxB = 0.0f;
-    [[maybe_unused]] const float* s_vyA = nullptr;
-    [[maybe_unused]] const float* s_vyB = nullptr;
-    [[maybe_unused]] __amdgpu_buffer_rsrc_t rmA_rsrc, rmB_rsrc;
-    [[maybe_unused]] unsigned int rmA_col = 0, rmB_col = 0;
-    if constexpr (FOV) {
-        // pix2view_direction (fvvdp_display_model.py:498-510) on the grids of level A and level B, pixel centres at +0.5
-        const float kxa = a.size_m0 / (float)w / a.dist_m, kxb = a.size_m0 / (float)wb / a.dist_m;
-        vxa = atanf((((float)X0 + 0.5f) + (-(float)w / 2.0f)) * kxa) * 57.29577951308232f;
-        vxb = atanf((((float)X1 + 0.5f) + (-(float)w / 2.0f)) * kxa) * 57.29577951308232f;
-        vxB = atanf((((float)J + 0.5f) + (-(float)wb / 2.0f)) * kxb) * 57.29577951308232f;
-        const float fxp = a.fix[2 * frame + 0] + 0.5f, fyp = a.fix[2 * frame + 1] + 0.5f;
-        const float gxm = (fxp + (-(float)a.frame_w / 2.0f)) * a.size_m0 / (float)a.frame_w;
-        const float gym = -(fyp + (-(float)a.frame_h / 2.0f)) * a.size_m1 / (float)a.frame_h;
-        gx = atanf(gxm / a.dist_m) * 57.29577951308232f;
-        gy = atanf(gym / a.dist_m) * 57.29577951308232f;
-        s_vyA = reinterpret_cast<const float*>(s_lut_dyn + a.lut2_entries);
-        s_vyB = s_vyA + h;
-        // the rho-map records through buffer resources: scalar row offset, loop-invariant lane offset
-        rmA_rsrc = level_rsrc(reinterpret_cast<float*>(const_cast<float4*>(a.rmapA)), (unsigned int)(h * a.rmapA_w) * 16u);
-        rmB_rsrc = level_rsrc(reinterpret_cast<float*>(const_cast<float2*>(a.rmapB)), (unsigned int)(hb * wb) * 8u);
-        rmA_col = (unsigned int)min(max(J, 0), a.rmapA_w - 1) * 16u;
-        rmB_col = (unsigned int)min(max(J, 0), wb - 1) * 8u;
-    }
-    [[maybe_unused]] auto rmap_a = [&](int row) -> float4 {          // records of level-A row `row`, columns X0, X1
-        return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rmA_rsrc, rmA_col, (unsigned int)(min(max(row, 0), h - 1) * a.rmapA_w) * 16u, 0));
-    };
-    [[maybe_unused]] auto rmap_b = [&](int row) -> float2 {          // record of level-B row `row`, column J
-        return __builtin_bit_cast(float2, __builtin_amdgcn_raw_buffer_load_b64(rmB_rsrc, rmB_col, (unsigned int)(min(max(row, 0), hb - 1) * wb) * 8u, 0));
-    };
-    [[maybe_unused]] auto fov_a = [&](const Px<P>& g, const Px<P>& e, float vx, float vy, float pre_fR, float pre_kR) -> FovQ {
-        FovQ q;
-        const float lb = fmaxf(e.h[0].y, a.lbkg_min);
-        const float dcap = a.cmax * lb;
-#pragma unroll
-        for (int k = 0; k < HP; ++k) q.d[k] = v2f{fminf(g.h[k].x - e.h[k].x, dcap), fminf(g.h[k].y - e.h[k].y, dcap)};
-        q.llb = fast_log2(lb);
-        const float yq = __builtin_amdgcn_fmed3f(q.llb, a.ly_lo, a.ly_hi);
-        const float dx = vx - gx, dy = vy - gy;
-        const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
-        const float eq = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fmed3f(ecc, a.ecc_lo, a.ecc_hi));
-        const float tY = fmaf(yq, a.f_inv_step[0], a.f_grid_off[0]);
-        const float iY = __builtin_amdgcn_fmed3f(floorf(tY), 0.0f, (float)(FVVDP_LUT_N - 2));
-        q.fY = (tY - iY) * a.f_frac_scale[0];
-        const float tE = fmaf(eq, a.f_inv_step[1], a.f_grid_off[1]);
-        const float iE = __builtin_amdgcn_fmed3f(floorf(tE), 0.0f, (float)(FVVDP_LUT_N - 2));
-        q.fE = (tE - iE) * a.f_frac_scale[1];
-        q.fR = pre_fR;
-        const int bo = (int)fmaf(iE, (float)(FOV_ROW * 16), fmaf(iY, 16.0f, pre_kR));
-        const float4* cell = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_lut_dyn) + bo);
-        q.v00 = cell[0];
-        q.v10 = cell[1];
-        q.v01 = cell[FOV_ROW];
-        q.v11 = cell[FOV_ROW + 1];
-        return q;
-    };
-    [[maybe_unused]] auto fov_b = [&](const FovQ& q, bool valid, const int band, float (&acc)[2]) {
-        const float fY = q.fY, fE = q.fE, fR = q.fR;
-        auto rho_blend = [&](const float4& v) { return pfma(v2f{v.z, v.w}, fR, v2f{v.x, v.y}); };
-        const v2f r00 = rho_blend(q.v00), r10 = rho_blend(q.v10), r01 = rho_blend(q.v01), r11 = rho_blend(q.v11);
-        const v2f y0 = pfma(r10 - r00, fY, r00), y1 = pfma(r11 - r01, fY, r01);
-        const v2f sl2 = pfma(y1 - y0, fE, y0);
-        const float vm = valid ? 1.0f : 0.0f;
-        const float lcn = lg_bm[band] - q.llb;
-        if constexpr (HP == 2) {
-            const v2f sl = sl2;
-            const v2f A = pfma(sl, pb, splat(fmaf(lcn, pb, pb_base)));
-            const v2f lsm = sl + splat(lcn + lg_mask);
-            const v2f ldiff = v2f{fast_log2(fabsf(q.d[0].x - q.d[0].y)), fast_log2(fabsf(q.d[1].x - q.d[1].y))};
-            const v2f lmin = v2f{fast_log2(fminf(fabsf(q.d[0].x), fabsf(q.d[0].y))), fast_log2(fminf(fabsf(q.d[1].x), fabsf(q.d[1].y)))};
-            const v2f ldb = pfma(ldiff, pb, A);
-            const v2f lm = (lmin + lsm) * v2f{a.q0, a.q1};
-            const v2f one_mq = v2f{fast_exp2(lm.x), fast_exp2(lm.y)} + splat(1.0f);
-            const v2f tb = pfma(v2f{fast_log2(one_mq.x), fast_log2(one_mq.y)}, -a.beta, ldb);
-            const v2f bl = v2f{fminf(tb.x, b_dmax), fminf(tb.y, b_dmax)};
-            const v2f term = v2f{fast_exp2(bl.x), fast_exp2(bl.y)};
-            const v2f av = __builtin_elementwise_fma(term, splat(vm), v2f{acc[0], acc[1]});
-            acc[0] = av.x;
-            acc[1] = av.y;
-        } else {
-            const float dT = q.d[0].x, dR = q.d[0].y;
-            const float ls = sl2.x + lcn;
-            const float ld = a.p * (fast_log2(fabsf(dT - dR)) + (ls + lg_base));
-            const float mq = fast_exp2(a.q0 * (fast_log2(fminf(fabsf(dT), fabsf(dR))) + (ls + lg_mask)));
-            const float ldd = fminf(ld - fast_log2(1.0f + mq), a.lg_dmax);
-            acc[0] = fmaf(fast_exp2(a.beta * ldd), vm, acc[0]);
-        }
-    };
-
     // band A for level-A rows 2c, 2c+1 (window rows 0, 1), expand from level-B rows c-1, c, c+1
-    auto band_a_rows = [&](auto base, int c, const Px<P>& Bm1, const Px<P>& B0, const Px<P>& Bp1,
-                           [[maybe_unused]] const float4 ra = float4{0, 0, 0, 0}, [[maybe_unused]] const float4 rb = float4{0, 0, 0, 0}) {
+    auto band_a_rows = [&](auto base, int c, const Px<P>& Bm1, const Px<P>& B0, const Px<P>& Bp1) {
         constexpr int B = decltype(base)::value;
         Px<P>(&W0)[2] = S[(B + 0) & 7]; Px<P>(&W1)[2] = S[(B + 1) & 7];
         Px<P> x00, x01, x10, x11, evE, evO;
@@ -478,39 +290,10 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
             dpp_expand_taps(evO.h[k], el, er, orr, x10.h[k], x11.h[k]);
         }
         const bool row1_ok = (2 * c + 1) < h;
-        if constexpr (FOV) {
-            const float vy0 = s_vyA[min(2 * c, h - 1)], vy1 = s_vyA[min(2 * c + 1, h - 1)];
-            __builtin_amdgcn_sched_barrier(0);
-#if FOV2_PHASE == 1      // one pixel at a time: 24 registers of LUT cell in flight instead of 48
-            { const FovQ q0 = fov_a(W0[0], x00, vxa, vy0, ra.x, ra.y); fov_b(q0, owned, 0, accA); }
-            __builtin_amdgcn_sched_barrier(0);
-            { const FovQ q1 = fov_a(W0[1], x01, vxb, vy0, ra.z, ra.w); fov_b(q1, owned && col1_ok, 0, accA); }
-            __builtin_amdgcn_sched_barrier(0);
-            { const FovQ q2 = fov_a(W1[0], x10, vxa, vy1, rb.x, rb.y); fov_b(q2, owned && row1_ok, 0, accA); }
-            __builtin_amdgcn_sched_barrier(0);
-            { const FovQ q3 = fov_a(W1[1], x11, vxb, vy1, rb.z, rb.w); fov_b(q3, owned && row1_ok && col1_ok, 0, accA); }
-#else
-            {
-                const FovQ q0 = fov_a(W0[0], x00, vxa, vy0, ra.x, ra.y);
-                const FovQ q1 = fov_a(W0[1], x01, vxb, vy0, ra.z, ra.w);
-                fov_b(q0, owned, 0, accA);
-                fov_b(q1, owned && col1_ok, 0, accA);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            {
-                const FovQ q2 = fov_a(W1[0], x10, vxa, vy1, rb.x, rb.y);
-                const FovQ q3 = fov_a(W1[1], x11, vxb, vy1, rb.z, rb.w);
-                fov_b(q2, owned && row1_ok, 0, accA);
-                fov_b(q3, owned && row1_ok && col1_ok, 0, accA);
-            }
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            tail(W0[0], x00, owned, 0, accA);
-            tail(W0[1], x01, owned && col1_ok, 0, accA);
-            tail(W1[0], x10, owned && row1_ok, 0, accA);
-            tail(W1[1], x11, owned && row1_ok && col1_ok, 0, accA);
-        }
+        tail(W0[0], x00, owned, 0, accA);
+        tail(W0[1], x01, owned && col1_ok, 0, accA);
+        tail(W1[0], x10, owned && row1_ok, 0, accA);
+        tail(W1[1], x11, owned && row1_ok && col1_ok, 0, accA);
     };
 
     // ---- prologue: level-B row 2*ks and the window of the first step ---------------------------------------
@@ -533,14 +316,9 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
     CH[0] = CH[1] = CH[2] = R[4];
     load_row(4 * ks + 3, S[3][0], S[3][1]);
     load_row(4 * ks + 4, S[4][0], S[4][1]);
-    if constexpr (STAGE) {
-        stage_issue(2 * ks, 0u);
-        stage_issue(2 * ks + 1, 1u);
-    }
 
     // band B for level-B rows g0 (even), g1 (odd) from the level-C history
-    auto band_b_rows = [&](const Px<P>& g0, const Px<P>& g1, int row0,
-                           [[maybe_unused]] const float2 qa = float2{0, 0}, [[maybe_unused]] const float2 qb = float2{0, 0}) {
+    auto band_b_rows = [&](const Px<P>& g0, const Px<P>& g1, int row0) {
         Px<P> evE, evO, e0, e1;
 #pragma unroll
         for (int k = 0; k < HP; ++k) {
@@ -554,24 +332,8 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
             e0.h[k] = dpp_expand2_taps(evE.h[k] * fc, evE.h[k], fl, fr);
             e1.h[k] = dpp_expand2_taps(evO.h[k] * fc, evO.h[k], fl, fr);
         }
-        if constexpr (FOV) {
-            const float vy0 = s_vyB[min(max(row0, 0), hb - 1)], vy1 = s_vyB[min(max(row0 + 1, 0), hb - 1)];
-            __builtin_amdgcn_sched_barrier(0);
-#if FOV2_PHASE == 1
-            { const FovQ q0 = fov_a(g0, e0, vxB, vy0, qa.x, qa.y); fov_b(q0, owned && row0 < hb, 1, accB); }
-            __builtin_amdgcn_sched_barrier(0);
-            { const FovQ q1 = fov_a(g1, e1, vxB, vy1, qb.x, qb.y); fov_b(q1, owned && (row0 + 1) < hb, 1, accB); }
-#else
-            const FovQ q0 = fov_a(g0, e0, vxB, vy0, qa.x, qa.y);
-            const FovQ q1 = fov_a(g1, e1, vxB, vy1, qb.x, qb.y);
-            fov_b(q0, owned && row0 < hb, 1, accB);
-            fov_b(q1, owned && (row0 + 1) < hb, 1, accB);
-#endif
-            __builtin_amdgcn_sched_barrier(0);
-        } else {
-            tail(g0, e0, owned && row0 < hb, 1, accB);
-            tail(g1, e1, owned && (row0 + 1) < hb, 1, accB);
-        }
+        tail(g0, e0, owned && row0 < hb, 1, accB);
+        tail(g1, e1, owned && (row0 + 1) < hb, 1, accB);
     };
 
     // ---- main loop: stage k = steps c = 2k, 2k+1, then level-C row k and band B of level-B rows 2k-2, 2k-1 ------
@@ -582,51 +344,22 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
         // contiguous piece of 4 level-A rows and their halo columns meet in the CU's vector cache (profiles/r04_lockstep.md)
         // (a soft barrier across the workgroups of a whole row of strips -- a counter in L2, bounded spin -- costs 6 us per use and
         // slows the launch down at every interval tried: profiles/r04_lockstep.md, section 6)
-        if constexpr (!FOV) if (in_step) __builtin_amdgcn_s_barrier();
+        if (in_step) __builtin_amdgcn_s_barrier();
         {   // step c = 2k: level-B row 2k+1
             const int c = 2 * k;
-            // foveated: the rho-map records of this step's rows are requested BEFORE the rows of the next step (loads return in
-            // order: behind the row prefetch, the wait for a record is a wait for HBM, every step -- round 3)
-            float4 ra = float4{0, 0, 0, 0}, rb = ra;
-            if constexpr (FOV) {
-                ra = rmap_a(2 * c);
-                rb = rmap_a(2 * c + 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (STAGE) {
-                stage_read(stage_q, S[(BA + 5) & 7], S[(BA + 6) & 7]);
-                stage_issue(c + 2, stage_q >= 1u ? stage_q - 1u : 2u);       // slot (q + 2) % 3
-                stage_q = stage_q >= 2u ? 0u : stage_q + 1u;
-            } else {
-                load_row(2 * c + 5, S[(BA + 5) & 7][0], S[(BA + 5) & 7][1]);
-                load_row(2 * c + 6, S[(BA + 6) & 7][0], S[(BA + 6) & 7][1]);
-            }
+            load_row(2 * c + 5, S[(BA + 5) & 7][0], S[(BA + 5) & 7][1]);
+            load_row(2 * c + 6, S[(BA + 6) & 7][0], S[(BA + 6) & 7][1]);
             Be = coarse_step(basea);
             if (c + 1 >= hb) Be = R[4];                               // B[hb] = B[hb-1]
-            if (c >= ca && c < cb) band_a_rows(basea, c, R[3], R[4], Be, ra, rb);
+            if (c >= ca && c < cb) band_a_rows(basea, c, R[3], R[4], Be);
         }
-        float2 qa = float2{0, 0}, qb = qa;
         {   // step c = 2k+1: level-B row 2k+2
             const int c = 2 * k + 1;
-            float4 ra = float4{0, 0, 0, 0}, rb = ra;
-            if constexpr (FOV) {
-                ra = rmap_a(2 * c);
-                rb = rmap_a(2 * c + 1);
-                qa = rmap_b(2 * k - 2);                  // band B of level-B rows 2k-2, 2k-1 is evaluated at the end of this stage
-                qb = rmap_b(2 * k - 1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            if constexpr (STAGE) {
-                stage_read(stage_q, S[(BB + 5) & 7], S[(BB + 6) & 7]);
-                stage_issue(c + 2, stage_q >= 1u ? stage_q - 1u : 2u);
-                stage_q = stage_q >= 2u ? 0u : stage_q + 1u;
-            } else {
-                load_row(2 * c + 5, S[(BB + 5) & 7][0], S[(BB + 5) & 7][1]);
-                load_row(2 * c + 6, S[(BB + 6) & 7][0], S[(BB + 6) & 7][1]);
-            }
+            load_row(2 * c + 5, S[(BB + 5) & 7][0], S[(BB + 5) & 7][1]);
+            load_row(2 * c + 6, S[(BB + 6) & 7][0], S[(BB + 6) & 7][1]);
             Bo = coarse_step(baseb);
             if (c + 1 >= hb) Bo = (c + 1 == hb) ? Be : R[3];          // B[hb] = B[hb-1];  B[hb+1] = B[hb-2]
-            if (c >= ca && c < cb) band_a_rows(baseb, c, R[4], Be, Bo, ra, rb);
+            if (c >= ca && c < cb) band_a_rows(baseb, c, R[4], Be, Bo);
         }
         // level-B window of this stage: rows 2k-2 .. 2k+2 (top: rows -2, -1 mirror to 1, 0)
         R[0] = R[2];
@@ -659,7 +392,7 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
         CH[2] = Cn;
         if (k == 0) CH[1] = Cn;                                       // C[-1] = C[0] (index clamp of the expand)
         const int row0 = 2 * k - 2;
-        if (row0 >= ca && row0 < cb) band_b_rows(R[0], R[1], row0, qa, qb);
+        if (row0 >= ca && row0 < cb) band_b_rows(R[0], R[1], row0);
     };
     {
         int k = ks;
@@ -674,17 +407,9 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
         const int row0 = 2 * hc - 2;
         CH[0] = CH[1];
         CH[1] = CH[2];
-        if (row0 >= ca && row0 < cb) {
-            float2 qa = float2{0, 0}, qb = qa;
-            if constexpr (FOV) {
-                qa = rmap_b(row0);
-                qb = rmap_b(row0 + 1);
-            }
-            band_b_rows(R[2], R[3], row0, qa, qb);
-        }
+        if (row0 >= ca && row0 < cb) band_b_rows(R[2], R[3], row0);
     }
 
-    if constexpr (STAGE) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // no LDS-DMA may outlive the workgroup's LDS
     const float a0 = wave_sum(accA[0]), a1 = wave_sum(accA[1]);
     const float b0 = wave_sum(accB[0]), b1 = wave_sum(accB[1]);
     if (lane == 0) {
@@ -715,7 +440,6 @@ __device__ unsigned long long g_band2_timeline[4 * 65536];
 template <int P, bool INRANGE = false>
 __global__ __launch_bounds__(64 * BAND2_WPB_MAX, BAND2_LB) void band2_kernel(const Band2Args a) {
     __shared__ float4 s_csf[2][FVVDP_LUT_N];
-    __shared__ float4 s_stage[band2_stage(P) ? 3 * 4 * 64 : 1];
     const int lane = threadIdx.x & 63;
 #ifdef BAND2_TIMELINE
     const unsigned long long tl_t0 = wall_clock64();
@@ -742,7 +466,7 @@ __global__ __launch_bounds__(64 * BAND2_WPB_MAX, BAND2_LB) void band2_kernel(con
         s_csf[1][threadIdx.x] = a.csfB[threadIdx.x];
     }
     __syncthreads();
-    band2_item<P, INRANGE, false>(a, strip, chunk, frame, lane, s_csf, s_stage, wpb > 1);
+    band2_item<P, INRANGE>(a, strip, chunk, frame, lane, s_csf, wpb > 1);
 #ifdef BAND2_TIMELINE
     if (lane == 0 && a.w >= 2560 && blockIdx.x * wpb + (threadIdx.x >> 6) < 65536) {       // (the large launch only)
         unsigned long long* t = g_band2_timeline + 4 * (size_t)(blockIdx.x * wpb + (threadIdx.x >> 6));
@@ -752,46 +476,4 @@ __global__ __launch_bounds__(64 * BAND2_WPB_MAX, BAND2_LB) void band2_kernel(con
         t[3] = ((unsigned long long)frame << 32) | (unsigned int)(chunk * a.n_strips + strip);
     }
 #endif
-}
-
-// Foveated two-level pass: FOV2_WPB independent waves per workgroup share the two bands' LUT slices and the row tables of
-// vertical view angles in dynamic LDS (layout: [lut2_entries float4][h floats][hb floats]); 2 workgroups per CU.
-#ifndef FOV2_WPB
-#define FOV2_WPB 4
-#endif
-#ifndef FOV2_MINB
-#define FOV2_MINB 2
-#endif
-template <int P>
-__global__ __launch_bounds__(64 * FOV2_WPB, FOV2_MINB) void band2_fov_kernel(const Band2Args a_byval) {
-    const Band2Args& a = *(const Band2Args*)__builtin_amdgcn_kernarg_segment_ptr();     // scalar loads where needed (see band_kernel)
-    (void)a_byval;
-    const int lane = (int)(threadIdx.x & 63);
-    int bid;
-    {
-        const int nb = gridDim.x, q8 = nb >> 3, r8 = nb & 7, x = blockIdx.x & 7;
-        bid = x * q8 + min(x, r8) + (blockIdx.x >> 3);
-        bid = bid * FOV2_WPB + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    }
-    // tables: LUT slices, then the vertical view angle of every row of level A and of level B (pix2view_direction,
-    // fvvdp_display_model.py:498-510: one atan per row and workgroup)
-    for (int i = (int)threadIdx.x; i < a.lut2_entries; i += 64 * FOV2_WPB) s_lut_dyn[i] = a.lut2[i];
-    float* s_vy = reinterpret_cast<float*>(s_lut_dyn + a.lut2_entries);
-    for (int i = (int)threadIdx.x; i < a.h + a.hb; i += 64 * FOV2_WPB) {
-        const bool lvA = i < a.h;
-        const int r = lvA ? i : i - a.h, hh = lvA ? a.h : a.hb;
-        const float kyb = a.size_m1 / (float)hh / a.dist_m;
-        const float yp = ((float)r + 0.5f) + (-(float)hh / 2.0f);
-        s_vy[i] = atanf(-yp * kyb) * 57.29577951308232f;
-    }
-    __syncthreads();
-    if (bid >= a.n_items) return;
-    // frame fastest: an XCD walks all frames of a tile before the next tile, the tile's slice of the (frame-invariant) rho
-    // maps stays in that XCD's L2
-    const int n_tiles = a.n_strips * a.n_chunks, n_frames = a.n_items / n_tiles;
-    const int frame = bid % n_frames;
-    bid /= n_frames;
-    const int strip = bid % a.n_strips;
-    const int chunk = bid / a.n_strips;
-    band2_item<P, false, true>(a, strip, chunk, frame, lane, nullptr, nullptr);
 }

@@ -52,28 +52,62 @@ extern "C" const char* fvvdp_last_error(void) { return g_err; }
 // ------------------------------------------------------------------------------------------------------------
 // context
 // ------------------------------------------------------------------------------------------------------------
+// Testing / A-B switches of the library.  Read ONCE, when a context is created (fvvdp_ctx_create), never inside a per-frame call;
+// none of them changes results beyond the grouping of fp32 partial sums.
+struct CtxEnv {
+    bool alloc_malloc = false;    // FVVDP_ALLOC=malloc: every scratch buffer from hipMalloc (default: large levels mapped from chunks)
+    size_t vmm_chunk = 0;         // FVVDP_VMM_CHUNK_MB: chunk size of the >= 256 MB levels (default 32 MB)
+    int probe_n = -1;             // FVVDP_PLACEMENT_PROBE=n: level-0 candidates timed at creation (0 / 1 = none; default 4)
+    bool inrange_off = false;     // FVVDP_BAND_INRANGE=0: always the pyramid kernels with clamps
+    int fuse_mode = -1;           // FVVDP_BAND_FUSE=0 / 1: two-level pyramid kernel never / wherever valid (default: large levels)
+    int band_cr = 0, band2_kr = 0, band2_kr2 = -1, band2_wpb = 0;   // FVVDP_BAND_CR, FVVDP_BAND2_KR, _KR2, _WPB: work decomposition overrides
+    int k1_ticket = -1;           // FVVDP_K1_TICKET=0 / 1: temporal kernel (16-slot ring) without / with its block counter
+    bool temporal_scalar = false; // FVVDP_TEMPORAL_SCALAR=1: the per-pixel temporal kernels (fallbacks for unaligned sizes)
+    bool fov_no_rhomap = false;   // FVVDP_FOV_NO_RHOMAP=1: foveated kernels evaluate the rho coordinate per pixel
+    bool debug_variant = false;   // FVVDP_DEBUG_VARIANT=1: print which kernel variants are launched (tests)
+};
+static CtxEnv read_env() {
+    CtxEnv e;
+    auto num = [](const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; };
+    if (const char* v = getenv("FVVDP_ALLOC")) e.alloc_malloc = strcmp(v, "malloc") == 0;
+    e.vmm_chunk = (size_t)(num("FVVDP_VMM_CHUNK_MB", 0) > 0 ? num("FVVDP_VMM_CHUNK_MB", 0) : 0) << 20;
+    e.probe_n = num("FVVDP_PLACEMENT_PROBE", -1);
+    if (const char* v = getenv("FVVDP_BAND_INRANGE")) e.inrange_off = v[0] == '0';
+    if (const char* v = getenv("FVVDP_BAND_FUSE")) e.fuse_mode = (v[0] == '0' || v[0] == '1') ? v[0] - '0' : -1;
+    e.band_cr = num("FVVDP_BAND_CR", 0);
+    e.band2_kr = num("FVVDP_BAND2_KR", 0);
+    e.band2_kr2 = num("FVVDP_BAND2_KR2", -1);
+    e.band2_wpb = num("FVVDP_BAND2_WPB", 0);
+    if (const char* v = getenv("FVVDP_K1_TICKET")) e.k1_ticket = v[0] != '0' ? 1 : 0;
+    e.temporal_scalar = getenv("FVVDP_TEMPORAL_SCALAR") != nullptr;
+    e.fov_no_rhomap = getenv("FVVDP_FOV_NO_RHOMAP") != nullptr;
+    e.debug_variant = getenv("FVVDP_DEBUG_VARIANT") != nullptr;
+    return e;
+}
+
 struct VmmBlock {               // a buffer that came from the virtual-memory API (see dev_alloc): one reserved range, one or
     void* ptr;                  // more physical allocations mapped into it
     size_t size;
     std::vector<hipMemGenericAllocationHandle_t> handles;
 };
 struct fvvdp_ctx {
+    CtxEnv env;
     int W = 0, H = 0, n_bands = 0, P = 0, max_frames = 0;
     fvvdp_params prm{};
     double rho_band[FVVDP_MAX_BANDS + 1]{};
     int lw[FVVDP_MAX_BANDS + 1]{}, lh[FVVDP_MAX_BANDS + 1]{};
     float* level[FVVDP_MAX_BANDS + 1]{};
-    // online choice of the level-0 allocation kind (selection_step): calls 0-1 warm up, 2-3 time the buffer in use, 4 switches to
-    // a candidate of the OTHER kind (chunk-mapped <-> hipMalloc; untimed: first touch), 5-6 time the candidate, 7 decides, 9 done
-    int sel_phase = 0;
-    float* sel_other = nullptr;     // the incumbent while the candidate is in use
-    hipEvent_t sel_ev[2] = {nullptr, nullptr};
-    int sel_n = 0;                  // frames of the timed batch
-    int sel_open = 0;               // 1: selection_end still has to record the end event
-    int sel_await = -1;             // whose timing (0 incumbent, 1 candidate) the next step has to read
-    bool sel_bad = false;
-    float sel_us[2] = {0.0f, 0.0f}; // (incumbent, candidate) us per frame, temporal kernel + pyramid pass, smaller of two calls
-    int sel_kept = -1;              // 0 incumbent, 1 candidate, -1 no comparison
+    // choice of the level-0 buffer at creation (choose_level0): sel_n candidates timed, sel_us[k] = temporal kernel + pyramid pass
+    // in us per frame on candidate k, sel_kept = the one in use (-1: no comparison); sel_phase 9 = settled (the only state a
+    // caller can observe: the comparison runs inside fvvdp_ctx_create)
+    int sel_phase = 9;
+    int sel_n = 0;
+    int sel_kept = -1;
+    float sel_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // host synchronisations / allocations / frees made INSIDE per-frame entry points since creation (fvvdp_ctx_call_stats): the
+    // standard video path makes none (SURVEY 8(b) "allocated once in ctx_create")
+    long long n_sync = 0, n_alloc = 0, n_free = 0;
+    bool created = false;         // fvvdp_ctx_create has returned: from here on allocations / syncs are counted
     // what is known about the values in level 0 (luminance_range): sustained planes in [lum_lo, lum_hi], no plane's values
     // further apart than lum_width; lum_known = false after fvvdp_load_channels_planar or a source without a display model
     bool lum_known = false;
@@ -96,15 +130,6 @@ struct fvvdp_ctx {
     float4* sublut[FVVDP_MAX_BANDS]{};         // per-band rho slices, rebuilt when the geometry changes
     float4* rmap[FVVDP_MAX_BANDS]{};           // per-band rho-axis coordinates of every pixel pair (stock geometry)
     int sub_rw[FVVDP_MAX_BANDS]{}, sub_ilo[FVVDP_MAX_BANDS]{};
-    // two-level foveated pass over levels 0+1 (band2_fov_kernel): both bands' LUT slices trimmed to the eccentricities the
-    // display can show, the rho maps that index them (level 0 per pixel pair, level 1 per pixel)
-    bool fov2_ok = false;
-    float4* lut2 = nullptr;
-    int lut2_entries = 0;
-    size_t fov2_lds = 0;
-    float4* rmap2A = nullptr;
-    float2* rmap2B = nullptr;
-    long long wave_capacity_fov2 = 2048;
     fvvdp_geom sub_geom{};
     const float* map_vx[FVVDP_MAX_BANDS]{};    // user-geometry maps (owned by the caller)
     const float* map_vy[FVVDP_MAX_BANDS]{};
@@ -153,8 +178,7 @@ template <typename T>
 static int dev_alloc(fvvdp_ctx* c, T** p, size_t count) {
     void* q = nullptr;
     const size_t bytes = count * sizeof(T);
-    static const bool use_vmm = [] { const char* e = getenv("FVVDP_ALLOC"); return !(e && strcmp(e, "malloc") == 0); }();
-    if (use_vmm && bytes >= VMM_MIN_BYTES && vmm_alloc(c, &q, bytes) == FVVDP_OK) {
+    if (!c->env.alloc_malloc && bytes >= VMM_MIN_BYTES && vmm_alloc(c, &q, bytes) == FVVDP_OK) {
         // mapped
     } else {
         q = nullptr;
@@ -164,6 +188,7 @@ static int dev_alloc(fvvdp_ctx* c, T** p, size_t count) {
     }
     *p = reinterpret_cast<T*>(q);
     c->scratch += bytes;
+    if (c->created) c->n_alloc += 1;               // an allocation inside a per-frame call (first use of an optional path)
     return FVVDP_OK;
 }
 
@@ -199,10 +224,7 @@ static int vmm_alloc(fvvdp_ctx* c, void** out, size_t bytes) {
     HIP_TRY(hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended));
     if (gran == 0) gran = (size_t)2 << 20;
     size_t chunk = bytes >= VMM_BIG_BYTES ? (size_t)32 << 20 : (size_t)4 << 20;
-    if (const char* g = getenv("FVVDP_VMM_CHUNK_MB")) {
-        const size_t v = (size_t)atoll(g) << 20;
-        if (v >= gran && bytes >= VMM_BIG_BYTES) chunk = v;
-    }
+    if (c->env.vmm_chunk >= gran && bytes >= VMM_BIG_BYTES) chunk = c->env.vmm_chunk;
     chunk = (chunk + gran - 1) / gran * gran;
     const size_t size = (bytes + chunk - 1) / chunk * chunk;
     const size_t n = size / chunk;
@@ -275,7 +297,7 @@ static int band_strips(int wc) { return wc <= 62 ? 1 : 1 + (wc - 62 + STRIP_J - 
 static int band2_strips(int wb) { return (wb + F2_PITCH - 1) / F2_PITCH; }
 
 // two-level kernel: a chunk of kr level-C rows costs 2*kr steps of level A plus 7 halo steps and the prologue
-static void chunking2(int hc, int n_strips, int n, long long capacity, int& n_chunks, int& kr) {
+static void chunking2(int hc, int n_strips, int n, long long capacity, int kr_override, int& n_chunks, int& kr) {
     double best = 1e300;
     kr = hc;
     for (int cand = 1; cand <= hc; ++cand) {
@@ -285,14 +307,11 @@ static void chunking2(int hc, int n_strips, int n, long long capacity, int& n_ch
         const double cost = (double)rounds * (2.0 * cand + 9.0) * (1.0 + 1e-4 * (double)chunks);
         if (cost < best) { best = cost; kr = cand; }
     }
-    if (const char* ov = getenv("FVVDP_BAND2_KR")) {      // tuning override
-        const int v = atoi(ov);
-        if (v >= 1) kr = v > hc ? hc : v;
-    }
+    if (kr_override >= 1) kr = kr_override > hc ? hc : kr_override;      // tuning override (FVVDP_BAND2_KR)
     n_chunks = (hc + kr - 1) / kr;
 }
 
-static void chunking(int hc, int n_strips, int n, long long capacity, int& n_chunks, int& cr) {
+static void chunking(int hc, int n_strips, int n, long long capacity, int cr_override, int& n_chunks, int& cr) {
     // Every single-wave workgroup does the same amount of work (cr steps + the prologue for the two halo coarse
     // rows, whose 7 extra fine rows are re-read from HBM: weighted as 8 steps), so the launch proceeds in "rounds"
     // of `capacity` resident waves.  Pick the chunk height that minimises rounds x per-wave cost.
@@ -307,12 +326,11 @@ static void chunking(int hc, int n_strips, int n, long long capacity, int& n_chu
         if (cost < best) { best = cost; cr = c; }
         if (cand >= hc) break;
     }
-    if (const char* ov = getenv("FVVDP_BAND_CR")) {       // tuning override
-        const int v = atoi(ov);
-        if (v >= 1) cr = v > hc ? hc : v;
-    }
+    if (cr_override >= 1) cr = cr_override > hc ? hc : cr_override;      // tuning override (FVVDP_BAND_CR)
     n_chunks = (hc + cr - 1) / cr;
 }
+
+static void choose_level0(fvvdp_ctx* c);
 
 extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_bands, int planes, int max_frames,
                                 const double* h_rho_band, const fvvdp_params* prm) {
@@ -322,6 +340,7 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
     if (max_frames < 1) return fail(FVVDP_EINVAL, "max_frames must be >= 1");
     if (width < 4 || height < 4) return fail(FVVDP_EINVAL, "frame %dx%d too small", width, height);
     fvvdp_ctx* c = new fvvdp_ctx();
+    c->env = read_env();
     c->W = width;
     c->H = height;
     c->n_bands = n_bands;
@@ -392,6 +411,8 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
         if (e != hipSuccess || per_cu2 < 1) per_cu2 = 16;
         c->wave_capacity2 = (long long)per_cu2 * cus;
     }
+    choose_level0(c);
+    c->created = true;
     *out = c;
     return FVVDP_OK;
 }
@@ -399,9 +420,6 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
 extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     if (!c) return;
     (void)hipDeviceSynchronize();                  // nothing may still read the scratch
-    dev_free(c, c->sel_other);                     // a comparison of level-0 allocations was under way
-    for (auto& e : c->sel_ev)
-        if (e) (void)hipEventDestroy(e);
     for (int i = 0; i <= FVVDP_MAX_BANDS; ++i)
         dev_free(c, c->level[i]);
     dev_free(c, c->partial);
@@ -420,9 +438,6 @@ extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
         dev_free(c, c->sublut[b]);
         dev_free(c, c->rmap[b]);
     }
-    dev_free(c, c->lut2);
-    dev_free(c, c->rmap2A);
-    dev_free(c, c->rmap2B);
     vmm_free_all(c);
     for (auto& v : c->ev)
         for (auto& pr : v) {
@@ -508,105 +523,18 @@ static EotfDev make_eotf(const fvvdp_eotf* e) {
 static int grow_lum_buf(fvvdp_ctx* c, size_t need_floats, int fl, hipStream_t st) {
     if (c->lum_floats >= need_floats) return FVVDP_OK;
     HIP_TRY(hipStreamSynchronize(st));                       // earlier calls may still read the old buffer
-    if (c->lum_buf) (void)hipFree(c->lum_buf);
+    c->n_sync += 1;
+    if (c->lum_buf) { (void)hipFree(c->lum_buf); c->n_free += 1; }
     c->lum_buf = nullptr;
     c->lum_floats = 0;
     void* q = nullptr;
     if (hipMalloc(&q, need_floats * sizeof(float)) != hipSuccess)
         return fail(FVVDP_ENOMEM, "hipMalloc(%zu bytes) for the luminance frames of a %d-tap filter failed", need_floats * sizeof(float), fl);
     c->lum_buf = reinterpret_cast<float*>(q);
+    c->n_alloc += 1;
     c->lum_floats = need_floats;
     c->scratch += need_floats * sizeof(float);
     return FVVDP_OK;
-}
-
-// ---- online choice of the level-0 allocation kind -----------------------------------------------------------------------------
-// The temporal kernel runs at 30.6-33.8 or at 35-38 us per 4K frame depending on where its destination lies physically; on most
-// boxes a range mapped from chunks is the fast one and hipMalloc the slow one, on some it is the other way round, and the pyramid
-// kernels do not care (profiles/r04_level0_chunks.md).  So a context that will be used repeatedly measures: calls 1-2 warm up,
-// calls 3-4 are timed (temporal kernel + pyramid pass of the batch in slot 0, the smaller of the two counts) on the buffer the
-// context has, call 5 runs on a fresh buffer of the OTHER kind untimed (first touch), calls 6-7 are timed on it, call 8 keeps the
-// faster one (the candidate has to win by 3 %) and frees the other.  No extra GPU work; the context holds level 0 twice for four
-// calls.  Results never depend on the buffer.  FVVDP_PLACEMENT_PROBE=0 turns it off.  Only for video contexts whose level 0 holds
-// >= 1 GiB, batches of >= 16 frames, and calls that rewrite every slot in use.
-static void selection_read(fvvdp_ctx* c) {          // the timed call before this one: keep the smaller of the two per buffer
-    if (c->sel_await < 0) return;
-    float ms = 0.0f;
-    const bool ok = !c->sel_open && hipEventSynchronize(c->sel_ev[1]) == hipSuccess &&
-                    hipEventElapsedTime(&ms, c->sel_ev[0], c->sel_ev[1]) == hipSuccess && ms > 0.0f;
-    if (!ok) { (void)hipGetLastError(); c->sel_bad = true; }
-    else {
-        const float us = ms * 1e3f / (float)(c->sel_n > 0 ? c->sel_n : 1);
-        float& slot = c->sel_us[c->sel_await];
-        slot = slot > 0.0f && slot < us ? slot : us;
-    }
-    c->sel_await = -1;
-}
-static void selection_time(fvvdp_ctx* c, int which, int n_out, hipStream_t st) {
-    for (int i = 0; i < 2; ++i)
-        if (!c->sel_ev[i] && hipEventCreate(&c->sel_ev[i]) != hipSuccess) { (void)hipGetLastError(); c->sel_bad = true; return; }
-    (void)hipEventRecord(c->sel_ev[0], st);
-    c->sel_n = n_out;
-    c->sel_open = 1;
-    c->sel_await = which;
-}
-static void selection_step(fvvdp_ctx* c, int n_out, hipStream_t st) {
-    const size_t floats = (size_t)c->max_frames * c->lw[0] * c->lh[0] * c->P;
-    selection_read(c);
-    if (c->sel_bad) {                                            // an event or a call out of order: stay with what is in use
-        if (c->sel_other) { float* cand = c->level[0]; c->level[0] = c->sel_other; c->sel_other = nullptr;
-                            (void)hipStreamSynchronize(st); if (vmm_owns(c, cand)) vmm_free_one(c, cand); else (void)hipFree(cand); }
-        c->sel_phase = 9;
-        return;
-    }
-    switch (c->sel_phase) {
-    case 0: case 1:                                              // warm-up calls
-        c->sel_phase += 1;
-        break;
-    case 2: case 3:                                              // two timed calls on the buffer in use
-        selection_time(c, 0, n_out, st);
-        c->sel_phase += 1;
-        break;
-    case 4: {                                                    // a candidate of the other kind; its first call is not timed
-        void* q = nullptr;
-        const bool inc_vmm = vmm_owns(c, c->level[0]);
-        const bool ok = inc_vmm ? hipMalloc(&q, floats * sizeof(float)) == hipSuccess
-                                : vmm_alloc(c, &q, floats * sizeof(float)) == FVVDP_OK;
-        if (!ok) { (void)hipGetLastError(); c->sel_phase = 9; break; }
-        c->sel_other = c->level[0];
-        c->level[0] = reinterpret_cast<float*>(q);
-        c->sel_phase = 5;
-        break;
-    }
-    case 5: case 6:                                              // two timed calls on the candidate
-        selection_time(c, 1, n_out, st);
-        c->sel_phase += 1;
-        break;
-    case 7: {
-        const float t_inc = c->sel_us[0], t_new = c->sel_us[1];
-        const bool ok = t_inc > 0.0f && t_new > 0.0f;
-        const bool take_new = ok && t_new < 0.97f * t_inc;        // single calls scatter by 1-2 %; real differences are 4-9 %
-        float* loser = take_new ? c->sel_other : c->level[0];
-        if (!take_new) c->level[0] = c->sel_other;
-        c->sel_other = nullptr;
-        (void)hipStreamSynchronize(st);                          // nothing reads the loser any more
-        if (vmm_owns(c, loser)) vmm_free_one(c, loser); else (void)hipFree(loser);
-        c->sel_kept = ok ? (take_new ? 1 : 0) : -1;
-        if (getenv("FVVDP_DEBUG_VARIANT"))
-            fprintf(stderr, "fvvdp: level-0 allocation: in use %.2f, candidate %.2f us per frame (temporal + pyramid) -> kept the %s (%s)\n",
-                    t_inc, t_new, take_new ? "candidate" : "incumbent", vmm_owns(c, c->level[0]) ? "chunk-mapped" : "hipMalloc");
-        c->sel_phase = 9;
-        break;
-    }
-    default:
-        break;
-    }
-}
-static void selection_end(fvvdp_ctx* c, hipStream_t st) {
-    if (c->sel_open) {
-        (void)hipEventRecord(c->sel_ev[1], st);
-        c->sel_open = 0;
-    }
 }
 
 // Range of the values the temporal kernels write into level 0, from the display model (every closed-form model clamps its
@@ -678,8 +606,7 @@ static void luminance_range(fvvdp_ctx* c, const fvvdp_eotf* e, int C, const floa
 // inside the range of level 0.
 static bool clamps_never_bind(const fvvdp_ctx* c, int b, int n_levels) {
     if (!c->lum_known || c->lum_state != 1) return false;
-    static const bool off = [] { const char* e = getenv("FVVDP_BAND_INRANGE"); return e && e[0] == '0'; }();   // A/B runs, tests
-    if (off) return false;
+    if (c->env.inrange_off) return false;                                  // A/B runs, tests
     for (int i = 0; i < b + n_levels; ++i)
         if ((c->lw[i] & 1) != (c->lh[i] & 1)) return false;
     const float lo = c->lum_lo, hi = c->lum_hi;
@@ -710,7 +637,7 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
     // register-ring kernels: up to 32 taps for every sample type, up to 64 taps (129-256 fps) for the cases of k1_ring64_ok()
     // (uint8; 16-bit / float RGB behind an sRGB or PQ display; float luminance frames); the 1-pixel-per-lane ring needs no alignment.  The 64-slot ring is not instantiated
     // for the other cases; they take the generic kernel, which re-reads the window for every output frame
-    const bool ring64 = (c->P == 4) && fl > 32 && fl <= 64 && !getenv("FVVDP_TEMPORAL_SCALAR") &&
+    const bool ring64 = (c->P == 4) && fl > 32 && fl <= 64 && !c->env.temporal_scalar &&
                         k1_ring64_ok(dtype, C, eotf->kind);
     const bool ring_ok = ((c->P == 4) && (fl <= 32)) || ring64;
     if (ring_ok) {
@@ -745,18 +672,15 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
                 // vector path needs the lane's PX consecutive samples to be naturally aligned
                 const int PXv = k1_px(FL, dtype);        // temporal_launch.hpp
                 const int es = dtype == FVVDP_U8 ? 1 : (dtype == FVVDP_U16 ? 2 : 4);
-                const bool vec_ok = !getenv("FVVDP_TEMPORAL_SCALAR") && (HW % PXv == 0) && (HW >= PXv) &&
+                const bool vec_ok = !c->env.temporal_scalar && (HW % PXv == 0) && (HW >= PXv) &&
                                     (chan_stride % PXv == 0) && (frame_stride % PXv == 0) &&
                                     (reinterpret_cast<uintptr_t>(d_test) % (size_t)(es * PXv) == 0) &&
                                     (reinterpret_cast<uintptr_t>(d_ref) % (size_t)(es * PXv) == 0);
                 if (vec_ok) {
                     // uint8, 9..16 taps (33-64 fps): resident workgroups that take their pixel blocks from a counter
-                    // (temporal_vec_kernel).  Measured on five boxes (profiles/r04_lockstep.md, section 5): -2 ... -6 % with the
-                    // 16-slot ring; -3 ... +1.5 % with the 8-slot ring, where it therefore stays off.  FVVDP_K1_TICKET=1 / 0
-                    // forces it on (<= 16 taps) / off.  Same blocks, same arithmetic.
-                    const char* tke = getenv("FVVDP_K1_TICKET");
-                    const bool tickets = tke ? tke[0] != '0' : FL == 16;
-                    if (tickets && dtype == FVVDP_U8 && FL <= 16 && c->d_ticket) {
+                    // (temporal_vec_kernel; FVVDP_K1_TICKET=0: one workgroup per block).  Same blocks, same arithmetic.
+                    const bool tickets = FL == 16 && c->env.k1_ticket != 0;
+                    if (tickets && dtype == FVVDP_U8 && c->d_ticket) {
                         if (hipMemsetAsync(c->d_ticket, 0, sizeof(int), st) == hipSuccess) a.ticket = c->d_ticket;
                         else (void)hipGetLastError();
                     }
@@ -770,22 +694,11 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
             }
             return FVVDP_OK;
         };
-        if (slot0 == 0 && c->sel_phase < 9) {
-            static const bool probe_on = [] { const char* e = getenv("FVVDP_PLACEMENT_PROBE"); return !(e && e[0] == '0'); }();
-            const size_t bytes = (size_t)c->max_frames * c->lw[0] * c->lh[0] * c->P * sizeof(float);
-            if (!probe_on || c->P != 4 || bytes < ((size_t)1 << 30) || c->lum_hold) c->sel_phase = 9;
-            else if (n_out >= 16 && c->lum_top == n_out) {                               // this call rewrites every slot in use
-                // (not while the stream is being captured into a graph: the comparison allocates, frees and reads events)
-                hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-                if (hipStreamIsCapturing(st, &cap) != hipSuccess) { (void)hipGetLastError(); cap = hipStreamCaptureStatusNone; }
-                if (cap == hipStreamCaptureStatusNone) selection_step(c, n_out, st);
-            }
-        }
         {
             const int rc = run(c->level[0], 0, n_out);
             if (rc != FVVDP_OK) return rc;
         }
-    } else if (c->P == 4 && fl > 32 && fl <= 64 && !h_frame_idx1 && !getenv("FVVDP_TEMPORAL_SCALAR") &&
+    } else if (c->P == 4 && fl > 32 && fl <= 64 && !h_frame_idx1 && !c->env.temporal_scalar &&
                fl - 1 + n_out <= T_MAX_IDX && k1_ring64_ok(FVVDP_F32, 1, FVVDP_EOTF_NONE)) {
         // 33..64 taps (129-256 fps) for a sample type / display model the 64-slot ring is not instantiated for: two passes.
         // Every source frame of the window -> fp32 luminance once (luminance_frames_kernel), then the 64-slot ring on those
@@ -841,6 +754,7 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
             for (int k = 0; k < fl - 1 + n_out; ++k) a.idx_i[k] = h_frame_idx[k];
         } else {
             HIP_TRY(hipStreamSynchronize(st));
+            c->n_sync += 1;                                      // (more than 32 taps without a ring kernel: tables through device memory)
             HIP_TRY(hipMemcpy(c->d_taps, h_taps, sizeof(float) * 2 * fl, hipMemcpyHostToDevice));
             HIP_TRY(hipMemcpy(c->d_idx, h_frame_idx, sizeof(int) * (fl - 1 + n_out), hipMemcpyHostToDevice));
         }
@@ -1019,7 +933,7 @@ extern "C" int fvvdp_temporal_channels_yuv(fvvdp_ctx* c, const void* d_test, con
         const int bytes = fmt->bit_depth > 8 ? 2 : 1;
         // vector kernel: 4 consecutive pixels per lane -> rows, planes and frames must keep 4-sample alignment
         const size_t al = (size_t)bytes * 4;
-        const bool vec_ok = !getenv("FVVDP_TEMPORAL_SCALAR") && FL <= 16 && (c->W % 4 == 0) && (frame_stride % 4 == 0) &&
+        const bool vec_ok = !c->env.temporal_scalar && FL <= 16 && (c->W % 4 == 0) && (frame_stride % 4 == 0) &&
                             (reinterpret_cast<uintptr_t>(d_test) % al == 0) && (reinterpret_cast<uintptr_t>(d_ref) % al == 0);
         if (vec_ok) {
             k1_launch_yuv_vec(FL, bytes, a.chroma420 != 0, a, st);
@@ -1116,111 +1030,13 @@ extern "C" int fvvdp_export_level(fvvdp_ctx* c, int level, int n, float* d_out, 
 // [ecc][Y][rho] of float4 {S0[i], S1[i], S0[i+1], S1[i+1]} so that one aligned 16-byte load returns the two rho
 // corners of both temporal channels (value at knot i and the step to knot i+1: v[i] + f*(v[i+1]-v[i])) and neighbouring
 // pixels (similar ecc, Y) share cache lines.
-// Tables of the two-level foveated pass over levels 0+1 (band2_fov_kernel): stock geometry only.  Both bands' slices must sit
-// in LDS next to the row tables of both levels with two workgroups per CU (80 KB each); they fit because the ecc axis is cut
-// at the largest eccentricity the display can show with the gaze on the screen (twice the view angle of its corner;
-// standard_hdr_pq at 4K: 23 of the 32 ecc rows, 4 planes of 13.4 KB + 13 KB of row tables).
-static int build_fov2(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
-    c->fov2_ok = false;
-    // OFF unless FVVDP_FOV_FUSE=1: built for VERDICT r3 item 2 and measured on configs[3] (profiles/r04_fov_two_level.md): 50.5-51.7
-    // us per 4K frame for levels 0+1 against 49.4-50.4 us for the two one-level launches -- the foveated tail is arithmetic (13
-    // transcendentals, 8 LDS reads and the trilinear blend per pixel), the two-level strips own 54 of 64 lanes where the
-    // one-level strips own 60, and with both slices in LDS and 196-205 registers only 2 waves per SIMD fit.
-    const char* fe = getenv("FVVDP_FOV_FUSE");
-    const bool off = !(fe && fe[0] == '1');
-    if (!g || off || getenv("FVVDP_FOV_NO_RHOMAP") || c->n_bands < 2) return FVVDP_OK;
-    if ((long long)c->lw[0] * c->lh[0] < 1500000 && !getenv("FVVDP_BAND_FUSE")) return FVVDP_OK;     // small frames: one level per launch
-    if (c->lw[1] < 4 || c->lh[1] < 4 || c->lw[2] < 2 || c->lh[2] < 2) return FVVDP_OK;
-    const double ax = atan(0.5 * g->display_size_m[0] / g->distance_m) * 180.0 / M_PI;
-    const double ay = atan(0.5 * g->display_size_m[1] / g->distance_m) * 180.0 / M_PI;
-    const double ecc_max = fmin(2.0 * sqrt(ax * ax + ay * ay) * 1.02, (double)c->ecc_hi);
-    const float* xe = c->h_axes[2];
-    const double e_step = ((double)xe[FVVDP_LUT_N - 1] - (double)xe[0]) / (FVVDP_LUT_N - 1);
-    int n_e = (int)floor((sqrt(ecc_max) - (double)xe[0]) / e_step) + 3;      // rows iE and iE + 1 of every reachable interval, + 1
-    if (const char* e = getenv("FVVDP_FOV2_NE")) n_e = atoi(e);            // debugging: rows of the ecc axis kept in the slices
-    if (n_e > FVVDP_LUT_N) n_e = FVVDP_LUT_N;
-    if (n_e < 2) n_e = 2;
-    const int plane_e = n_e * FOV_ROW + 8;
-    const int rwA = c->sub_rw[0], rwB = c->sub_rw[1];
-    const size_t entries = (size_t)(rwA + rwB) * plane_e;
-    const size_t lds = entries * sizeof(float4) + (size_t)(c->lh[0] + c->lh[1]) * sizeof(float);
-    if (lds > 80 * 1024) return FVVDP_OK;                                   // two workgroups per CU or not at all
-    std::vector<float4> h(entries, make_float4(0.0f, 0.0f, 0.0f, 0.0f));
-    const float* L0 = c->h_lut3[0].data();
-    const float* L1 = c->h_lut3[1].empty() ? L0 : c->h_lut3[1].data();
-    for (int b = 0; b < 2; ++b) {
-        const int base_plane = b == 0 ? 0 : rwA, rw = c->sub_rw[b], i_lo = c->sub_ilo[b];
-        for (int i = 0; i < rw; ++i)
-            for (int k = 0; k < n_e; ++k)
-                for (int j = 0; j < FVVDP_LUT_N; ++j) {
-                    const size_t s0 = ((size_t)j * FVVDP_LUT_N + (i_lo + i)) * FVVDP_LUT_N + k;       // [Y][rho][ecc]
-                    const size_t s1 = ((size_t)j * FVVDP_LUT_N + (i_lo + i + 1)) * FVVDP_LUT_N + k;
-                    h[(size_t)(base_plane + i) * plane_e + (size_t)k * FOV_ROW + j] = make_float4(L0[s0], L1[s0], L0[s1] - L0[s0], L1[s1] - L1[s0]);
-                }
-    }
-    if (c->lut2 && c->lut2_entries != (int)entries) {
-        dev_free(c, c->lut2);
-        c->lut2 = nullptr;
-    }
-    int rc = FVVDP_OK;
-    if (!c->lut2) rc = dev_alloc(c, &c->lut2, entries);
-    if (rc == FVVDP_OK && !c->rmap2A) rc = dev_alloc(c, &c->rmap2A, (size_t)((c->lw[0] + 1) / 2) * c->lh[0]);
-    if (rc == FVVDP_OK && !c->rmap2B) rc = dev_alloc(c, &c->rmap2B, (size_t)c->lw[1] * c->lh[1]);
-    if (rc != FVVDP_OK) return rc;
-    HIP_TRY(hipMemcpy(c->lut2, h.data(), entries * sizeof(float4), hipMemcpyHostToDevice));
-    c->lut2_entries = (int)entries;
-    c->fov2_lds = lds;
-    for (int b = 0; b < 2; ++b) {
-        RhoMapArgs ra;
-        memset(&ra, 0, sizeof(ra));
-        ra.w = c->lw[b];
-        ra.h = c->lh[b];
-        ra.size_m0 = g->display_size_m[0];
-        ra.size_m1 = g->display_size_m[1];
-        ra.dist_m = g->distance_m;
-        const double delta = (1.0 / (double)g->ppd_centre) / 2.0 * M_PI / 180.0;
-        ra.delta_rad = (float)delta;
-        ra.cos_delta = (float)cos(delta);
-        ra.rho_band = (float)c->rho_band[b];
-        ra.rho_lo = c->rho_lo;
-        ra.rho_hi = c->rho_hi;
-        ra.first = c->h_axes[1][0];
-        ra.inv_step = (float)(FVVDP_LUT_N - 1) / (c->h_axes[1][FVVDP_LUT_N - 1] - c->h_axes[1][0]);
-        ra.i_lo = c->sub_ilo[b];
-        ra.rw = c->sub_rw[b];
-        ra.axis = c->d_axes + FVVDP_LUT_N;
-        ra.plane_bytes = plane_e * 16;
-        ra.base_bytes = b == 0 ? 0 : rwA * plane_e * 16;
-        if (b == 0) ra.out = c->rmap2A; else ra.out_px = c->rmap2B;
-        const int pw = (c->lw[b] + 1) / 2;
-        hipLaunchKernelGGL(fov_rho_map_kernel, dim3((pw + 255) / 256, c->lh[b]), dim3(256), 0, st, ra);
-    }
-    {
-        int per_cu = 2, cus = 256, dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) cus = prop.multiProcessorCount;
-        hipError_t e;
-        if (c->P == 4) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band2_fov_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, band2_fov_kernel<4>, 64 * FOV2_WPB, lds);
-        } else {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(band2_fov_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, band2_fov_kernel<2>, 64 * FOV2_WPB, lds);
-        }
-        if (e != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 1; }
-        c->wave_capacity_fov2 = (long long)per_cu * FOV2_WPB * cus;
-    }
-    HIP_TRY(hipGetLastError());
-    c->fov2_ok = true;
-    return FVVDP_OK;
-}
-
 static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
     fvvdp_geom key;
     memset(&key, 0, sizeof(key));
     if (g) key = *g;
     if (c->sub_valid && memcmp(&c->sub_geom, &key, sizeof(key)) == 0) return FVVDP_OK;
     HIP_TRY(hipStreamSynchronize(st));            // geometry changed: kernels of earlier calls may still read the old slices
+    c->n_sync += 1;
     double mag_max = 1.0, mag_min = 1.0;
     if (g) {
         const double delta = (1.0 / (double)g->ppd_centre) / 2.0 * M_PI / 180.0;
@@ -1247,6 +1063,7 @@ static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
         const int rw = i_hi - i_lo;                                                       // intervals covered
         if (c->sublut[b] && c->sub_rw[b] != rw) {
             (void)hipFree(c->sublut[b]);
+            c->n_free += 1;
             c->sublut[b] = nullptr;
         }
         const size_t n = (size_t)FOV_PLANE * rw;                 // padded layout, see FOV_ROW / FOV_PLANE (band_kernel.hpp)
@@ -1268,7 +1085,7 @@ static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
         HIP_TRY(hipMemcpy(c->sublut[b], h.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         c->sub_rw[b] = rw;
         c->sub_ilo[b] = i_lo;
-        if (g && !getenv("FVVDP_FOV_NO_RHOMAP")) {   // frame-invariant rho-axis coordinates of every pixel (stock geometry)
+        if (g && !c->env.fov_no_rhomap) {   // frame-invariant rho-axis coordinates of every pixel (stock geometry)
             const int pw = (c->lw[b] + 1) / 2;
             if (!c->rmap[b]) {
                 int rc = dev_alloc(c, &c->rmap[b], (size_t)pw * c->lh[b]);
@@ -1296,10 +1113,6 @@ static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
             ra.plane_bytes = FOV_PLANE * 16;
             hipLaunchKernelGGL(fov_rho_map_kernel, dim3((pw + 255) / 256, c->lh[b]), dim3(256), 0, st, ra);
         }
-    }
-    {
-        int rc = build_fov2(c, g, st);
-        if (rc != FVVDP_OK) return rc;
     }
     c->sub_geom = key;
     c->sub_valid = true;
@@ -1385,18 +1198,11 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
     // It pays where the one-level kernel is bound by HBM (large levels: 4K levels 0+1 39 vs 46 us per frame); the
     // two-level kernel's arithmetic takes as long as its data flow (its strips own 54 of 64 lanes), so small levels stay on the one-level kernel
     // (960x540 + 480x270: 3.1 vs 2.95 us).  FVVDP_BAND_FUSE=0 / 1 forces never / wherever valid (tests, A/B runs).
-    const char* fuse_env = getenv("FVVDP_BAND_FUSE");
-    const int fuse_mode = (fuse_env && (fuse_env[0] == '0' || fuse_env[0] == '1')) ? fuse_env[0] - '0' : -1;   // anything else: automatic
+    const int fuse_mode = c->env.fuse_mode;                      // 0 / 1, anything else: automatic
     const bool fuse_ok = !fov && !any_maps && fuse_mode != 0;
-    // foveated: levels 0+1 in one pass when the tables of build_fov2 exist and every gaze point lies on the screen (their ecc axis
-    // is cut at the eccentricities such a gaze can produce)
-    bool fov2 = fov && geom && c->fov2_ok && !any_maps && fuse_mode != 0;
-    if (fov2)
-        for (int f = 0; f < n; ++f)
-            if (!(h_fixation[2 * f] >= -0.5f && h_fixation[2 * f] <= (float)c->W && h_fixation[2 * f + 1] >= -0.5f && h_fixation[2 * f + 1] <= (float)c->H)) fov2 = false;
     for (int b = 0; b < c->n_bands; ++b) {
         const bool big = (long long)c->lw[b] * c->lh[b] >= 500000;      // (4K: levels 0+1 and 2+3; 2+3 in one launch: 3.06 -> 2.67 us per frame)
-        if ((fuse_ok || (fov2 && b == 0)) && (big || fuse_mode == 1) && b + 1 < c->n_bands && c->lw[b + 1] >= 4 && c->lh[b + 1] >= 4 &&
+        if (fuse_ok && (big || fuse_mode == 1) && b + 1 < c->n_bands && c->lw[b + 1] >= 4 && c->lh[b + 1] >= 4 &&
             c->lw[b + 2] >= 2 && c->lh[b + 2] >= 2) {
             Band2Args a;
             memset(&a, 0, sizeof(a));
@@ -1409,16 +1215,16 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
             a.wc = c->lw[b + 2];
             a.hc = c->lh[b + 2];
             a.n_strips = band2_strips(a.wb);
-            chunking2(a.hc, a.n_strips, n, fov ? c->wave_capacity_fov2 : c->wave_capacity2, a.n_chunks, a.kr);
+            chunking2(a.hc, a.n_strips, n, c->wave_capacity2, c->env.band2_kr, a.n_chunks, a.kr);
             a.n_big = a.n_chunks;
             a.kr2 = a.kr;
             a.n_frames = n;
-            if (!fov) {
+            {
                 // a launch of several rounds of tall chunks: the last chunk of every frame is cut into four and dispatched after
                 // all tall ones (band2_kernel's two phases)
                 const long long waves = (long long)n * a.n_strips * a.n_chunks;
                 int kr2 = (waves >= 2 * c->wave_capacity2 && a.n_chunks >= 3 && a.kr >= 16) ? (a.kr + 3) / 4 : 0;
-                if (const char* ov = getenv("FVVDP_BAND2_KR2")) kr2 = atoi(ov);       // tuning override; 0 = uniform chunks
+                if (c->env.band2_kr2 >= 0) kr2 = c->env.band2_kr2;                  // tuning override (FVVDP_BAND2_KR2); 0 = uniform chunks
                 if (kr2 >= 1 && kr2 < a.kr && a.n_chunks >= 2) {
                     a.n_big = a.n_chunks - 1;
                     a.kr2 = kr2;
@@ -1448,34 +1254,6 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
             if (nblk > c->max_blk[b] || nblk > c->max_blk[b + 1]) return fail(FVVDP_ESTATE, "internal: partial buffer too small");
             {
                 Timed tm(c, 1 + b, st);
-                if (fov) {
-                    a.lut2 = c->lut2;
-                    a.lut2_entries = c->lut2_entries;
-                    a.n_items = nblk * n;
-                    a.rmapA = c->rmap2A;
-                    a.rmapA_w = (c->lw[0] + 1) / 2;
-                    a.rmapB = c->rmap2B;
-                    a.fix = c->d_fix;
-                    a.size_m0 = geom->display_size_m[0];
-                    a.size_m1 = geom->display_size_m[1];
-                    a.dist_m = geom->distance_m;
-                    a.frame_w = c->W;
-                    a.frame_h = c->H;
-                    a.ecc_lo = c->ecc_lo;
-                    a.ecc_hi = c->ecc_hi;
-                    for (int ax = 0; ax < 2; ++ax) {
-                        const int src = ax == 0 ? 0 : 2;                       // Y axis, ecc axis
-                        const float first = c->h_axes[src][0];
-                        a.f_inv_step[ax] = (float)(FVVDP_LUT_N - 1) / (c->h_axes[src][FVVDP_LUT_N - 1] - first);
-                        const double step = ((double)c->h_axes[src][FVVDP_LUT_N - 1] - (double)first) / (FVVDP_LUT_N - 1);
-                        a.f_frac_scale[ax] = (float)(step / (step + 1e-6));
-                        a.f_grid_off[ax] = -first * a.f_inv_step[ax];
-                    }
-                    if (getenv("FVVDP_DEBUG_VARIANT")) fprintf(stderr, "fvvdp: levels %d+%d: band2_fov_kernel<%d>, %d waves, %zu bytes of LDS per workgroup\n", b, b + 1, c->P, nblk * n, c->fov2_lds);
-                    const dim3 gridf((nblk * n + FOV2_WPB - 1) / FOV2_WPB), blockf(64 * FOV2_WPB);
-                    if (c->P == 4) hipLaunchKernelGGL((band2_fov_kernel<4>), gridf, blockf, c->fov2_lds, st, a);
-                    else hipLaunchKernelGGL((band2_fov_kernel<2>), gridf, blockf, c->fov2_lds, st, a);
-                } else {
                 const bool inrange = clamps_never_bind(c, b, 2);
                 // Waves per workgroup: 4 adjacent strips walked in step (one barrier per stage).  Free-running single waves drift
                 // apart over a long launch (items started in the first round of a 4K x 60 launch, all in step, take 316 us, later
@@ -1484,9 +1262,9 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
                 // 8K, 0 ... -3 % at 2560x1440; slower where the strips do not fill whole groups (a workgroup holds its four wave
                 // slots) and below 2560 columns (short launches stay in step by themselves).  Same work items, same partial sums.
                 int wpb = (a.w >= 2560 && a.n_strips % BAND2_WPB_MAX == 0) ? BAND2_WPB_MAX : 1;
-                if (const char* ov = getenv("FVVDP_BAND2_WPB")) { const int v = atoi(ov); if (v >= 1 && v <= BAND2_WPB_MAX && a.n_strips % v == 0) wpb = v; }
+                { const int v = c->env.band2_wpb; if (v >= 1 && v <= BAND2_WPB_MAX && a.n_strips % v == 0) wpb = v; }      // FVVDP_BAND2_WPB
                 const dim3 grid2((unsigned int)((a.n_strips / wpb) * a.n_chunks * n)), block2(64 * wpb);
-                if (getenv("FVVDP_DEBUG_VARIANT"))       // tests: which variant was launched
+                if (c->env.debug_variant)                // tests: which variant was launched
                     fprintf(stderr, "fvvdp: levels %d+%d: band2_kernel<%d, %s>, luminance range %s [%g, %g], widest plane range %g, %d waves per workgroup\n",
                                  b, b + 1, c->P, inrange ? "true" : "false", c->lum_state == 1 ? "known" : "unknown", c->lum_lo, c->lum_hi, c->lum_width, wpb);
                 if (c->P == 4) {
@@ -1495,7 +1273,6 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
                 } else {
                     if (inrange) hipLaunchKernelGGL((band2_kernel<2, true>), grid2, block2, 0, st, a);
                     else hipLaunchKernelGGL((band2_kernel<2, false>), grid2, block2, 0, st, a);
-                }
                 }
             }
             for (int bb = b; bb <= b + 1; ++bb) {
@@ -1515,7 +1292,7 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
         a.wc = c->lw[b + 1];
         a.hc = c->lh[b + 1];
         a.n_strips = band_strips(a.wc);
-        chunking(a.hc, a.n_strips, n, c->wave_capacity, a.n_chunks, a.cr);
+        chunking(a.hc, a.n_strips, n, c->wave_capacity, c->env.band_cr, a.n_chunks, a.cr);
         a.band_mul = (b == 0) ? 1.0f : 2.0f;                 // lpyr.get_band, fvvdp_lpyr_dec.py:57-63
         a.csf = c->csf + (size_t)b * FVVDP_LUT_N;
         a.csf_y = c->csf_y;
@@ -1576,7 +1353,7 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
             }
             a.frame_w = c->W;
             a.frame_h = c->H;
-            a.rmap = (geom && !getenv("FVVDP_FOV_NO_RHOMAP")) ? c->rmap[b] : nullptr;
+            a.rmap = (geom && !c->env.fov_no_rhomap) ? c->rmap[b] : nullptr;
             a.rmap_w = (c->lw[b] + 1) / 2;
         }
         const int nblk = a.n_strips * a.n_chunks;
@@ -1615,7 +1392,6 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
         fill_pool_args(pa, d_Q, c->n_bands, 2, q_stride, q_stride, pool, d_jod);
         hipLaunchKernelGGL(pool_jod_kernel, dim3(1), dim3(256), 0, st, pa);
     }
-    if (slot0 == 0) selection_end(c, st);
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;
 }
@@ -1625,17 +1401,141 @@ extern "C" int fvvdp_bands_forward(fvvdp_ctx* c, int n, float* d_Q, int q_stride
     return bands_forward_core(c, 0, n, d_Q, q_stride, q_col0, h_fixation, geom, maps, nullptr, nullptr, stream);
 }
 
-extern "C" int fvvdp_bands_forward_at(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
-                                      const fvvdp_geom* geom, const fvvdp_band_maps* maps, const fvvdp_pool_params* pool,
-                                      float* d_jod, void* stream) {
-    return bands_forward_core(c, slot0, n, d_Q, q_stride, q_col0, h_fixation, geom, maps, pool, d_jod, stream);
-}
-
 extern "C" int fvvdp_bands_forward_pool(fvvdp_ctx* c, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
                                         const fvvdp_geom* geom, const fvvdp_band_maps* maps, const fvvdp_pool_params* pool,
                                         float* d_jod, void* stream) {
     if (!pool) return fail(FVVDP_EINVAL, "null argument");
     return bands_forward_core(c, 0, n, d_Q, q_stride, q_col0, h_fixation, geom, maps, pool, d_jod, stream);
+}
+
+// ---- choice of the level-0 buffer, at context creation ---------------------------------------------------------------------------
+// Where the 8 GB of a 4K x 60 level 0 lie physically decides how fast they can be WRITTEN: the temporal kernel runs at 31-33 or at
+// 36-38 us per 4K frame on the same clip, stable for the life of an allocation, and a kernel that only replays its store stream
+// (four 1 KiB runs per wave and frame, nothing read) shows the same two speeds on the same buffers (19 / 24.5 us); on the slow ones
+// the L2's write requests wait 6-20 times longer for DRAM credits (TCC_EA0_WRREQ_DRAM_CREDIT_STALL, TCC_TAG_STALL) --
+// profiles/r05_k1_mode.md, tools/microbench/k1_stream.hip.  Which allocations are slow differs by box (hipMalloc ranges mostly
+// slow and 32 MB-chunk mappings mostly fast on most boxes, the reverse on some), and the pyramid pass that READS the buffer tends
+// the other way by ~1 us.  Nothing in the kernels' control changes it, so the context draws: it times the temporal kernel + the
+// pyramid pass on N candidate buffers (default 4, alternating chunk-mapped / hipMalloc; FVVDP_PLACEMENT_PROBE=n, 0 = off) filled
+// from a synthetic uint8 clip and keeps the fastest.  All of it happens here, before the first user call: per-frame calls never
+// allocate, free or synchronise for it.  Results never depend on the buffer.  Video contexts whose level 0 holds >= 1 GiB only.
+static void choose_level0(fvvdp_ctx* c) {
+    c->sel_phase = 9;
+    const int HW = c->W * c->H;
+    const size_t floats = (size_t)c->max_frames * HW * c->P;
+    const size_t bytes = floats * sizeof(float);
+    int n_cand = c->env.probe_n < 0 ? 4 : c->env.probe_n;
+    if (n_cand > 8) n_cand = 8;
+    if (n_cand < 2 || c->P != 4 || bytes < ((size_t)1 << 30) || c->max_frames < 16 || (HW % 4) != 0) return;
+    const int SRC_FRAMES = 16, FL = 8, n = c->max_frames < 128 ? c->max_frames : 128;
+    const size_t src_bytes = (size_t)SRC_FRAMES * 3 * HW;
+    unsigned char* src[2] = {nullptr, nullptr};
+    float* d_lut = nullptr;
+    float* d_q = nullptr;
+    int32_t* d_oob = nullptr;
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    const bool timing = c->timing, inrange_off = c->env.inrange_off;
+    auto cleanup = [&]() {
+        (void)hipDeviceSynchronize();
+        for (auto& p : src) if (p) (void)hipFree(p);
+        if (d_lut) (void)hipFree(d_lut);
+        if (d_q) (void)hipFree(d_q);
+        if (d_oob) (void)hipFree(d_oob);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        if (st) (void)hipStreamDestroy(st);
+        (void)hipGetLastError();
+        c->timing = timing;
+        c->env.inrange_off = inrange_off;
+        c->csf_set = false;                                   // the caller's tables come with fvvdp_ctx_set_csf_1d / _3d
+        c->lum_state = 0; c->lum_known = false; c->lum_top = 0;
+    };
+    {   // room for one more candidate next to the one in use, the synthetic clip and a margin
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + 2 * src_bytes + ((size_t)2 << 30)) { (void)hipGetLastError(); return; }
+    }
+    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&ev[0]) == hipSuccess &&
+              hipEventCreate(&ev[1]) == hipSuccess && hipMalloc((void**)&src[0], src_bytes) == hipSuccess &&
+              hipMalloc((void**)&src[1], src_bytes) == hipSuccess && hipMalloc((void**)&d_lut, 256 * sizeof(float)) == hipSuccess &&
+              hipMalloc((void**)&d_q, (size_t)c->n_bands * 2 * n * sizeof(float)) == hipSuccess && hipMalloc((void**)&d_oob, 64) == hipSuccess;
+    if (!ok) { cleanup(); return; }
+    float h_lut[256];
+    for (int i = 0; i < 256; ++i) h_lut[i] = 0.6f + 199.4f * powf((float)i / 255.0f, 2.2f);          // an sRGB-like display, 0.6 ... 200 cd/m^2
+    ok = hipMemcpy(d_lut, h_lut, sizeof(h_lut), hipMemcpyHostToDevice) == hipSuccess && hipMemsetAsync(d_oob, 0, 64, st) == hipSuccess &&
+         hipMemsetAsync(c->csf, 0, (size_t)c->n_bands * FVVDP_LUT_N * sizeof(float4), st) == hipSuccess;   // a flat sensitivity table
+    for (int s = 0; s < 2 && ok; ++s)
+        hipLaunchKernelGGL(hash_fill_kernel, dim3(4096), dim3(256), 0, st, reinterpret_cast<unsigned int*>(src[s]), src_bytes / 4, 0x9E3779B9u * (unsigned int)(s + 1));
+    if (!ok) { cleanup(); return; }
+    c->timing = false;
+    c->env.inrange_off = true;                                // the variant with clamps: defined for any table and any data
+    c->y_first = -10.0f; c->y_inv_step = 1.0f; c->y_lo = exp2f(-10.0f); c->y_hi = exp2f(21.0f);
+    c->csf_set = true;
+    fvvdp_eotf e;
+    memset(&e, 0, sizeof(e));
+    e.kind = FVVDP_EOTF_LUT;
+    e.d_lut = d_lut;
+    e.L_min = h_lut[0];
+    e.L_max = h_lut[255];
+    const float rgb2y[3] = {0.2126f, 0.7152f, 0.0722f};
+    float taps[2 * 8];
+    for (int k = 0; k < FL; ++k) { taps[k] = 0.25f / (float)(1 + k); taps[FL + k] = (k & 1) ? -0.1f : 0.1f; }
+    std::vector<int32_t> idx(FL - 1 + n);
+    for (size_t u = 0; u < idx.size(); ++u) idx[u] = (int32_t)(u % SRC_FRAMES);
+    auto one_pass = [&]() -> bool {
+        return temporal_channels_core(c, src[0], src[1], FVVDP_U8, 3, (size_t)HW, (size_t)3 * HW, &e, rgb2y, idx.data(), nullptr, taps, FL, n, 0,
+                                      d_oob, st) == FVVDP_OK &&
+               bands_forward_core(c, 0, n, d_q, n, 0, nullptr, nullptr, nullptr, nullptr, nullptr, st) == FVVDP_OK;
+    };
+    auto time_current = [&](float& us) -> bool {
+        if (!one_pass()) return false;                        // first touch of a fresh buffer, untimed
+        us = 0.0f;
+        for (int rep = 0; rep < 2; ++rep) {
+            if (hipEventRecord(ev[0], st) != hipSuccess || !one_pass() || hipEventRecord(ev[1], st) != hipSuccess ||
+                hipEventSynchronize(ev[1]) != hipSuccess) return false;
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess || !(ms > 0.0f)) return false;
+            const float t = ms * 1e3f / (float)n;
+            us = (rep == 0 || t < us) ? t : us;
+        }
+        return true;
+    };
+    auto release = [&](float* p) {
+        (void)hipDeviceSynchronize();                         // nothing reads it any more (once per freed candidate, at creation)
+        if (vmm_owns(c, p)) vmm_free_one(c, p); else (void)hipFree(p);
+    };
+    float best = 0.0f;
+    if (!time_current(best)) { cleanup(); return; }
+    c->sel_us[0] = best;
+    c->sel_n = 1;
+    c->sel_kept = 0;
+    const bool first_vmm = vmm_owns(c, c->level[0]);
+    for (int k = 1; k < n_cand; ++k) {
+        // the kinds alternate (FVVDP_ALLOC=malloc: hipMalloc only)
+        const bool want_vmm = !c->env.alloc_malloc && ((k & 1) ? !first_vmm : first_vmm);
+        void* q = nullptr;
+        const bool got = want_vmm ? vmm_alloc(c, &q, bytes) == FVVDP_OK : hipMalloc(&q, bytes) == hipSuccess;
+        if (!got) { (void)hipGetLastError(); break; }
+        float* incumbent = c->level[0];
+        c->level[0] = reinterpret_cast<float*>(q);
+        float us = 0.0f;
+        const bool timed = time_current(us);
+        if (timed) { c->sel_us[k] = us; c->sel_n = k + 1; }
+        if (timed && us < best) {
+            best = us;
+            c->sel_kept = k;
+            release(incumbent);
+        } else {
+            c->level[0] = incumbent;
+            release(reinterpret_cast<float*>(q));
+            if (!timed) break;
+        }
+    }
+    if (c->env.debug_variant) {
+        fprintf(stderr, "fvvdp: level-0 candidates (temporal + pyramid, us per frame):");
+        for (int k = 0; k < c->sel_n; ++k) fprintf(stderr, " %.2f", c->sel_us[k]);
+        fprintf(stderr, " -> kept #%d (%s)\n", c->sel_kept, vmm_owns(c, c->level[0]) ? "chunk-mapped" : "hipMalloc");
+    }
+    cleanup();
 }
 
 extern "C" int fvvdp_ctx_set_view_maps(fvvdp_ctx* c, int band, const float* d_view_x, const float* d_view_y,
@@ -1726,6 +1626,7 @@ extern "C" int fvvdp_heatmap_colorize(fvvdp_ctx* c, int n, const float* d_dmap, 
         float* l = reinterpret_cast<float*>(c->colour_ws + (size_t)c->max_frames * per_frame);
         HIP_TRY(hipMemcpyAsync(l, h_lin01, COLOUR_BINS * sizeof(float), hipMemcpyHostToDevice, st));
         HIP_TRY(hipStreamSynchronize(st));
+        c->n_sync += 1;
     }
     range = c->colour_ws;                                            // [2][max_frames]: min positive, max
     unsigned int* hist = range + 2 * (size_t)c->max_frames;
@@ -1798,13 +1699,22 @@ extern "C" int fvvdp_ctx_timing_read(fvvdp_ctx* c, float* h_ms, int32_t* h_count
 }
 
 
-extern "C" int fvvdp_ctx_alloc_info(const fvvdp_ctx* c, int* state, int* chunk_mapped, float* h_us2, int* kept) {
-    if (!c || !state || !chunk_mapped || !h_us2 || !kept) return fail(FVVDP_EINVAL, "null argument");
+extern "C" int fvvdp_ctx_alloc_info(const fvvdp_ctx* c, int* state, int* chunk_mapped, float* h_us, int capacity, int* n_timed,
+                                    int* kept) {
+    if (!c || !state || !chunk_mapped || !h_us || !n_timed || !kept || capacity < 1) return fail(FVVDP_EINVAL, "null argument");
     *state = c->sel_phase;
     *chunk_mapped = vmm_owns(c, c->level[0]) ? 1 : 0;
-    h_us2[0] = c->sel_us[0];
-    h_us2[1] = c->sel_us[1];
+    for (int k = 0; k < capacity; ++k) h_us[k] = k < c->sel_n ? c->sel_us[k] : 0.0f;
+    *n_timed = c->sel_n;
     *kept = c->sel_kept;
+    return FVVDP_OK;
+}
+
+extern "C" int fvvdp_ctx_call_stats(const fvvdp_ctx* c, int64_t* h_counts3) {
+    if (!c || !h_counts3) return fail(FVVDP_EINVAL, "null argument");
+    h_counts3[0] = c->n_sync;
+    h_counts3[1] = c->n_alloc;
+    h_counts3[2] = c->n_free;
     return FVVDP_OK;
 }
 

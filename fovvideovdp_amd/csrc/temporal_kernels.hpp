@@ -545,7 +545,7 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
     const karg_p ka = (karg_p)__builtin_amdgcn_kernarg_segment_ptr();
     const karg_int_p idx0 = (karg_int_p)(ka + offsetof(TemporalArgs, idx));
     const karg_int_p idx1 = (karg_int_p)(ka + offsetof(TemporalArgs, idx1));
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;              // (workgroups of several waves: each wave walks its own pixel block)
     const int p0 = block * (64 * PX);               // first pixel of this wave
     const int pl = min(p0 + lane * PX, a.HW - PX);  // this lane's PX consecutive pixels (clamped: loads stay in range)
     const float w[3] = {CC == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};
@@ -727,10 +727,11 @@ void temporal_vec_kernel(const TemporalArgs a_byval) {
     if constexpr (SRC == SRC_U8) build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 64);
     __syncthreads();
     // colour-channel count and display model as compile-time constants of the loop body (see temporal_vec_body)
-    if constexpr (SRC == SRC_U8 && FL <= 16) {
-        // uint8 at <= 64 fps (the BASELINE configs): with a ticket counter the grid is the resident capacity and a workgroup that
-        // has finished a block of pixels takes the next one -- the XCDs of a box run this memory-bound kernel 5-8 % apart, and the
-        // hardware hands each of them exactly an eighth of the workgroups (profiles/r04_lockstep.md, section 5)
+    if constexpr (SRC == SRC_U8 && FL == 16) {
+        // uint8 at 33-64 fps: with a ticket counter the grid is the resident capacity and a workgroup that has finished a block of
+        // pixels takes the next one -- the XCDs of a box run this memory-bound kernel 5-8 % apart, and the hardware hands each of
+        // them exactly an eighth of the workgroups (profiles/r04_lockstep.md, section 5: -2 ... -6 % with the 16-slot ring; no gain
+        // with the 8-slot ring, which takes the plain path below)
         typedef const char __attribute__((address_space(4)))* karg_p;
         int block = (int)blockIdx.x;
         const int n_blocks = (a.HW + 64 * PX - 1) / (64 * PX);

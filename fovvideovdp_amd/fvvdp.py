@@ -11,7 +11,6 @@ import ctypes as C
 import json
 import logging
 import math
-import os
 
 import numpy as np
 import torch
@@ -121,18 +120,6 @@ class fvvdp:
             device = torch.device('cuda:0') if (torch.cuda.is_available() and torch.cuda.device_count() > 0) else torch.device('cpu')
         self.device = self._indexed(torch.device(device))
         self.batch_frames = batch_frames
-        # Stage overlap (extension, OFF by default): with `pipeline` = k >= 2 a clip is cut into k batches whose temporal kernel
-        # runs on one internal stream while the pyramid pass of the previous batch runs on another, the two halves of the level-0
-        # scratch alternating between them.  0 = the strictly sequential order of the reference's frame loop
-        # (pyfvvdp/fvvdp.py:248-311) on the caller's stream.  Built for VERDICT r3 item 1 and measured on MI355X
-        # (profiles/r04_stage_overlap.md): both stages are bound by the same HBM, the two kernels side by side take as long as
-        # one after the other (4K x 60: 4.30-4.34 against 4.12-4.38 ms per pair in a queue of 8 pairs, 4.50-4.68 against
-        # 4.25-4.28 ms for a single pair in two halves), so the sequential order stays the default.  Results are identical up
-        # to the grouping of the fp32 partial sums (the batch size decides the work split of the pooling), <= 3e-6 relative.
-        self.pipeline = int(os.environ.get("FVVDP_PIPELINE", "0"))
-        self._pipe = None
-        self._defer_wait = False
-        self._pending = None
         self._ctx = None
         self._lut_dev = code_value_tables()
         self._chan_w = {}
@@ -162,7 +149,6 @@ class fvvdp:
         self._lut_dev.clear()
         self._chan_w = {}
         self._copy_stream = None
-        self._pipe = None
 
     def _drop_context(self):
         """Everything baked into the native context at creation (band frequencies, CSF tables, model constants,
@@ -217,7 +203,9 @@ class fvvdp:
         and Q_JOD is None (the caller pools after combining shards).
         `sync=False` queues the whole call on the current stream and returns without waiting for the GPU:
         `stats['Q_per_ch']` is then a DEVICE tensor [bands, 2, frames] (not numpy) and the out-of-range flag is left in
-        `stats['range_flag']` (int32 device tensor; `fvvdp.finish(stats)` converts both and emits the warning).  Many
+        `stats['range_flag']` (int32 device tensor; `fvvdp.finish(stats)` converts both and emits the warning);
+        `stats['result_buffer']` is the flat device buffer behind them (Q_per_ch | flag | JOD), the row a multi-GPU caller
+        all-reduces.  Many
         pairs can be queued back to back this way (one per call); the context's scratch is reused in stream order.
         """
         if self.device.type != "cuda":
@@ -231,23 +219,12 @@ class fvvdp:
             return self._predict_on_device(vid_source, fixation_point, frame_range, pool, sync)
 
     def predict_batch(self, pairs, dim_order="BCFHW", frames_per_second=0, fixation_point=None):
-        """Extension (BASELINE configs[4]: many independent pairs per GPU): queues every (test, reference) pair of `pairs`
-        without host synchronisation and without making the caller's stream wait between pairs, so that with the stage overlap
-        (`pipeline` >= 2) the temporal kernel of pair p+1 runs against the pyramid pass of pair p.  The caller's stream joins
-        once, after the last pair.  Returns [(Q_JOD, stats)] as `predict(..., sync=False)` does: `stats['Q_per_ch']` are device
-        tensors, `fvvdp.finish(stats)` brings one to the host."""
-        out = []
-        self._defer_wait, self._pending = True, None
-        try:
-            for (t, r) in pairs:
-                out.append(self.predict(t, r, dim_order=dim_order, frames_per_second=frames_per_second,
-                                        fixation_point=fixation_point, sync=False))
-        finally:
-            self._defer_wait = False
-            if self._pending is not None:
-                torch.cuda.current_stream(self.device).wait_event(self._pending)
-                self._pending = None
-        return out
+        """Extension (BASELINE configs[4]: many independent pairs per GPU): queues every (test, reference) pair of `pairs` on the
+        caller's stream without host synchronisation (the context's scratch is reused in stream order).  Returns
+        [(Q_JOD, stats)] as `predict(..., sync=False)` does: `stats['Q_per_ch']` are device tensors, `fvvdp.finish(stats)`
+        brings one to the host."""
+        return [self.predict(t, r, dim_order=dim_order, frames_per_second=frames_per_second, fixation_point=fixation_point,
+                             sync=False) for (t, r) in pairs]
 
     @staticmethod
     def finish(stats):
@@ -255,6 +232,7 @@ class fvvdp:
         reference's out-of-range warning."""
         if isinstance(stats.get('Q_per_ch'), torch.Tensor):
             flag = stats.pop('range_flag', None)
+            stats.pop('result_buffer', None)
             q = stats['Q_per_ch']
             both = torch.cat([q.reshape(-1), flag.view(torch.float32)]).cpu() if flag is not None else q.reshape(-1).cpu()
             stats['Q_per_ch'] = both[:q.numel()].view(q.shape).numpy()
@@ -303,15 +281,6 @@ class fvvdp:
         feeder = self._make_feeder(vid_source, width, height, need)
         batch = self._batch_size(width, height, planes, n_out, fl)
         schedule = None
-        # stage overlap: sources the kernels read where they lie (arrays, raw YUV frames), plain evaluation, stock geometry
-        n_pipe = self.pipeline if (self.batch_frames is None and not self.do_heatmap and not is_image and
-                                   getattr(feeder, "takes_slot", False) and
-                                   (not self.foveated or native_geometry(self.display_geometry) is not None)) else 0
-        bank = 0
-        if n_pipe >= 2 and n_out >= 8 * n_pipe:
-            bank = min(-(-n_out // n_pipe), max(8, batch // 2))     # frames per batch = per bank of the level-0 scratch
-            batch = 2 * bank                                          # the context holds two banks
-            schedule = [min(bank, f1 - b) for b in range(f0, f1, bank)]
         if self.batch_frames is None and getattr(feeder, "preferred_batch", None):
             batch = max(1, min(batch, feeder.preferred_batch))
             if not self.do_heatmap:
@@ -337,48 +306,11 @@ class fvvdp:
         pp = nat.PoolParams(self.beta_sch, self.beta_tch, self.beta_t, self.w_transient, self.jod_a,
                             float(10.0 ** self.log_jod_exp))
         b0 = f0
-        pipe = self._pipeline_state() if bank else None
-        if pipe is not None:
-            # both internal streams start after everything the caller's stream has queued so far (uploads, the zeroed result
-            # buffer, the caller's own producers of the frames)
-            main = torch.cuda.current_stream(self.device)
-            pipe["ev_in"].record(main)
-            pipe["s1"].wait_event(pipe["ev_in"])
-            pipe["s2"].wait_event(pipe["ev_in"])
-            st1, st2 = C.c_void_p(pipe["s1"].cuda_stream), C.c_void_p(pipe["s2"].cuda_stream)
         bi = -1
         while bi + 1 < len(schedule):
             bi += 1
             nb = schedule[bi]
             idx = np.ascontiguousarray(widx[b0:b0 + fl - 1 + nb])          # history + newest frames of this batch
-            if pipe is not None:
-                k = bi & 1
-                slot0 = k * bank
-                pipe["s1"].wait_event(pipe["ev_k2"][k])       # the pass that last read this bank (also of the previous call)
-                if bi > 0:
-                    # released together with the previous batch's pass, whose first kernel is then dispatched first: the pass
-                    # keeps the wave slots it needs and the temporal kernel fills in (the other order measured 5 % slower)
-                    pipe["s1"].wait_event(pipe["ev_start"])
-                feeder(ctx, idx, taps, fl, nb, oob, st1, slot0)
-                pipe["ev_k1"][k].record(pipe["s1"])
-                pipe["s2"].wait_event(pipe["ev_k1"][k])
-                pipe["ev_start"].record(pipe["s2"])
-                fx, g = None, None
-                if self.foveated:
-                    fx = nat.fptr(np.ascontiguousarray(fix[b0:b0 + nb], dtype=np.float32))
-                    g = C.byref(self._geom_struct())
-                last = pool and b0 + nb == f1
-                nat.check(nat.lib().fvvdp_bands_forward_at(ctx.handle, slot0, nb, C.c_void_p(Q.data_ptr()), n_out, b0 - f0, fx, g, None,
-                                                           C.byref(pp) if last else None,
-                                                           C.c_void_p(res[nq + 1:].data_ptr()) if last else None, st2))
-                pipe["ev_k2"][k].record(pipe["s2"])
-                b0 += nb
-                if b0 == f1:
-                    if self._defer_wait:
-                        self._pending = pipe["ev_k2"][k]      # predict_batch joins once, after the last pair
-                    else:
-                        main.wait_event(pipe["ev_k2"][k])     # the caller's stream continues after the last pass (s2 is in order)
-                continue
             try:
                 feeder(ctx, idx, taps, fl, nb, oob, stream)
             except _SourceRecyclesBuffers:
@@ -431,6 +363,7 @@ class fvvdp:
                 raise RuntimeError("sync=False is not available together with heat-map output")
             stats['Q_per_ch'] = Q
             stats['range_flag'] = oob
+            stats['result_buffer'] = res          # [Q_per_ch (bands x 2 x frames) | range flag (int32 bits) | JOD]: one row per pair
         stats['rho_band'] = rho_band
         stats['frames_per_second'] = vid_source.get_frames_per_second()
         stats['width'] = width
@@ -443,15 +376,6 @@ class fvvdp:
         if hasattr(feeder, "release"):
             feeder.release(synced=sync)
         return (Q_jod, stats)
-
-    def _pipeline_state(self):
-        """The two internal streams of the stage overlap and the events that order them: created once per metric and device."""
-        if self._pipe is None or self._pipe["dev"] != self.device:
-            s1, s2 = torch.cuda.Stream(device=self.device), torch.cuda.Stream(device=self.device)
-            self._pipe = {"dev": self.device, "s1": s1, "s2": s2,
-                          "ev_in": torch.cuda.Event(), "ev_k1": [torch.cuda.Event(), torch.cuda.Event()],
-                          "ev_k2": [torch.cuda.Event(), torch.cuda.Event()], "ev_start": torch.cuda.Event()}
-        return self._pipe
 
     @staticmethod
     def _host_buffer(shape):
@@ -798,7 +722,6 @@ class fvvdp:
                         ctx.handle, C.c_void_p(test_d.data_ptr()), C.c_void_p(ref_d.data_ptr()), dtype, C_ch,
                         N * HW, HW, C.byref(e), nat.fptr(w), idx.ctypes.data_as(C.POINTER(C.c_int32)),
                         nat.fptr(taps), fl, n_out, slot0, C.c_void_p(oob.data_ptr()), stream))
-                feed.takes_slot = True
                 return feed
         if (isinstance(vs, fvvdp_video_source_yuv_frames) and native_eotf(vs.dm_photometry) is not None
                 and not (hasattr(vs, "_resizing") and vs._resizing())
@@ -828,7 +751,6 @@ class fvvdp:
                     ctx.handle, C.c_void_p(test_d.data_ptr()), C.c_void_p(ref_d.data_ptr()), C.byref(fmt), vs.frame_elems,
                     C.byref(e), nat.fptr(w), idx.ctypes.data_as(C.POINTER(C.c_int32)), nat.fptr(taps), fl, n_out, slot0,
                     C.c_void_p(oob.data_ptr()), stream))
-            feed_yuv.takes_slot = True
             return feed_yuv
         # generic sources (user subclasses, custom float photometry): luminance frames come from the source's own
         # get_*_frame (the user's code, run on the device); the kernels take over from the temporal filter on.

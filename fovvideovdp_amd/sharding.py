@@ -28,10 +28,13 @@ def _all_reduce_sum(buf, group=None):
 
 
 def gather_pair_results(q_local, rank, world, group=None):
-    """q_local: this rank's Q_per_ch [bands, 2, N] (or a stack [k, bands, 2, N] for k pairs per rank, equal k on all
-    ranks) -> [world(*k), bands, 2, N] on every rank through one all-reduce."""
+    """q_local: this rank's Q_per_ch [bands, 2, N] (or a stack [k, ...] of k result rows per rank -- Q_per_ch tensors or the flat
+    `stats['result_buffer']` rows of `predict(..., sync=False)` --, equal k on all ranks) -> [world * k, ...] on every rank through
+    one all-reduce."""
     if q_local.dim() == 3:
         q_local = q_local.unsqueeze(0)
+    if world == 1:
+        return q_local                         # one rank: its rows are the result (no buffer, no collective)
     k = q_local.shape[0]
     buf = torch.zeros((world * k,) + tuple(q_local.shape[1:]), dtype=q_local.dtype, device=q_local.device)
     buf[rank * k:(rank + 1) * k] = q_local

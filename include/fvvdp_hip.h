@@ -251,16 +251,6 @@ int fvvdp_bands_forward_pool(fvvdp_ctx* ctx, int n, float* d_Q, int q_stride, in
                              const fvvdp_geom* geom, const fvvdp_band_maps* maps, const fvvdp_pool_params* pool,
                              float* d_jod, void* stream);
 
-/* The same pass on the batch in level-0 frame slots [slot0, slot0 + n) (what fvvdp_temporal_channels was given as `slot0`);
- * `pool` / `d_jod` may be NULL (then as fvvdp_bands_forward).  With two halves ("banks") of the level-0 scratch the temporal
- * kernel of batch b+1 can fill one bank on one stream while this pass reads the other on a second stream -- the reference's
- * frame loop is strictly sequential (fvvdp.py:248-311, "TODO: process multiple frames at a time" :360); the only state the two
- * stages share is level 0, everything below it belongs to this pass and is reused in stream order.  The caller orders the
- * streams with events: temporal(b) -> pass(b), and pass(b) -> temporal(b+2) for the bank they share.                        */
-int fvvdp_bands_forward_at(fvvdp_ctx* ctx, int slot0, int n, float* d_Q, int q_stride, int q_col0, const float* h_fixation,
-                           const fvvdp_geom* geom, const fvvdp_band_maps* maps, const fvvdp_pool_params* pool,
-                           float* d_jod, void* stream);
-
 /* Colouring of difference maps for heatmap = "threshold" / "supra-threshold" (reference: visualize_diff_map,
  * vis_tonemap, log_luminance in pyfvvdp/visualize_diff_map.py, called at fvvdp.py:474-476): the map d_dmap[n][H][W]
  * (clamped to [0,1]) indexes a colour map (n_knots <= 8 knots h_knots, luminance-normalised colours h_rgb[n_knots][3])
@@ -286,14 +276,23 @@ int fvvdp_ctx_timing_enable(fvvdp_ctx* ctx, int on);
 int fvvdp_ctx_timing_read(fvvdp_ctx* ctx, float* h_ms, int32_t* h_count, int capacity, int reset);
 
 /* Where level 0 of the context's scratch lives and how that was decided.  The large scratch levels are mapped from physical
- * chunks (HIP virtual-memory API) by default; a video context whose level 0 holds >= 1 GiB compares that with a hipMalloc range
- * on its first eight batches of >= 16 frames (two warm-ups, two timed on the buffer in use, one untimed and two timed on the
- * other kind, then the faster is kept: the temporal kernel's speed depends on the physical placement of its destination, box by
- * box; environment FVVDP_PLACEMENT_PROBE=0 turns the comparison off).  Results never depend on it.
- *   *state: 0..7 = comparison in progress, 9 = finished or not applicable;  *chunk_mapped: 1 = level 0 is chunk-mapped now
- *   h_us2: {buffer in use, candidate} microseconds per frame (temporal kernel + pyramid pass), 0 = not measured
- *   *kept: 0 = the first buffer, 1 = the candidate, -1 = no comparison                                                   */
-int fvvdp_ctx_alloc_info(const fvvdp_ctx* ctx, int* state, int* chunk_mapped, float* h_us2, int* kept);
+ * chunks (HIP virtual-memory API) by default.  How fast a buffer of this size can be WRITTEN depends on its physical placement
+ * (the temporal kernel: 31-33 or 36-38 us per 4K frame, box by box and allocation by allocation; profiles/r05_k1_mode.md), so
+ * fvvdp_ctx_create of a video context whose level 0 holds >= 1 GiB times the temporal kernel + the pyramid pass on N candidate
+ * buffers (default 4, alternating chunk-mapped / hipMalloc, a synthetic uint8 clip as input; environment
+ * FVVDP_PLACEMENT_PROBE=n, 0 = off) and keeps the fastest: ~0.1-0.2 s at creation, one extra level 0 held while a candidate is
+ * timed, nothing in any per-frame call.  Results never depend on it.
+ *   *state: always 9 (settled) -- the comparison runs inside fvvdp_ctx_create;  *chunk_mapped: 1 = level 0 is chunk-mapped
+ *   h_us[capacity]: microseconds per frame (temporal kernel + pyramid pass) of candidates 0 .. *n_timed - 1, 0 beyond
+ *   *kept: index of the candidate in use, -1 = no comparison (small context, still image, switched off, not enough memory) */
+int fvvdp_ctx_alloc_info(const fvvdp_ctx* ctx, int* state, int* chunk_mapped, float* h_us, int capacity, int* n_timed, int* kept);
+
+/* Host synchronisations, device allocations and frees made INSIDE per-frame entry points (fvvdp_temporal_channels*,
+ * fvvdp_bands_forward*, heat-map functions) since the context was created: h_counts3 = {syncs, allocations, frees}.  The video
+ * path of the BASELINE configs makes none, from the first call on ("allocated once in ctx_create; no hidden
+ * allocation in per-frame calls").  What does count: first use of an optional path (foveated tables when the geometry
+ * changes, the luminance frames of a 33..64-tap filter, heat-map images, the colouring workspace).                      */
+int fvvdp_ctx_call_stats(const fvvdp_ctx* ctx, int64_t* h_counts3);
 
 
 /* ---- PU21-PSNR side metric ---------------------------------------------------

@@ -76,13 +76,6 @@ class Pipeline:
         nat.check(self.lib.fvvdp_export_level(self.handle, level, n, C.c_void_p(out.data_ptr()), self.stream()))
         return out
 
-    def bands_forward_at(self, slot0, n):
-        """Plain evaluation of level-0 slots [slot0, slot0 + n) (fvvdp_bands_forward_at): Q[n_bands,2,n]."""
-        Q = torch.zeros((self.n_bands, 2, n), dtype=torch.float32, device=self.dev)
-        nat.check(self.lib.fvvdp_bands_forward_at(self.handle, slot0, n, C.c_void_p(Q.data_ptr()), n, 0, None, None, None, None, None,
-                                                  self.stream()))
-        return Q
-
     def bands_forward(self, n, want_maps=False, fixation=None):
         """Returns Q[n_bands,2,n] (CUDA) and, if want_maps, a list of per-band dicts D/contrast/lbkg/S."""
         Q = torch.zeros((self.n_bands, 2, n), dtype=torch.float32, device=self.dev)

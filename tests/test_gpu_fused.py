@@ -213,84 +213,3 @@ def test_clamp_free_variant_is_taken_only_where_proven_and_changes_nothing(tmp_p
     assert v["hdr_pq"] == {False}             # black level 0.0174 cd/m^2 < 0.1: max(L_bkg, 0.1) binds, contrast can reach 1000
     assert v["user_src"] == {False}           # luminance frames from the source's own get_*_frame: range unknown to the library
     assert v["user_then"] == {False} and v["array_after_user"] == {True}     # a call that rewrites every slot starts the range afresh
-
-
-def _run_fov(monkeypatch, test, ref, fuse, gaze, band_fuse=None, disp="standard_hdr_pq", **kw):
-    import fovvideovdp_amd as fv
-    if band_fuse is None:
-        monkeypatch.delenv("FVVDP_BAND_FUSE", raising=False)
-    else:
-        monkeypatch.setenv("FVVDP_BAND_FUSE", str(band_fuse))
-    monkeypatch.delenv("FVVDP_BAND2_KR", raising=False)
-    monkeypatch.setenv("FVVDP_FOV_FUSE", str(fuse))
-    m = fv.fvvdp(display_name=disp, foveated=True)
-    q, st = m.predict(test, ref, fixation_point=gaze, **kw)
-    return float(q), st["Q_per_ch"].astype(np.float64)
-
-
-@pytest.mark.parametrize("H,W", [(64, 120), (65, 121), (66, 123), (67, 118), (135, 240), (131, 217), (270, 480), (301, 533)])
-def test_foveated_two_level_pass_equals_one_level_small_sizes(monkeypatch, H, W):
-    """band2_fov_kernel (levels 0+1 of a foveated call in one pass, both bands' LUT slices in LDS; opt-in, FVVDP_FOV_FUSE=1: it
-    measured no faster than the two one-level launches, profiles/r04_fov_two_level.md) against the one-level foveated kernels: the same per-pixel expressions, only the grouping of the pooled partial sums differs.  Forced onto
-    small frames (FVVDP_BAND_FUSE=1) so that strip seams, chunk seams and every row / column parity are exercised; moving gaze."""
-    N = 5
-    test, ref = _pair(H, W, 3 * H + W, N)
-    # gaze between pixel centres: a gaze ON a pixel centre makes that pixel's eccentricity a difference of two nearly equal view
-    # directions (~1e-6 deg of rounding noise under a square root: 1e-3 on that pixel's D, and two separately compiled kernels
-    # round it differently; measured 1.3e-3 on band-0 entries of 4e-7 when the gaze sits in a corner -- the same noise the
-    # foveated tests against the reference document)
-    gaze = np.stack([np.linspace(0.37, W - 1.37, N), np.linspace(H - 1.41, 0.41, N)], 1).astype(np.float32)
-    kw = dict(dim_order="FHW", frames_per_second=30)
-    q0, Q0 = _run_fov(monkeypatch, test, ref, 0, gaze, band_fuse=1, **kw)
-    for kr in (None, 1, 3, 7):
-        if kr is not None:
-            monkeypatch.setenv("FVVDP_BAND2_KR", str(kr))
-        import fovvideovdp_amd as fv
-        monkeypatch.setenv("FVVDP_BAND_FUSE", "1")
-        monkeypatch.setenv("FVVDP_FOV_FUSE", "1")
-        m = fv.fvvdp(display_name="standard_hdr_pq", foveated=True)
-        q1, st = m.predict(test, ref, fixation_point=gaze, **kw)
-        assert abs(float(q1) - q0) < 2e-6, (kr, float(q1), q0)
-        _close(st["Q_per_ch"].astype(np.float64), Q0, rel=1e-4)
-    monkeypatch.delenv("FVVDP_BAND2_KR", raising=False)
-
-
-def test_foveated_two_level_pass_full_hd_against_one_level_and_oracle(monkeypatch, capfd):
-    """1920x1080 (levels 0+1 take the two-level pass by default), image and video, gaze fixed / moving / off the screen (then the
-    one-level kernels run: the LUT slices of the two-level pass are cut at the eccentricities an on-screen gaze can produce)."""
-    from fovvideovdp_amd.synth import synth_video_pair, synth_gaze
-    from oracle import fvvdp_oracle as orc
-    H, W, N = 1080, 1920, 4
-    t, r = synth_video_pair(N, H, W)
-    gaze = synth_gaze(N, H, W).numpy() * 0.999 + 0.4          # between pixel centres (see the small-size test)
-    monkeypatch.setenv("FVVDP_DEBUG_VARIANT", "1")
-    kw = dict(frames_per_second=30)
-    for disp in ("standard_hdr_pq", "standard_fhd"):
-        q0, Q0 = _run_fov(monkeypatch, t, r, 0, gaze, disp=disp, **kw)
-        capfd.readouterr()
-        q1, Q1 = _run_fov(monkeypatch, t, r, 1, gaze, disp=disp, **kw)
-        assert "band2_fov_kernel<4>" in capfd.readouterr().err               # the two-level pass really ran
-        assert abs(q1 - q0) < 2e-6, (disp, q1, q0)
-        _close(Q1, Q0, rel=1e-4)
-    # still image (two planes), gaze in a corner
-    ti, ri = t[0, :, 0].permute(1, 2, 0).numpy(), r[0, :, 0].permute(1, 2, 0).numpy()
-    q0, Q0 = _run_fov(monkeypatch, ti, ri, 0, [3.3, 1070.6], dim_order="HWC")
-    capfd.readouterr()
-    q1, Q1 = _run_fov(monkeypatch, ti, ri, 1, [3.3, 1070.6], dim_order="HWC")
-    assert "band2_fov_kernel<2>" in capfd.readouterr().err
-    assert abs(q1 - q0) < 2e-6
-    _close(Q1[:, :1], Q0[:, :1], rel=1e-4)
-    # a gaze point off the screen: falls back to one level per launch, same results as FVVDP_FOV_FUSE=0
-    off = gaze.copy()
-    off[2] = [-40.0, 500.0]
-    q0, Q0 = _run_fov(monkeypatch, t, r, 0, off, **kw)
-    capfd.readouterr()
-    q1, Q1 = _run_fov(monkeypatch, t, r, 1, off, **kw)
-    assert "band2_fov_kernel" not in capfd.readouterr().err
-    assert q1 == q0 and np.array_equal(Q1, Q0)
-    # against the oracle (2 frames: the oracle takes ~10 s per foveated FHD frame)
-    oq, ost = orc.Oracle("standard_hdr_pq", foveated=True).predict(t[:, :, :2].numpy(), r[:, :, :2].numpy(), frames_per_second=30, fixation_point=gaze[:2])
-    q1, Q1 = _run_fov(monkeypatch, t[:, :, :2], r[:, :, :2], 1, gaze[:2], **kw)
-    assert abs(q1 - float(oq)) < 1e-4
-    b = ost["Q_per_ch"].astype(np.float64)
-    assert np.all(np.abs(Q1 - b) <= 3e-3 * np.abs(b) + 1e-6 * np.max(b))

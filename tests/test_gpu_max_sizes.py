@@ -83,9 +83,11 @@ def test_8k_video_properties(monkeypatch):
     assert 3.0 < float(q) < 10.0 and np.all(np.isfinite(st["Q_per_ch"]))
     r_vec = channels()
     monkeypatch.setenv("FVVDP_TEMPORAL_SCALAR", "1")
+    m._drop_context()          # the library reads its switches when a context is created
     q_sca, s_sca = m.predict(test, ref, frames_per_second=fps)
     r_sca = channels()
     monkeypatch.delenv("FVVDP_TEMPORAL_SCALAR")
+    m._drop_context()          # the library reads its switches when a context is created
     scale = torch.clamp(r_sca[:, :2].abs(), min=1e-3)
     assert float(((r_vec[:, :2] - r_sca[:, :2]).abs() / scale).max()) < 2e-6
     assert float(((r_vec[:, 2:] - r_sca[:, 2:]).abs() / scale).max()) < 2e-6
@@ -93,8 +95,11 @@ def test_8k_video_properties(monkeypatch):
     assert abs(float(q) - float(q_sca)) < 1e-5
 
     monkeypatch.setenv("FVVDP_BAND_FUSE", "0")
+
+    m._drop_context()          # the library reads its switches when a context is created
     q_one, s_one = m.predict(test, ref, frames_per_second=fps)
     monkeypatch.delenv("FVVDP_BAND_FUSE")
+    m._drop_context()          # the library reads its switches when a context is created
     assert abs(float(q) - float(q_one)) < 3e-6                              # summation order of the partial sums only
     assert np.allclose(st["Q_per_ch"], s_one["Q_per_ch"], rtol=2e-5, atol=1e-7 * float(np.max(s_one["Q_per_ch"])))
 

@@ -111,48 +111,64 @@ def test_use_checkpoints_flag_is_accepted_and_gradients_are_refused():
         m.predict(t, ref.to(torch.float32) / 255, frames_per_second=FPS)
 
 
-def _run_bench_two_ranks(backend):
-    """bench.py launched the way the driver launches it (torch.distributed.run, one process per rank); returns the JSON line."""
+def _run_bench(backend, world, extra=(), dims=(960, 540, 20, 2)):
+    """bench.py launched the way the driver launches it (torch.distributed.run, one process per rank; a plain process for one rank);
+    returns the JSON line."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    W, H, N, K = 960, 540, 20, 2
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--backend", backend,
-           "--pairs-per-gpu", str(K), "--width", str(W), "--height", str(H), "--frames", str(N), "--steps", "3", "--warmup", "1",
-           "--no-cpu-baseline", "--no-h2d", "--no-measure-traffic"]
+    W, H, N, K = dims
+    args = [os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", backend,
+            "--pairs-per-gpu", str(K), "--width", str(W), "--height", str(H), "--frames", str(N), "--steps", "3", "--warmup", "1",
+            "--no-cpu-baseline", "--no-h2d", "--no-measure-traffic"] + list(extra)
+    if world > 1:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + args
+    else:
+        cmd = [sys.executable] + args
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1")
-    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=540)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    p = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=840)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]                   # ONE JSON line, from rank 0
     return json.loads(lines[0]), (W, H, N, K)
 
 
-def _check_bench_line(out, dims, backend):
+def _check_bench_line(out, dims, backend, world=2):
     import fovvideovdp_amd as fv
     from fovvideovdp_amd.synth import synth_video_pair
     W, H, N, K = dims
-    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    assert out["n_gpus"] == world and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
     assert out["config"]["pairs_per_gpu"] == K and out["value"] > 0 and out["higher_is_better"] is True
+    assert out["config"]["shard"] == "pairs" and out["step_path"].startswith("predict_batch")     # ONE step path for every N
+    assert "not a BASELINE.json configuration" in out["config"]["workload"]                       # the label follows the arguments
     assert out["roofline"] is not None and out["roofline"]["bound"] == "hbm"
     assert out["roofline_k1"]["bound"] == "hbm" and out["roofline_k1"]["frac"] > 0
+    assert out["level0_alloc"]["per_frame_calls"] == {"host_syncs": 0, "allocations": 0, "frees": 0}
     # value is the median step (SURVEY 8(d)); the mean is carried beside it, and the two are consistent with their times
     tm = out["timing"]
-    px = 2.0 * W * H * N * K * 2
+    px = 2.0 * W * H * N * K * world
     assert abs(out["value"] - px / (out["ms_per_step"] * 1e-3) / 1e6) <= 2e-3 * out["value"]
     assert abs(tm["value_mean"] - px / (tm["ms_per_step_mean"] * 1e-3) / 1e6) <= 2e-3 * tm["value_mean"]
     assert tm["ms_per_step_min"] <= out["ms_per_step"] <= tm["ms_per_step_max"]
-    # what the communicator reports: backend, size, one entry per rank
-    cm = out["communicator"]
-    assert cm["backend"] == backend and cm["world_size"] == 2 and [r["rank"] for r in cm["ranks"]] == [0, 1]
-    assert len(set(r["pid"] for r in cm["ranks"])) == 2
-    if backend == "nccl":
-        assert cm["distinct_devices"] == 2 and cm["rccl_version"]
-    assert len(out["jod"]) == 2 * K
+    if world > 1:
+        # what the communicator reports: backend, size, one entry per rank
+        cm = out["communicator"]
+        assert cm["backend"] == backend and cm["world_size"] == world and [r["rank"] for r in cm["ranks"]] == list(range(world))
+        assert len(set(r["pid"] for r in cm["ranks"])) == world
+        if backend == "nccl":
+            assert cm["distinct_devices"] == world and cm["rccl_version"]
+        else:
+            assert cm["distinct_devices"] == min(world, torch.cuda.device_count())      # dry run: the ranks share the GPUs there are
+        assert out["predict_call_ms"] is None
+    else:
+        assert "communicator" not in out and out["predict_call_ms"] > 0
+    assert len(out["jod"]) == min(8, world * K)
     m = fv.fvvdp(display_name="standard_4k")
-    for pidx in range(2 * K):
+    for pidx in range(len(out["jod"])):
         t, r = synth_video_pair(N, H, W, device="cuda", pair=pidx)
         q, _ = m.predict(t, r, frames_per_second=30)
         assert abs(float(q) - out["jod"][pidx]) < 2e-6, (pidx, float(q), out["jod"][pidx])
@@ -160,12 +176,44 @@ def _check_bench_line(out, dims, backend):
 
 @pytest.mark.timeout(600)
 def test_bench_multi_rank_step_under_gloo():
-    """bench.py's own multi-rank step (pairs queued with sync=False -> gather_pair_results -> one pooling call), launched the
+    """bench.py's step (pairs queued with predict_batch -> all-reduce of the result rows -> one device-to-host copy), launched the
     way the driver launches it (torch.distributed.run, one process per rank), here with 2 gloo ranks sharing the GPU.  The
     JSON line must carry n_gpus 2, the communicator's own facts, median and mean timing, and the 4 JODs of the 4 pairs,
     equal to single-rank calls on the same pairs."""
-    out, dims = _run_bench_two_ranks("gloo")
+    out, dims = _run_bench("gloo", 2)
     _check_bench_line(out, dims, "gloo")
+
+
+@pytest.mark.timeout(600)
+def test_bench_one_rank_takes_the_same_step_path():
+    """N = 1 runs the SAME step path as N > 1 (predict_batch + the gather, a no-op on one rank, + one copy) -- the scaling curve
+    compares like with like -- and reports the reference-style synchronous predict() once beside it (`predict_call_ms`)."""
+    out, dims = _run_bench("nccl", 1)
+    _check_bench_line(out, dims, "nccl", world=1)
+
+
+@pytest.mark.timeout(900)
+def test_bench_eight_ranks_dry_run_under_gloo():
+    """The 8-rank launch of the round-end scaling run, dry: 8 gloo ranks sharing this box's GPU(s) at reduced size, one pair each."""
+    out, dims = _run_bench("gloo", 8, dims=(480, 270, 12, 1))
+    _check_bench_line(out, dims, "gloo", world=8)
+
+
+@pytest.mark.timeout(600)
+def test_bench_frame_sharded_under_gloo():
+    """`--shard frames`: ONE pair of --frames x N frames, every rank evaluates its own output frames (+ fl-1 frames of halo) and one
+    all-reduce of Q_per_ch completes the clip on every rank.  JOD equal to the unsharded call on the same clip."""
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair
+    W, H, N = 960, 540, 12
+    out, _ = _run_bench("gloo", 2, extra=("--shard", "frames"), dims=(W, H, N, 1))
+    assert out["config"]["shard"] == "frames" and out["step_path"].startswith("predict_frame_sharded") and out["scaling"] == "weak"
+    assert "one pair of %d frames" % (2 * N) in out["config"]["parallelism"]
+    px = 2.0 * W * H * N * 2
+    assert abs(out["value"] - px / (out["ms_per_step"] * 1e-3) / 1e6) <= 2e-3 * out["value"]
+    t, r = synth_video_pair(2 * N, H, W, device="cuda")
+    q, _ = fv.fvvdp(display_name="standard_4k").predict(t, r, frames_per_second=30)
+    assert len(out["jod"]) == 1 and abs(float(q) - out["jod"][0]) < 2e-6
 
 
 @pytest.mark.timeout(600)
@@ -173,35 +221,87 @@ def test_bench_multi_rank_step_under_gloo():
 def test_bench_multi_rank_step_under_rccl():
     """The same launch with backend nccl (= RCCL over xGMI), one GPU per rank: init with device_id, the all-reduce of the
     device buffer, the barrier before destroy_process_group.  Skipped on single-GPU boxes."""
-    out, dims = _run_bench_two_ranks("nccl")
+    out, dims = _run_bench("nccl", 2)
     _check_bench_line(out, dims, "nccl")
 
 
+def _worker8(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import fovvideovdp_amd as fv
+        from fovvideovdp_amd.sharding import predict_frame_sharded, shard_range
+        from fovvideovdp_amd.synth import synth_video_pair
+        dev = torch.device("cuda", rank % torch.cuda.device_count())
+        m = fv.fvvdp(display_name="standard_fhd", device=dev)
+        res = {}
+        for n in (5, 19):                                        # 5 frames over 8 ranks: three ranks have an empty shard
+            test, ref = synth_video_pair(n, 54, 96, device=dev)
+            vs = fv.fvvdp_video_source_array(test, ref, FPS, display_photometry=m.display_photometry)
+            jod, st = predict_frame_sharded(m, vs, rank, world)
+            res["jod%d" % n], res["Q%d" % n] = float(jod), st["Q_per_ch"]
+            res["share%d" % n] = np.asarray(shard_range(n, rank, world))
+        np.savez(os.path.join(out_dir, f"r8_{rank}.npz"), **res)
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_eight_ranks_frame_sharding_with_empty_shards(tmp_path):
+    """World 8 (the node the path is meant for) as 8 gloo ranks sharing this box's GPU(s): a 5-frame clip leaves three ranks without
+    a frame -- they still take part in both collectives and return the same result -- and a 19-frame clip gives shares of 3 and 2."""
+    import torch.multiprocessing as mp
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd.synth import synth_video_pair
+    world = 8
+    mp.spawn(_worker8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), f"r8_{k}.npz")) for k in range(world)]
+    m = fv.fvvdp(display_name="standard_fhd")
+    for n in (5, 19):
+        test, ref = synth_video_pair(n, 54, 96, device="cuda")
+        q, st = m.predict(test, ref, frames_per_second=FPS)
+        shares = [tuple(int(v) for v in res[k]["share%d" % n]) for k in range(world)]
+        assert shares[0][0] == 0 and shares[-1][1] == n and all(a[1] == b[0] for a, b in zip(shares[:-1], shares[1:]))
+        if n == 5:
+            assert sum(1 for (a, b) in shares if a == b) == 3
+        for k in range(world):
+            assert np.array_equal(res[k]["Q%d" % n], st["Q_per_ch"]), (n, k)
+            assert abs(float(res[k]["jod%d" % n]) - float(q)) < 2e-6
+
+
 def test_predict_batch_equals_single_calls():
-    """fvvdp.predict_batch (BASELINE configs[4]: many independent pairs per GPU): every pair queued without host synchronisation,
-    the caller's stream joins once.  Same numbers as one synchronous predict() per pair, in the sequential order and with the
-    stage overlap; a failing pair (shape mismatch) does not leave the metric in the deferred state."""
+    """fvvdp.predict_batch (BASELINE configs[4]: many independent pairs per GPU): every pair queued on the caller's stream without
+    host synchronisation.  Same bits as one synchronous predict() per pair; a failing pair (shape mismatch) raises and leaves the
+    metric usable; host-resident, non-contiguous and mixed-dtype pairs (their device copies are temporaries of the caller's
+    stream, reused in stream order) give the same results as resident ones."""
     import fovvideovdp_amd as fv
     from fovvideovdp_amd.synth import synth_video_pair
     pairs = [synth_video_pair(24, 135, 240, device="cuda", pair=k) for k in range(5)]
     ref = fv.fvvdp(display_name="standard_fhd")
     want = [ref.predict(t, r, frames_per_second=FPS) for (t, r) in pairs]
-    for pl in (0, 2):
-        m = fv.fvvdp(display_name="standard_fhd")
-        m.pipeline = pl
-        out = m.predict_batch(pairs, frames_per_second=FPS)
-        assert len(out) == len(pairs) and not m._defer_wait and m._pending is None
-        for (q, st), (q0, st0) in zip(out, want):
-            assert st["Q_per_ch"].is_cuda
+    m = fv.fvvdp(display_name="standard_fhd")
+    out = m.predict_batch(pairs, frames_per_second=FPS)
+    assert len(out) == len(pairs)
+    for (q, st), (q0, st0) in zip(out, want):
+        assert st["Q_per_ch"].is_cuda
+        fv.fvvdp.finish(st)
+        assert float(q) == float(q0) and np.array_equal(st["Q_per_ch"], st0["Q_per_ch"])
+    # sources the call has to copy or convert first: host arrays, a non-contiguous view, float reference against uint8 test
+    odd = [(pairs[0][0].cpu(), pairs[0][1].cpu()),
+           (torch.cat([pairs[1][0], pairs[1][0]], 4)[..., :240], pairs[1][1]),
+           (pairs[2][0], pairs[2][1].to(torch.float32) / 255)]
+    want_odd = [ref.predict(t, r, frames_per_second=FPS) for (t, r) in odd]
+    for rep in range(2):
+        got = m.predict_batch(odd, frames_per_second=FPS)
+        for (q, st), (q0, st0) in zip(got, want_odd):
             fv.fvvdp.finish(st)
-            if pl == 0:
-                assert float(q) == float(q0) and np.array_equal(st["Q_per_ch"], st0["Q_per_ch"])
-            else:
-                assert abs(float(q) - float(q0)) < 2e-6
-                assert np.allclose(st["Q_per_ch"], st0["Q_per_ch"], rtol=3e-6, atol=1e-9 * st0["Q_per_ch"].max())
-        bad = pairs[:2] + [(pairs[0][0], pairs[1][1][:, :, :5])]
-        with pytest.raises(RuntimeError):
-            m.predict_batch(bad, frames_per_second=FPS)
-        assert not m._defer_wait and m._pending is None
-        q, st = m.predict(pairs[3][0], pairs[3][1], frames_per_second=FPS)          # still usable, synchronous
-        assert abs(float(q) - float(want[3][0])) < 2e-6
+            assert float(q) == float(q0) and np.array_equal(st["Q_per_ch"], st0["Q_per_ch"])
+    bad = pairs[:2] + [(pairs[0][0], pairs[1][1][:, :, :5])]
+    with pytest.raises(RuntimeError):
+        m.predict_batch(bad, frames_per_second=FPS)
+    q, st = m.predict(pairs[3][0], pairs[3][1], frames_per_second=FPS)          # still usable, synchronous
+    assert float(q) == float(want[3][0])

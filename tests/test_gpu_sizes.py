@@ -87,9 +87,11 @@ def test_yuv_vector_kernel_equals_scalar_kernel(H, W, bd, css, fps, monkeypatch)
     q_vec, s_vec = m.predict_video_source(vs)
     r_vec = channels()
     monkeypatch.setenv("FVVDP_TEMPORAL_SCALAR", "1")
+    m._drop_context()          # the library reads its switches when a context is created
     q_sca, s_sca = m.predict_video_source(vs)
     r_sca = channels()
     monkeypatch.delenv("FVVDP_TEMPORAL_SCALAR")
+    m._drop_context()          # the library reads its switches when a context is created
     assert np.isfinite(r_vec).all() and r_sca[:, :2].min() > 0
     # per pixel: a few ulp of the sustained luminance (fused-multiply-add contraction may differ between the kernels)
     scale = np.maximum(np.abs(r_sca[:, :2]), 1e-3)
@@ -151,9 +153,11 @@ def test_full_size_temporal_vector_kernel_equals_scalar_kernel(fps, kind, monkey
     q_vec, s_vec = m.predict(test, ref, frames_per_second=fps)
     r_vec = channels()
     monkeypatch.setenv("FVVDP_TEMPORAL_SCALAR", "1")
+    m._drop_context()          # the library reads its switches when a context is created
     q_sca, s_sca = m.predict(test, ref, frames_per_second=fps)
     r_sca = channels()
     monkeypatch.delenv("FVVDP_TEMPORAL_SCALAR")
+    m._drop_context()          # the library reads its switches when a context is created
     assert bool(torch.isfinite(r_vec).all()) and float(r_sca[:, :2].min()) > 0
     scale = torch.clamp(r_sca[:, :2].abs(), min=1e-3)
     assert float(((r_vec[:, :2] - r_sca[:, :2]).abs() / scale).max()) < 2e-6      # sustained channels (test, reference)

@@ -447,12 +447,12 @@ def test_chunk_mapped_scratch_gives_the_same_results_as_hipmalloc(tmp_path):
     assert np.array_equal(res["vmm"], res["malloc"]) and np.array_equal(res["vmm"], res["vmm8"])
 
 
-def test_level0_allocation_choice_changes_no_bits_and_settles(tmp_path):
-    """A video context whose level 0 holds >= 1 GiB compares the two allocation kinds of that buffer on its first eight full-size
-    calls (fvvdp_ctx_alloc_info; two warm-ups, two timed, switched, two timed, decided) and keeps the faster.  Every call --
-    before, on the candidate, after -- returns the same bits as a process where the comparison is off; it settles in state 9 with
-    both timings recorded and one level-0 buffer freed again; calls that do not rewrite every slot in use (stage overlap, frame
-    sub-batches at slot > 0) never switch; small contexts and images never start."""
+def test_level0_choice_happens_at_creation_and_changes_no_bits(tmp_path):
+    """A video context whose level 0 holds >= 1 GiB times the temporal kernel + pyramid pass on N candidate level-0 buffers INSIDE
+    fvvdp_ctx_create (fvvdp_ctx_alloc_info: state 9 from the first call on, N timings, the index kept) and keeps the fastest; the
+    losers are freed before the first user call.  Per-frame calls never allocate, free or synchronise (fvvdp_ctx_call_stats: all
+    zero from the FIRST call on -- SURVEY 8(b) "allocated once in ctx_create").  Same bits with the comparison off, with hipMalloc
+    candidates only, with 2 or 6 candidates; small contexts and images never compare."""
     import subprocess
     import sys
     import os
@@ -464,63 +464,99 @@ def test_level0_allocation_choice_changes_no_bits_and_settles(tmp_path):
         "from fovvideovdp_amd import _native as nat\n"
         "from fovvideovdp_amd.synth import synth_video_pair\n"
         "def info(m):\n"
-        "    st, cm, kept = C.c_int(0), C.c_int(0), C.c_int(-1); us = (C.c_float * 2)()\n"
-        "    nat.check(nat.lib().fvvdp_ctx_alloc_info(m._ctx.handle, C.byref(st), C.byref(cm), us, C.byref(kept)))\n"
-        "    return st.value, cm.value, kept.value, us[0], us[1]\n"
+        "    st, cm, n, kept = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(-1); us = (C.c_float * 8)()\n"
+        "    nat.check(nat.lib().fvvdp_ctx_alloc_info(m._ctx.handle, C.byref(st), C.byref(cm), us, 8, C.byref(n), C.byref(kept)))\n"
+        "    cs = (C.c_int64 * 3)()\n"
+        "    nat.check(nat.lib().fvvdp_ctx_call_stats(m._ctx.handle, cs))\n"
+        "    return [st.value, cm.value, n.value, kept.value, cs[0], cs[1], cs[2]] + [round(us[k], 2) for k in range(8)]\n"
         "t, r = synth_video_pair(40, 1080, 1920, device='cuda')\n"
+        "torch.cuda.synchronize()\n"
+        "free0 = torch.cuda.mem_get_info()[0]\n"
         "m = fv.fvvdp(display_name='standard_fhd')\n"
         "out = []\n"
-        "free = []\n"
-        "for k in range(11):\n"
-        "    if k == 2: m.pipeline = 2\n"                                     # a call in two banks in between: must not advance
+        "for k in range(4):\n"
         "    q, st = m.predict(t, r, frames_per_second=30)\n"
-        "    m.pipeline = 0\n"
         "    out.append(np.concatenate([st['Q_per_ch'].reshape(-1), [float(q)]]))\n"
         "    print('INFO', k, *info(m))\n"
-        "    free.append(torch.cuda.mem_get_info()[0])\n"
-        "print('FREE', *free)\n"
+        "scratch = nat.lib().fvvdp_ctx_scratch_bytes(m._ctx.handle)\n"
+        "print('MEM', free0 - torch.cuda.mem_get_info()[0], scratch)\n"
         "m2 = fv.fvvdp(display_name='standard_fhd')\n"
         "t2, r2 = synth_video_pair(20, 270, 480, device='cuda')\n"
-        "for k in range(7): m2.predict(t2, r2, frames_per_second=30)\n"
+        "for k in range(3): m2.predict(t2, r2, frames_per_second=30)\n"
         "print('SMALL', *info(m2))\n"
         "np.save(sys.argv[1], np.stack(out))\n" % root)
-    res, infos = {}, {}
-    for mode, env in (("on", {}), ("off", {"FVVDP_PLACEMENT_PROBE": "0"}), ("on_malloc", {"FVVDP_ALLOC": "malloc"})):
+    res = {}
+    modes = (("default", {}, 4), ("off", {"FVVDP_PLACEMENT_PROBE": "0"}, 0), ("malloc", {"FVVDP_ALLOC": "malloc"}, 4),
+             ("two", {"FVVDP_PLACEMENT_PROBE": "2"}, 2), ("six", {"FVVDP_PLACEMENT_PROBE": "6"}, 6))
+    for mode, env, n_want in modes:
         f = str(tmp_path / ("s_%s.npy" % mode))
         p = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=400)
         assert p.returncode == 0, p.stderr[-1500:]
         res[mode] = np.load(f)
-        infos[mode] = [l.split()[1:] for l in p.stdout.splitlines() if l.startswith("INFO")]
+        infos = [l.split()[2:] for l in p.stdout.splitlines() if l.startswith("INFO")]
         small = [l.split()[1:] for l in p.stdout.splitlines() if l.startswith("SMALL")][0]
-        assert int(small[2]) == -1 and int(small[0]) in (0, 9)                  # a 130 MB level 0 never starts a comparison
-        if mode != "off":
-            free = [int(v) for v in [l for l in p.stdout.splitlines() if l.startswith("FREE")][0].split()[1:]]
-            # (k = 2 ran in two banks and did not count) states after calls 0..10: 1 2 2 3 4 5 6 7 9 9 9
-            assert [int(i[1]) for i in infos[mode]] == [1, 2, 2, 3, 4, 5, 6, 7, 9, 9, 9], infos[mode]
-            kinds = [int(i[2]) for i in infos[mode]]
-            first = 0 if mode == "on_malloc" else 1
-            assert kinds[:5] == [first] * 5 and kinds[5:8] == [1 - first] * 3, kinds      # the candidate is the other kind
-            kept = int(infos[mode][-1][3])
-            assert kept in (0, 1) and kinds[-1] == (first if kept == 0 else 1 - first)
-            assert float(infos[mode][-1][4]) > 0 and float(infos[mode][-1][5]) > 0
-            assert free[5] < free[4] - 1.2e9 and free[10] > free[7] + 1.2e9, free   # held twice for four calls, then freed
-        else:
-            assert all(int(i[1]) == 9 and int(i[3]) == -1 for i in infos[mode][1:])
+        assert int(small[0]) == 9 and int(small[2]) == 0 and int(small[3]) == -1            # a 130 MB level 0 never compares
+        assert [int(v) for v in small[4:7]] == [0, 0, 0]
+        assert len(infos) == 4
+        for i in infos:
+            state, chunk, n, kept = (int(v) for v in i[:4])
+            assert state == 9 and n == n_want, (mode, i)
+            assert [int(v) for v in i[4:7]] == [0, 0, 0], (mode, i)                      # no sync / alloc / free in per-frame calls
+            us = [float(v) for v in i[7:]]
+            if n_want:
+                assert 0 <= kept < n_want and all(u > 0 for u in us[:n_want]) and all(u == 0 for u in us[n_want:]), (mode, i)
+                assert us[kept] == min(us[:n_want]), (mode, i)
+                if mode == "malloc":
+                    assert chunk == 0
+                else:
+                    first_chunk = 1                                                       # candidates alternate chunk-mapped / hipMalloc
+                    assert chunk == (first_chunk if kept % 2 == 0 else 1 - first_chunk), (mode, i)
+            else:
+                assert kept == -1
+        assert infos[0] == infos[3]                                                       # settled at creation: nothing moves afterwards
+        used, scratch = [int(v) for v in [l for l in p.stdout.splitlines() if l.startswith("MEM")][0].split()[1:]]
+        assert used < scratch + (600 << 20), (mode, used, scratch)                       # the losing candidates and the synthetic clip are gone
     for mode in res:
-        assert all(np.array_equal(res[mode][k], res[mode][0]) for k in (0, 1, 3, 4, 5, 6, 7, 8, 9, 10)), mode
-    # (call 2 ran as two batches: equal up to the grouping of the partial sums, test_stage_overlap_equals_the_sequential_order)
-    assert np.allclose(res["on"][2], res["on"][0], rtol=1e-5)
-    assert np.array_equal(res["on"], res["off"]) and np.array_equal(res["on"], res["on_malloc"])
+        assert all(np.array_equal(res[mode][k], res[mode][0]) for k in range(4)), mode
+        assert np.array_equal(res[mode], res["default"]), mode
+
+
+def test_per_frame_calls_do_not_sync_or_allocate_optional_paths_only_on_first_use():
+    """fvvdp_ctx_call_stats over the optional paths: the foveated tables are built in the first call of a context (one sync, their
+    allocations) and never again while the geometry stays; 60 fps (16-slot ring + block counter), uint16 and float sources: nothing."""
+    import ctypes as C
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd import _native as nat
+    from fovvideovdp_amd.synth import synth_video_pair
+
+    def stats(m):
+        cs = (C.c_int64 * 3)()
+        nat.check(nat.lib().fvvdp_ctx_call_stats(m._ctx.handle, cs))
+        return [int(cs[0]), int(cs[1]), int(cs[2])]
+    t, r = synth_video_pair(12, 270, 480, device="cuda")
+    for kw, src in ((dict(frames_per_second=60), (t, r)), (dict(frames_per_second=30), ((t.to(torch.int16) * 257), (r.to(torch.int16) * 257))),
+                    (dict(frames_per_second=30), (t.float() / 255, r.float() / 255)), (dict(frames_per_second=30, dim_order="BCFHW"), (t[:, 1:2], r[:, 1:2]))):
+        m = fv.fvvdp(display_name="standard_fhd")
+        for rep in range(3):
+            m.predict(src[0], src[1], **kw)
+            assert stats(m) == [0, 0, 0], (kw, rep)
+    mf = fv.fvvdp(display_name="standard_fhd", foveated=True)
+    mf.predict(t, r, frames_per_second=30, fixation_point=[100, 60])
+    first = stats(mf)
+    assert first[0] == 1 and first[1] >= 1 and first[2] == 0, first
+    for rep in range(3):
+        mf.predict(t, r, frames_per_second=30, fixation_point=[200 + rep, 90])
+        assert stats(mf) == first
 
 
 def test_ticketed_temporal_kernel_changes_no_bits(monkeypatch):
-    """uint8 sources with 9..16 taps (and with <= 8 taps under FVVDP_K1_TICKET=1) run the temporal kernel as resident workgroups
-    that take their pixel blocks from a counter (more than two rounds of blocks only; FVVDP_K1_TICKET=0 = one workgroup per block).  Same blocks, same arithmetic: level 0 and
-    the results are bit-identical, at 30 and 60 fps, RGB and gray, for a frame whose last block is partial, and call after call
-    (the counter is zeroed before every launch)."""
+    """uint8 sources with 9..16 taps (33-64 fps) run the temporal kernel as resident workgroups that take their pixel blocks from a
+    counter (more than two rounds of blocks only; FVVDP_K1_TICKET=0 = one workgroup per block).  Same blocks, same arithmetic: the
+    results are bit-identical, RGB and gray, for a frame whose last block is partial, and call after call (the counter is zeroed
+    before every launch)."""
     import fovvideovdp_amd as fv
     from fovvideovdp_amd.synth import synth_video_pair
-    for (N, H, W, fps) in ((12, 2160, 3840, 30), (20, 2160, 3840, 60), (10, 1442, 2564, 30), (9, 1080, 1920, 30)):
+    for (N, H, W, fps) in ((20, 2160, 3840, 60), (10, 1442, 2564, 50), (9, 1080, 1920, 60)):
         t, r = synth_video_pair(N, H, W, device="cuda")
         for gray in (False, True):
             tt, rr = (t[:, :1], r[:, :1]) if gray else (t, r)
@@ -535,61 +571,3 @@ def test_ticketed_temporal_kernel_changes_no_bits(monkeypatch):
                 out[mode] = np.stack(res)
             assert np.array_equal(out["1"], out["0"]), (N, H, W, fps, gray)
             assert np.array_equal(out["1"][0], out["1"][2])
-
-
-def test_stage_overlap_equals_the_sequential_order():
-    """`pipeline` = k cuts a clip into k batches whose temporal kernel runs on one internal stream against the pyramid pass of
-    the previous batch on another (two banks of the level-0 scratch).  Against the strictly sequential order: equal up to the
-    grouping of the partial sums; against the same batches run sequentially (batch_frames): bit-identical -- the overlap itself
-    changes nothing.  Also with calls queued back to back (sync=False), a frame range, foveated mode and YUV sources."""
-    import fovvideovdp_amd as fv
-    from fovvideovdp_amd.synth import synth_video_pair, synth_gaze, synth_yuv_pair
-    H, W, N = 270, 480, 50
-    pairs = [synth_video_pair(N, H, W, device="cuda", pair=k) for k in range(4)]
-    seq = fv.fvvdp(display_name="standard_fhd")
-    seq.pipeline = 0
-    want = [seq.predict(t, r, frames_per_second=30) for (t, r) in pairs]
-    for k in (2, 3, 5):
-        m = fv.fvvdp(display_name="standard_fhd")
-        m.pipeline = k
-        bank = -(-N // k)
-        same = fv.fvvdp(display_name="standard_fhd", batch_frames=bank)         # the same batches, one after the other
-        same.pipeline = 0
-        for rep in range(2):
-            # queued without host synchronisation: the temporal kernel of pair p+1 starts while pair p's last pass runs
-            st = [m.predict(t, r, frames_per_second=30, sync=False)[1] for (t, r) in pairs]
-            qj = [m.predict(t, r, frames_per_second=30, sync=False)[0] for (t, r) in pairs]
-            for p, s in enumerate(st):
-                fv.fvvdp.finish(s)
-                a, b = s["Q_per_ch"].astype(np.float64), want[p][1]["Q_per_ch"].astype(np.float64)
-                assert np.all(np.abs(a - b) <= 3e-6 * np.abs(b) + 1e-9 * np.max(b)), (k, p)
-                assert abs(float(qj[p]) - float(want[p][0])) < 2e-6
-                qs, ss = same.predict(pairs[p][0], pairs[p][1], frames_per_second=30)
-                assert np.array_equal(s["Q_per_ch"], ss["Q_per_ch"]), (k, p)
-                assert float(qj[p]) == float(qs)
-        # frame range (frame sharding) through the overlap
-        qa, sa = m.predict_video_source(fv.fvvdp_video_source_array(pairs[1][0], pairs[1][1], 30, display_photometry=m.display_photometry),
-                                        frame_range=(7, 47), pool=False)
-        b = want[1][1]["Q_per_ch"][:, :, 7:47].astype(np.float64)
-        assert np.all(np.abs(sa["Q_per_ch"] - b) <= 3e-6 * np.abs(b) + 1e-9 * np.max(b))
-    # foveated with a moving gaze: the gaze rows follow the batches
-    gaze = synth_gaze(N, H, W).numpy()
-    f0 = fv.fvvdp(display_name="standard_hdr_pq", foveated=True)
-    f0.pipeline = 0
-    f2 = fv.fvvdp(display_name="standard_hdr_pq", foveated=True)
-    f2.pipeline = 2
-    q0, s0 = f0.predict(pairs[0][0], pairs[0][1], frames_per_second=30, fixation_point=gaze)
-    q2, s2 = f2.predict(pairs[0][0], pairs[0][1], frames_per_second=30, fixation_point=gaze)
-    assert abs(float(q0) - float(q2)) < 2e-6
-    assert np.all(np.abs(s2["Q_per_ch"] - s0["Q_per_ch"]) <= 3e-6 * np.abs(s0["Q_per_ch"]) + 1e-9 * np.max(s0["Q_per_ch"]))
-    # raw YUV frames
-    ty, ry = synth_yuv_pair(40, 180, 320, 8, "420", device="cuda")
-    res = []
-    for pl in (0, 2):
-        m = fv.fvvdp(display_name="standard_fhd")
-        m.pipeline = pl
-        vs = fv.fvvdp_video_source_yuv_frames(ty, ry, 30, 320, 180, bit_depth=8, chroma_ss="420", display_photometry=m.display_photometry)
-        res.append(m.predict_video_source(vs))
-    assert abs(float(res[0][0]) - float(res[1][0])) < 2e-6
-    a, b = res[1][1]["Q_per_ch"].astype(np.float64), res[0][1]["Q_per_ch"].astype(np.float64)
-    assert np.all(np.abs(a - b) <= 3e-6 * np.abs(b) + 1e-9 * np.max(b))

@@ -42,6 +42,20 @@ out = {"kernel": ("band2_kernel<4> levels 0+1" if fused else "band_kernel<4> lev
                           "kernel, whose level 1 never leaves the chip); strips overlap by 20 of 128 columns (halo re-reads)",
        "launches_averaged": [n1, n2], "avg_duration_us_under_pmc": [dur_f, dur_w],
        "correction": "FETCH_SIZE x2 (gfx950: 128-B requests tallied at 64 B), WRITE_SIZE x1, KiB units"}
+def temporal(db, counter):
+    """the temporal kernel's dispatches of the same pass (present when the target ran whole predict() calls: STAGE=all)"""
+    con = sqlite3.connect(db)
+    rows = con.execute("select dispatch_id, sum(value), max(duration) from counters_collection where kernel_name like '%temporal_vec_kernel%' "
+                       "and counter_name = ? group by dispatch_id", (counter,)).fetchall()
+    return (sum(r[1] for r in rows) / len(rows), sum(r[2] for r in rows) / len(rows) / 1e3, len(rows)) if rows else None
+
+
+kf, kw = temporal(sys.argv[1], "FETCH_SIZE"), temporal(sys.argv[2], "WRITE_SIZE")
+if kf and kw:
+    out["k1"] = {"kernel": "temporal_vec_kernel<8,4,u8>, 60 output frames per launch (3840x2160, 67 source frames read)",
+                 "read_bytes": 2.0 * kf[0] * 1024, "write_bytes": kw[0] * 1024, "traffic_bytes": 2.0 * kf[0] * 1024 + kw[0] * 1024,
+                 "algorithmic_bytes": (6.0 + 16.0) * px[0] * N, "history_bytes": 6.0 * px[0] * 7,
+                 "launches_averaged": [kf[2], kw[2]], "avg_duration_us_under_pmc": [kf[1], kw[1]]}
 out["traffic_over_algorithmic"] = out["traffic_bytes"] / alg
 out["traffic_over_compulsory"] = out["traffic_bytes"] / moved
 json.dump(out, open(sys.argv[3], "w"), indent=1)
