@@ -245,10 +245,13 @@ template <int P, bool DBG, int FOVM>
 __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, const int chunk, const int frame, const int lane,
                                           const float4* s_csf, const float2* s_ax) {
     constexpr bool FOV = FOVM != 0;
-    constexpr bool LUT_LDS = FOVM == 1 || FOVM == 3;
+    constexpr bool LUT_LDS = FOVM == 1 || FOVM == 3 || FOVM == 4;
     // FOVM 1: stock geometry with the frame-invariant rho map (the fast path: no code for the other cases in the loop);
+    // FOVM 4: the same where the host has PROVEN that the CSF query of every pixel lies strictly inside the table on the Y and
+    //         the eccentricity axis (fov_query_in_range, fvvdp_hip.hip): the four clamps of the two axes are dropped (same bits);
     // FOVM 3: LUT slice in LDS, user geometry maps or no rho map;  FOVM 2: LUT slice in global memory (any case, DBG)
-    constexpr bool LEAN = FOVM == 1;
+    constexpr bool LEAN = FOVM == 1 || FOVM == 4;
+    constexpr bool FIN = FOVM == 4;
     constexpr int HP = P / 2;   // (test, ref) pairs = temporal channels
     const int blk = chunk * a.n_strips + strip;
 
@@ -391,6 +394,12 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
             gy = atanf(gym / a.dist_m) * 57.29577951308232f;
         }
     }
+
+    // eccentricity^2 = (vx - gx)^2 + (vy - gy)^2: the column term is the same for every row of the work item, the row term the
+    // same for both columns of a row -- computed once each, one add per pixel is left (fvvdp.py:431-433)
+    const float dxa = vxa - gx, dxb = vxb - gx;
+    const float dxa2 = dxa * dxa, dxb2 = dxb * dxb;
+    (void)dxa2; (void)dxb2;
 
     const float lg_bm = __log2f(a.band_mul);
     const float lg_base = a.lg_gain;              // log2(S) = interp + log2(gain)      (fvvdp.py:447)
@@ -536,7 +545,7 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
         float fY, fE, fR, llb;
         v2f d[HP];
     };
-    auto fov_a = [&](const Px<P>& g, const Px<P>& e, float vx, float vy, float pre_fR, float pre_kR) -> FovQ {
+    auto fov_a = [&](const Px<P>& g, const Px<P>& e, float dx2, float dy2, float pre_fR, float pre_kR) -> FovQ {
         FovQ q;
         const float lb = fmaxf(e.h[0].y, a.lbkg_min);
         const float dcap = a.cmax * lb;
@@ -547,12 +556,24 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
             q.d[k] = v2f{fminf(g.h[k].x - e.h[k].x, dcap), fminf(g.h[k].y - e.h[k].y, dcap)};
         }
         q.llb = fast_log2(lb);
+        int bo;
+        if constexpr (FIN) {
+            // both queries strictly inside their axes (proven by the host): no clamp of the query, none of the interval index;
+            // interval = v_cvt_flr_i32_f32, fraction = v_fract_f32 of the grid position
+            const float ecc = __builtin_amdgcn_sqrtf(dx2 + dy2);
+            const float eq = __builtin_amdgcn_sqrtf(ecc);
+            const float tY = fmaf(q.llb, a.inv_step[0], a.grid_off[0]);
+            const float tE = fmaf(eq, a.inv_step[2], a.grid_off[2]);
+            q.fY = __builtin_amdgcn_fractf(tY) * a.frac_scale[0];
+            q.fE = __builtin_amdgcn_fractf(tE) * a.frac_scale[2];
+            // byte offset of the cell: rho plane + ecc * (FOV_ROW * 16) + Y * 16, integer multiply-adds
+            bo = floor_to_int(tY) * 16 + (floor_to_int(tE) * (FOV_ROW * 16) + (int)pre_kR);
+        } else {
         const float yq = __builtin_amdgcn_fmed3f(q.llb, a.ly_lo, a.ly_hi);
 #ifdef FOV_ABLATE_ECC     // timing experiment only: what the eccentricity arithmetic costs (results are wrong)
-        const float eq = vx + vy;
+        const float eq = dx2 + dy2;
 #else
-        const float dx = vx - gx, dy = vy - gy;
-        const float ecc = __builtin_amdgcn_sqrtf(dx * dx + dy * dy);
+        const float ecc = __builtin_amdgcn_sqrtf(dx2 + dy2);
         const float eq = __builtin_amdgcn_sqrtf(__builtin_amdgcn_fmed3f(ecc, a.ecc_lo, a.ecc_hi));
 #endif
         // Y and ecc axes are uniform: interval = floor of the grid position t, fraction = (t - interval) * step/(step+1e-6)
@@ -569,9 +590,10 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
         const float iE = __builtin_amdgcn_fmed3f(floorf(tE), 0.0f, (float)(FVVDP_LUT_N - 2));
         q.fE = (tE - iE) * a.frac_scale[2];
 #endif
-        q.fR = pre_fR;
         // byte offset of the cell (rho plane + ecc * 512 + Y * 16) in float: small integers are exact, one conversion
-        const int bo = (int)fmaf(iE, (float)(FOV_ROW * 16), fmaf(iY, 16.0f, pre_kR));
+        bo = (int)fmaf(iE, (float)(FOV_ROW * 16), fmaf(iY, 16.0f, pre_kR));
+        }
+        q.fR = pre_fR;
         const float4* cell = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_lut_dyn) + bo);
         constexpr int sj = 1, sk = FOV_ROW;
 #ifdef FOV_ABLATE_LDS      // timing experiment only: no LUT reads (results are wrong)
@@ -700,6 +722,8 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
             vy1 = s_vy[min(2 * c + 1, h - 1)];
         }
         if constexpr (FOV) {
+            const float dy0 = vy0 - gy, dy1 = vy1 - gy;
+            [[maybe_unused]] const float dy02 = dy0 * dy0, dy12 = dy1 * dy1;      // row terms of the squared eccentricity (stock geometry)
             float vx4[4] = {vxa, vxb, vxa, vxb}, vy4[4] = {vy0, vy0, vy1, vy1}, rm4[4] = {1.0f, 1.0f, 1.0f, 1.0f};
             if (!LEAN && a.mvx) {
 #pragma unroll
@@ -718,10 +742,10 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
             if constexpr (LUT_LDS && !DBG) {
                 if (FOV_PHASE != 0 && (LEAN || (a.rmap && !a.mvx))) {   // stock geometry: phased evaluation (see fov_a / fov_b)
 #if FOV_PHASE == 4
-                    const FovQ q0 = fov_a(W0[0], x00, vx4[0], vy4[0], ra.x, ra.y);
-                    const FovQ q1 = fov_a(W0[1], x01, vx4[1], vy4[1], ra.z, ra.w);
-                    const FovQ q2 = fov_a(W1[0], x10, vx4[2], vy4[2], rb.x, rb.y);
-                    const FovQ q3 = fov_a(W1[1], x11, vx4[3], vy4[3], rb.z, rb.w);
+                    const FovQ q0 = fov_a(W0[0], x00, dxa2, dy02, ra.x, ra.y);
+                    const FovQ q1 = fov_a(W0[1], x01, dxb2, dy02, ra.z, ra.w);
+                    const FovQ q2 = fov_a(W1[0], x10, dxa2, dy12, rb.x, rb.y);
+                    const FovQ q3 = fov_a(W1[1], x11, dxb2, dy12, rb.z, rb.w);
                     fov_b(q0, active);
                     fov_b(q1, active && col1_ok);
                     fov_b(q2, active && row1_ok);
@@ -729,15 +753,15 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
 #else               // two pixels per phase (default): half the registers in flight; the scheduler may not interleave the phases
                     __builtin_amdgcn_sched_barrier(0);
                     {
-                        const FovQ q0 = fov_a(W0[0], x00, vx4[0], vy4[0], ra.x, ra.y);
-                        const FovQ q1 = fov_a(W0[1], x01, vx4[1], vy4[1], ra.z, ra.w);
+                        const FovQ q0 = fov_a(W0[0], x00, dxa2, dy02, ra.x, ra.y);
+                        const FovQ q1 = fov_a(W0[1], x01, dxb2, dy02, ra.z, ra.w);
                         fov_b(q0, active);
                         fov_b(q1, active && col1_ok);
                     }
                     __builtin_amdgcn_sched_barrier(0);
                     {
-                        const FovQ q2 = fov_a(W1[0], x10, vx4[2], vy4[2], rb.x, rb.y);
-                        const FovQ q3 = fov_a(W1[1], x11, vx4[3], vy4[3], rb.z, rb.w);
+                        const FovQ q2 = fov_a(W1[0], x10, dxa2, dy12, rb.x, rb.y);
+                        const FovQ q3 = fov_a(W1[1], x11, dxb2, dy12, rb.z, rb.w);
                         fov_b(q2, active && row1_ok);
                         fov_b(q3, active && row1_ok && col1_ok);
                     }
@@ -789,7 +813,7 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
 template <int FOVM>
 __device__ __forceinline__ void band_load_tables(const BandArgs& a, float4* s_csf, float2* s_ax, const int tid, const int nthreads) {
     constexpr bool FOV = FOVM != 0;
-    constexpr bool LUT_LDS = FOVM == 1 || FOVM == 3;
+    constexpr bool LUT_LDS = FOVM == 1 || FOVM == 3 || FOVM == 4;
     if constexpr (!FOV) {
         if (tid < FVVDP_LUT_N) s_csf[tid] = a.csf[tid];
     } else {
@@ -821,7 +845,7 @@ __device__ __forceinline__ void band_load_tables(const BandArgs& a, float4* s_cs
 #define FOV_FRAME_FASTEST 1
 #endif
 template <int P, bool DBG, int FOVM>
-__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_MINW_LEAN : FOV_MINW) : (DBG ? 2 : 4)) void band_kernel(const BandArgs a_byval) {
+__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? ((FOVM == 1 || FOVM == 4) ? FOV_MINW_LEAN : FOV_MINW) : (DBG ? 2 : 4)) void band_kernel(const BandArgs a_byval) {
     // the argument block is read from the kernel-argument segment where it is needed (scalar loads) instead of being held in
     // scalar registers from the top of the kernel: the variants with many arguments in use (difference maps, caller-built view
     // maps) otherwise keep 13-48 of them in vector-register lanes
@@ -846,7 +870,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_M
     }
     const bool wave_has_work = !FOV || bid < a.n_items;
     int strip, chunk, frame;
-    if constexpr (FOVM == 1 && FOV_FRAME_FASTEST) {
+    if constexpr ((FOVM == 1 || FOVM == 4) && FOV_FRAME_FASTEST) {
         // frame fastest: an XCD walks all frames of a tile before the next tile, the tile's slice of the (frame-invariant)
         // rho map stays in that XCD's L2 instead of being fetched once per frame
         const int n_tiles = a.n_strips * a.n_chunks, n_frames = a.n_items / n_tiles;

@@ -1119,8 +1119,9 @@ static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
     return FVVDP_OK;
 }
 
+// fin: the foveated query provably never leaves the table (fov_query_in_range): the variant without its four axis clamps
 template <int P>
-static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, hipStream_t st) {
+static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, bool fin, hipStream_t st) {
     dim3 grid(nblocks), block(64);
     if (fov) {
         const dim3 gridf((nblocks + FOV_WPB - 1) / FOV_WPB), blockf(64 * FOV_WPB);
@@ -1128,6 +1129,7 @@ static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, hipS
         const size_t lds_vy = (size_t)a.h * sizeof(float);
         const size_t lds_lut = (size_t)FOV_PLANE * a.rw * sizeof(float4);
         if (dbg) hipLaunchKernelGGL((band_kernel<P, true, 2>), gridf, blockf, lds_vy, st, a);
+        else if (a.lut_lds && a.rmap && !a.mvx && fin) hipLaunchKernelGGL((band_kernel<P, false, 4>), gridf, blockf, lds_lut + lds_vy, st, a);
         else if (a.lut_lds && a.rmap && !a.mvx) hipLaunchKernelGGL((band_kernel<P, false, 1>), gridf, blockf, lds_lut + lds_vy, st, a);
         else if (a.lut_lds) hipLaunchKernelGGL((band_kernel<P, false, 3>), gridf, blockf, lds_lut + lds_vy, st, a);
         else hipLaunchKernelGGL((band_kernel<P, false, 2>), gridf, blockf, lds_vy, st, a);
@@ -1152,6 +1154,31 @@ static void fill_pool_args(PoolArgs& a, const float* d_Q, int n_bands, int n_cha
     a.jod_a = prm->jod_a;
     a.beta_jod = prm->beta_jod;
     a.out = d_jod;
+}
+
+// Foveated mode: may the kernels drop the clamps of the CSF query on the Y and the eccentricity axis (band_kernel<P, false, 4>)?
+// Y axis (fvvdp.py:530, interp.py:11-20): L_bkg = max(expanded reference, lbkg_min) of band b lies in [max(lum_lo, lbkg_min),
+// lum_hi] when every reduce step down to level b + 1 is a convex combination (as clamps_never_bind), and that must sit well
+// inside the table's Y range.  Eccentricity axis: with the gaze on the screen no pixel is further than twice the view angle of
+// the screen's corner from it (per axis), and that must sit well inside the table (0 ... 120 deg); the axis has to start at 0.
+static bool fov_luminance_in_range(const fvvdp_ctx* c, int b) {
+    if (!c->lum_known || c->lum_state != 1 || c->env.inrange_off) return false;
+    for (int i = 0; i < b + 1; ++i)
+        if ((c->lw[i] & 1) != (c->lh[i] & 1)) return false;
+    const float lo = fmaxf(c->lum_lo, c->prm.lbkg_min), hi = fmaxf(c->lum_hi, c->prm.lbkg_min);
+    return lo >= 2.0f * c->y_lo && hi <= 0.5f * c->y_hi;
+}
+static bool fov_gaze_in_range(const fvvdp_ctx* c, const fvvdp_geom* g, const float* h_fixation, int n) {
+    if (!g || !h_fixation || c->env.inrange_off) return false;
+    if (c->ecc_lo != 0.0f || c->h_axes[2][0] != 0.0f) return false;
+    for (int f = 0; f < n; ++f) {
+        const float x = h_fixation[2 * f], y = h_fixation[2 * f + 1];
+        if (!(x >= -0.5f && x <= (float)c->W && y >= -0.5f && y <= (float)c->H)) return false;      // (also refuses NaN)
+    }
+    const double ax = atan(0.5 * g->display_size_m[0] / g->distance_m) * 180.0 / M_PI;
+    const double ay = atan(0.5 * g->display_size_m[1] / g->distance_m) * 180.0 / M_PI;
+    const double ecc_max = 2.0 * sqrt(ax * ax + ay * ay) * 1.02 + 0.5;                    // half a degree for the gaze half a pixel off the screen
+    return ecc_max < 0.96 * (double)c->ecc_hi;
 }
 
 static int check_pool_params(const fvvdp_pool_params* prm) {
@@ -1188,6 +1215,7 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
         int rc = build_sublut(c, geom, st);
         if (rc != FVVDP_OK) return rc;
     }
+    const bool fov_geom_in_range = fov && fov_gaze_in_range(c, geom, h_fixation, n);
     FinalizeArgs fa;
     memset(&fa, 0, sizeof(fa));
     // Two pyramid levels per pass where possible (band2_kernel): plain evaluation only -- the map-writing and the
@@ -1367,8 +1395,11 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
         }
         {
             Timed tm(c, 1 + b, st);
-            if (c->P == 4) launch_band<4>(a, nblk * n, dbg, fov, st);
-            else launch_band<2>(a, nblk * n, dbg, fov, st);
+            const bool fin = fov && fov_geom_in_range && fov_luminance_in_range(c, b);
+            if (fov && c->env.debug_variant)
+                fprintf(stderr, "fvvdp: level %d: foveated band_kernel<%d>, CSF query %s\n", b, c->P, fin ? "provably inside the table (no axis clamps)" : "clamped");
+            if (c->P == 4) launch_band<4>(a, nblk * n, dbg, fov, fin, st);
+            else launch_band<2>(a, nblk * n, dbg, fov, fin, st);
         }
         fa.nblk[b] = nblk;
         fa.off[b] = c->partial_off[b];

@@ -713,8 +713,17 @@ __device__ __forceinline__ void k1_clock_record(int block, unsigned long long t0
     }
 }
 #endif
+// Waves per workgroup: the 8-slot ring runs K1_WPB8 = 4 waves per workgroup, each on its own pixel block, the four blocks adjacent
+// in memory (1 KiB of every source plane and 16 KiB of level 0 per frame and workgroup instead of 256 B / 4 KiB).  The waves share
+// the code-value table and nothing else (no barrier after the table is built); a workgroup's waves start together and stay close,
+// so the memory system sees longer contiguous runs: -1.3 ... -1.5 us per 4K frame on every destination buffer, slow or fast
+// (tools/microbench/k1_stream.hip "k1_4w" against "k1", profiles/r05_k1_mode.md; 8 waves: the same; 2 waves: half of it).
+#ifndef K1_WPB8
+#define K1_WPB8 4
+#endif
+constexpr int k1_wpb(int FL) { return FL == 8 ? K1_WPB8 : 1; }
 template <int FL, int PX, int SRC, int TD = 1>
-__global__ __launch_bounds__(64, k1_waves(FL, SRC))
+__global__ __launch_bounds__(64 * k1_wpb(FL), k1_waves(FL, SRC))
 void temporal_vec_kernel(const TemporalArgs a_byval) {
 
     // All reads of the argument block go to the kernel-argument segment itself (scalar loads).  Through the by-value
@@ -722,10 +731,17 @@ void temporal_vec_kernel(const TemporalArgs a_byval) {
     // scratch per lane and every filter tap reloaded from it.
     const TemporalArgs& a = *(const TemporalArgs*)__builtin_amdgcn_kernarg_segment_ptr();
     (void)a_byval;
+    constexpr int WPB = k1_wpb(FL);
     __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
-    __shared__ float4 s_t[64 * (PX + 1)];          // one padded row of PX float4 per lane
-    if constexpr (SRC == SRC_U8) build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 64);
+    __shared__ float4 s_t_all[WPB][64 * (PX + 1)];  // per wave: one padded row of PX float4 per lane
+    if constexpr (SRC == SRC_U8) build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 64 * WPB);
     __syncthreads();
+    const int wave = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    float4* const s_t = s_t_all[wave];
+    const int block0 = (int)blockIdx.x * WPB + wave;          // this wave's pixel block
+    if constexpr (WPB > 1) {
+        if (block0 * (64 * PX) >= a.HW) return;                // (the last workgroup of a frame whose block count is not a multiple)
+    }
     // colour-channel count and display model as compile-time constants of the loop body (see temporal_vec_body)
     if constexpr (SRC == SRC_U8 && FL == 16) {
         // uint8 at 33-64 fps: with a ticket counter the grid is the resident capacity and a workgroup that has finished a block of
@@ -733,7 +749,7 @@ void temporal_vec_kernel(const TemporalArgs a_byval) {
         // them exactly an eighth of the workgroups (profiles/r04_lockstep.md, section 5: -2 ... -6 % with the 16-slot ring; no gain
         // with the 8-slot ring, which takes the plain path below)
         typedef const char __attribute__((address_space(4)))* karg_p;
-        int block = (int)blockIdx.x;
+        int block = block0;
         const int n_blocks = (a.HW + 64 * PX - 1) / (64 * PX);
         for (;;) {
             int next = 0x7fffffff;
@@ -755,26 +771,26 @@ void temporal_vec_kernel(const TemporalArgs a_byval) {
             wave_lds_order();                        // the transposes of the next block reuse s_t
         }
     } else if constexpr (SRC == SRC_U8) {
-        temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LUT>(a, lutw, s_t);
+        temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LUT>(a, lutw, s_t, block0);
     } else if constexpr (FL == 64) {
         // 64-slot ring for 16-bit / float input (k1_ring64_ok() is the host-side list): RGB behind an sRGB or PQ display,
         // and float luminance frames (what custom video sources deliver).  Everything else above 128 fps: generic kernel.
-        if (a.C == 3 && a.e.kind == FVVDP_EOTF_SRGB) temporal_vec_body<FL, PX, SRC, TD, 3, FVVDP_EOTF_SRGB>(a, lutw, s_t);
-        else if (a.C == 3 && a.e.kind == FVVDP_EOTF_PQ) temporal_vec_body<FL, PX, SRC, TD, 3, FVVDP_EOTF_PQ>(a, lutw, s_t);
+        if (a.C == 3 && a.e.kind == FVVDP_EOTF_SRGB) temporal_vec_body<FL, PX, SRC, TD, 3, FVVDP_EOTF_SRGB>(a, lutw, s_t, block0);
+        else if (a.C == 3 && a.e.kind == FVVDP_EOTF_PQ) temporal_vec_body<FL, PX, SRC, TD, 3, FVVDP_EOTF_PQ>(a, lutw, s_t, block0);
         else if constexpr (SRC == SRC_F32) {
-            if (a.C == 1 && a.e.kind == FVVDP_EOTF_NONE) temporal_vec_body<FL, PX, SRC, TD, 1, FVVDP_EOTF_NONE>(a, lutw, s_t);
+            if (a.C == 1 && a.e.kind == FVVDP_EOTF_NONE) temporal_vec_body<FL, PX, SRC, TD, 1, FVVDP_EOTF_NONE>(a, lutw, s_t, block0);
         }
     } else {
         switch (a.e.kind) {
-            case FVVDP_EOTF_SRGB: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_SRGB>(a, lutw, s_t); break;
-            case FVVDP_EOTF_GAMMA: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_GAMMA>(a, lutw, s_t); break;
-            case FVVDP_EOTF_PQ: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_PQ>(a, lutw, s_t); break;
-            case FVVDP_EOTF_LINEAR: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LINEAR>(a, lutw, s_t); break;
-            case FVVDP_EOTF_ABSOLUTE: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_ABSOLUTE>(a, lutw, s_t); break;
+            case FVVDP_EOTF_SRGB: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_SRGB>(a, lutw, s_t, block0); break;
+            case FVVDP_EOTF_GAMMA: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_GAMMA>(a, lutw, s_t, block0); break;
+            case FVVDP_EOTF_PQ: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_PQ>(a, lutw, s_t, block0); break;
+            case FVVDP_EOTF_LINEAR: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LINEAR>(a, lutw, s_t, block0); break;
+            case FVVDP_EOTF_ABSOLUTE: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_ABSOLUTE>(a, lutw, s_t, block0); break;
             case FVVDP_EOTF_LUT:
-                if constexpr (SRC == SRC_U16) temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LUT>(a, lutw, s_t);
+                if constexpr (SRC == SRC_U16) temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_LUT>(a, lutw, s_t, block0);
                 break;                               // (a table for a float source is refused by the host side)
-            default: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_NONE>(a, lutw, s_t); break;   // luminances already
+            default: temporal_vec_cc<FL, PX, SRC, TD, FVVDP_EOTF_NONE>(a, lutw, s_t, block0); break;   // luminances already
         }
     }
 }

@@ -21,7 +21,9 @@ template <int FL>
 static void launch_vec(const TemporalArgs& a, hipStream_t st) {
     constexpr int PX = k1_px(FL, DT);
     constexpr int TD = FL == 8 ? K1_TD8 : (FL == 16 ? K1_TD16 : (FL == 32 ? K1_TD32 : 1));
-    dim3 grid((a.HW + 64 * PX - 1) / (64 * PX)), block(64);
+    constexpr int WPB = k1_wpb(FL);                       // waves per workgroup, one pixel block each
+    const int n_blocks = (a.HW + 64 * PX - 1) / (64 * PX);
+    dim3 grid((n_blocks + WPB - 1) / WPB), block(64 * WPB);
     if (a.ticket) {          // resident workgroups that take their pixel blocks from a.ticket (uint8, FL <= 16; the caller zeroed it)
         static int resident = 0;
         if (!resident) {

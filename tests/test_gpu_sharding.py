@@ -188,7 +188,7 @@ def test_bench_multi_rank_step_under_gloo():
 def test_bench_one_rank_takes_the_same_step_path():
     """N = 1 runs the SAME step path as N > 1 (predict_batch + the gather, a no-op on one rank, + one copy) -- the scaling curve
     compares like with like -- and reports the reference-style synchronous predict() once beside it (`predict_call_ms`)."""
-    out, dims = _run_bench("nccl", 1)
+    out, dims = _run_bench("nccl", 1, dims=(960, 540, 20, 1))
     _check_bench_line(out, dims, "nccl", world=1)
 
 

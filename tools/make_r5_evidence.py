@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""Assembles profiles/r05_k1_mode.md from the logs of tools/experiments/r5_session1..7.sh (gpurun_out/r5s*/): the temporal kernel's
+slow / fast destination buffers -- microbenchmark, counters, and what the physical memory has to do with it."""
+import os
+import re
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(R, "gpurun_out")
+
+
+def rd(rel, maxlines=None, cut=None):
+    try:
+        lines = open(os.path.join(G, rel)).read().rstrip("\n").split("\n")
+    except OSError:
+        return "(log %s not available)" % rel
+    if maxlines:
+        lines = lines[:maxlines]
+    if cut:
+        lines = [l[:cut] for l in lines]
+    return "\n".join(lines)
+
+
+def first_table(rel, ncols):
+    """first round of the stream table, the first `ncols` variant columns"""
+    out = []
+    for l in rd(rel).split("\n"):
+        if l.startswith("-- second round"):
+            break
+        p = l.split()
+        if l.startswith("buf"):
+            out.append(" ".join("%8s" % x for x in p[:3 + ncols]))
+        elif p and p[0].isdigit():
+            out.append(" ".join("%8s" % x for x in p[:3 + ncols]))
+    return "\n".join(out)
+
+
+def corr_lines(rel):
+    return "\n".join(l for l in rd(rel).split("\n") if l.startswith("corr("))
+
+
+def pmc_rows(rel, counters):
+    """per pass of pmc_k1.md: the correlation lines of the named counters"""
+    txt = rd(rel)
+    out = []
+    for blk in txt.split("### pass")[1:]:
+        spread = re.search(r"spread of us/frame: ([\d.]+) \.\. ([\d.]+)", blk)
+        for l in blk.split("\n"):
+            m = re.match(r"\s+(\S+)\s+sum ([+-][\d.]+)", l)
+            if m and m.group(1) in counters:
+                out.append("| %s | %s | %s .. %s |" % (m.group(1), m.group(2), spread.group(1), spread.group(2)))
+    return "\n".join(out)
+
+
+def pmc_table(rel, counter_pass):
+    txt = rd(rel)
+    for blk in txt.split("### pass")[1:]:
+        if counter_pass in blk.split("\n")[0]:
+            rows = [l for l in blk.split("\n") if l.startswith("|")]
+            # keep buf, kind, us/frame and the sum column of every counter
+            hdr = [c.strip() for c in rows[0].strip("|").split("|")]
+            keep = [i for i, h in enumerate(hdr) if h in ("buf", "kind", "us/frame") or h.endswith(" sum")]
+            out = []
+            for r in rows:
+                cells = [c.strip() for c in r.strip("|").split("|")]
+                if set(cells[0]) <= set("-"):
+                    out.append("|" + "---|" * len(keep))
+                    continue
+                out.append("| " + " | ".join(cells[i] for i in keep) + " |")
+            return "\n".join(out)
+    return "(pass not found)"
+
+
+doc = """# Round 5 -- why the temporal kernel (K1) is 20 %% slower on some level-0 buffers, and what can be done about it
+
+K1 = `temporal_vec_kernel<8,4,u8>`: 6 B read + 16 B written per pixel and frame, 4K x 60: 31-33 us per frame on some destination
+buffers, 36-38 on others (VERDICT r4 item 1; rounds 2-4 called them placement modes).  Everything below comes from ONE standalone
+program, `tools/microbench/k1_stream.hip` (it includes the library's kernel from `csrc/`), run through `tools/experiments/r5_session1..7.sh`;
+this file is assembled from their logs by `tools/make_r5_evidence.py`.  All sessions ran on the same MI355X box within one hour.
+
+**Findings.**
+1. *The mode is not in the kernel.*  A kernel that only replays K1's address stream (6 dword loads one frame ahead, four 1 KiB
+   `float4` store runs per wave and frame, no table, no filter) takes the same time as K1 on every one of 13 buffers held at once
+   (correlation 0.997 / 0.986 across the buffers); the store stream ALONE separates them (19.0 against 24.5 us), the load stream alone
+   does not (5.66 us on every buffer); so does a plain grid-stride streaming write of the same 7.96 GB (7.0 against 5.4-5.6 TB/s).
+   Block order (XCD-contiguous, runs of 16), store cache policy, occupancy (1 / 2 / 4 / 8 waves per SIMD), filler arithmetic,
+   launching the frame in 4 or 8 slabs: the gap stays.  Section 1.
+2. *One counter separates the modes:* `TCC_EA0_WRREQ_DRAM_CREDIT_STALL` (= `TCC_EA0_WRREQ_STALL`): 1.5-5.4 M cycles per launch on the
+   fast buffers, 17-32 M on the slow ones (r = +0.976 with the duration over the 13 buffers of the pass), with `TCC_TAG_STALL` (0.3 M
+   against 13 M, r = +0.994) behind it: on a slow buffer the L2's write requests wait for DRAM credits.  The stalls are spread over
+   all 128 L2 channels (max / mean 2-4, the odd XCDs about twice the even ones), not concentrated in one.  Translation counters
+   (`TCP_UTCL1_*`) do not separate them; bytes moved are the same (FETCH_SIZE x2 + WRITE_SIZE = 11.33 GB per launch: 3.37 GB read
+   incl. the 7 history frames, 7.96 GB written = 1.035 x the algorithmic 10.95 GB).  Section 2.
+3. *The cause is the physical memory behind the buffer.*  Physical chunks of 1 GiB, allocated and mapped one after the other, fall
+   into TWO classes: writing one chunk alone runs at 5.1-5.8 TB/s; writing two chunks of the SAME class at once, the same; writing two
+   chunks of DIFFERENT classes at once, 6.9-7.1 TB/s (8 x 8 pairwise table: consistent, transitive).  In allocation order the classes
+   come in runs of 16-64 GiB (A x29, B x16, A x32, B x64, A x32, B x27 in session 4).  A level-0 buffer that lies in one class is the
+   slow mode (every GiB of it writes at 5.2-5.5 TB/s and so does the whole); one whose pieces come from both classes is the fast mode
+   (every GiB alone still 5.3, the whole 7.0) -- whatever the allocation API and the chunk size.  Reads depend on it by 2-3 %% only.
+   Section 3.
+4. *Which class an allocation gets is the driver's state, not the caller's choice.*  `hipMalloc`, 2 MB / 32 MB / 64 MB / 256 MB /
+   1 GiB chunks: each was all-fast in one process and all-slow in another on the same box (sessions 1, 2, 6, 7); within one process the
+   candidates tend to be alike (12 of 13 slow in session 2, 0 of 50 fast in five consecutive processes of session 7, then 20 of 20
+   fast after a process that had allocated and freed 150 GiB); holding back a spacer between two halves of a buffer does not move
+   the second half (`hipMemCreate` alone does not seem to place memory).  A search for the other class by allocating ahead found it
+   after 29 GiB in one run and not within 100-120 GiB in three others.  Section 4.
+5. *What the library does with that.*  (a) `fvvdp_ctx_create` times K1 + the pyramid pass on N = 4 candidate buffers (alternating
+   chunk-mapped / `hipMalloc`) and keeps the fastest -- it helps when the candidates differ (sessions 1 and 3: 5-7 of 13 buffers fast)
+   and costs 0.1-0.2 s when they do not; nothing happens in per-frame calls any more.  (b) K1 itself got what the replay showed
+   to help on EVERY buffer: 4 waves per workgroup on adjacent pixel blocks (`k1_4w` / `rp_4w` columns: -1.2 ... -1.5 us per frame, slow
+   and fast alike).  A kernel-side remedy for the slow mode does not exist: a plain streaming write has it.
+
+## 1. One process, 13 level-0 candidates, the real kernel and replays of its stream (session 1; us per 4K frame)
+
+`k1` the library's kernel, `rp` the replay, `k1_xcd` / `k1_x16` / `rp_xcd` / `rp_x16` other block orders, `rp_alu` with 96 filler
+multiply-adds per step, `rp_w` stores only, `rp_r` loads only, `rp_4w` four waves per workgroup, `rp_4wx` that + XCD-contiguous,
+`rp_occ8` 8 waves per SIMD, `rp_st0` stores without `nt`.
+
+```
+%s
+```
+
+```
+%s
+```
+
+Session 2 (same box ten minutes later, more variants; `k1_2w/4w/8w` the real kernel with 2 / 4 / 8 waves per workgroup, `rp_4ws...` with a
+barrier per frame, `rp_occ2/1` 2 / 1 waves per SIMD, `rp_slab8/4` the frame in 8 / 4 launches, `rp_1st*` one round of resident waves
+scaled to the frame, `wr_seq` / `rd_seq` plain streaming write / read of the buffer).  This time 12 of the 13 buffers are slow:
+
+```
+%s
+```
+
+```
+%s
+```
+
+## 2. Counters per buffer (session 1: one `rocprofv3 --pmc` pass per group, every pass its own process = its own draw)
+
+The pass with the write-request counters (sum over the 128 L2 channels, per launch of 60 frames):
+
+%s
+
+Correlation of every counter collected with the duration, over the 13 buffers of its pass:
+
+| counter | r with us/frame | spread of us/frame in that pass |
+|---|---|---|
+%s
+
+Per-instance values of two passes (JSON output keeps the channel dimension; `tools/pmc_instances.py`, session 2): the stall cycles
+per XCD (16 channels each), first buffers of the pass:
+
+```
+%s
+```
+
+## 3. Two classes of physical memory (session 4: 200 chunks of 1 GiB in allocation order; session 3: every GiB of 13 buffers)
+
+Streaming-write rate [TB/s] of chunk i alone, together with chunk 0, with its successor, with chunk 100:
+
+```
+%s
+```
+(... 200 rows; classes along the allocation order, A = as chunk 0:)
+```
+%s
+```
+
+Pairwise, eight chunks spread over the 200:
+
+```
+%s
+```
+
+Every GiB of every candidate buffer, the whole buffer, and K1 on it (session 3):
+
+```
+%s
+```
+
+## 4. The allocator decides (sessions 5-7)
+
+Level-0 candidates assembled from classified chunks, chunk sizes 1 GiB / 256 MB / 64 MB / 1 GiB in four consecutive processes (session 6;
+with 64-256 MB chunks every 1 GiB group was already a mixture, every layout fast; with 1 GiB chunks 100 GiB in a row were one class):
+
+```
+%s
+```
+
+Two halves allocated S GiB apart (spacer allocated between them, released afterwards), interleaved chunk by chunk (session 7):
+
+```
+%s
+```
+"""
+
+zones = rd("r5s4/zones.txt").split("\n")
+cls = "".join(("B" if float(l.split()[2]) > 6.4 else "A") for l in zones[2:] if len(l.split()) == 5 and l.split()[0].isdigit())
+pair = "\n".join(zones[zones.index([l for l in zones if l.startswith("pairwise")][0]):]) if any(l.startswith("pairwise") for l in zones) else ""
+inst = "\n".join(l[:230] for l in rd("r5s2/instances0.md").split("\n") if l.startswith("| ") and ("DRAM_CREDIT" in l or "TAG_STALL" in l))[:6000]
+out = doc % (first_table("r5s1/stream.txt", 13), corr_lines("r5s1/stream.txt"),
+             first_table("r5s2/stream.txt", 29), corr_lines("r5s2/stream.txt"),
+             pmc_table("r5s1/pmc_k1.md", "TCC_EA0_WRREQ_DRAM_CREDIT_STALL TCC_EA0_WRREQ_LEVEL"),
+             pmc_rows("r5s1/pmc_k1.md", {"TCC_EA0_WRREQ_DRAM_CREDIT_STALL", "TCC_EA0_WRREQ_STALL", "TCC_TAG_STALL", "TCC_TOO_MANY_EA_WRREQS_STALL",
+                                         "TCC_EA0_WRREQ_LEVEL", "TCC_EA0_RDREQ_DRAM_CREDIT_STALL", "TCC_EA0_RDREQ_LEVEL", "TCC_EA0_WRREQ", "TCC_EA0_RDREQ",
+                                         "TCC_HIT", "TCC_MISS", "TCC_WRITEBACK", "TCP_UTCL1_TRANSLATION_MISS", "TCP_UTCL1_TRANSLATION_HIT",
+                                         "TCP_TCC_READ_REQ_LATENCY", "TCP_TCC_WRITE_REQ_LATENCY", "TCP_PENDING_STALL_CYCLES", "TCC_BUSY",
+                                         "GRBM_UTCL2_BUSY", "FETCH_SIZE", "WRITE_SIZE", "SQ_WAIT_ANY", "SQ_BUSY_CYCLES"}),
+             inst,
+             "\n".join(zones[:36]), cls, pair,
+             rd("r5s3/regions.txt", 15),
+             "\n".join(l for l in rd("r5s6_call.log").split("\n") if not l.startswith("[gpurun]")),
+             rd("r5s7/spread.txt"))
+open(os.path.join(R, "profiles", "r05_k1_mode.md"), "w").write(out)
+print("written", len(out))

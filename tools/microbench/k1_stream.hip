@@ -1,6 +1,7 @@
 // Round 5: what separates the temporal kernel's slow (37-38 us per 4K frame) from its fast (31-33 us) destination buffers?
 // One process, NB level-0 candidates of three kinds (hipMalloc, 32 MB chunks, 2 MB chunks through the virtual-memory API) held at
-// once, and on EACH of them (a) the library's real temporal_vec_kernel<8,4,u8> (included from csrc/), (b) the same kernel with an
+// once, and on EACH of them (a) the library's real temporal_vec_kernel<8,4,u8> (included from csrc/; "k1" = as the library launches it,
+// since round 5 with 4 waves per workgroup; "k1_x16" = its body with one wave per workgroup, blocks in runs of 16), (b) the same kernel with an
 // XCD-contiguous block order, (c) kernels that only replay its address stream -- 6 byte-plane dword loads one frame ahead, four
 // 1 KiB float4 store runs per frame and wave -- in several variants (block order, waves per workgroup, read-only, write-only,
 // store cache policy, filler arithmetic).  Not part of the product.
@@ -219,9 +220,9 @@ static size_t out_bytes_c(int hw) { return (size_t)NOUT * hw * 16; }
 
 int main(int argc, char** argv) {
     int n_malloc = 4, n_v32 = 4, n_v2 = 2;
-    bool pmc = false, regions = false, zones = false, balanced = false;
+    bool pmc = false, regions = false, zones = false, balanced = false, spread = false;
     std::vector<int> nums;
-    for (int i = 1; i < argc; ++i) { if (!strcmp(argv[i], "pmc")) pmc = true; else if (!strcmp(argv[i], "regions")) regions = true; else if (!strcmp(argv[i], "zones")) zones = true; else if (!strcmp(argv[i], "balanced")) balanced = true; else nums.push_back(atoi(argv[i])); }
+    for (int i = 1; i < argc; ++i) { if (!strcmp(argv[i], "pmc")) pmc = true; else if (!strcmp(argv[i], "regions")) regions = true; else if (!strcmp(argv[i], "zones")) zones = true; else if (!strcmp(argv[i], "balanced")) balanced = true; else if (!strcmp(argv[i], "spread")) spread = true; else nums.push_back(atoi(argv[i])); }
     if (nums.size() >= 3) { n_malloc = nums[0]; n_v32 = nums[1]; n_v2 = nums[2]; }
     if (zones) {
         // G physical chunks of 1 GiB in allocation order, each mapped on its own; write rate of every chunk alone, of chunk 0
@@ -263,12 +264,69 @@ int main(int argc, char** argv) {
         return 0;
     }
     const size_t src_bytes = (size_t)NSRC * 3 * HW;
+    if (spread) {
+        // Level-0 candidates whose two halves come from two allocation points S GiB apart (a spacer of S physical GiB is allocated in
+        // between and released afterwards), the halves interleaved chunk by chunk.  usage: k1_stream <chunk MB> spread
+        const size_t chunk = (size_t)(nums.size() >= 1 ? nums[0] : 32) << 20, gib = (size_t)1 << 30;
+        int dev = 0; CK(hipGetDevice(&dev));
+        hipMemAllocationProp prop; memset(&prop, 0, sizeof(prop));
+        prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
+        hipMemAccessDesc acc; memset(&acc, 0, sizeof(acc)); acc.location = prop.location; acc.flags = hipMemAccessFlagsProtReadWrite;
+        unsigned char* srcb[2];
+        for (int s2 = 0; s2 < 2; ++s2) { CK(hipMalloc((void**)&srcb[s2], src_bytes)); hipLaunchKernelGGL(fill_u8, dim3(4096), dim3(256), 0, 0, srcb[s2], src_bytes); }
+        float* d_lut2; CK(hipMalloc((void**)&d_lut2, 256 * sizeof(float)));
+        { float h[256]; for (int i = 0; i < 256; ++i) h[i] = 0.6f + 199.4f * powf(i / 255.0f, 2.2f); CK(hipMemcpy(d_lut2, h, sizeof(h), hipMemcpyHostToDevice)); }
+        int* d_oob2; CK(hipMalloc((void**)&d_oob2, 64)); CK(hipMemset(d_oob2, 0, 64));
+        const size_t n_chunks = (out_bytes_c(HW) + chunk - 1) / chunk;
+        void* va = nullptr; CK(hipMemAddressReserve(&va, n_chunks * chunk, chunk, nullptr, 0));
+        auto wall = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+        printf("chunks of %zu MB, %zu per level 0\n%-28s %8s %8s %8s %10s\n", chunk >> 20, n_chunks, "layout", "write", "rp_w", "k1", "build ms");
+        const int spacers[] = {0, 4, 8, 16, 24, 32, 48, 64, 96, 0};
+        for (int sp : spacers) {
+            const double t0 = wall();
+            std::vector<hipMemGenericAllocationHandle_t> h1, h2, hs;
+            bool okc = true;
+            auto grab = [&](std::vector<hipMemGenericAllocationHandle_t>& v, size_t n, size_t sz) {
+                for (size_t k = 0; k < n && okc; ++k) { hipMemGenericAllocationHandle_t h; okc = hipMemCreate(&h, sz, &prop, 0) == hipSuccess; if (okc) v.push_back(h); }
+            };
+            grab(h1, (n_chunks + 1) / 2, chunk);
+            grab(hs, (size_t)sp, gib);
+            grab(h2, n_chunks / 2, chunk);
+            for (auto h : hs) (void)hipMemRelease(h);
+            if (!okc) { (void)hipGetLastError(); printf("spacer %d GiB: allocation failed\n", sp); for (auto h : h1) (void)hipMemRelease(h); for (auto h : h2) (void)hipMemRelease(h); continue; }
+            for (size_t k = 0; k < n_chunks; ++k) CK(hipMemMap((char*)va + k * chunk, chunk, 0, (k & 1) ? h2[k / 2] : h1[k / 2], 0));
+            CK(hipMemSetAccess(va, n_chunks * chunk, &acc, 1));
+            const double t_build = wall() - t0;
+            const size_t n4 = (size_t)NOUT * HW;
+            auto fw = [&] { hipLaunchKernelGGL(stream_write, dim3(32768), dim3(256), 0, 0, (float4*)va, n4, 1.0f); };
+            TemporalArgs ta2; memset(&ta2, 0, sizeof(ta2));
+            ta2.src[0] = srcb[0]; ta2.src[1] = srcb[1]; ta2.chan_stride = HW; ta2.frame_stride = (size_t)3 * HW; ta2.C = 3; ta2.HW = HW;
+            ta2.e.kind = FVVDP_EOTF_LUT; ta2.e.lut = d_lut2; ta2.w[0] = 0.2126f; ta2.w[1] = 0.7152f; ta2.w[2] = 0.0722f;
+            ta2.n_out = NOUT; ta2.fl = FLEN; ta2.oob = d_oob2; ta2.out = (float*)va;
+            for (int q = 0; q < FLEN; ++q) { ta2.taps2[q][0] = 0.3f / (1 + q); ta2.taps2[q][1] = (q & 1) ? -0.1f : 0.1f; }
+            for (int u = 0; u < NSRC; ++u) ta2.idx[u] = ta2.idx1[u] = u;
+            ReplayArgs ra2; ra2.wg0 = 0; ra2.src[0] = srcb[0]; ra2.src[1] = srcb[1]; ra2.chan_stride = HW; ra2.frame_stride = (size_t)3 * HW; ra2.HW = HW; ra2.n_out = NOUT;
+            ra2.n_blocks = (HW + 255) / 256; ra2.out = (float*)va;
+            auto fk = [&] { hipLaunchKernelGGL((temporal_vec_kernel<8, 4, SRC_U8, 1>), dim3((ra2.n_blocks + k1_wpb(8) - 1) / k1_wpb(8)), dim3(64 * k1_wpb(8)), 0, 0, ta2); };
+            auto fp = [&] { hipLaunchKernelGGL((replay<0, false, true, 1, 2, 0>), dim3(ra2.n_blocks), dim3(64), 10240, 0, ra2); };
+            fw(); fk(); fp(); CK(hipDeviceSynchronize());
+            const double tw = time_us(fw, 5), tp = time_us(fp, 5), tk = time_us(fk, 5);
+            char name[64]; snprintf(name, sizeof(name), "halves %d GiB apart", sp);
+            printf("%-28s %8.2f %8.2f %8.2f %10.1f\n", name, n4 * 16.0 / tw / 1e6, tp / NOUT, tk / NOUT, t_build);
+            fflush(stdout);
+            CK(hipMemUnmap(va, n_chunks * chunk));
+            for (auto h : h1) (void)hipMemRelease(h);
+            for (auto h : h2) (void)hipMemRelease(h);
+        }
+        return 0;
+    }
     if (balanced) {
         // Level-0 candidates assembled from 32 MB physical chunks of KNOWN class (groups of 32 chunks = 1 GiB classified by the
         // pair-write rate against the first group): one class only, both classes interleaved at several granularities and ratios.
         // On each: streaming write / read rate, the store-stream replay and the real temporal kernel.
-        const size_t chunk = (size_t)32 << 20, gib = (size_t)1 << 30, n4g = gib / 16;
-        const int per = 32, max_groups = nums.size() >= 1 ? nums[0] : 120;
+        // usage: k1_stream <max groups> <chunk MB> balanced
+        const size_t chunk = (size_t)(nums.size() >= 2 ? nums[1] : 32) << 20, gib = (size_t)1 << 30, n4g = gib / 16;
+        const int per = (int)(gib / chunk), max_groups = nums.size() >= 1 ? nums[0] : 120;
         int dev = 0; CK(hipGetDevice(&dev));
         hipMemAllocationProp prop; memset(&prop, 0, sizeof(prop));
         prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
@@ -310,7 +368,7 @@ int main(int argc, char** argv) {
         }
         unmap_group((char*)probe_va);
         const double t_class = wall() - t_start;
-        printf("classified %zu groups of 1 GiB in %.1f ms (solo %.2f TB/s): ", groups.size(), t_class, solo);
+        printf("chunks of %zu MB: classified %zu groups of 1 GiB in %.1f ms (solo %.2f TB/s): ", chunk >> 20, groups.size(), t_class, solo);
         for (int c2 : cls) printf("%c", c2 ? 'B' : 'A');
         printf("\n");
         std::vector<hipMemGenericAllocationHandle_t> hA, hB;
@@ -318,8 +376,10 @@ int main(int argc, char** argv) {
         const size_t n_chunks = (out_bytes_c(HW) + chunk - 1) / chunk;
         void* va = nullptr; CK(hipMemAddressReserve(&va, n_chunks * chunk, chunk, nullptr, 0));
         struct Cfg { const char* name; int runA, runB; };      // runA chunks of class A, then runB of class B, repeating
-        const Cfg cfgs[] = {{"A only", 1, 0}, {"B only", 0, 1}, {"A/B 32 MB", 1, 1}, {"A/B 64 MB", 2, 2}, {"A/B 256 MB", 8, 8}, {"A/B 1 GiB", 32, 32},
-                            {"A/B 4 GiB", 128, 128}, {"3A/1B 32 MB", 3, 1}, {"1A/3B 32 MB", 1, 3}, {"7A/1B 32 MB", 7, 1}, {"A/B 32 MB again", 1, 1}};
+        const int u = per;                                     // chunks per GiB
+        const Cfg cfgs[] = {{"A only", 1, 0}, {"B only", 0, 1}, {"A/B 1 chunk", 1, 1}, {"A/B 2 chunks", 2, 2}, {"A/B 1 GiB", u, u}, {"A/B 2 GiB", 2 * u, 2 * u},
+                            {"A/B 4 GiB", 4 * u, 4 * u}, {"3A/1B chunks", 3, 1}, {"1A/3B chunks", 1, 3}, {"7A/1B chunks", 7, 1}, {"6 GiB A, 2 GiB B", 6 * u, 2 * u},
+                            {"A/B 1 chunk again", 1, 1}};
         printf("%-18s %10s %10s %10s %10s   (write / read TB/s of the whole 7.96 GB; store-stream replay and real temporal kernel us per 4K frame)\n", "level-0 layout", "write", "read", "rp_w", "k1");
         for (const Cfg& cf : cfgs) {
             size_t ia = 0, ib = 0, k = 0; bool okm = true;
@@ -340,7 +400,7 @@ int main(int argc, char** argv) {
             for (int u = 0; u < NSRC; ++u) ta2.idx[u] = ta2.idx1[u] = u;
             ReplayArgs ra2; ra2.wg0 = 0; ra2.src[0] = srcb[0]; ra2.src[1] = srcb[1]; ra2.chan_stride = HW; ra2.frame_stride = (size_t)3 * HW; ra2.HW = HW; ra2.n_out = NOUT;
             ra2.n_blocks = (HW + 255) / 256; ra2.out = (float*)va;
-            auto fk = [&] { hipLaunchKernelGGL((temporal_vec_kernel<8, 4, SRC_U8, 1>), dim3(ra2.n_blocks), dim3(64), 0, 0, ta2); };
+            auto fk = [&] { hipLaunchKernelGGL((temporal_vec_kernel<8, 4, SRC_U8, 1>), dim3((ra2.n_blocks + k1_wpb(8) - 1) / k1_wpb(8)), dim3(64 * k1_wpb(8)), 0, 0, ta2); };
             auto fp = [&] { hipLaunchKernelGGL((replay<0, false, true, 1, 2, 0>), dim3(ra2.n_blocks), dim3(64), 10240, 0, ra2); };
             fw(); fr(); fk(); fp(); CK(hipDeviceSynchronize());
             const double tw = time_us(fw, 5), tr = time_us(fr, 5), tp = time_us(fp, 5), tk = time_us(fk, 5);
@@ -377,7 +437,7 @@ int main(int argc, char** argv) {
     const int nb = ra.n_blocks, nb8 = (nb + 7) / 8 * 8;
     struct Variant { const char* name; std::function<void(float*)> run; };
     std::vector<Variant> vars;
-    vars.push_back({"k1", [&](float* o) { TemporalArgs a = ta; a.out = o; hipLaunchKernelGGL((temporal_vec_kernel<8, 4, SRC_U8, 1>), dim3(nb), dim3(64), 0, 0, a); }});
+    vars.push_back({"k1", [&](float* o) { TemporalArgs a = ta; a.out = o; hipLaunchKernelGGL((temporal_vec_kernel<8, 4, SRC_U8, 1>), dim3((nb + k1_wpb(8) - 1) / k1_wpb(8)), dim3(64 * k1_wpb(8)), 0, 0, a); }});
     vars.push_back({"rp", [&](float* o) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, true, 1, 2, 0>), dim3(nb), dim3(64), 10240, 0, a); }});
     if (!pmc) {
         vars.push_back({"k1_xcd", [&](float* o) { TemporalArgs a = ta; a.out = o; hipLaunchKernelGGL((k1_mapped<1>), dim3(nb8), dim3(64), 0, 0, a); }});
@@ -431,7 +491,7 @@ int main(int argc, char** argv) {
             auto fw = [&] { hipLaunchKernelGGL(stream_write, dim3(32768), dim3(256), 0, 0, (float4*)bufs[b].ptr, n4, 1.0f); };
             fw(); CK(hipDeviceSynchronize());
             printf(" | %5.2f", n4 * 16.0 / time_us(fw, 5) / 1e6);
-            auto fk = [&] { TemporalArgs a = ta; a.out = (float*)bufs[b].ptr; hipLaunchKernelGGL((temporal_vec_kernel<8, 4, SRC_U8, 1>), dim3(nb), dim3(64), 0, 0, a); };
+            auto fk = [&] { TemporalArgs a = ta; a.out = (float*)bufs[b].ptr; hipLaunchKernelGGL((temporal_vec_kernel<8, 4, SRC_U8, 1>), dim3((nb + k1_wpb(8) - 1) / k1_wpb(8)), dim3(64 * k1_wpb(8)), 0, 0, a); };
             fk(); CK(hipDeviceSynchronize());
             printf(" | %5.2f\n", time_us(fk, 5) / NOUT);
             fflush(stdout);
