@@ -42,6 +42,8 @@ struct Band2Args {
     float lg_gain, lg_k, p, q0, q1, beta, lbkg_min, cmax, lg_dmax;
     float* partialA;        // [n][n_strips*n_chunks][2]
     float* partialB;
+    int* tickets;           // nullptr: workgroup b takes item b (static split).  Else 16 zeroed counters -- [phase][XCD] -- and a grid larger
+    int n_items;            //   than the n_items work items: see band2_kernel
 };
 
 // (dpp_reduce_taps / dpp_expand_taps: band_kernel.hpp)
@@ -437,9 +439,16 @@ __device__ unsigned long long g_band2_timeline[4 * 65536];
 // Resident workgroups that take their items from per-XCD atomic queues and steal from the slowest XCD (the XCDs of one box
 // finish their eighth 5-8 % apart) were built and measured 3.5 % SLOWER than the hardware's dispatch (the loop around the item
 // costs registers: 13-18 scalar spills) -- profiles/r04_lockstep.md, section 4.
+// With `tickets` (round 5) the SAME item order is handed out at run time: every XCD has its own counter per phase; a workgroup takes the
+// next item of the XCD it runs on -- own tall chunks, then own short ones -- and when its XCD has none left the next item of another
+// XCD (tall first).  The grid is ~12 % larger than the number of items and workgroups that find nothing exit at once, so an XCD that
+// runs ahead executes more items than an eighth and one that lags fewer: the hardware's equal split of workgroups no longer fixes
+// the split of work.  One atomic per workgroup at its START, no loop around the item (the kernel's registers are untouched); the
+// partial sums are indexed by item, so the results do not depend on who ran what.
 template <int P, bool INRANGE = false>
 __global__ __launch_bounds__(64 * BAND2_WPB_MAX, BAND2_LB) void band2_kernel(const Band2Args a) {
     __shared__ float4 s_csf[2][FVVDP_LUT_N];
+    __shared__ int s_item[2];
     const int lane = threadIdx.x & 63;
 #ifdef BAND2_TIMELINE
     const unsigned long long tl_t0 = wall_clock64();
@@ -447,11 +456,35 @@ __global__ __launch_bounds__(64 * BAND2_WPB_MAX, BAND2_LB) void band2_kernel(con
     const int wpb = (int)(blockDim.x >> 6);
     const int n_groups = a.n_strips / wpb;                    // (the launch makes wpb divide n_strips)
     const int first = n_groups * a.n_big * a.n_frames;        // workgroups of the first phase
-    int v = (int)blockIdx.x, nb = first;
-    const bool tall = v < first;
-    if (!tall) { v -= first; nb = (int)gridDim.x - first; }
     int bid;
-    {   // XCD-aware work order within a phase
+    bool tall;
+    if (a.tickets) {
+        if (threadIdx.x == 0) {
+            const int x = (int)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7;       // XCC_ID: the XCD this workgroup runs on
+            const int nbp[2] = {first, a.n_items - first};
+            int item = -1, ph_found = 0;
+            for (int k = 0; k < 16 && item < 0; ++k) {
+                // own tall, own short, the other XCDs' tall, the other XCDs' short
+                const int ph = (k == 0) ? 0 : (k == 1 ? 1 : (k < 9 ? 0 : 1));
+                const int y = (k < 2) ? x : ((x + (k < 9 ? k - 1 : k - 8)) & 7);
+                const int q8 = nbp[ph] >> 3, r8 = nbp[ph] & 7, cnt = q8 + (y < r8 ? 1 : 0);
+                int* tk = a.tickets + ph * 8 + y;
+                if (__hip_atomic_load(tk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= cnt) continue;
+                const int t = atomicAdd(tk, 1);
+                if (t < cnt) { item = y * q8 + min(y, r8) + t; ph_found = ph; }
+            }
+            s_item[0] = item;
+            s_item[1] = ph_found;
+        }
+        __syncthreads();
+        bid = s_item[0];
+        tall = s_item[1] == 0;
+        if (bid < 0) return;                                  // (uniform: every thread of the workgroup reads the same value)
+    } else {
+        int v = (int)blockIdx.x, nb = first;
+        tall = v < first;
+        if (!tall) { v -= first; nb = (int)gridDim.x - first; }
+        // XCD-aware work order within a phase
         const int q8 = nb >> 3, r8 = nb & 7, x = v & 7;
         bid = x * q8 + min(x, r8) + (v >> 3);
     }

@@ -245,13 +245,12 @@ template <int P, bool DBG, int FOVM>
 __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, const int chunk, const int frame, const int lane,
                                           const float4* s_csf, const float2* s_ax) {
     constexpr bool FOV = FOVM != 0;
-    constexpr bool LUT_LDS = FOVM == 1 || FOVM == 3 || FOVM == 4;
+    constexpr bool LUT_LDS = FOVM == 1 || FOVM == 3;
     // FOVM 1: stock geometry with the frame-invariant rho map (the fast path: no code for the other cases in the loop);
-    // FOVM 4: the same where the host has PROVEN that the CSF query of every pixel lies strictly inside the table on the Y and
-    //         the eccentricity axis (fov_query_in_range, fvvdp_hip.hip): the four clamps of the two axes are dropped (same bits);
     // FOVM 3: LUT slice in LDS, user geometry maps or no rho map;  FOVM 2: LUT slice in global memory (any case, DBG)
-    constexpr bool LEAN = FOVM == 1 || FOVM == 4;
-    constexpr bool FIN = FOVM == 4;
+    // (round 5: a variant of FOVM 1 without the four clamps of the Y / eccentricity query where the host proves them unreachable --
+    // 54 of 1452 VALU instructions per 16 pixels -- measured no faster, same box: profiles/r05_fov_budget.md; not kept)
+    constexpr bool LEAN = FOVM == 1;
     constexpr int HP = P / 2;   // (test, ref) pairs = temporal channels
     const int blk = chunk * a.n_strips + strip;
 
@@ -556,19 +555,6 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
             q.d[k] = v2f{fminf(g.h[k].x - e.h[k].x, dcap), fminf(g.h[k].y - e.h[k].y, dcap)};
         }
         q.llb = fast_log2(lb);
-        int bo;
-        if constexpr (FIN) {
-            // both queries strictly inside their axes (proven by the host): no clamp of the query, none of the interval index;
-            // interval = v_cvt_flr_i32_f32, fraction = v_fract_f32 of the grid position
-            const float ecc = __builtin_amdgcn_sqrtf(dx2 + dy2);
-            const float eq = __builtin_amdgcn_sqrtf(ecc);
-            const float tY = fmaf(q.llb, a.inv_step[0], a.grid_off[0]);
-            const float tE = fmaf(eq, a.inv_step[2], a.grid_off[2]);
-            q.fY = __builtin_amdgcn_fractf(tY) * a.frac_scale[0];
-            q.fE = __builtin_amdgcn_fractf(tE) * a.frac_scale[2];
-            // byte offset of the cell: rho plane + ecc * (FOV_ROW * 16) + Y * 16, integer multiply-adds
-            bo = floor_to_int(tY) * 16 + (floor_to_int(tE) * (FOV_ROW * 16) + (int)pre_kR);
-        } else {
         const float yq = __builtin_amdgcn_fmed3f(q.llb, a.ly_lo, a.ly_hi);
 #ifdef FOV_ABLATE_ECC     // timing experiment only: what the eccentricity arithmetic costs (results are wrong)
         const float eq = dx2 + dy2;
@@ -591,8 +577,7 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
         q.fE = (tE - iE) * a.frac_scale[2];
 #endif
         // byte offset of the cell (rho plane + ecc * 512 + Y * 16) in float: small integers are exact, one conversion
-        bo = (int)fmaf(iE, (float)(FOV_ROW * 16), fmaf(iY, 16.0f, pre_kR));
-        }
+        const int bo = (int)fmaf(iE, (float)(FOV_ROW * 16), fmaf(iY, 16.0f, pre_kR));
         q.fR = pre_fR;
         const float4* cell = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(s_lut_dyn) + bo);
         constexpr int sj = 1, sk = FOV_ROW;
@@ -813,7 +798,7 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
 template <int FOVM>
 __device__ __forceinline__ void band_load_tables(const BandArgs& a, float4* s_csf, float2* s_ax, const int tid, const int nthreads) {
     constexpr bool FOV = FOVM != 0;
-    constexpr bool LUT_LDS = FOVM == 1 || FOVM == 3 || FOVM == 4;
+    constexpr bool LUT_LDS = FOVM == 1 || FOVM == 3;
     if constexpr (!FOV) {
         if (tid < FVVDP_LUT_N) s_csf[tid] = a.csf[tid];
     } else {
@@ -845,7 +830,7 @@ __device__ __forceinline__ void band_load_tables(const BandArgs& a, float4* s_cs
 #define FOV_FRAME_FASTEST 1
 #endif
 template <int P, bool DBG, int FOVM>
-__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? ((FOVM == 1 || FOVM == 4) ? FOV_MINW_LEAN : FOV_MINW) : (DBG ? 2 : 4)) void band_kernel(const BandArgs a_byval) {
+__global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? (FOVM == 1 ? FOV_MINW_LEAN : FOV_MINW) : (DBG ? 2 : 4)) void band_kernel(const BandArgs a_byval) {
     // the argument block is read from the kernel-argument segment where it is needed (scalar loads) instead of being held in
     // scalar registers from the top of the kernel: the variants with many arguments in use (difference maps, caller-built view
     // maps) otherwise keep 13-48 of them in vector-register lanes
@@ -870,7 +855,7 @@ __global__ __launch_bounds__(FOVM ? 64 * FOV_WPB : 64, FOVM ? ((FOVM == 1 || FOV
     }
     const bool wave_has_work = !FOV || bid < a.n_items;
     int strip, chunk, frame;
-    if constexpr ((FOVM == 1 || FOVM == 4) && FOV_FRAME_FASTEST) {
+    if constexpr (FOVM == 1 && FOV_FRAME_FASTEST) {
         // frame fastest: an XCD walks all frames of a tile before the next tile, the tile's slice of the (frame-invariant)
         // rho map stays in that XCD's L2 instead of being fetched once per frame
         const int n_tiles = a.n_strips * a.n_chunks, n_frames = a.n_items / n_tiles;

@@ -62,6 +62,7 @@ struct CtxEnv {
     int fuse_mode = -1;           // FVVDP_BAND_FUSE=0 / 1: two-level pyramid kernel never / wherever valid (default: large levels)
     int band_cr = 0, band2_kr = 0, band2_kr2 = -1, band2_wpb = 0;   // FVVDP_BAND_CR, FVVDP_BAND2_KR, _KR2, _WPB: work decomposition overrides
     int k1_ticket = -1;           // FVVDP_K1_TICKET=0 / 1: temporal kernel (16-slot ring) without / with its block counter
+    int band2_ticket = -1;        // FVVDP_BAND2_TICKET=0 / 1: two-level pyramid kernel with the static split of work / per-XCD counters
     bool temporal_scalar = false; // FVVDP_TEMPORAL_SCALAR=1: the per-pixel temporal kernels (fallbacks for unaligned sizes)
     bool fov_no_rhomap = false;   // FVVDP_FOV_NO_RHOMAP=1: foveated kernels evaluate the rho coordinate per pixel
     bool debug_variant = false;   // FVVDP_DEBUG_VARIANT=1: print which kernel variants are launched (tests)
@@ -79,6 +80,7 @@ static CtxEnv read_env() {
     e.band2_kr2 = num("FVVDP_BAND2_KR2", -1);
     e.band2_wpb = num("FVVDP_BAND2_WPB", 0);
     if (const char* v = getenv("FVVDP_K1_TICKET")) e.k1_ticket = v[0] != '0' ? 1 : 0;
+    if (const char* v = getenv("FVVDP_BAND2_TICKET")) e.band2_ticket = v[0] != '0' ? 1 : 0;
     e.temporal_scalar = getenv("FVVDP_TEMPORAL_SCALAR") != nullptr;
     e.fov_no_rhomap = getenv("FVVDP_FOV_NO_RHOMAP") != nullptr;
     e.debug_variant = getenv("FVVDP_DEBUG_VARIANT") != nullptr;
@@ -1119,9 +1121,8 @@ static int build_sublut(fvvdp_ctx* c, const fvvdp_geom* g, hipStream_t st) {
     return FVVDP_OK;
 }
 
-// fin: the foveated query provably never leaves the table (fov_query_in_range): the variant without its four axis clamps
 template <int P>
-static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, bool fin, hipStream_t st) {
+static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, hipStream_t st) {
     dim3 grid(nblocks), block(64);
     if (fov) {
         const dim3 gridf((nblocks + FOV_WPB - 1) / FOV_WPB), blockf(64 * FOV_WPB);
@@ -1129,7 +1130,6 @@ static void launch_band(const BandArgs& a, int nblocks, bool dbg, bool fov, bool
         const size_t lds_vy = (size_t)a.h * sizeof(float);
         const size_t lds_lut = (size_t)FOV_PLANE * a.rw * sizeof(float4);
         if (dbg) hipLaunchKernelGGL((band_kernel<P, true, 2>), gridf, blockf, lds_vy, st, a);
-        else if (a.lut_lds && a.rmap && !a.mvx && fin) hipLaunchKernelGGL((band_kernel<P, false, 4>), gridf, blockf, lds_lut + lds_vy, st, a);
         else if (a.lut_lds && a.rmap && !a.mvx) hipLaunchKernelGGL((band_kernel<P, false, 1>), gridf, blockf, lds_lut + lds_vy, st, a);
         else if (a.lut_lds) hipLaunchKernelGGL((band_kernel<P, false, 3>), gridf, blockf, lds_lut + lds_vy, st, a);
         else hipLaunchKernelGGL((band_kernel<P, false, 2>), gridf, blockf, lds_vy, st, a);
@@ -1154,31 +1154,6 @@ static void fill_pool_args(PoolArgs& a, const float* d_Q, int n_bands, int n_cha
     a.jod_a = prm->jod_a;
     a.beta_jod = prm->beta_jod;
     a.out = d_jod;
-}
-
-// Foveated mode: may the kernels drop the clamps of the CSF query on the Y and the eccentricity axis (band_kernel<P, false, 4>)?
-// Y axis (fvvdp.py:530, interp.py:11-20): L_bkg = max(expanded reference, lbkg_min) of band b lies in [max(lum_lo, lbkg_min),
-// lum_hi] when every reduce step down to level b + 1 is a convex combination (as clamps_never_bind), and that must sit well
-// inside the table's Y range.  Eccentricity axis: with the gaze on the screen no pixel is further than twice the view angle of
-// the screen's corner from it (per axis), and that must sit well inside the table (0 ... 120 deg); the axis has to start at 0.
-static bool fov_luminance_in_range(const fvvdp_ctx* c, int b) {
-    if (!c->lum_known || c->lum_state != 1 || c->env.inrange_off) return false;
-    for (int i = 0; i < b + 1; ++i)
-        if ((c->lw[i] & 1) != (c->lh[i] & 1)) return false;
-    const float lo = fmaxf(c->lum_lo, c->prm.lbkg_min), hi = fmaxf(c->lum_hi, c->prm.lbkg_min);
-    return lo >= 2.0f * c->y_lo && hi <= 0.5f * c->y_hi;
-}
-static bool fov_gaze_in_range(const fvvdp_ctx* c, const fvvdp_geom* g, const float* h_fixation, int n) {
-    if (!g || !h_fixation || c->env.inrange_off) return false;
-    if (c->ecc_lo != 0.0f || c->h_axes[2][0] != 0.0f) return false;
-    for (int f = 0; f < n; ++f) {
-        const float x = h_fixation[2 * f], y = h_fixation[2 * f + 1];
-        if (!(x >= -0.5f && x <= (float)c->W && y >= -0.5f && y <= (float)c->H)) return false;      // (also refuses NaN)
-    }
-    const double ax = atan(0.5 * g->display_size_m[0] / g->distance_m) * 180.0 / M_PI;
-    const double ay = atan(0.5 * g->display_size_m[1] / g->distance_m) * 180.0 / M_PI;
-    const double ecc_max = 2.0 * sqrt(ax * ax + ay * ay) * 1.02 + 0.5;                    // half a degree for the gaze half a pixel off the screen
-    return ecc_max < 0.96 * (double)c->ecc_hi;
 }
 
 static int check_pool_params(const fvvdp_pool_params* prm) {
@@ -1215,7 +1190,6 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
         int rc = build_sublut(c, geom, st);
         if (rc != FVVDP_OK) return rc;
     }
-    const bool fov_geom_in_range = fov && fov_gaze_in_range(c, geom, h_fixation, n);
     FinalizeArgs fa;
     memset(&fa, 0, sizeof(fa));
     // Two pyramid levels per pass where possible (band2_kernel): plain evaluation only -- the map-writing and the
@@ -1291,7 +1265,21 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
                 // slots) and below 2560 columns (short launches stay in step by themselves).  Same work items, same partial sums.
                 int wpb = (a.w >= 2560 && a.n_strips % BAND2_WPB_MAX == 0) ? BAND2_WPB_MAX : 1;
                 { const int v = c->env.band2_wpb; if (v >= 1 && v <= BAND2_WPB_MAX && a.n_strips % v == 0) wpb = v; }      // FVVDP_BAND2_WPB
-                const dim3 grid2((unsigned int)((a.n_strips / wpb) * a.n_chunks * n)), block2(64 * wpb);
+                // work items handed out per XCD at run time (band2_kernel, `tickets`): launches of several rounds only;
+                // FVVDP_BAND2_TICKET=0 / 1 forces the static split / the counters
+                const int n_items = (a.n_strips / wpb) * a.n_chunks * n;
+                const long long waves2 = (long long)n * a.n_strips * a.n_chunks;
+                // Measured (profiles/r05_band2_tickets.md): 4K levels 0+1 (6000 items of ~300 us, 4 waves each) -0.4 ... -1.9 %; launches of
+                // many short items lose -- every workgroup's atomic is served at the memory side, ~0.3 us each and one after the other
+                // per counter (1080p levels 0+1, 8640 single-wave items: 8.8 -> 14.3 us per frame; 4K levels 2+3: 2.8 -> 3.7) -- so the
+                // counters are on only for the wide launches whose workgroups carry 4 strips
+                bool tickets = c->d_ticket && (c->env.band2_ticket == 1 ||
+                                               (c->env.band2_ticket != 0 && waves2 >= 2 * c->wave_capacity2 && wpb == BAND2_WPB_MAX && a.w >= 2560));
+                if (tickets && hipMemsetAsync(c->d_ticket, 0, 16 * sizeof(int), st) != hipSuccess) { (void)hipGetLastError(); tickets = false; }
+                a.n_items = n_items;
+                a.tickets = tickets ? c->d_ticket : nullptr;
+                const int n_wg = tickets ? ((n_items + n_items / 8 + 7) / 8 * 8) : n_items;
+                const dim3 grid2((unsigned int)n_wg), block2(64 * wpb);
                 if (c->env.debug_variant)                // tests: which variant was launched
                     fprintf(stderr, "fvvdp: levels %d+%d: band2_kernel<%d, %s>, luminance range %s [%g, %g], widest plane range %g, %d waves per workgroup\n",
                                  b, b + 1, c->P, inrange ? "true" : "false", c->lum_state == 1 ? "known" : "unknown", c->lum_lo, c->lum_hi, c->lum_width, wpb);
@@ -1395,11 +1383,8 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
         }
         {
             Timed tm(c, 1 + b, st);
-            const bool fin = fov && fov_geom_in_range && fov_luminance_in_range(c, b);
-            if (fov && c->env.debug_variant)
-                fprintf(stderr, "fvvdp: level %d: foveated band_kernel<%d>, CSF query %s\n", b, c->P, fin ? "provably inside the table (no axis clamps)" : "clamped");
-            if (c->P == 4) launch_band<4>(a, nblk * n, dbg, fov, fin, st);
-            else launch_band<2>(a, nblk * n, dbg, fov, fin, st);
+            if (c->P == 4) launch_band<4>(a, nblk * n, dbg, fov, st);
+            else launch_band<2>(a, nblk * n, dbg, fov, st);
         }
         fa.nblk[b] = nblk;
         fa.off[b] = c->partial_off[b];

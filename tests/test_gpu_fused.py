@@ -213,3 +213,30 @@ def test_clamp_free_variant_is_taken_only_where_proven_and_changes_nothing(tmp_p
     assert v["hdr_pq"] == {False}             # black level 0.0174 cd/m^2 < 0.1: max(L_bkg, 0.1) binds, contrast can reach 1000
     assert v["user_src"] == {False}           # luminance frames from the source's own get_*_frame: range unknown to the library
     assert v["user_then"] == {False} and v["array_after_user"] == {True}     # a call that rewrites every slot starts the range afresh
+
+
+@pytest.mark.parametrize("H,W,N", [(66, 325, 5), (72, 1000, 6), (131, 433, None), (300, 2600, 3)])
+def test_band2_tickets_change_no_bits(monkeypatch, H, W, N):
+    """band2_kernel with its work items handed out per XCD at run time (FVVDP_BAND2_TICKET=1: a grid larger than the number of items,
+    one atomic ticket per workgroup, stealing between XCDs) against the static split: the same items, partial sums indexed by item ->
+    bit-identical, with 1 and 4 waves per workgroup, uniform and two-phase chunking, call after call (the counters are zeroed per launch)."""
+    import fovvideovdp_amd as fv
+    test, ref = _pair(H, W, 11 * H + W, N)
+    kw = dict(dim_order="HW") if N is None else dict(dim_order="FHW", frames_per_second=30)
+    monkeypatch.setenv("FVVDP_BAND_FUSE", "1")
+    for kr in (None, 2, 5):
+        if kr is None:
+            monkeypatch.delenv("FVVDP_BAND2_KR", raising=False)
+        else:
+            monkeypatch.setenv("FVVDP_BAND2_KR", str(kr))
+        out = {}
+        for t in ("0", "1"):
+            monkeypatch.setenv("FVVDP_BAND2_TICKET", t)
+            m = fv.fvvdp(display_name="standard_4k")
+            res = []
+            for rep in range(3):
+                q, st = m.predict(test, ref, **kw)
+                res.append(np.concatenate([st["Q_per_ch"].reshape(-1), [float(q)]]))
+            out[t] = np.stack(res)
+        assert np.array_equal(out["0"], out["1"]), (H, W, N, kr)
+        assert np.array_equal(out["1"][0], out["1"][2])
