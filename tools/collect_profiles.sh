@@ -67,4 +67,7 @@ python $R/bench.py --width 1920 --height 1080 --display standard_fhd --no-cpu-ba
 FVVDP_ALLOC=malloc FVVDP_PLACEMENT_PROBE=0 python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_malloc.json 2>/dev/null
 FVVDP_PLACEMENT_PROBE=0 python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_chunks.json 2>/dev/null
 FVVDP_BAND_INRANGE=0 python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_clamps.json 2>/dev/null
+[ -f $R/build_variants/k1wpb1.so ] && FVVDP_LIB=$R/build_variants/k1wpb1.so python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_k1wpb1.json 2>/dev/null
+FVVDP_BAND2_TICKET=0 python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_noticket.json 2>/dev/null
+python $R/bench.py --shard frames --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_frames.json 2>/dev/null
 ls -la $OUT

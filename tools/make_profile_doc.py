@@ -100,7 +100,8 @@ def quoted_figures():
     rs = jp["roofline_step"]
     out.append("* whole step: %.2f GB per pair, %.2f TB/s = %.3f; kernels back to back %.3f ms of %.3f ms" % (
         rs["bytes_per_step"] / 1e9, rs["achieved"] / 1e3, rs["frac"], rs["kernels_back_to_back_ms"], rs["ms_per_step"]))
-    for name in ("bench_malloc.json", "bench_chunks.json", "bench_clamps.json", "bench_pairs8.json", "bench_fhd.json", "bench_fhd_plain.json"):
+    for name in ("bench_malloc.json", "bench_chunks.json", "bench_clamps.json", "bench_k1wpb1.json", "bench_noticket.json", "bench_pairs8.json", "bench_frames.json",
+                 "bench_fhd.json", "bench_fhd_plain.json"):
         try:
             j = json.loads(rd(name).split("\n")[-1])
             gg = j["graded_pass"]
@@ -110,10 +111,17 @@ def quoted_figures():
             pass
     la = jp.get("level0_alloc")
     if isinstance(la, dict):
-        cmp_ = la.get("compared_us_per_frame")
-        out.append("* level-0 scratch of the unprofiled run: started as %s, in use %s%s" % (la.get("start"), la.get("in_use"),
-                   (" (the context compared %.2f us per frame on the first buffer with %.2f on the other kind, temporal kernel + pyramid pass, and kept the %s)" % (
-                       cmp_["first"], cmp_["other_kind"], {"first": "first", "other_kind": "other kind"}.get(la.get("kept"), "?"))) if cmp_ else ""))
+        cand = la.get("candidates_us_per_frame") or []
+        out.append("* level-0 scratch of the unprofiled run: in use %s%s; host syncs / allocations / frees inside per-frame calls: %s" % (
+            la.get("in_use"),
+            (" (fvvdp_ctx_create timed the temporal kernel + pyramid pass on %d candidates: %s us per frame, kept #%s)" % (
+                len(cand), " / ".join("%.2f" % v for v in cand), la.get("kept_index"))) if cand else "",
+            "/".join(str(v) for v in (la.get("per_frame_calls") or {}).values())))
+    if jp.get("predict_call_ms"):
+        out.append("* step path: %s; the reference-style synchronous `predict()` on the same pair: %.3f ms" % (jp.get("step_path"), jp["predict_call_ms"]))
+    if k1.get("traffic"):
+        out.append("* real traffic of the temporal kernel: %.2f GB per launch = %.3f of its algorithmic %.2f GB (the excess is the 7 history frames)" % (
+            k1["traffic"] / 1e9, k1.get("traffic_over_algorithmic", 0), k1["bytes_per_launch"] / 1e9))
     out.append("* JOD %s, |delta| to the real reference %.3g (north-star bound 1e-3)" % (jp.get("jod"), jp.get("jod_delta_vs_reference") or 0.0))
     fov = [l for l in rd("fov_probe.txt").split("\n") if l.startswith("kernel us/frame")]
     fms = [l.split()[4] for l in rd("fov_probe.txt").split("\n") if l.startswith("config4")]
@@ -190,14 +198,24 @@ bench.py JSON of the unprofiled run on the same box, right before:
 {rd('bench_pairs8.json')}
 ```
 
-Same box, the switches of round 4: the level-0 buffer fixed to one kind, comparison off (`FVVDP_ALLOC=malloc FVVDP_PLACEMENT_PROBE=0`,
-then `FVVDP_PLACEMENT_PROBE=0` = 32 MB chunks; the default line above chooses between the two, `level0_alloc` says what it kept;
-`profiles/r04_level0_chunks.md`) and `FVVDP_BAND_INRANGE=0` (the pyramid kernel with its clamps, `profiles/r04_pyramid_kernel.md`):
+Same box, one switch at a time: the level-0 buffer fixed to one kind and no comparison at creation (`FVVDP_ALLOC=malloc
+FVVDP_PLACEMENT_PROBE=0`, then `FVVDP_PLACEMENT_PROBE=0` = 32 MB chunks; the default line above keeps the fastest of four candidates,
+`level0_alloc` says which: `profiles/r05_k1_mode.md`), `FVVDP_BAND_INRANGE=0` (the pyramid kernel with its clamps), the temporal kernel
+with ONE wave per workgroup (`FVVDP_LIB=build_variants/k1wpb1.so`, built with `-DK1_WPB8=1`: round 4's launch shape), and
+`FVVDP_BAND2_TICKET=0` (static split of the pyramid kernel's work items, `profiles/r05_band2_tickets.md`):
 
 ```
 {rd('bench_malloc.json')}
 {rd('bench_chunks.json')}
 {rd('bench_clamps.json')}
+{rd('bench_k1wpb1.json')}
+{rd('bench_noticket.json')}
+```
+
+`--shard frames` on one rank (the frame-sharded step path: `predict_frame_sharded`, all-reduce skipped), same box:
+
+```
+{rd('bench_frames.json')}
 ```
 
 ## BASELINE configs[1]: 1920x1080 x60, standard_fhd (6 bands) -- kernel table of `bench.py --width 1920 --height 1080 --display standard_fhd`

@@ -48,7 +48,10 @@ def main():
         order.append((label, dur, start, prev))
         prev = name
     total = sum(sum(a["d"]) for a in agg.values()) or 1
-    print("| kernel | calls | total ms | avg us | median us | steady med us (first %d dropped) | min us | max us | %% | vgpr | sgpr | lds B | grid_x | wg |" % skip)
+    # the two register columns are what rocprofv3 records per dispatch (arch VGPRs in use as it counts them, SGPRs); they are NOT the
+    # allocation that decides occupancy -- that is the code-object figure (tools/codeobj_report.py, "Registers, spills ..." table of
+    # the bundle: e.g. band2_kernel<4, true> 156, temporal_vec_kernel<8, 4, 0, 1> 105)
+    print("| kernel | calls | total ms | avg us | median us | steady med us (first %d dropped) | min us | max us | %% | vgpr (rocprof's count, not the allocation) | sgpr | lds B | grid_x | wg |" % skip)
     print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
     for label, a in sorted(agg.items(), key=lambda kv: -sum(kv[1]["d"])):
         if only and only not in label:
