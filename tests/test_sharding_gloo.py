@@ -150,3 +150,48 @@ def test_frame_sharding_with_an_empty_shard_world2(tmp_path):
         assert np.array_equal(res[k]["Q3"][0, 0], [1.0, 2.0, 3.0])
         assert res[k]["jod1"] == res[0]["jod1"] and res[k]["jod3"] == res[0]["jod3"]
     assert res[0]["calls1"].tolist() == [[0, 1]] and res[1]["calls1"].size == 0
+
+
+def _rows_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # bench.py's step: k result rows per rank (Q_per_ch | range flag | JOD, flat), all ranks' rows through ONE all-reduce
+        k, nq = 3, 17
+        rows = torch.arange(k * (nq + 2), dtype=torch.float32).reshape(k, nq + 2) + 1000.0 * rank
+        allr = gather_pair_results(rows, rank, world)
+        np.save(os.path.join(out_dir, f"rows{rank}.npy"), allr.numpy())
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_result_rows_of_all_ranks_through_one_all_reduce(tmp_path):
+    """gather_pair_results on the flat result rows of `predict(..., sync=False)` (what bench.py all-reduces): world 4 on CPU, every
+    rank ends up with all 12 rows in rank order; one rank: the rows come back as they are (no buffer, no collective)."""
+    world = 4
+    mp.spawn(_rows_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [np.load(os.path.join(str(tmp_path), f"rows{k}.npy")) for k in range(world)]
+    want = np.concatenate([np.arange(3 * 19, dtype=np.float32).reshape(3, 19) + 1000.0 * r for r in range(world)])
+    for r in res:
+        assert r.shape == (12, 19) and np.array_equal(r, want)
+    rows = torch.randn(2, 19)
+    assert gather_pair_results(rows, 0, 1) is rows
+    q = torch.randn(7, 2, 5)
+    out = gather_pair_results(q, 0, 1)
+    assert out.shape == (1, 7, 2, 5) and torch.equal(out[0], q)
+
+
+def test_bench_labels_follow_the_arguments():
+    """bench.py names the BASELINE.json configs[] entry its ARGUMENTS describe (the 1080p lines carried configs[2])."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.baseline_label(3840, 2160, 60, 30, "standard_4k", 1, 1, False) == "BASELINE.json configs[2]"
+    assert "configs[4]" in b.baseline_label(3840, 2160, 60, 30, "standard_4k", 8, 8, False)
+    assert b.baseline_label(1920, 1080, 60, 30, "standard_fhd", 1, 1, False) == "BASELINE.json configs[1]"
+    assert "not a BASELINE" in b.baseline_label(960, 540, 20, 30, "standard_4k", 2, 2, False)
+    assert "frame sharding" in b.baseline_label(3840, 2160, 60, 30, "standard_4k", 8, 1, True)

@@ -175,6 +175,11 @@ static Buf alloc_buf(size_t bytes, size_t chunk) {
     Buf b; b.chunk = chunk; b.size = bytes; b.ptr = nullptr;
     b.kind = chunk ? ("vmm" + std::to_string(chunk >> 20)) : "malloc";
     if (!chunk) { CK(hipMalloc(&b.ptr, bytes)); return b; }
+    if (chunk == 1 || chunk == 2) {          // other memory kinds of the runtime: fine-grained (coherent) / uncached device memory
+        b.kind = chunk == 1 ? "fine" : "uncached";
+        if (hipExtMallocWithFlags(&b.ptr, bytes, chunk == 1 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached) != hipSuccess) { (void)hipGetLastError(); b.ptr = nullptr; }
+        return b;
+    }
     int dev = 0; CK(hipGetDevice(&dev));
     hipMemAllocationProp prop; memset(&prop, 0, sizeof(prop));
     prop.type = hipMemAllocationTypePinned; prop.location.type = hipMemLocationTypeDevice; prop.location.id = dev;
@@ -219,11 +224,12 @@ __global__ void checksum_f4(const float4* p, size_t n4, double* out) {
 static size_t out_bytes_c(int hw) { return (size_t)NOUT * hw * 16; }
 
 int main(int argc, char** argv) {
-    int n_malloc = 4, n_v32 = 4, n_v2 = 2;
+    int n_malloc = 4, n_v32 = 4, n_v2 = 2, n_other = 0;
     bool pmc = false, regions = false, zones = false, balanced = false, spread = false;
     std::vector<int> nums;
     for (int i = 1; i < argc; ++i) { if (!strcmp(argv[i], "pmc")) pmc = true; else if (!strcmp(argv[i], "regions")) regions = true; else if (!strcmp(argv[i], "zones")) zones = true; else if (!strcmp(argv[i], "balanced")) balanced = true; else if (!strcmp(argv[i], "spread")) spread = true; else nums.push_back(atoi(argv[i])); }
     if (nums.size() >= 3) { n_malloc = nums[0]; n_v32 = nums[1]; n_v2 = nums[2]; }
+    if (nums.size() >= 4) n_other = nums[3];
     if (zones) {
         // G physical chunks of 1 GiB in allocation order, each mapped on its own; write rate of every chunk alone, of chunk 0
         // together with chunk i, and of neighbours (i, i+1): which chunks share the resource that caps one chunk at ~5.3 TB/s?
@@ -419,10 +425,11 @@ int main(int argc, char** argv) {
     const size_t out_bytes = (size_t)NOUT * HW * 16;
     std::vector<Buf> bufs;
     // interleave the kinds so that allocation order does not line up with kind
-    for (int i = 0; i < std::max(n_malloc, std::max(n_v32, n_v2)); ++i) {
+    for (int i = 0; i < std::max(std::max(n_malloc, n_other), std::max(n_v32, n_v2)); ++i) {
         if (i < n_malloc) bufs.push_back(alloc_buf(out_bytes, 0));
         if (i < n_v32) bufs.push_back(alloc_buf(out_bytes, (size_t)32 << 20));
         if (i < n_v2) bufs.push_back(alloc_buf(out_bytes, (size_t)2 << 20));
+        if (i < n_other) { Buf f = alloc_buf(out_bytes, 1); if (f.ptr) bufs.push_back(f); Buf u = alloc_buf(out_bytes, 2); if (u.ptr) bufs.push_back(u); }
     }
     for (auto& b : bufs) CK(hipMemset(b.ptr, 0, out_bytes));
     CK(hipDeviceSynchronize());
