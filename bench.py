@@ -159,8 +159,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    t_first = time.perf_counter()
+    for w in range(args.warmup):
         jods = step()
+        if w == 0:
+            torch.cuda.synchronize(dev)
+            t_first = time.perf_counter() - t_first        # incl. context creation (scratch allocation + the level-0 choice)
     fence()
     t0 = time.perf_counter()
     stamps = [t0]
@@ -206,10 +210,12 @@ def main():
         nat.check(nat.lib().fvvdp_ctx_alloc_info(ctx.handle, C.byref(st_), C.byref(cm_), us_, 8, C.byref(nt_), C.byref(kept_)))
         nat.check(nat.lib().fvvdp_ctx_call_stats(ctx.handle, cs_))
         extra["level0_alloc"] = {
-            "in_use": ("virtual-memory API, physical chunks of %s MB" % os.environ.get("FVVDP_VMM_CHUNK_MB", "32")) if cm_.value else "hipMalloc",
+            "in_use": {0: "hipMalloc", 1: "virtual-memory API, physical chunks of %s MB" % os.environ.get("FVVDP_VMM_CHUNK_MB", "32"),
+                       2: "uncached device memory (hipExtMallocWithFlags, hipDeviceMallocUncached)"}.get(cm_.value, str(cm_.value)),
             # the context timed the temporal kernel + pyramid pass on these candidates inside fvvdp_ctx_create and kept the fastest
             "candidates_us_per_frame": [round(us_[k], 2) for k in range(nt_.value)], "kept_index": kept_.value, "state": st_.value,
             "per_frame_calls": {"host_syncs": int(cs_[0]), "allocations": int(cs_[1]), "frees": int(cs_[2])},
+            "first_step_ms_incl_context_creation": round(t_first * 1e3, 1) if args.warmup > 0 else None,
             "evidence": "profiles/r05_k1_mode.md"}
         nat.check(nat.lib().fvvdp_ctx_timing_enable(ctx.handle, 1))
         nk = 16 + 2

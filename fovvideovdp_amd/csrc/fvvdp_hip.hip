@@ -56,8 +56,9 @@ extern "C" const char* fvvdp_last_error(void) { return g_err; }
 // none of them changes results beyond the grouping of fp32 partial sums.
 struct CtxEnv {
     bool alloc_malloc = false;    // FVVDP_ALLOC=malloc: every scratch buffer from hipMalloc (default: large levels mapped from chunks)
+    bool alloc_uncached = false;  // FVVDP_ALLOC=uncached: level 0 (and every level-0 candidate) as uncached device memory
     size_t vmm_chunk = 0;         // FVVDP_VMM_CHUNK_MB: chunk size of the >= 256 MB levels (default 32 MB)
-    int probe_n = -1;             // FVVDP_PLACEMENT_PROBE=n: level-0 candidates timed at creation (0 / 1 = none; default 4)
+    int probe_n = -1;             // FVVDP_PLACEMENT_PROBE=n: level-0 candidates timed at creation (0 / 1 = none; default 6)
     bool inrange_off = false;     // FVVDP_BAND_INRANGE=0: always the pyramid kernels with clamps
     int fuse_mode = -1;           // FVVDP_BAND_FUSE=0 / 1: two-level pyramid kernel never / wherever valid (default: large levels)
     int band_cr = 0, band2_kr = 0, band2_kr2 = -1, band2_wpb = 0;   // FVVDP_BAND_CR, FVVDP_BAND2_KR, _KR2, _WPB: work decomposition overrides
@@ -70,7 +71,7 @@ struct CtxEnv {
 static CtxEnv read_env() {
     CtxEnv e;
     auto num = [](const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; };
-    if (const char* v = getenv("FVVDP_ALLOC")) e.alloc_malloc = strcmp(v, "malloc") == 0;
+    if (const char* v = getenv("FVVDP_ALLOC")) { e.alloc_malloc = strcmp(v, "malloc") == 0; e.alloc_uncached = strcmp(v, "uncached") == 0; }
     e.vmm_chunk = (size_t)(num("FVVDP_VMM_CHUNK_MB", 0) > 0 ? num("FVVDP_VMM_CHUNK_MB", 0) : 0) << 20;
     e.probe_n = num("FVVDP_PLACEMENT_PROBE", -1);
     if (const char* v = getenv("FVVDP_BAND_INRANGE")) e.inrange_off = v[0] == '0';
@@ -106,6 +107,7 @@ struct fvvdp_ctx {
     int sel_n = 0;
     int sel_kept = -1;
     float sel_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int level0_kind = 0;          // 0 hipMalloc, 1 mapped from physical chunks, 2 uncached device memory (hipDeviceMallocUncached)
     // host synchronisations / allocations / frees made INSIDE per-frame entry points since creation (fvvdp_ctx_call_stats): the
     // standard video path makes none (SURVEY 8(b) "allocated once in ctx_create")
     long long n_sync = 0, n_alloc = 0, n_free = 0;
@@ -1432,17 +1434,28 @@ extern "C" int fvvdp_bands_forward_pool(fvvdp_ctx* c, int n, float* d_Q, int q_s
 // profiles/r05_k1_mode.md, tools/microbench/k1_stream.hip.  Which allocations are slow differs by box (hipMalloc ranges mostly
 // slow and 32 MB-chunk mappings mostly fast on most boxes, the reverse on some), and the pyramid pass that READS the buffer tends
 // the other way by ~1 us.  Nothing in the kernels' control changes it, so the context draws: it times the temporal kernel + the
-// pyramid pass on N candidate buffers (default 4, alternating chunk-mapped / hipMalloc; FVVDP_PLACEMENT_PROBE=n, 0 = off) filled
+// pyramid pass on N candidate buffers (default 6: chunk-mapped, hipMalloc, uncached, ...; FVVDP_PLACEMENT_PROBE=n, 0 = off) filled
 // from a synthetic uint8 clip and keeps the fastest.  All of it happens here, before the first user call: per-frame calls never
 // allocate, free or synchronise for it.  Results never depend on the buffer.  Video contexts whose level 0 holds >= 1 GiB only.
 static void choose_level0(fvvdp_ctx* c) {
     c->sel_phase = 9;
+    c->level0_kind = vmm_owns(c, c->level[0]) ? 1 : 0;
     const int HW = c->W * c->H;
     const size_t floats = (size_t)c->max_frames * HW * c->P;
     const size_t bytes = floats * sizeof(float);
-    int n_cand = c->env.probe_n < 0 ? 4 : c->env.probe_n;
+    int n_cand = c->env.probe_n < 0 ? 6 : c->env.probe_n;
     if (n_cand > 8) n_cand = 8;
-    if (n_cand < 2 || c->P != 4 || bytes < ((size_t)1 << 30) || c->max_frames < 16 || (HW % 4) != 0) return;
+    if (c->P != 4 || bytes < ((size_t)1 << 30) || c->max_frames < 16 || (HW % 4) != 0) return;
+    if (c->env.alloc_uncached) {                             // FVVDP_ALLOC=uncached: the first buffer as well (A/B runs)
+        void* q = nullptr;
+        if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) == hipSuccess) {
+            float* old = c->level[0];
+            c->level[0] = reinterpret_cast<float*>(q);
+            c->level0_kind = 2;
+            if (vmm_owns(c, old)) vmm_free_one(c, old); else (void)hipFree(old);
+        } else (void)hipGetLastError();
+    }
+    if (n_cand < 2) return;
     const int SRC_FRAMES = 16, FL = 8, n = c->max_frames < 128 ? c->max_frames : 128;
     const size_t src_bytes = (size_t)SRC_FRAMES * 3 * HW;
     unsigned char* src[2] = {nullptr, nullptr};
@@ -1524,12 +1537,15 @@ static void choose_level0(fvvdp_ctx* c) {
     c->sel_us[0] = best;
     c->sel_n = 1;
     c->sel_kept = 0;
-    const bool first_vmm = vmm_owns(c, c->level[0]);
+    // kinds of the candidates: chunk-mapped (the buffer the context came with), hipMalloc, uncached device memory, chunk-mapped, ...
+    // (FVVDP_ALLOC=malloc / uncached: that kind only).  Uncached memory takes streaming writes 5-15 % faster than cached memory of
+    // the same placement (6.4 against 5.5 TB/s inside one class of physical memory, 7.25 against 7.0 across both) and the
+    // pyramid pass reads it about as fast (profiles/r05_k1_mode.md, section 5): the timing decides.
     for (int k = 1; k < n_cand; ++k) {
-        // the kinds alternate (FVVDP_ALLOC=malloc: hipMalloc only)
-        const bool want_vmm = !c->env.alloc_malloc && ((k & 1) ? !first_vmm : first_vmm);
+        const int kind = c->env.alloc_malloc ? 0 : (c->env.alloc_uncached ? 2 : (k % 3 == 1 ? 0 : (k % 3 == 2 ? 2 : 1)));
         void* q = nullptr;
-        const bool got = want_vmm ? vmm_alloc(c, &q, bytes) == FVVDP_OK : hipMalloc(&q, bytes) == hipSuccess;
+        const bool got = kind == 1 ? vmm_alloc(c, &q, bytes) == FVVDP_OK
+                                   : (kind == 2 ? hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) == hipSuccess : hipMalloc(&q, bytes) == hipSuccess);
         if (!got) { (void)hipGetLastError(); break; }
         float* incumbent = c->level[0];
         c->level[0] = reinterpret_cast<float*>(q);
@@ -1539,6 +1555,7 @@ static void choose_level0(fvvdp_ctx* c) {
         if (timed && us < best) {
             best = us;
             c->sel_kept = k;
+            c->level0_kind = kind;
             release(incumbent);
         } else {
             c->level[0] = incumbent;
@@ -1549,7 +1566,7 @@ static void choose_level0(fvvdp_ctx* c) {
     if (c->env.debug_variant) {
         fprintf(stderr, "fvvdp: level-0 candidates (temporal + pyramid, us per frame):");
         for (int k = 0; k < c->sel_n; ++k) fprintf(stderr, " %.2f", c->sel_us[k]);
-        fprintf(stderr, " -> kept #%d (%s)\n", c->sel_kept, vmm_owns(c, c->level[0]) ? "chunk-mapped" : "hipMalloc");
+        fprintf(stderr, " -> kept #%d (%s)\n", c->sel_kept, c->level0_kind == 1 ? "chunk-mapped" : (c->level0_kind == 2 ? "uncached" : "hipMalloc"));
     }
     cleanup();
 }
@@ -1719,7 +1736,7 @@ extern "C" int fvvdp_ctx_alloc_info(const fvvdp_ctx* c, int* state, int* chunk_m
                                     int* kept) {
     if (!c || !state || !chunk_mapped || !h_us || !n_timed || !kept || capacity < 1) return fail(FVVDP_EINVAL, "null argument");
     *state = c->sel_phase;
-    *chunk_mapped = vmm_owns(c, c->level[0]) ? 1 : 0;
+    *chunk_mapped = vmm_owns(c, c->level[0]) ? 1 : c->level0_kind;      // 0 hipMalloc, 1 chunk-mapped, 2 uncached device memory
     for (int k = 0; k < capacity; ++k) h_us[k] = k < c->sel_n ? c->sel_us[k] : 0.0f;
     *n_timed = c->sel_n;
     *kept = c->sel_kept;

@@ -354,7 +354,7 @@ class fvvdp:
         Q_jod = res[nq + 1] if pool else None                 # pooled with the last batch (fvvdp_bands_forward_pool)
         stats = {}
         if sync:
-            res_h = res.detach().cpu()                       # the one host synchronisation of the call
+            res_h = self._to_host(res)                       # the one host synchronisation of the call
             if self.do_heatmap and self._copy_stream is not None:
                 self._copy_stream.synchronize()              # ... plus the side stream that carries the maps
             stats['Q_per_ch'] = res_h[:nq].view(n_bands, 2, n_out).numpy()
@@ -376,6 +376,23 @@ class fvvdp:
         if hasattr(feeder, "release"):
             feeder.release(synced=sync)
         return (Q_jod, stats)
+
+    def _to_host(self, res):
+        """Result buffer -> host through a page-locked staging buffer kept by the metric (a pageable `.cpu()` costs ~0.1 ms more per
+        call: 4K x 60, 4.25 against 4.15 ms); the caller gets its own copy.  Falls back to `.cpu()` where page-locking is refused."""
+        n = res.numel()
+        pin = self.__dict__.get("_res_pin")
+        if pin is None or pin.numel() < n:
+            try:
+                pin = torch.empty(max(n, 4096), dtype=torch.float32, pin_memory=True)
+            except RuntimeError:
+                pin = False
+            self._res_pin = pin
+        if pin is False:
+            return res.detach().cpu()
+        pin[:n].copy_(res.detach(), non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        return pin[:n].clone()
 
     @staticmethod
     def _host_buffer(shape):

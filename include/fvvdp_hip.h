@@ -279,10 +279,11 @@ int fvvdp_ctx_timing_read(fvvdp_ctx* ctx, float* h_ms, int32_t* h_count, int cap
  * chunks (HIP virtual-memory API) by default.  How fast a buffer of this size can be WRITTEN depends on its physical placement
  * (the temporal kernel: 31-33 or 36-38 us per 4K frame, box by box and allocation by allocation; profiles/r05_k1_mode.md), so
  * fvvdp_ctx_create of a video context whose level 0 holds >= 1 GiB times the temporal kernel + the pyramid pass on N candidate
- * buffers (default 4, alternating chunk-mapped / hipMalloc, a synthetic uint8 clip as input; environment
- * FVVDP_PLACEMENT_PROBE=n, 0 = off) and keeps the fastest: ~0.1-0.2 s at creation, one extra level 0 held while a candidate is
+ * buffers (default 6: chunk-mapped, hipMalloc, uncached device memory, and the three again; a synthetic uint8 clip as input; environment
+ * FVVDP_PLACEMENT_PROBE=n, 0 = off) and keeps the fastest: ~0.2-0.3 s at creation, one extra level 0 held while a candidate is
  * timed, nothing in any per-frame call.  Results never depend on it.
- *   *state: always 9 (settled) -- the comparison runs inside fvvdp_ctx_create;  *chunk_mapped: 1 = level 0 is chunk-mapped
+ *   *state: always 9 (settled) -- the comparison runs inside fvvdp_ctx_create;  *chunk_mapped: kind of level 0 -- 0 hipMalloc,
+ *   1 mapped from physical chunks, 2 uncached device memory (a candidate kind since round 5: takes streaming writes faster)
  *   h_us[capacity]: microseconds per frame (temporal kernel + pyramid pass) of candidates 0 .. *n_timed - 1, 0 beyond
  *   *kept: index of the candidate in use, -1 = no comparison (small context, still image, switched off, not enough memory) */
 int fvvdp_ctx_alloc_info(const fvvdp_ctx* ctx, int* state, int* chunk_mapped, float* h_us, int capacity, int* n_timed, int* kept);

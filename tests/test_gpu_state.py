@@ -486,8 +486,8 @@ def test_level0_choice_happens_at_creation_and_changes_no_bits(tmp_path):
         "print('SMALL', *info(m2))\n"
         "np.save(sys.argv[1], np.stack(out))\n" % root)
     res = {}
-    modes = (("default", {}, 4), ("off", {"FVVDP_PLACEMENT_PROBE": "0"}, 0), ("malloc", {"FVVDP_ALLOC": "malloc"}, 4),
-             ("two", {"FVVDP_PLACEMENT_PROBE": "2"}, 2), ("six", {"FVVDP_PLACEMENT_PROBE": "6"}, 6))
+    modes = (("default", {}, 6), ("off", {"FVVDP_PLACEMENT_PROBE": "0"}, 0), ("malloc", {"FVVDP_ALLOC": "malloc"}, 6), ("uncached", {"FVVDP_ALLOC": "uncached"}, 6),
+             ("two", {"FVVDP_PLACEMENT_PROBE": "2"}, 2), ("four", {"FVVDP_PLACEMENT_PROBE": "4"}, 4))
     for mode, env, n_want in modes:
         f = str(tmp_path / ("s_%s.npy" % mode))
         p = subprocess.run([sys.executable, "-c", code, f], env=dict(os.environ, **env), capture_output=True, text=True, timeout=400)
@@ -508,9 +508,10 @@ def test_level0_choice_happens_at_creation_and_changes_no_bits(tmp_path):
                 assert us[kept] == min(us[:n_want]), (mode, i)
                 if mode == "malloc":
                     assert chunk == 0
-                else:
-                    first_chunk = 1                                                       # candidates alternate chunk-mapped / hipMalloc
-                    assert chunk == (first_chunk if kept % 2 == 0 else 1 - first_chunk), (mode, i)
+                elif mode == "uncached":
+                    assert chunk == 2
+                else:                                # candidate kinds: chunk-mapped, hipMalloc, uncached device memory, chunk-mapped, ...
+                    assert chunk == [1, 0, 2, 1, 0, 2][kept], (mode, i)
             else:
                 assert kept == -1
         assert infos[0] == infos[3]                                                       # settled at creation: nothing moves afterwards

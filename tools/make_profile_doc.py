@@ -85,6 +85,10 @@ def quoted_figures():
     for label, (calls, avg, med, steady) in rows.items():
         if "band2_kernel" in label and "levels 0+1" in label:
             b = r["bytes_per_launch"]
+            if "false" in label and jp["roofline"]["kernel"].startswith("band2_kernel<4, true>"):
+                out.append("* `%s`: %d launches, rocprof AVERAGE %.1f us -- not the timed steps: the level-0 choice inside `fvvdp_ctx_create` (4 candidates x 3 passes "
+                           "of the variant WITH clamps on a synthetic clip, incl. the first touch of every candidate)" % (label.strip("`"), calls, avg))
+                continue
             out.append("* `%s`: %.4f GB algorithmic per launch / rocprof AVERAGE %.1f us = %.2f TB/s = %.3f of 8 TB/s; / steady median %.1f us = %.3f; unprofiled HIP-event median %.1f us = %.4f" % (
                 label.strip("`"), b / 1e9, avg, b / avg / 1e6, b / avg / 1e6 / 8.0, steady, b / steady / 1e6 / 8.0, r["median_launch_ms"] * 1e3, r["frac"]))
         if "temporal_vec_kernel" in label:

@@ -103,8 +103,8 @@ this file is assembled from their logs by `tools/make_r5_evidence.py`.  All sess
    fast after a process that had allocated and freed 150 GiB); holding back a spacer between two halves of a buffer does not move
    the second half (`hipMemCreate` alone does not seem to place memory).  A search for the other class by allocating ahead found it
    after 29 GiB in one run and not within 100-120 GiB in three others.  Section 4.
-5. *What the library does with that.*  (a) `fvvdp_ctx_create` times K1 + the pyramid pass on N = 4 candidate buffers (alternating
-   chunk-mapped / `hipMalloc`) and keeps the fastest -- it helps when the candidates differ (sessions 1 and 3: 5-7 of 13 buffers fast)
+5. *What the library does with that.*  (a) `fvvdp_ctx_create` times K1 + the pyramid pass on N = 6 candidate buffers (chunk-mapped,
+   `hipMalloc`, uncached device memory, twice: section 5) and keeps the fastest -- it helps when the candidates differ (sessions 1 and 3: 5-7 of 13 buffers fast)
    and costs 0.1-0.2 s when they do not; nothing happens in per-frame calls any more.  (b) K1 itself got what the replay showed
    to help on EVERY buffer: 4 waves per workgroup on adjacent pixel blocks (`k1_4w` / `rp_4w` columns: -1.2 ... -1.5 us per frame, slow
    and fast alike).  A kernel-side remedy for the slow mode does not exist: a plain streaming write has it.
@@ -192,6 +192,29 @@ Two halves allocated S GiB apart (spacer allocated between them, released afterw
 ```
 %s
 ```
+
+## 5. Other kinds of device memory as candidates (sessions 11-13, a second box)
+
+`fine` = `hipExtMallocWithFlags(hipDeviceMallocFinegrained)`, `uncached` = `hipDeviceMallocUncached`; columns: the real kernel (4 waves per
+workgroup), the store-stream replay, plain streaming write and read of the buffer, us per 4K frame.  Uncached memory takes streaming
+writes faster than cached memory of the same placement (18.2-18.4 us = 7.2-7.3 TB/s where the best cached buffers reach 18.8-19.0;
+20-23 where a cached buffer in one class needs 24) and reads as fast; but it is a draw like the others (7 of 9 fast in session 13, where
+`hipMalloc` had 7 of 9 and the chunk mappings 0 of 9 -- the reverse of session 1):
+
+```
+%s
+```
+
+The library with one kind forced (no choice) and with the choice among the kinds, alternating processes (`bench.py`; session 12; the rows
+`uncached` of this session ran chunk-mapped -- the switch did not reach one-candidate contexts yet --; `best-of4` = chunk-mapped, hipMalloc,
+uncached, chunk-mapped), then uncached only / best of four uncached (session 13):
+
+```
+%s
+%s
+```
+
+The default since then: six candidates, two of each kind.
 """
 
 zones = rd("r5s4/zones.txt").split("\n")
@@ -210,6 +233,9 @@ out = doc % (first_table("r5s1/stream.txt", 13), corr_lines("r5s1/stream.txt"),
              "\n".join(zones[:36]), cls, pair,
              rd("r5s3/regions.txt", 15),
              "\n".join(l for l in rd("r5s6_call.log").split("\n") if not l.startswith("[gpurun]")),
-             rd("r5s7/spread.txt"))
+             rd("r5s7/spread.txt"),
+             "\n".join(l for l in rd("r5s13_call.log").split("\n") if l.startswith("==") or (l[:1].isdigit() and len(l.split()) == 6) or l.startswith("buf kind")),
+             rd("r5s12/kinds.txt"),
+             "\n".join(l for l in rd("r5s13_call.log").split("\n") if l.startswith("uncached ")))
 open(os.path.join(R, "profiles", "r05_k1_mode.md"), "w").write(out)
 print("written", len(out))
