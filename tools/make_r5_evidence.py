@@ -215,6 +215,35 @@ uncached, chunk-mapped), then uncached only / best of four uncached (session 13)
 ```
 
 The default since then: six candidates, two of each kind.
+
+## 6. Both classes ARE within reach of one process -- and a level 0 assembled from them on purpose (sessions 15, 16, 19)
+
+Pairwise: first halves of buffers i and j (12 candidates of 8 GB, four kinds, one process) written at once, TB/s; diagonal = buffer i alone.
+The buffers split into two groups in every process; any two of different groups reach 6.9-7.3 TB/s together (session 15, process 1 of 3):
+
+```
+%s
+```
+
+Built on that (`tools/experiments/patches/r05_balance_levels_across_memory_classes.patch`): at context creation, probe the write rate of
+level 0; if it lies in one class, allocate further chunk mappings behind other allocations until one writes fast TOGETHER with it, map the
+32 MB chunks of the two alternately into level 0's range (no kernel sees a difference), rebuild levels 1-2 from the chunks left over.
+Session 16, three processes in a row: a mapping of the other class after ONE further allocation every time, whole-buffer write rate 5.6-6.0
+-> 6.5-6.6 TB/s, K1 30.9-31.3 us, creation 66-83 ms (best of six: 118-128 ms, K1 31.0-33.0):
+
+```
+%s
+```
+
+Session 19, the same box an hour later: every chunk mapping within four tries was dominated by the SAME class as the first (level 0 as
+allocated 5.8-6.2 TB/s, no pair above 1.1 x that), the search fell through to the best of six candidates (which found `hipMalloc` buffers
+at 68 us as it does without the search) -- after 64-128 GB of allocations whose release made the following ones wait: 4.5 s for the
+first call.  Chunk mappings alone do not reach both classes reliably; the candidates of three kinds do more often, at a bounded price.
+The search is not in the product.
+
+```
+%s
+```
 """
 
 zones = rd("r5s4/zones.txt").split("\n")
@@ -236,6 +265,9 @@ out = doc % (first_table("r5s1/stream.txt", 13), corr_lines("r5s1/stream.txt"),
              rd("r5s7/spread.txt"),
              "\n".join(l for l in rd("r5s13_call.log").split("\n") if l.startswith("==") or (l[:1].isdigit() and len(l.split()) == 6) or l.startswith("buf kind")),
              rd("r5s12/kinds.txt"),
-             "\n".join(l for l in rd("r5s13_call.log").split("\n") if l.startswith("uncached ")))
+             "\n".join(l for l in rd("r5s13_call.log").split("\n") if l.startswith("uncached ")),
+             "\n".join(rd("r5s15_call.log").split("\n")[5:19]),
+             rd("r5s16/balance.txt", cut=330),
+             "\n".join(l[:330] for l in rd("r5s19/ab.txt").split("\n") if l.startswith("4K") or l.startswith("fvvdp: level write")))
 open(os.path.join(R, "profiles", "r05_k1_mode.md"), "w").write(out)
 print("written", len(out))

@@ -525,6 +525,27 @@ int main(int argc, char** argv) {
         }
         if (rnd == 0 && !pmc) printf("-- second round, same buffers\n");
     }
+    if (!pmc) {
+        // Which buffers differ in class?  Streaming write into the first half of buffer i and the first half of buffer j at once
+        // (3.98 GB each) [TB/s]; the diagonal is the whole buffer i.  Two slow buffers that reach 7 TB/s together are of different classes:
+        // a level 0 with its even frames in one and its odd frames in the other would be the fast mode.
+        const size_t half4 = (size_t)NOUT * HW / 2;
+        printf("pairwise streaming-write rate [TB/s], first halves of buffers i and j together (diagonal: buffer i alone, whole)\n     ");
+        for (size_t j = 0; j < bufs.size(); ++j) printf(" %5zu", j);
+        printf("\n");
+        for (size_t i = 0; i < bufs.size(); ++i) {
+            printf("%-2zu %-3.3s", i, bufs[i].kind.c_str());
+            for (size_t j = 0; j < bufs.size(); ++j) {
+                auto f = [&] {
+                    if (i == j) hipLaunchKernelGGL(stream_write, dim3(32768), dim3(256), 0, 0, (float4*)bufs[i].ptr, 2 * half4, 1.0f);
+                    else hipLaunchKernelGGL(stream_write2, dim3(32768), dim3(256), 0, 0, (float4*)bufs[i].ptr, (float4*)bufs[j].ptr, half4, 1.0f);
+                };
+                f();
+                printf(" %5.2f", 2.0 * half4 * 16.0 / time_us(f, 3) / 1e6);
+            }
+            printf("\n"); fflush(stdout);
+        }
+    }
     // the remapped real kernels write the same bits as the real kernel
     if (!pmc) {
         double ref = 0.0;
