@@ -240,3 +240,24 @@ def test_band2_tickets_change_no_bits(monkeypatch, H, W, N):
             out[t] = np.stack(res)
         assert np.array_equal(out["0"], out["1"]), (H, W, N, kr)
         assert np.array_equal(out["1"][0], out["1"][2])
+
+
+@pytest.mark.parametrize("H,W,N", [(67, 119, 4), (66, 118, None), (131, 219, 3), (135, 243, None), (301, 2605, 2), (70, 1002, 3), (73, 333, 5)])
+def test_clamp_free_variant_bit_identity_on_odd_sizes_and_ragged_widths(monkeypatch, capfd, H, W, N):
+    """band2_kernel<P, true> (no clamps) against <P, false> on odd x odd frames and on widths that are not a multiple of the
+    strip pitch (108 level-A columns), forced onto small frames; every halo / invalid lane must stay inside the proven range too:
+    bit-identical, and the clamp-free variant really ran."""
+    import fovvideovdp_amd as fv
+    test, ref = _pair(H, W, 5 * H + W, N)
+    kw = dict(dim_order="HW") if N is None else dict(dim_order="FHW", frames_per_second=30)
+    monkeypatch.setenv("FVVDP_BAND_FUSE", "1")
+    monkeypatch.setenv("FVVDP_DEBUG_VARIANT", "1")
+    out = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("FVVDP_BAND_INRANGE", mode)
+        capfd.readouterr()
+        q, st = fv.fvvdp(display_name="standard_4k").predict(test, ref, **kw)
+        err = capfd.readouterr().err
+        out[mode] = (float(q), st["Q_per_ch"].copy(), "true>" in err, "band2_kernel<" in err)
+    assert out["1"][3] and out["1"][2] and not out["0"][2], (H, W, N)
+    assert out["1"][0] == out["0"][0] and np.array_equal(out["1"][1], out["0"][1]), (H, W, N)

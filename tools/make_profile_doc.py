@@ -94,8 +94,11 @@ def quoted_figures():
         if "temporal_vec_kernel" in label:
             b = k1["bytes_per_launch"]
             n = k1["frames_per_launch"]
-            out.append("* `%s`: %.1f MB per frame; rocprof AVERAGE %.1f us per %d frames = %.1f us per frame = %.2f TB/s = %.3f; unprofiled HIP events %.2f us per frame = %.4f" % (
-                label.strip("`"), b / n / 1e6, avg, n, avg / n, b / avg / 1e6, b / avg / 1e6 / 8.0, g["temporal_us_per_frame_median"], k1["frac"]))
+            out.append("* `%s`: %.1f MB per frame; %d launches, rocprof AVERAGE %.1f us per %d frames = %.1f us per frame = %.2f TB/s = %.3f (the average includes the 18 launches "
+                       "of the level-0 choice at context creation: six candidate buffers, slow ones among them, first touch included); rocprof MEDIAN %.1f us = %.1f us per frame = %.3f; "
+                       "unprofiled HIP events %.2f us per frame = %.4f" % (
+                label.strip("`"), b / n / 1e6, calls, avg, n, avg / n, b / avg / 1e6, b / avg / 1e6 / 8.0, med, med / n, b / med / 1e6 / 8.0,
+                g["temporal_us_per_frame_median"], k1["frac"]))
     if r.get("traffic"):
         out.append("* real traffic of the dominant kernel: %.2f GB per launch = %.3f of the algorithmic bytes; %.2f TB/s = %.3f of the peak" % (
             r["traffic"] / 1e9, r["traffic_over_algorithmic"], r["achieved_traffic"] / 1e3, r["frac_traffic"]))
