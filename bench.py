@@ -209,11 +209,16 @@ def main():
         cs_ = (C.c_int64 * 3)()
         nat.check(nat.lib().fvvdp_ctx_alloc_info(ctx.handle, C.byref(st_), C.byref(cm_), us_, 8, C.byref(nt_), C.byref(kept_)))
         nat.check(nat.lib().fvvdp_ctx_call_stats(ctx.handle, cs_))
+        kinds = {0: "hipMalloc", 1: "virtual-memory API, physical chunks of %s MB" % os.environ.get("FVVDP_VMM_CHUNK_MB", "32")}
+        two = cm_.value >= 100
         extra["level0_alloc"] = {
-            "in_use": {0: "hipMalloc", 1: "virtual-memory API, physical chunks of %s MB" % os.environ.get("FVVDP_VMM_CHUNK_MB", "32"),
-                       2: "uncached device memory (hipExtMallocWithFlags, hipDeviceMallocUncached)"}.get(cm_.value, str(cm_.value)),
-            # the context timed the temporal kernel + pyramid pass on these candidates inside fvvdp_ctx_create and kept the fastest
-            "candidates_us_per_frame": [round(us_[k], 2) for k in range(nt_.value)], "kept_index": kept_.value, "state": st_.value,
+            # level 0 lives in two ranges (even / odd frame slots) that fvvdp_ctx_create chose among half-size candidates: the pair that a
+            # streaming-write probe wrote fastest at once, i.e. two ranges of different classes of the box's physical memory where there are any
+            "in_use": ("even frame slots: %s; odd frame slots: %s" % (kinds.get(cm_.value % 10), kinds.get((cm_.value // 10) % 10))) if two
+                      else kinds.get(cm_.value, str(cm_.value)),
+            "half_size_candidates": nt_.value, "kept_indices": [kept_.value % 8, kept_.value // 8] if kept_.value >= 0 else None,
+            "pair_write_rate_tbs": {"kept": round(us_[1], 2), "lowest": round(us_[2], 2)} if nt_.value else None,
+            "temporal_plus_pyramid_us_per_frame_at_creation": round(us_[0], 2) if nt_.value else None, "state": st_.value,
             "per_frame_calls": {"host_syncs": int(cs_[0]), "allocations": int(cs_[1]), "frees": int(cs_[2])},
             "first_step_ms_incl_context_creation": round(t_first * 1e3, 1) if args.warmup > 0 else None,
             "evidence": "profiles/r05_k1_mode.md"}

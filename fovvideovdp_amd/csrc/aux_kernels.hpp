@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void heat_level_kernel(const HeatArgs a) {
 //   colour_map_kernel    per pixel: tone curve look-up x colour-map look-up -> fp16, planar [3][n][H][W]
 #define COLOUR_BINS 1024
 struct ColourArgs {
-    const float* ctx;        // level 0: [n][HW][P]
+    L0Addr ctx;              // level 0: frame f at l0_frame(ctx, f), [HW][P]
     int P;
     unsigned int HW;
     unsigned int* range;     // [2][range_stride]: bit patterns of the smallest positive y / the largest y of a frame
@@ -150,7 +150,7 @@ struct ColourArgs {
 
 __global__ __launch_bounds__(256) void colour_range_kernel(const ColourArgs a) {
     const int f = blockIdx.y;
-    const float* y = a.ctx + (size_t)f * a.HW * a.P;
+    const float* y = l0_frame(a.ctx, f);
     unsigned int mn = 0x7F800000u, mx = 0u;          // +inf, 0: positive floats order like their bit patterns
     for (unsigned int p = blockIdx.x * 256 + threadIdx.x; p < a.HW; p += gridDim.x * 256) {
         const float v = y[(size_t)p * a.P];
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void colour_hist_kernel(const ColourArgs a) {
     __syncthreads();
     const ColourFrame c = colour_frame(a, f);
     const float scale = (float)COLOUR_BINS / fmaxf(c.span, 1e-30f);
-    const float* y = a.ctx + (size_t)f * a.HW * a.P;
+    const float* y = l0_frame(a.ctx, f);
     for (unsigned int p = blockIdx.x * 256 + threadIdx.x; p < a.HW; p += gridDim.x * 256) {
         const float b = logf(fmaxf(y[(size_t)p * a.P], c.floor_y));
         int bin = (int)((b - c.b_min) * scale);       // torch.histc: last bin closed
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(256) void colour_map_kernel(const ColourArgs a) {
     __syncthreads();
     const bool flat = c.span < a.dr;                  // low dynamic range: linear mapping (vis_tonemap :38-39)
     const float inv_step = (float)(COLOUR_BINS - 1) / fmaxf(c.span, 1e-30f);
-    const float* y = a.ctx + (size_t)f * a.HW * a.P;
+    const float* y = l0_frame(a.ctx, f);
     const float* dm = a.dmap + (size_t)f * a.HW;
     for (unsigned int p = blockIdx.x * 256 + threadIdx.x; p < a.HW; p += gridDim.x * 256) {
         const float b = logf(fmaxf(y[(size_t)p * a.P], c.floor_y));
@@ -291,5 +291,17 @@ __global__ __launch_bounds__(256) void hash_fill_kernel(unsigned int* __restrict
         unsigned int x = (unsigned int)i * 2654435761u + seed;
         x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
         p[i] = x;
+    }
+}
+
+// Streaming write of n4 float4 into each of q0 and q1 at once (even workgroups -> q0, odd -> q1): the probe of choose_level0.  Two ranges
+// of different classes of physical memory take ~7 TB/s together, two of the same class ~5.5.  Grid-stride, 16 B per lane, non-temporal.
+__global__ __launch_bounds__(256) void stream_write_probe_kernel(float4* __restrict__ q0, float4* __restrict__ q1, size_t n4, float v) {
+    float4* q = (blockIdx.x & 1) ? q1 : q0;
+    size_t i = (size_t)(blockIdx.x >> 1) * 1024 + threadIdx.x;
+    const size_t stride = (size_t)(gridDim.x >> 1) * 1024;
+    for (; i + 768 < n4; i += stride) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) __builtin_nontemporal_store(v4f{v, v + (float)u, v, v}, reinterpret_cast<v4f*>(q + i + u * 256));
     }
 }

@@ -30,7 +30,7 @@
 #endif
 
 struct Band2Args {
-    const float* Ga;        // level A [n][h][w][P]
+    L0Addr A;               // level A, frame f at l0_frame(A, f): [h][w][P] (level 0 may live in two ranges, device_common.hpp)
     float* Gc;              // level C [n][hc][wc][P]
     int w, h, wb, hb, wc, hc;
     int n_strips, n_chunks, kr;       // kr = level-C rows per chunk
@@ -146,7 +146,7 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
     const float fr = k_r ? 0.0f : (jeven ? 0.1f : 0.5f);
     const float fc = jeven ? (0.8f + (k_l ? 0.1f : 0.0f) + (k_r ? 0.1f : 0.0f)) : (k_r ? 1.0f : 0.5f);
 
-    const float* Ga = a.Ga + (size_t)frame * h * w * P;
+    const float* Ga = l0_frame(a.A, frame);
     float* Gc = a.Gc + (size_t)frame * hc * wc * P;
     const __amdgpu_buffer_rsrc_t Gc_rsrc = level_rsrc(Gc, (unsigned int)(hc * wc * P) * 4u);
 
@@ -155,7 +155,7 @@ __device__ __forceinline__ void band2_item(const Band2Args& a, const int strip, 
     // instruction goes into addressing (flat loads cost one 64-bit v_lshl_add_u64 each: 16 per loop iteration of a kernel
     // whose arithmetic is as long as its data flow).
 #if defined(BAND2_ABLATE_MEM)      // profiling ablation: every wave re-reads 8 rows of frame 0 (L2 hits), nothing is stored
-    const __amdgpu_buffer_rsrc_t Ga_rsrc = level_rsrc(const_cast<float*>(a.Ga), (unsigned int)(h * w * P) * 4u);
+    const __amdgpu_buffer_rsrc_t Ga_rsrc = level_rsrc(a.A.lo, (unsigned int)(h * w * P) * 4u);
 #else
     const __amdgpu_buffer_rsrc_t Ga_rsrc = level_rsrc(const_cast<float*>(Ga), (unsigned int)(h * w * P) * 4u);   // <= 133 MB per frame
 #endif

@@ -129,7 +129,7 @@ __device__ __forceinline__ void dpp_expand_taps(v2f e, float el, float er, float
 #endif
 
 struct BandArgs {
-    const float* Gf;        // fine level   [n][h][w][P]
+    L0Addr F;               // fine level, frame f at l0_frame(F, f): [h][w][P] (level 0 may live in two ranges, device_common.hpp)
     float* Gc;              // coarse level [n][hc][wc][P]
     int w, h, wc, hc;
     int n_strips, n_chunks, cr;
@@ -298,14 +298,14 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
     const float orr = at_r ? 0.0f : 0.5f;
     const float oc = at_r ? 1.0f : 0.5f;
 
-    const float* Gf = a.Gf + (size_t)frame * h * w * P;
+    const float* Gf = l0_frame(a.F, frame);
     float* Gc = a.Gc + (size_t)frame * hc * wc * P;
     const __amdgpu_buffer_rsrc_t Gc_rsrc = level_rsrc(Gc, (unsigned int)(hc * wc * P) * 4u);     // <= 33 MB per frame
 
     // rows of the fine level through a buffer resource: scalar row offset + loop-invariant lane offset, no vector address
     // arithmetic (see ld_px_buf)
 #if defined(BAND_ABLATE_MEM)       // profiling ablation: every wave re-reads 8 rows of frame 0 (L2 hits), nothing is stored
-    const __amdgpu_buffer_rsrc_t Gf_rsrc = level_rsrc(const_cast<float*>(a.Gf), (unsigned int)(h * w * P) * 4u);
+    const __amdgpu_buffer_rsrc_t Gf_rsrc = level_rsrc(a.F.lo, (unsigned int)(h * w * P) * 4u);
 #else
     const __amdgpu_buffer_rsrc_t Gf_rsrc = level_rsrc(const_cast<float*>(Gf), (unsigned int)(h * w * P) * 4u);    // <= 133 MB per frame
 #endif

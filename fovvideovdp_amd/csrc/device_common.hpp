@@ -49,6 +49,20 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t level_rsrc(float* base, unsigned int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
 }
+// Level 0 of a context lives in ONE range, or in TWO: its even frame slots in one allocation and its odd slots in another, so that the
+// temporal kernel's writes fall on both classes of the box's physical memory at any time (place_level0 in fvvdp_hip.hip,
+// profiles/r05_k1_mode.md).  One formula serves both: slot s sits at (s odd ? hi : lo) + (s >> 1) * half_stride floats; a single range
+// is hi = lo + one frame, half_stride = two frames.  slot0 = absolute slot of the launch's frame 0.
+struct L0Addr {
+    float* lo;
+    float* hi;
+    size_t half_stride;
+    int slot0;
+};
+__device__ __forceinline__ float* l0_frame(const L0Addr& a, int f) {
+    const int s = a.slot0 + f;
+    return ((s & 1) ? a.hi : a.lo) + (size_t)(s >> 1) * a.half_stride;
+}
 __device__ __forceinline__ v2f splat(float s) { return v2f{s, s}; }
 __device__ __forceinline__ v2f pfma(v2f a, float s, v2f c) { return __builtin_elementwise_fma(a, splat(s), c); }
 // clamp to [lo, hi] as one v_med3_f32 per component (fminf(fmaxf()) costs three: IEEE max first canonicalises its input)

@@ -56,13 +56,13 @@ extern "C" const char* fvvdp_last_error(void) { return g_err; }
 // none of them changes results beyond the grouping of fp32 partial sums.
 struct CtxEnv {
     bool alloc_malloc = false;    // FVVDP_ALLOC=malloc: every scratch buffer from hipMalloc (default: large levels mapped from chunks)
-    bool alloc_uncached = false;  // FVVDP_ALLOC=uncached: level 0 (and every level-0 candidate) as uncached device memory
     size_t vmm_chunk = 0;         // FVVDP_VMM_CHUNK_MB: chunk size of the >= 256 MB levels (default 32 MB)
     int probe_n = -1;             // FVVDP_PLACEMENT_PROBE=n: level-0 candidates timed at creation (0 / 1 = none; default 6)
     bool inrange_off = false;     // FVVDP_BAND_INRANGE=0: always the pyramid kernels with clamps
     int fuse_mode = -1;           // FVVDP_BAND_FUSE=0 / 1: two-level pyramid kernel never / wherever valid (default: large levels)
     int band_cr = 0, band2_kr = 0, band2_kr2 = -1, band2_wpb = 0;   // FVVDP_BAND_CR, FVVDP_BAND2_KR, _KR2, _WPB: work decomposition overrides
     int k1_ticket = -1;           // FVVDP_K1_TICKET=0 / 1: temporal kernel (16-slot ring) without / with its block counter
+    int level0_split = -1;        // FVVDP_LEVEL0_SPLIT=1: level 0 in two ranges for ANY context, no choice among candidates (tests)
     int band2_ticket = -1;        // FVVDP_BAND2_TICKET=0 / 1: two-level pyramid kernel with the static split of work / per-XCD counters
     bool temporal_scalar = false; // FVVDP_TEMPORAL_SCALAR=1: the per-pixel temporal kernels (fallbacks for unaligned sizes)
     bool fov_no_rhomap = false;   // FVVDP_FOV_NO_RHOMAP=1: foveated kernels evaluate the rho coordinate per pixel
@@ -71,7 +71,7 @@ struct CtxEnv {
 static CtxEnv read_env() {
     CtxEnv e;
     auto num = [](const char* name, int dflt) { const char* v = getenv(name); return (v && v[0]) ? atoi(v) : dflt; };
-    if (const char* v = getenv("FVVDP_ALLOC")) { e.alloc_malloc = strcmp(v, "malloc") == 0; e.alloc_uncached = strcmp(v, "uncached") == 0; }
+    if (const char* v = getenv("FVVDP_ALLOC")) e.alloc_malloc = strcmp(v, "malloc") == 0;
     e.vmm_chunk = (size_t)(num("FVVDP_VMM_CHUNK_MB", 0) > 0 ? num("FVVDP_VMM_CHUNK_MB", 0) : 0) << 20;
     e.probe_n = num("FVVDP_PLACEMENT_PROBE", -1);
     if (const char* v = getenv("FVVDP_BAND_INRANGE")) e.inrange_off = v[0] == '0';
@@ -82,6 +82,7 @@ static CtxEnv read_env() {
     e.band2_wpb = num("FVVDP_BAND2_WPB", 0);
     if (const char* v = getenv("FVVDP_K1_TICKET")) e.k1_ticket = v[0] != '0' ? 1 : 0;
     if (const char* v = getenv("FVVDP_BAND2_TICKET")) e.band2_ticket = v[0] != '0' ? 1 : 0;
+    if (const char* v = getenv("FVVDP_LEVEL0_SPLIT")) e.level0_split = v[0] != '0' ? 1 : 0;
     e.temporal_scalar = getenv("FVVDP_TEMPORAL_SCALAR") != nullptr;
     e.fov_no_rhomap = getenv("FVVDP_FOV_NO_RHOMAP") != nullptr;
     e.debug_variant = getenv("FVVDP_DEBUG_VARIANT") != nullptr;
@@ -100,6 +101,7 @@ struct fvvdp_ctx {
     double rho_band[FVVDP_MAX_BANDS + 1]{};
     int lw[FVVDP_MAX_BANDS + 1]{}, lh[FVVDP_MAX_BANDS + 1]{};
     float* level[FVVDP_MAX_BANDS + 1]{};
+    float* level0_hi = nullptr;   // != nullptr: level 0 lives in TWO ranges -- even frame slots in level[0], odd slots here (place_level0)
     // choice of the level-0 buffer at creation (choose_level0): sel_n candidates timed, sel_us[k] = temporal kernel + pyramid pass
     // in us per frame on candidate k, sel_kept = the one in use (-1: no comparison); sel_phase 9 = settled (the only state a
     // caller can observe: the comparison runs inside fvvdp_ctx_create)
@@ -107,7 +109,8 @@ struct fvvdp_ctx {
     int sel_n = 0;
     int sel_kept = -1;
     float sel_us[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    int level0_kind = 0;          // 0 hipMalloc, 1 mapped from physical chunks, 2 uncached device memory (hipDeviceMallocUncached)
+    int level0_kind = 0;          // 0 hipMalloc, 1 mapped from physical chunks
+    int level0_kind_hi = -1;      // the same for the range of the odd slots (-1: level 0 is one range)
     // host synchronisations / allocations / frees made INSIDE per-frame entry points since creation (fvvdp_ctx_call_stats): the
     // standard video path makes none (SURVEY 8(b) "allocated once in ctx_create")
     long long n_sync = 0, n_alloc = 0, n_free = 0;
@@ -194,6 +197,17 @@ static int dev_alloc(fvvdp_ctx* c, T** p, size_t count) {
     c->scratch += bytes;
     if (c->created) c->n_alloc += 1;               // an allocation inside a per-frame call (first use of an optional path)
     return FVVDP_OK;
+}
+
+// where frame slot `slot0 + f` of pyramid level L lies (device_common.hpp, L0Addr): level 0 in one or two ranges, the others in one
+static L0Addr level_addr(const fvvdp_ctx* c, int L, int slot0) {
+    L0Addr a;
+    const size_t fr = (size_t)c->lw[L] * c->lh[L] * c->P;
+    a.lo = c->level[L];
+    a.slot0 = slot0;
+    if (L == 0 && c->level0_hi) { a.hi = c->level0_hi; a.half_stride = fr; }
+    else { a.hi = c->level[L] + fr; a.half_stride = 2 * fr; }
+    return a;
 }
 
 struct Timed {
@@ -426,6 +440,7 @@ extern "C" void fvvdp_ctx_destroy(fvvdp_ctx* c) {
     (void)hipDeviceSynchronize();                  // nothing may still read the scratch
     for (int i = 0; i <= FVVDP_MAX_BANDS; ++i)
         dev_free(c, c->level[i]);
+    dev_free(c, c->level0_hi);
     dev_free(c, c->partial);
     dev_free(c, c->d_ticket);
     if (c->csf) (void)hipFree(c->csf);
@@ -648,7 +663,7 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
         const int FL = fl <= 8 ? 8 : (fl <= 16 ? 16 : (fl <= 32 ? 32 : 64));
         const int max_out = T_MAX_IDX - (FL - 1);
         // output frames [t_begin, t_end) of this call into the level-0 buffer `level0`
-        auto run = [&](float* level0, int t_begin, int t_end) -> int {
+        auto run = [&](int t_begin, int t_end) -> int {
             for (int t0 = t_begin; t0 < t_end; t0 += max_out) {
                 const int nn = (t_end - t0) < max_out ? (t_end - t0) : max_out;
                 TemporalArgs a;
@@ -663,7 +678,7 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
                 if (C == 3) { a.w[0] = h_rgb2y[0]; a.w[1] = h_rgb2y[1]; a.w[2] = h_rgb2y[2]; } else { a.w[0] = 1.0f; }
                 a.n_out = nn;
                 a.fl = fl;
-                a.out = level0 + (size_t)(slot0 + t0) * HW * 4;
+                a.out = level_addr(c, 0, slot0 + t0);
                 a.oob = d_oob_flag;
                 for (int k = 0; k < fl; ++k) { a.taps2[k][0] = h_taps[k]; a.taps2[k][1] = h_taps[fl + k]; }
                 // virtual time of h_frame_idx: entry (fl-1+t) is the newest frame of output t; pad older history
@@ -699,7 +714,7 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
             return FVVDP_OK;
         };
         {
-            const int rc = run(c->level[0], 0, n_out);
+            const int rc = run(0, n_out);
             if (rc != FVVDP_OK) return rc;
         }
     } else if (c->P == 4 && fl > 32 && fl <= 64 && !h_frame_idx1 && !c->env.temporal_scalar &&
@@ -772,7 +787,7 @@ static int temporal_channels_core(fvvdp_ctx* c, const void* d_test, const void* 
         if (C == 3) { a.w[0] = h_rgb2y[0]; a.w[1] = h_rgb2y[1]; a.w[2] = h_rgb2y[2]; } else { a.w[0] = 1.0f; }
         a.n_out = n_out;
         a.fl = fl;
-        a.out = c->level[0] + (size_t)slot0 * HW * c->P;
+        a.out = level_addr(c, 0, slot0);
         a.oob = d_oob_flag;
         a.taps = c->d_taps;
         a.idx = c->d_idx;
@@ -926,7 +941,7 @@ extern "C" int fvvdp_temporal_channels_yuv(fvvdp_ctx* c, const void* d_test, con
         a.w[0] = h_rgb2y[0]; a.w[1] = h_rgb2y[1]; a.w[2] = h_rgb2y[2];
         a.n_out = nn;
         a.fl = fl;
-        a.out = c->level[0] + (size_t)(slot0 + t0) * c->W * c->H * 4;
+        a.out = level_addr(c, 0, slot0 + t0);
         a.oob = d_oob_flag;
         for (int k = 0; k < fl; ++k) { a.taps2[k][0] = h_taps[k]; a.taps2[k][1] = h_taps[fl + k]; }
         const int pad = FL - fl;
@@ -955,11 +970,11 @@ extern "C" int fvvdp_load_channels_planar(fvvdp_ctx* c, const float* d_R, int n,
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int HW = c->W * c->H;
     dim3 grid((HW + 255) / 256, n), block(256);
-    float* out = c->level[0] + (size_t)slot0 * HW * c->P;
+    const L0Addr out = level_addr(c, 0, slot0);
     luminance_slots(c, slot0, n);
     luminance_unknown(c);                            // the caller's own temporal channels
-    if (c->P == 4) hipLaunchKernelGGL((interleave_kernel<4>), grid, block, 0, st, d_R, out, HW, 1);
-    else hipLaunchKernelGGL((interleave_kernel<2>), grid, block, 0, st, d_R, out, HW, 1);
+    if (c->P == 4) hipLaunchKernelGGL((interleave_kernel<4>), grid, block, 0, st, const_cast<float*>(d_R), out, HW, 1);
+    else hipLaunchKernelGGL((interleave_kernel<2>), grid, block, 0, st, const_cast<float*>(d_R), out, HW, 1);
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;
 }
@@ -1020,8 +1035,8 @@ extern "C" int fvvdp_export_level(fvvdp_ctx* c, int level, int n, float* d_out, 
     hipStream_t st = reinterpret_cast<hipStream_t>(stream);
     const int HW = c->lw[level] * c->lh[level];
     dim3 grid((HW + 255) / 256, n), block(256);
-    if (c->P == 4) hipLaunchKernelGGL((interleave_kernel<4>), grid, block, 0, st, c->level[level], d_out, HW, 0);
-    else hipLaunchKernelGGL((interleave_kernel<2>), grid, block, 0, st, c->level[level], d_out, HW, 0);
+    if (c->P == 4) hipLaunchKernelGGL((interleave_kernel<4>), grid, block, 0, st, d_out, level_addr(c, level, 0), HW, 0);
+    else hipLaunchKernelGGL((interleave_kernel<2>), grid, block, 0, st, d_out, level_addr(c, level, 0), HW, 0);
     HIP_TRY(hipGetLastError());
     return FVVDP_OK;
 }
@@ -1210,7 +1225,7 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
             c->lw[b + 2] >= 2 && c->lh[b + 2] >= 2) {
             Band2Args a;
             memset(&a, 0, sizeof(a));
-            a.Ga = c->level[b] + (b == 0 ? (size_t)slot0 * c->lw[0] * c->lh[0] * c->P : (size_t)0);
+            a.A = level_addr(c, b, b == 0 ? slot0 : 0);
             a.Gc = c->level[b + 2];
             a.w = c->lw[b];
             a.h = c->lh[b];
@@ -1303,7 +1318,7 @@ static int bands_forward_core(fvvdp_ctx* c, int slot0, int n, float* d_Q, int q_
         }
         BandArgs a;
         memset(&a, 0, sizeof(a));
-        a.Gf = c->level[b] + (b == 0 ? (size_t)slot0 * c->lw[0] * c->lh[0] * c->P : (size_t)0);
+        a.F = level_addr(c, b, b == 0 ? slot0 : 0);
         a.Gc = c->level[b + 1];
         a.w = c->lw[b];
         a.h = c->lh[b];
@@ -1426,44 +1441,138 @@ extern "C" int fvvdp_bands_forward_pool(fvvdp_ctx* c, int n, float* d_Q, int q_s
     return bands_forward_core(c, 0, n, d_Q, q_stride, q_col0, h_fixation, geom, maps, pool, d_jod, stream);
 }
 
-// ---- choice of the level-0 buffer, at context creation ---------------------------------------------------------------------------
-// Where the 8 GB of a 4K x 60 level 0 lie physically decides how fast they can be WRITTEN: the temporal kernel runs at 31-33 or at
-// 36-38 us per 4K frame on the same clip, stable for the life of an allocation, and a kernel that only replays its store stream
-// (four 1 KiB runs per wave and frame, nothing read) shows the same two speeds on the same buffers (19 / 24.5 us); on the slow ones
-// the L2's write requests wait 6-20 times longer for DRAM credits (TCC_EA0_WRREQ_DRAM_CREDIT_STALL, TCC_TAG_STALL) --
-// profiles/r05_k1_mode.md, tools/microbench/k1_stream.hip.  Which allocations are slow differs by box (hipMalloc ranges mostly
-// slow and 32 MB-chunk mappings mostly fast on most boxes, the reverse on some), and the pyramid pass that READS the buffer tends
-// the other way by ~1 us.  Nothing in the kernels' control changes it, so the context draws: it times the temporal kernel + the
-// pyramid pass on N candidate buffers (default 6: chunk-mapped, hipMalloc, uncached, ...; FVVDP_PLACEMENT_PROBE=n, 0 = off) filled
-// from a synthetic uint8 clip and keeps the fastest.  All of it happens here, before the first user call: per-frame calls never
-// allocate, free or synchronise for it.  Results never depend on the buffer.  Video contexts whose level 0 holds >= 1 GiB only.
+// ---- placement of level 0, at context creation ------------------------------------------------------------------------------
+// profiles/r05_k1_mode.md: the memory of a box comes in two classes.  Streaming writes into ONE class top out at ~5.5 TB/s, into both at
+// once at 7.0 -- and that, not anything in the kernel, is the temporal kernel's slow and fast
+// mode (35-36 against 30-31 us per 4K frame).  An allocation of several GB lies in one class or across both as the driver's allocator
+// happens to stand, whatever the API; but among a handful of allocations of different kinds both classes turn up (12 buffers of one
+// process split cleanly in two groups, in each of three processes: section 6 of the file).  So level 0 of a large video context lives in
+// TWO ranges -- even frame slots in one, odd slots in the other (L0Addr, device_common.hpp: one address formula in every kernel that
+// touches level 0) -- and the two are CHOSEN: N half-size candidates (default 6: chunk-mapped and hipMalloc in
+// turn), every pair written at once by a streaming-write probe (4 ms per pair), the pair with the highest rate is kept, the
+// rest freed.  Two halves of different classes are the fast mode by construction; if every candidate lies in one class the best pair is
+// as good as any single buffer.  All of it happens here, before the first user call (~0.15 s, N x half a level 0 held for the moment);
+// per-frame calls never allocate, free or synchronise for it.  Results never depend on it.  Video contexts whose level 0 holds >= 1 GiB
+// (FVVDP_PLACEMENT_PROBE=n candidates, 0 / 1 = level 0 stays the single range it was allocated as; FVVDP_LEVEL0_SPLIT=1 splits any
+// context without probing: tests).
 static void choose_level0(fvvdp_ctx* c) {
     c->sel_phase = 9;
     c->level0_kind = vmm_owns(c, c->level[0]) ? 1 : 0;
     const int HW = c->W * c->H;
-    const size_t floats = (size_t)c->max_frames * HW * c->P;
-    const size_t bytes = floats * sizeof(float);
+    const size_t frame_floats = (size_t)HW * c->P;
+    const size_t bytes = (size_t)c->max_frames * frame_floats * sizeof(float);
+    const int half_frames = (c->max_frames + 1) / 2;
+    const size_t half_bytes = (size_t)half_frames * frame_floats * sizeof(float);
     int n_cand = c->env.probe_n < 0 ? 6 : c->env.probe_n;
     if (n_cand > 8) n_cand = 8;
-    if (c->P != 4 || bytes < ((size_t)1 << 30) || c->max_frames < 16 || (HW % 4) != 0) return;
-    if (c->env.alloc_uncached) {                             // FVVDP_ALLOC=uncached: the first buffer as well (A/B runs)
+    const bool eligible = c->P == 4 && bytes >= ((size_t)1 << 30) && c->max_frames >= 16 && (HW % 4) == 0;
+    auto alloc_kind = [&](int kind, size_t nbytes) -> float* {
         void* q = nullptr;
-        if (hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) == hipSuccess) {
-            float* old = c->level[0];
-            c->level[0] = reinterpret_cast<float*>(q);
-            c->level0_kind = 2;
-            if (vmm_owns(c, old)) vmm_free_one(c, old); else (void)hipFree(old);
-        } else (void)hipGetLastError();
+        const bool got = kind == 1 ? vmm_alloc(c, &q, nbytes) == FVVDP_OK : hipMalloc(&q, nbytes) == hipSuccess;
+        if (!got) { (void)hipGetLastError(); return nullptr; }
+        return reinterpret_cast<float*>(q);
+    };
+    auto free_any = [&](float* p) {
+        if (!p) return;
+        if (vmm_owns(c, p)) vmm_free_one(c, p); else (void)hipFree(p);
+    };
+    if (c->env.level0_split == 1 && !(eligible && n_cand >= 2)) {
+        // tests: two ranges without a choice (any context; the range the context came with keeps the even slots)
+        c->level0_hi = alloc_kind(0, half_bytes);
+        c->level0_kind_hi = c->level0_hi ? 0 : -1;
+        return;
     }
-    if (n_cand < 2) return;
+    if (!eligible || n_cand < 2) return;
+    {   // room for the candidates next to a margin (the full-size range the context came with is given back first)
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); return; }
+        while (n_cand >= 2 && free_b + bytes < (size_t)n_cand * half_bytes + ((size_t)3 << 30)) --n_cand;
+        if (n_cand < 2) return;
+    }
+    hipStream_t st = nullptr;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess || hipEventCreate(&ev[0]) != hipSuccess || hipEventCreate(&ev[1]) != hipSuccess) {
+        (void)hipGetLastError();
+        if (st) (void)hipStreamDestroy(st);
+        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
+        return;
+    }
+    // candidates: halves of level 0 (the first one of the kind the context's allocation mode asks for)
+    (void)hipDeviceSynchronize();
+    free_any(c->level[0]);
+    c->level[0] = nullptr;
+    float* cand[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    int kind[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int n_got = 0;
+    for (int k = 0; k < n_cand; ++k) {
+        const int kd = c->env.alloc_malloc ? 0 : (k % 2 == 0 ? 1 : 0);
+        float* q = alloc_kind(kd, half_bytes);
+        if (!q) break;
+        cand[n_got] = q;
+        kind[n_got] = kd;
+        ++n_got;
+    }
+    auto pair_rate = [&](float* p0, float* p1) -> float {                    // TB/s of writing both halves at once; 0 on failure
+        const size_t n4 = half_bytes / 16;
+        float best = 0.0f;
+        for (int rep = 0; rep < 3; ++rep) {
+            if (rep) (void)hipEventRecord(ev[0], st);
+            hipLaunchKernelGGL(stream_write_probe_kernel, dim3(32768), dim3(256), 0, st, reinterpret_cast<float4*>(p0), reinterpret_cast<float4*>(p1), n4, 1.0f);
+            if (!rep) continue;                                              // first touch / warm-up, untimed
+            float ms = 0.0f;
+            if (hipEventRecord(ev[1], st) != hipSuccess || hipEventSynchronize(ev[1]) != hipSuccess ||
+                hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess || !(ms > 0.0f)) { (void)hipGetLastError(); return 0.0f; }
+            const float r = (float)(2.0 * (double)half_bytes / (ms * 1e-3) / 1e12);
+            best = r > best ? r : best;
+        }
+        return best;
+    };
+    int bi = 0, bj = n_got > 1 ? 1 : 0;
+    float r_best = 0.0f, r_worst = 0.0f;
+    if (n_got >= 2) {
+        for (int i = 0; i < n_got; ++i)
+            for (int j = i + 1; j < n_got; ++j) {
+                const float r = pair_rate(cand[i], cand[j]);
+                if (r > r_best) { r_best = r; bi = i; bj = j; }
+                if (r > 0.0f && (r_worst == 0.0f || r < r_worst)) r_worst = r;
+            }
+    }
+    (void)hipStreamSynchronize(st);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    (void)hipStreamDestroy(st);
+    (void)hipGetLastError();
+    if (n_got >= 2) {
+        c->level[0] = cand[bi];
+        c->level0_hi = cand[bj];
+        c->level0_kind = kind[bi];
+        c->level0_kind_hi = kind[bj];
+        for (int k = 0; k < n_got; ++k)
+            if (k != bi && k != bj) free_any(cand[k]);
+    } else {
+        // not even two halves: back to one range
+        for (int k = 0; k < n_got; ++k) free_any(cand[k]);
+        float* q = alloc_kind(c->env.alloc_malloc ? 0 : 1, bytes);
+        if (!q) q = alloc_kind(0, bytes);
+        c->level[0] = q;
+        c->level0_kind = vmm_owns(c, q) ? 1 : 0;
+        return;
+    }
+    c->sel_n = n_got;
+    c->sel_kept = bi + 8 * bj;
+    c->sel_us[1] = r_best;
+    c->sel_us[2] = r_worst;
+    if (c->env.debug_variant)
+        fprintf(stderr, "fvvdp: level 0 in two ranges: %d half-size candidates, pairs written at once at %.2f ... %.2f TB/s -> kept #%d (kind %d) + #%d (kind %d)\n",
+                n_got, r_worst, r_best, bi, kind[bi], bj, kind[bj]);
+    // for the record: the temporal kernel + the pyramid pass on the chosen layout, a synthetic uint8 clip as input (us per frame)
     const int SRC_FRAMES = 16, FL = 8, n = c->max_frames < 128 ? c->max_frames : 128;
     const size_t src_bytes = (size_t)SRC_FRAMES * 3 * HW;
     unsigned char* src[2] = {nullptr, nullptr};
     float* d_lut = nullptr;
     float* d_q = nullptr;
     int32_t* d_oob = nullptr;
-    hipStream_t st = nullptr;
-    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t st2 = nullptr;
+    hipEvent_t ev2[2] = {nullptr, nullptr};
     const bool timing = c->timing, inrange_off = c->env.inrange_off;
     auto cleanup = [&]() {
         (void)hipDeviceSynchronize();
@@ -1471,29 +1580,25 @@ static void choose_level0(fvvdp_ctx* c) {
         if (d_lut) (void)hipFree(d_lut);
         if (d_q) (void)hipFree(d_q);
         if (d_oob) (void)hipFree(d_oob);
-        for (auto& e : ev) if (e) (void)hipEventDestroy(e);
-        if (st) (void)hipStreamDestroy(st);
+        for (auto& e : ev2) if (e) (void)hipEventDestroy(e);
+        if (st2) (void)hipStreamDestroy(st2);
         (void)hipGetLastError();
         c->timing = timing;
         c->env.inrange_off = inrange_off;
         c->csf_set = false;                                   // the caller's tables come with fvvdp_ctx_set_csf_1d / _3d
         c->lum_state = 0; c->lum_known = false; c->lum_top = 0;
     };
-    {   // room for one more candidate next to the one in use, the synthetic clip and a margin
-        size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || free_b < bytes + 2 * src_bytes + ((size_t)2 << 30)) { (void)hipGetLastError(); return; }
-    }
-    bool ok = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&ev[0]) == hipSuccess &&
-              hipEventCreate(&ev[1]) == hipSuccess && hipMalloc((void**)&src[0], src_bytes) == hipSuccess &&
+    bool ok = hipStreamCreateWithFlags(&st2, hipStreamNonBlocking) == hipSuccess && hipEventCreate(&ev2[0]) == hipSuccess &&
+              hipEventCreate(&ev2[1]) == hipSuccess && hipMalloc((void**)&src[0], src_bytes) == hipSuccess &&
               hipMalloc((void**)&src[1], src_bytes) == hipSuccess && hipMalloc((void**)&d_lut, 256 * sizeof(float)) == hipSuccess &&
               hipMalloc((void**)&d_q, (size_t)c->n_bands * 2 * n * sizeof(float)) == hipSuccess && hipMalloc((void**)&d_oob, 64) == hipSuccess;
     if (!ok) { cleanup(); return; }
     float h_lut[256];
     for (int i = 0; i < 256; ++i) h_lut[i] = 0.6f + 199.4f * powf((float)i / 255.0f, 2.2f);          // an sRGB-like display, 0.6 ... 200 cd/m^2
-    ok = hipMemcpy(d_lut, h_lut, sizeof(h_lut), hipMemcpyHostToDevice) == hipSuccess && hipMemsetAsync(d_oob, 0, 64, st) == hipSuccess &&
-         hipMemsetAsync(c->csf, 0, (size_t)c->n_bands * FVVDP_LUT_N * sizeof(float4), st) == hipSuccess;   // a flat sensitivity table
+    ok = hipMemcpy(d_lut, h_lut, sizeof(h_lut), hipMemcpyHostToDevice) == hipSuccess && hipMemsetAsync(d_oob, 0, 64, st2) == hipSuccess &&
+         hipMemsetAsync(c->csf, 0, (size_t)c->n_bands * FVVDP_LUT_N * sizeof(float4), st2) == hipSuccess;   // a flat sensitivity table
     for (int s = 0; s < 2 && ok; ++s)
-        hipLaunchKernelGGL(hash_fill_kernel, dim3(4096), dim3(256), 0, st, reinterpret_cast<unsigned int*>(src[s]), src_bytes / 4, 0x9E3779B9u * (unsigned int)(s + 1));
+        hipLaunchKernelGGL(hash_fill_kernel, dim3(4096), dim3(256), 0, st2, reinterpret_cast<unsigned int*>(src[s]), src_bytes / 4, 0x9E3779B9u * (unsigned int)(s + 1));
     if (!ok) { cleanup(); return; }
     c->timing = false;
     c->env.inrange_off = true;                                // the variant with clamps: defined for any table and any data
@@ -1512,62 +1617,20 @@ static void choose_level0(fvvdp_ctx* c) {
     for (size_t u = 0; u < idx.size(); ++u) idx[u] = (int32_t)(u % SRC_FRAMES);
     auto one_pass = [&]() -> bool {
         return temporal_channels_core(c, src[0], src[1], FVVDP_U8, 3, (size_t)HW, (size_t)3 * HW, &e, rgb2y, idx.data(), nullptr, taps, FL, n, 0,
-                                      d_oob, st) == FVVDP_OK &&
-               bands_forward_core(c, 0, n, d_q, n, 0, nullptr, nullptr, nullptr, nullptr, nullptr, st) == FVVDP_OK;
+                                      d_oob, st2) == FVVDP_OK &&
+               bands_forward_core(c, 0, n, d_q, n, 0, nullptr, nullptr, nullptr, nullptr, nullptr, st2) == FVVDP_OK;
     };
-    auto time_current = [&](float& us) -> bool {
-        if (!one_pass()) return false;                        // first touch of a fresh buffer, untimed
-        us = 0.0f;
-        for (int rep = 0; rep < 2; ++rep) {
-            if (hipEventRecord(ev[0], st) != hipSuccess || !one_pass() || hipEventRecord(ev[1], st) != hipSuccess ||
-                hipEventSynchronize(ev[1]) != hipSuccess) return false;
-            float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, ev[0], ev[1]) != hipSuccess || !(ms > 0.0f)) return false;
-            const float t = ms * 1e3f / (float)n;
-            us = (rep == 0 || t < us) ? t : us;
-        }
-        return true;
-    };
-    auto release = [&](float* p) {
-        (void)hipDeviceSynchronize();                         // nothing reads it any more (once per freed candidate, at creation)
-        if (vmm_owns(c, p)) vmm_free_one(c, p); else (void)hipFree(p);
-    };
-    float best = 0.0f;
-    if (!time_current(best)) { cleanup(); return; }
-    c->sel_us[0] = best;
-    c->sel_n = 1;
-    c->sel_kept = 0;
-    // kinds of the candidates: chunk-mapped (the buffer the context came with), hipMalloc, uncached device memory, chunk-mapped, ...
-    // (FVVDP_ALLOC=malloc / uncached: that kind only).  Uncached memory takes streaming writes 5-15 % faster than cached memory of
-    // the same placement (6.4 against 5.5 TB/s inside one class of physical memory, 7.25 against 7.0 across both) and the
-    // pyramid pass reads it about as fast (profiles/r05_k1_mode.md, section 5): the timing decides.
-    for (int k = 1; k < n_cand; ++k) {
-        const int kind = c->env.alloc_malloc ? 0 : (c->env.alloc_uncached ? 2 : (k % 3 == 1 ? 0 : (k % 3 == 2 ? 2 : 1)));
-        void* q = nullptr;
-        const bool got = kind == 1 ? vmm_alloc(c, &q, bytes) == FVVDP_OK
-                                   : (kind == 2 ? hipExtMallocWithFlags(&q, bytes, hipDeviceMallocUncached) == hipSuccess : hipMalloc(&q, bytes) == hipSuccess);
-        if (!got) { (void)hipGetLastError(); break; }
-        float* incumbent = c->level[0];
-        c->level[0] = reinterpret_cast<float*>(q);
-        float us = 0.0f;
-        const bool timed = time_current(us);
-        if (timed) { c->sel_us[k] = us; c->sel_n = k + 1; }
-        if (timed && us < best) {
-            best = us;
-            c->sel_kept = k;
-            c->level0_kind = kind;
-            release(incumbent);
-        } else {
-            c->level[0] = incumbent;
-            release(reinterpret_cast<float*>(q));
-            if (!timed) break;
-        }
+    float us = 0.0f;
+    bool timed = one_pass();
+    for (int rep = 0; rep < 2 && timed; ++rep) {
+        timed = hipEventRecord(ev2[0], st2) == hipSuccess && one_pass() && hipEventRecord(ev2[1], st2) == hipSuccess &&
+                hipEventSynchronize(ev2[1]) == hipSuccess;
+        float ms = 0.0f;
+        timed = timed && hipEventElapsedTime(&ms, ev2[0], ev2[1]) == hipSuccess && ms > 0.0f;
+        const float t = ms * 1e3f / (float)n;
+        if (timed) us = (rep == 0 || t < us) ? t : us;
     }
-    if (c->env.debug_variant) {
-        fprintf(stderr, "fvvdp: level-0 candidates (temporal + pyramid, us per frame):");
-        for (int k = 0; k < c->sel_n; ++k) fprintf(stderr, " %.2f", c->sel_us[k]);
-        fprintf(stderr, " -> kept #%d (%s)\n", c->sel_kept, c->level0_kind == 1 ? "chunk-mapped" : (c->level0_kind == 2 ? "uncached" : "hipMalloc"));
-    }
+    if (timed) c->sel_us[0] = us;
     cleanup();
 }
 
@@ -1670,7 +1733,7 @@ extern "C" int fvvdp_heatmap_colorize(fvvdp_ctx* c, int n, const float* d_dmap, 
     HIP_TRY(hipMemsetAsync(hist, 0, (size_t)n * COLOUR_BINS * sizeof(unsigned int), st));
     ColourArgs a;
     memset(&a, 0, sizeof(a));
-    a.ctx = c->level[0];
+    a.ctx = level_addr(c, 0, 0);
     a.P = c->P;
     a.HW = (unsigned int)(c->W * c->H);
     a.range = range;
@@ -1736,8 +1799,9 @@ extern "C" int fvvdp_ctx_alloc_info(const fvvdp_ctx* c, int* state, int* chunk_m
                                     int* kept) {
     if (!c || !state || !chunk_mapped || !h_us || !n_timed || !kept || capacity < 1) return fail(FVVDP_EINVAL, "null argument");
     *state = c->sel_phase;
-    *chunk_mapped = vmm_owns(c, c->level[0]) ? 1 : c->level0_kind;      // 0 hipMalloc, 1 chunk-mapped, 2 uncached device memory
-    for (int k = 0; k < capacity; ++k) h_us[k] = k < c->sel_n ? c->sel_us[k] : 0.0f;
+    // one range: its kind (0 hipMalloc, 1 chunk-mapped); two ranges: 100 + 10 * kind of the odd slots + kind of the even slots
+    *chunk_mapped = c->level0_hi ? 100 + 10 * c->level0_kind_hi + c->level0_kind : c->level0_kind;
+    for (int k = 0; k < capacity; ++k) h_us[k] = (k < 3 && c->sel_n > 0) ? c->sel_us[k] : 0.0f;
     *n_timed = c->sel_n;
     *kept = c->sel_kept;
     return FVVDP_OK;

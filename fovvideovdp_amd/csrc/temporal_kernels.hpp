@@ -193,7 +193,7 @@ struct TemporalArgs {
     float w[3];
     int n_out;
     int fl;                // true filter length (<= FL)
-    float* out;            // level 0 of the first output slot: [n_out][HW][4]
+    L0Addr out;            // level 0: output frame t of the launch goes to l0_frame(out, t), [HW][4] floats
     int* oob;
     int* ticket;           // nullptr: one workgroup per pixel block; else a zeroed counter -- the grid is the resident capacity and a
                            // workgroup that has finished a block takes the next one (temporal_vec_kernel)
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a
                     }
                     int t_opaque = v - (FL - 1);              // laundered: no per-step 64-bit offsets pre-computed outside the loop
                     asm volatile("" : "+s"(t_opaque));
-                    float* o = a.out + (size_t)t_opaque * a.HW * 4;
+                    float* o = l0_frame(a.out, t_opaque);
 #pragma unroll
                     for (int i = 0; i < PX; ++i)
                         if (ok[i])
@@ -653,7 +653,7 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
             // the loop and, in the long rings, spilled
             int t_opaque = t;
             asm volatile("" : "+s"(t_opaque));
-            const __amdgpu_buffer_rsrc_t o = level_rsrc(a.out + (size_t)t_opaque * a.HW * 4, frame_bytes);
+            const __amdgpu_buffer_rsrc_t o = level_rsrc(l0_frame(a.out, t_opaque), frame_bytes);
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
                 const int q = i * 64 + lane;
@@ -811,7 +811,7 @@ struct YuvArgs {
     EotfDev e;
     float w[3];
     int n_out, fl;
-    float* out;
+    L0Addr out;               // level 0 (see TemporalArgs::out)
     int* oob;
     float taps2[32][2];     // {sustained, transient} tap k, see TemporalArgs
     int idx[T_MAX_IDX];
@@ -904,7 +904,7 @@ __global__ __launch_bounds__(256) void temporal_yuv_kernel(const YuvArgs a) {
                     }
                     int t_opaque = v - (FL - 1);
                     asm volatile("" : "+s"(t_opaque));
-                    float* o = a.out + (size_t)t_opaque * HW * 4;
+                    float* o = l0_frame(a.out, t_opaque);
 #pragma unroll
                     for (int i = 0; i < PX; ++i)
                         if (ok[i])
@@ -1247,7 +1247,7 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
 #else
             const bool live = (v >= FL - 1) && (v < total);
 #endif
-            const __amdgpu_buffer_rsrc_t o = level_rsrc(a.out + (size_t)max(v - (FL - 1), 0) * HW * 4, frame_bytes);
+            const __amdgpu_buffer_rsrc_t o = level_rsrc(l0_frame(a.out, max(v - (FL - 1), 0)), frame_bytes);
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
                 const int qq = min(i * 64 + lane, YUV_QUADS * PX - 1);
@@ -1288,7 +1288,7 @@ struct GenericArgs {
     EotfDev e;
     float w[3];
     int n_out, fl;
-    float* out;
+    L0Addr out;               // level 0 (see TemporalArgs::out)
     int* oob;
     const float* taps;   // device [2][fl]                        (used when inline_tables == 0)
     const int* idx;      // device [fl-1+n_out]
@@ -1326,7 +1326,7 @@ __global__ __launch_bounds__(256) void temporal_generic_kernel(const GenericArgs
         const size_t off = (size_t)(a.inline_tables ? a.idx_i[t] : a.idx[t]) * a.frame_stride + p;
         S[0].lum(off, lt, bad);
         S[1].lum(off, lr, bad);
-        *reinterpret_cast<float2*>(a.out + ((size_t)t * a.HW + p) * 2) = make_float2(lt[0], lr[0]);
+        *reinterpret_cast<float2*>(l0_frame(a.out, t) + (size_t)p * 2) = make_float2(lt[0], lr[0]);
     } else {
         float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
         for (int k = a.fl - 1; k >= 0; --k) {
@@ -1342,7 +1342,7 @@ __global__ __launch_bounds__(256) void temporal_generic_kernel(const GenericArgs
             acc[2] = fmaf(lt[0], f1, acc[2]);
             acc[3] = fmaf(lr[0], f1, acc[3]);
         }
-        *reinterpret_cast<float4*>(a.out + ((size_t)t * a.HW + p) * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(l0_frame(a.out, t) + (size_t)p * 4) = make_float4(acc[0], acc[1], acc[2], acc[3]);
     }
     if (bad && a.oob) atomicOr(a.oob, 1);
 }
@@ -1420,18 +1420,19 @@ __global__ __launch_bounds__(256) void yuv_luminance_frames_kernel(const YuvLumA
     if (bad && a.y.oob) atomicOr(a.y.oob, 1);
 }
 
-// planar [n][P][HW] <-> interleaved [n][HW][P]
+// planar [n][P][HW] <-> interleaved: frame f of a pyramid level at l0_frame(il, f), [HW][P]
 template <int P>
-__global__ void interleave_kernel(const float* __restrict__ in, float* __restrict__ out, int HW, int to_interleaved) {
+__global__ void interleave_kernel(float* __restrict__ planar, const L0Addr il, int HW, int to_interleaved) {
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int f = blockIdx.y;
     if (p >= HW) return;
+    float* q = l0_frame(il, f) + (size_t)p * P;
 #pragma unroll
     for (int k = 0; k < P; ++k) {
         if (to_interleaved)
-            out[((size_t)f * HW + p) * P + k] = in[((size_t)f * P + k) * HW + p];
+            q[k] = planar[((size_t)f * P + k) * HW + p];
         else
-            out[((size_t)f * P + k) * HW + p] = in[((size_t)f * HW + p) * P + k];
+            planar[((size_t)f * P + k) * HW + p] = q[k];
     }
 }
 

@@ -276,16 +276,18 @@ int fvvdp_ctx_timing_enable(fvvdp_ctx* ctx, int on);
 int fvvdp_ctx_timing_read(fvvdp_ctx* ctx, float* h_ms, int32_t* h_count, int capacity, int reset);
 
 /* Where level 0 of the context's scratch lives and how that was decided.  The large scratch levels are mapped from physical
- * chunks (HIP virtual-memory API) by default.  How fast a buffer of this size can be WRITTEN depends on its physical placement
- * (the temporal kernel: 31-33 or 36-38 us per 4K frame, box by box and allocation by allocation; profiles/r05_k1_mode.md), so
- * fvvdp_ctx_create of a video context whose level 0 holds >= 1 GiB times the temporal kernel + the pyramid pass on N candidate
- * buffers (default 6: chunk-mapped, hipMalloc, uncached device memory, and the three again; a synthetic uint8 clip as input; environment
- * FVVDP_PLACEMENT_PROBE=n, 0 = off) and keeps the fastest: ~0.2-0.3 s at creation, one extra level 0 held while a candidate is
- * timed, nothing in any per-frame call.  Results never depend on it.
- *   *state: always 9 (settled) -- the comparison runs inside fvvdp_ctx_create;  *chunk_mapped: kind of level 0 -- 0 hipMalloc,
- *   1 mapped from physical chunks, 2 uncached device memory (a candidate kind since round 5: takes streaming writes faster)
- *   h_us[capacity]: microseconds per frame (temporal kernel + pyramid pass) of candidates 0 .. *n_timed - 1, 0 beyond
- *   *kept: index of the candidate in use, -1 = no comparison (small context, still image, switched off, not enough memory) */
+ * chunks (HIP virtual-memory API).  How fast a buffer of several GB can be WRITTEN depends on the physical memory behind it: a box's
+ * memory comes in two classes, streaming writes into one class top out at ~5.5 TB/s, into both at once at 7.0 (the temporal kernel:
+ * 35-36 or 30-31 us per 4K frame; profiles/r05_k1_mode.md), and which class an allocation gets is the driver's business.  Level 0 of
+ * a video context that holds >= 1 GiB therefore lives in TWO ranges -- even frame slots in one, odd slots in the other -- chosen by
+ * fvvdp_ctx_create among N half-size candidates (default 6: chunk-mapped and hipMalloc in turn;
+ * environment FVVDP_PLACEMENT_PROBE=n, 0 / 1 = one range as allocated): every pair is written at once by a streaming-write probe and
+ * the pair with the highest rate is kept.  ~0.15 s at creation, N halves of level 0 held for the moment, nothing in any per-frame
+ * call.  Results never depend on it.
+ *   *state: always 9 (settled);  *chunk_mapped: one range: its kind (0 hipMalloc, 1 mapped from physical chunks); two ranges: 100 + 10 * kind of the odd slots' range + kind of the even slots' range
+ *   h_us[capacity]: [0] microseconds per frame of the temporal kernel + pyramid pass on the layout in use (a synthetic clip, timed once at
+ *   creation; 0 = not timed), [1] / [2] highest / lowest streaming-write rate [TB/s] over the candidate pairs, 0 beyond
+ *   *n_timed: number of half-size candidates (0: no choice);  *kept: index of the even slots' candidate + 8 * index of the odd slots' (-1: no choice) */
 int fvvdp_ctx_alloc_info(const fvvdp_ctx* ctx, int* state, int* chunk_mapped, float* h_us, int capacity, int* n_timed, int* kept);
 
 /* Host synchronisations, device allocations and frees made INSIDE per-frame entry points (fvvdp_temporal_channels*,

@@ -447,12 +447,13 @@ def test_chunk_mapped_scratch_gives_the_same_results_as_hipmalloc(tmp_path):
     assert np.array_equal(res["vmm"], res["malloc"]) and np.array_equal(res["vmm"], res["vmm8"])
 
 
-def test_level0_choice_happens_at_creation_and_changes_no_bits(tmp_path):
-    """A video context whose level 0 holds >= 1 GiB times the temporal kernel + pyramid pass on N candidate level-0 buffers INSIDE
-    fvvdp_ctx_create (fvvdp_ctx_alloc_info: state 9 from the first call on, N timings, the index kept) and keeps the fastest; the
-    losers are freed before the first user call.  Per-frame calls never allocate, free or synchronise (fvvdp_ctx_call_stats: all
-    zero from the FIRST call on -- SURVEY 8(b) "allocated once in ctx_create").  Same bits with the comparison off, with hipMalloc
-    candidates only, with 2 or 6 candidates; small contexts and images never compare."""
+def test_level0_in_two_chosen_ranges_changes_no_bits(tmp_path):
+    """Level 0 of a video context that holds >= 1 GiB lives in TWO ranges (even / odd frame slots) that fvvdp_ctx_create chooses among N
+    half-size candidates of two kinds by a streaming-write probe over all pairs (fvvdp_ctx_alloc_info: state 9 from the first call on,
+    the kinds of the two ranges, the highest / lowest pair rate, the layout's timing); the other candidates are freed before the first user
+    call.  Per-frame calls never allocate, free or synchronise (fvvdp_ctx_call_stats: all zero from the FIRST call on -- SURVEY 8(b)
+    "allocated once in ctx_create").  Same bits with one range (choice off), with hipMalloc candidates only, with 2 or 4
+    candidates; small contexts and images keep their one range."""
     import subprocess
     import sys
     import os
@@ -469,7 +470,7 @@ def test_level0_choice_happens_at_creation_and_changes_no_bits(tmp_path):
         "    cs = (C.c_int64 * 3)()\n"
         "    nat.check(nat.lib().fvvdp_ctx_call_stats(m._ctx.handle, cs))\n"
         "    return [st.value, cm.value, n.value, kept.value, cs[0], cs[1], cs[2]] + [round(us[k], 2) for k in range(8)]\n"
-        "t, r = synth_video_pair(40, 1080, 1920, device='cuda')\n"
+        "t, r = synth_video_pair(41, 1080, 1920, device='cuda')\n"
         "torch.cuda.synchronize()\n"
         "free0 = torch.cuda.mem_get_info()[0]\n"
         "m = fv.fvvdp(display_name='standard_fhd')\n"
@@ -486,7 +487,7 @@ def test_level0_choice_happens_at_creation_and_changes_no_bits(tmp_path):
         "print('SMALL', *info(m2))\n"
         "np.save(sys.argv[1], np.stack(out))\n" % root)
     res = {}
-    modes = (("default", {}, 6), ("off", {"FVVDP_PLACEMENT_PROBE": "0"}, 0), ("malloc", {"FVVDP_ALLOC": "malloc"}, 6), ("uncached", {"FVVDP_ALLOC": "uncached"}, 6),
+    modes = (("default", {}, 6), ("off", {"FVVDP_PLACEMENT_PROBE": "0"}, 0), ("malloc", {"FVVDP_ALLOC": "malloc"}, 6),
              ("two", {"FVVDP_PLACEMENT_PROBE": "2"}, 2), ("four", {"FVVDP_PLACEMENT_PROBE": "4"}, 4))
     for mode, env, n_want in modes:
         f = str(tmp_path / ("s_%s.npy" % mode))
@@ -495,31 +496,88 @@ def test_level0_choice_happens_at_creation_and_changes_no_bits(tmp_path):
         res[mode] = np.load(f)
         infos = [l.split()[2:] for l in p.stdout.splitlines() if l.startswith("INFO")]
         small = [l.split()[1:] for l in p.stdout.splitlines() if l.startswith("SMALL")][0]
-        assert int(small[0]) == 9 and int(small[2]) == 0 and int(small[3]) == -1            # a 130 MB level 0 never compares
+        assert int(small[0]) == 9 and int(small[1]) < 100 and int(small[2]) == 0 and int(small[3]) == -1      # a 130 MB level 0 stays one range
         assert [int(v) for v in small[4:7]] == [0, 0, 0]
         assert len(infos) == 4
         for i in infos:
-            state, chunk, n, kept = (int(v) for v in i[:4])
+            state, kind, n, kept = (int(v) for v in i[:4])
             assert state == 9 and n == n_want, (mode, i)
             assert [int(v) for v in i[4:7]] == [0, 0, 0], (mode, i)                      # no sync / alloc / free in per-frame calls
             us = [float(v) for v in i[7:]]
             if n_want:
-                assert 0 <= kept < n_want and all(u > 0 for u in us[:n_want]) and all(u == 0 for u in us[n_want:]), (mode, i)
-                assert us[kept] == min(us[:n_want]), (mode, i)
-                if mode == "malloc":
-                    assert chunk == 0
-                elif mode == "uncached":
-                    assert chunk == 2
-                else:                                # candidate kinds: chunk-mapped, hipMalloc, uncached device memory, chunk-mapped, ...
-                    assert chunk == [1, 0, 2, 1, 0, 2][kept], (mode, i)
+                lo, hi = kept % 8, kept // 8
+                assert 0 <= lo < hi < n_want and kind >= 100, (mode, i)
+                assert us[0] > 0 and us[1] >= us[2] > 0 and all(u == 0 for u in us[3:]), (mode, i)
+                want = {"malloc": [0] * 6}.get(mode, [1, 0, 1, 0, 1, 0])    # candidate kinds: chunk-mapped and hipMalloc in turn
+                assert kind == 100 + 10 * want[hi] + want[lo], (mode, i)
             else:
-                assert kept == -1
+                assert kept == -1 and kind == 1
         assert infos[0] == infos[3]                                                       # settled at creation: nothing moves afterwards
         used, scratch = [int(v) for v in [l for l in p.stdout.splitlines() if l.startswith("MEM")][0].split()[1:]]
-        assert used < scratch + (600 << 20), (mode, used, scratch)                       # the losing candidates and the synthetic clip are gone
+        assert used < scratch + (700 << 20), (mode, used, scratch)                       # the other candidates and the synthetic clip are gone
     for mode in res:
         assert all(np.array_equal(res[mode][k], res[mode][0]) for k in range(4)), mode
         assert np.array_equal(res[mode], res["default"]), mode
+
+
+def test_level0_in_two_ranges_every_path_same_bits(monkeypatch):
+    """FVVDP_LEVEL0_SPLIT=1 puts level 0 of ANY context in two ranges (even / odd frame slots; L0Addr in every kernel that touches level
+    0) without a choice: every writer and reader of level 0 -- the vector, per-pixel, generic, two-pass and YUV temporal kernels, the
+    planar hand-over and export, both pyramid kernels incl. the foveated and the map-writing variants, the colouring of heat maps --
+    gives the bits of the one-range layout, with odd and even frame counts and with slot offsets."""
+    import ctypes as C
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd import _native as nat
+    from fovvideovdp_amd.synth import synth_video_pair, synth_yuv_pair, synth_gaze
+    from lowlevel import Pipeline
+
+    def kind_of(m):
+        st, cm, n, kept = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(-1)
+        us = (C.c_float * 8)()
+        nat.check(nat.lib().fvvdp_ctx_alloc_info(m._ctx.handle, C.byref(st), C.byref(cm), us, 8, C.byref(n), C.byref(kept)))
+        return cm.value
+    t, r = synth_video_pair(11, 136, 244, device="cuda")
+    to, ro = synth_video_pair(6, 135, 241, device="cuda")                    # pixel count not a multiple of 4: per-pixel ring kernel
+    ty, ry = synth_yuv_pair(10, 136, 244, 8, "420", device="cuda")
+    gaze = synth_gaze(11, 136, 244).numpy()
+    cases = [
+        ("video u8", dict(display_name="standard_fhd"), lambda m: m.predict(t, r, frames_per_second=30)),
+        ("video u8 60 fps", dict(display_name="standard_fhd"), lambda m: m.predict(t, r, frames_per_second=60)),
+        ("video f32", dict(display_name="standard_fhd"), lambda m: m.predict(t.float() / 255, r.float() / 255, frames_per_second=30)),
+        ("video u16 gray", dict(display_name="standard_hdr_pq"), lambda m: m.predict((t[:, 1:2].to(torch.int32) * 257).to(torch.int16), (r[:, 1:2].to(torch.int32) * 257).to(torch.int16), frames_per_second=30)),
+        ("video 240 fps (two-pass path for float input)", dict(display_name="standard_fhd"), lambda m: m.predict(t.float() / 255, r.float() / 255, frames_per_second=240)),
+        ("odd size", dict(display_name="standard_fhd"), lambda m: m.predict(to, ro, frames_per_second=30)),
+        ("sub-batches", dict(display_name="standard_fhd", batch_frames=4), lambda m: m.predict(t, r, frames_per_second=30)),
+        ("image", dict(display_name="standard_4k"), lambda m: m.predict(t[0, :, 0].permute(1, 2, 0), r[0, :, 0].permute(1, 2, 0), dim_order="HWC")),
+        ("foveated", dict(display_name="standard_hdr_pq", foveated=True), lambda m: m.predict(t, r, frames_per_second=30, fixation_point=gaze)),
+        ("heat map", dict(display_name="standard_fhd", heatmap="threshold"), lambda m: m.predict(t, r, frames_per_second=30)),
+        ("yuv", dict(display_name="standard_fhd"), lambda m: m.predict_video_source(
+            fv.fvvdp_video_source_yuv_frames(ty, ry, 30, 244, 136, bit_depth=8, chroma_ss="420", display_photometry=m.display_photometry))),
+    ]
+    out = {}
+    R = torch.rand((7, 4, 136, 244), device="cuda") * 100 + 1
+    for split in ("0", "1"):
+        monkeypatch.setenv("FVVDP_LEVEL0_SPLIT", split)
+        for name, kw, call in cases:
+            m = fv.fvvdp(**kw)
+            q, st = call(m)
+            assert (kind_of(m) >= 100) == (split == "1"), (name, split, kind_of(m))
+            res = [st["Q_per_ch"].copy(), np.float64(float(q))]
+            if "heatmap" in st:
+                res.append(st["heatmap"].clone().numpy())
+            out[(name, split)] = res
+        # the planar hand-over and the export of level 0 through the C ABI, slots 3 .. 9 of a 10-slot context
+        m = fv.fvvdp(display_name="standard_fhd")
+        pl = Pipeline(m, 244, 136, 4, 10)
+        pl.load_planar(R, slot0=3)
+        pl.load_planar(R[:3] * 0.5, slot0=0)
+        back = pl.export_level(0, 10)
+        assert torch.equal(back[3:], R) and torch.equal(back[:3], R[:3] * 0.5), split
+        out[("planar", split)] = [pl.bands_forward(10).cpu().numpy()]
+        pl.close()
+    differ = [name for name in [c[0] for c in cases] + ["planar"]
+              if not (len(out[(name, "0")]) == len(out[(name, "1")]) and all(np.array_equal(x, y) for x, y in zip(out[(name, "0")], out[(name, "1")])))]
+    assert not differ, differ
 
 
 def test_per_frame_calls_do_not_sync_or_allocate_optional_paths_only_on_first_use():

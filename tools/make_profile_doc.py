@@ -86,16 +86,16 @@ def quoted_figures():
         if "band2_kernel" in label and "levels 0+1" in label:
             b = r["bytes_per_launch"]
             if "false" in label and jp["roofline"]["kernel"].startswith("band2_kernel<4, true>"):
-                out.append("* `%s`: %d launches, rocprof AVERAGE %.1f us -- not the timed steps: the level-0 choice inside `fvvdp_ctx_create` (4 candidates x 3 passes "
-                           "of the variant WITH clamps on a synthetic clip, incl. the first touch of every candidate)" % (label.strip("`"), calls, avg))
+                out.append("* `%s`: %d launches, rocprof AVERAGE %.1f us -- not the timed steps: `fvvdp_ctx_create` times the layout it chose once (3 passes of the variant "
+                           "WITH clamps on a synthetic clip, the first touch included)" % (label.strip("`"), calls, avg))
                 continue
             out.append("* `%s`: %.4f GB algorithmic per launch / rocprof AVERAGE %.1f us = %.2f TB/s = %.3f of 8 TB/s; / steady median %.1f us = %.3f; unprofiled HIP-event median %.1f us = %.4f" % (
                 label.strip("`"), b / 1e9, avg, b / avg / 1e6, b / avg / 1e6 / 8.0, steady, b / steady / 1e6 / 8.0, r["median_launch_ms"] * 1e3, r["frac"]))
         if "temporal_vec_kernel" in label:
             b = k1["bytes_per_launch"]
             n = k1["frames_per_launch"]
-            out.append("* `%s`: %.1f MB per frame; %d launches, rocprof AVERAGE %.1f us per %d frames = %.1f us per frame = %.2f TB/s = %.3f (the average includes the 18 launches "
-                       "of the level-0 choice at context creation: six candidate buffers, slow ones among them, first touch included); rocprof MEDIAN %.1f us = %.1f us per frame = %.3f; "
+            out.append("* `%s`: %.1f MB per frame; %d launches, rocprof AVERAGE %.1f us per %d frames = %.1f us per frame = %.2f TB/s = %.3f (the average includes the 3 launches "
+                       "on a synthetic clip at context creation, first touch included); rocprof MEDIAN %.1f us = %.1f us per frame = %.3f; "
                        "unprofiled HIP events %.2f us per frame = %.4f" % (
                 label.strip("`"), b / n / 1e6, calls, avg, n, avg / n, b / avg / 1e6, b / avg / 1e6 / 8.0, med, med / n, b / med / 1e6 / 8.0,
                 g["temporal_us_per_frame_median"], k1["frac"]))
@@ -118,12 +118,13 @@ def quoted_figures():
             pass
     la = jp.get("level0_alloc")
     if isinstance(la, dict):
-        cand = la.get("candidates_us_per_frame") or []
-        out.append("* level-0 scratch of the unprofiled run: in use %s%s; host syncs / allocations / frees inside per-frame calls: %s" % (
+        pr = la.get("pair_write_rate_tbs") or {}
+        out.append("* level 0 of the unprofiled run: %s%s; host syncs / allocations / frees inside per-frame calls: %s; first step incl. context creation %s ms" % (
             la.get("in_use"),
-            (" (fvvdp_ctx_create timed the temporal kernel + pyramid pass on %d candidates: %s us per frame, kept #%s)" % (
-                len(cand), " / ".join("%.2f" % v for v in cand), la.get("kept_index"))) if cand else "",
-            "/".join(str(v) for v in (la.get("per_frame_calls") or {}).values())))
+            (" (fvvdp_ctx_create wrote every pair of %s half-size candidates at once: %.2f TB/s for the pair kept, %.2f for the slowest; temporal kernel + pyramid pass "
+             "on the layout kept: %s us per frame)" % (la.get("half_size_candidates"), pr.get("kept", 0), pr.get("lowest", 0), la.get("temporal_plus_pyramid_us_per_frame_at_creation")))
+            if la.get("half_size_candidates") else "",
+            "/".join(str(v) for v in (la.get("per_frame_calls") or {}).values()), la.get("first_step_ms_incl_context_creation")))
     if jp.get("predict_call_ms"):
         out.append("* step path: %s; the reference-style synchronous `predict()` on the same pair: %.3f ms" % (jp.get("step_path"), jp["predict_call_ms"]))
     if k1.get("traffic"):

@@ -27,6 +27,8 @@
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
 static const int W = 3840, H = 2160, HW = W * H, NOUT = 60, FLEN = 8, NSRC = NOUT + FLEN - 1;
+// level 0 in one contiguous range (L0Addr, device_common.hpp)
+static L0Addr one_range(float* o) { L0Addr a; a.lo = o; a.hi = o + (size_t)HW * 4; a.half_stride = (size_t)HW * 8; a.slot0 = 0; return a; }
 
 // ---- the real kernel with another block order --------------------------------------------------------------------------------
 // Workgroup i runs on XCD i % 8.  "XCD-contiguous": XCD x takes the x-th eighth of the pixel blocks, neighbours in dispatch order on
@@ -308,7 +310,7 @@ int main(int argc, char** argv) {
             TemporalArgs ta2; memset(&ta2, 0, sizeof(ta2));
             ta2.src[0] = srcb[0]; ta2.src[1] = srcb[1]; ta2.chan_stride = HW; ta2.frame_stride = (size_t)3 * HW; ta2.C = 3; ta2.HW = HW;
             ta2.e.kind = FVVDP_EOTF_LUT; ta2.e.lut = d_lut2; ta2.w[0] = 0.2126f; ta2.w[1] = 0.7152f; ta2.w[2] = 0.0722f;
-            ta2.n_out = NOUT; ta2.fl = FLEN; ta2.oob = d_oob2; ta2.out = (float*)va;
+            ta2.n_out = NOUT; ta2.fl = FLEN; ta2.oob = d_oob2; ta2.out = one_range((float*)va);
             for (int q = 0; q < FLEN; ++q) { ta2.taps2[q][0] = 0.3f / (1 + q); ta2.taps2[q][1] = (q & 1) ? -0.1f : 0.1f; }
             for (int u = 0; u < NSRC; ++u) ta2.idx[u] = ta2.idx1[u] = u;
             ReplayArgs ra2; ra2.wg0 = 0; ra2.src[0] = srcb[0]; ra2.src[1] = srcb[1]; ra2.chan_stride = HW; ra2.frame_stride = (size_t)3 * HW; ra2.HW = HW; ra2.n_out = NOUT;
@@ -401,7 +403,7 @@ int main(int argc, char** argv) {
             TemporalArgs ta2; memset(&ta2, 0, sizeof(ta2));
             ta2.src[0] = srcb[0]; ta2.src[1] = srcb[1]; ta2.chan_stride = HW; ta2.frame_stride = (size_t)3 * HW; ta2.C = 3; ta2.HW = HW;
             ta2.e.kind = FVVDP_EOTF_LUT; ta2.e.lut = d_lut2; ta2.w[0] = 0.2126f; ta2.w[1] = 0.7152f; ta2.w[2] = 0.0722f;
-            ta2.n_out = NOUT; ta2.fl = FLEN; ta2.oob = d_oob2; ta2.out = (float*)va;
+            ta2.n_out = NOUT; ta2.fl = FLEN; ta2.oob = d_oob2; ta2.out = one_range((float*)va);
             for (int q = 0; q < FLEN; ++q) { ta2.taps2[q][0] = 0.3f / (1 + q); ta2.taps2[q][1] = (q & 1) ? -0.1f : 0.1f; }
             for (int u = 0; u < NSRC; ++u) ta2.idx[u] = ta2.idx1[u] = u;
             ReplayArgs ra2; ra2.wg0 = 0; ra2.src[0] = srcb[0]; ra2.src[1] = srcb[1]; ra2.chan_stride = HW; ra2.frame_stride = (size_t)3 * HW; ra2.HW = HW; ra2.n_out = NOUT;
@@ -444,11 +446,11 @@ int main(int argc, char** argv) {
     const int nb = ra.n_blocks, nb8 = (nb + 7) / 8 * 8;
     struct Variant { const char* name; std::function<void(float*)> run; };
     std::vector<Variant> vars;
-    vars.push_back({"k1", [&](float* o) { TemporalArgs a = ta; a.out = o; hipLaunchKernelGGL((temporal_vec_kernel<8, 4, SRC_U8, 1>), dim3((nb + k1_wpb(8) - 1) / k1_wpb(8)), dim3(64 * k1_wpb(8)), 0, 0, a); }});
+    vars.push_back({"k1", [&](float* o) { TemporalArgs a = ta; a.out = one_range(o); hipLaunchKernelGGL((temporal_vec_kernel<8, 4, SRC_U8, 1>), dim3((nb + k1_wpb(8) - 1) / k1_wpb(8)), dim3(64 * k1_wpb(8)), 0, 0, a); }});
     vars.push_back({"rp", [&](float* o) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, true, 1, 2, 0>), dim3(nb), dim3(64), 10240, 0, a); }});
     if (!pmc) {
-        vars.push_back({"k1_xcd", [&](float* o) { TemporalArgs a = ta; a.out = o; hipLaunchKernelGGL((k1_mapped<1>), dim3(nb8), dim3(64), 0, 0, a); }});
-        vars.push_back({"k1_x16", [&](float* o) { TemporalArgs a = ta; a.out = o; hipLaunchKernelGGL((k1_mapped<2>), dim3((nb + 127) / 128 * 128), dim3(64), 0, 0, a); }});
+        vars.push_back({"k1_xcd", [&](float* o) { TemporalArgs a = ta; a.out = one_range(o); hipLaunchKernelGGL((k1_mapped<1>), dim3(nb8), dim3(64), 0, 0, a); }});
+        vars.push_back({"k1_x16", [&](float* o) { TemporalArgs a = ta; a.out = one_range(o); hipLaunchKernelGGL((k1_mapped<2>), dim3((nb + 127) / 128 * 128), dim3(64), 0, 0, a); }});
         vars.push_back({"rp_alu", [&](float* o) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, true, 1, 2, 48>), dim3(nb), dim3(64), 10240, 0, a); }});
         vars.push_back({"rp_xcd", [&](float* o) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<1, true, true, 1, 2, 0>), dim3(nb8), dim3(64), 10240, 0, a); }});
         vars.push_back({"rp_x16", [&](float* o) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<2, true, true, 1, 2, 0>), dim3((nb + 127) / 128 * 128), dim3(64), 10240, 0, a); }});
@@ -457,9 +459,9 @@ int main(int argc, char** argv) {
         vars.push_back({"rp_4w", [&](float* o) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, true, 4, 2, 0>), dim3((nb + 3) / 4), dim3(256), 40960, 0, a); }});
         vars.push_back({"rp_4wx", [&](float* o) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<1, true, true, 4, 2, 0>), dim3(((nb + 3) / 4 + 7) / 8 * 8), dim3(256), 40960, 0, a); }});
         vars.push_back({"rp_occ8", [&](float* o) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, true, 1, 2, 0>), dim3(nb), dim3(64), 0, 0, a); }});
-        vars.push_back({"k1_2w", [&](float* o) { TemporalArgs a = ta; a.out = o; hipLaunchKernelGGL((k1_multi<2>), dim3((nb + 1) / 2), dim3(128), 0, 0, a); }});
-        vars.push_back({"k1_4w", [&](float* o) { TemporalArgs a = ta; a.out = o; hipLaunchKernelGGL((k1_multi<4>), dim3((nb + 3) / 4), dim3(256), 0, 0, a); }});
-        vars.push_back({"k1_8w", [&](float* o) { TemporalArgs a = ta; a.out = o; hipLaunchKernelGGL((k1_multi<8>), dim3((nb + 7) / 8), dim3(512), 0, 0, a); }});
+        vars.push_back({"k1_2w", [&](float* o) { TemporalArgs a = ta; a.out = one_range(o); hipLaunchKernelGGL((k1_multi<2>), dim3((nb + 1) / 2), dim3(128), 0, 0, a); }});
+        vars.push_back({"k1_4w", [&](float* o) { TemporalArgs a = ta; a.out = one_range(o); hipLaunchKernelGGL((k1_multi<4>), dim3((nb + 3) / 4), dim3(256), 0, 0, a); }});
+        vars.push_back({"k1_8w", [&](float* o) { TemporalArgs a = ta; a.out = one_range(o); hipLaunchKernelGGL((k1_multi<8>), dim3((nb + 7) / 8), dim3(512), 0, 0, a); }});
         vars.push_back({"rp_2w", [&](float* o) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, true, 2, 2, 0>), dim3((nb + 1) / 2), dim3(128), 20480, 0, a); }});
         vars.push_back({"rp_8w", [&](float* o) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, true, 8, 2, 0>), dim3((nb + 7) / 8), dim3(512), 65536, 0, a); }});
         vars.push_back({"rp_16w", [&](float* o) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, true, 16, 2, 0>), dim3((nb + 15) / 16), dim3(1024), 65536, 0, a); }});
@@ -498,7 +500,7 @@ int main(int argc, char** argv) {
             auto fw = [&] { hipLaunchKernelGGL(stream_write, dim3(32768), dim3(256), 0, 0, (float4*)bufs[b].ptr, n4, 1.0f); };
             fw(); CK(hipDeviceSynchronize());
             printf(" | %5.2f", n4 * 16.0 / time_us(fw, 5) / 1e6);
-            auto fk = [&] { TemporalArgs a = ta; a.out = (float*)bufs[b].ptr; hipLaunchKernelGGL((temporal_vec_kernel<8, 4, SRC_U8, 1>), dim3((nb + k1_wpb(8) - 1) / k1_wpb(8)), dim3(64 * k1_wpb(8)), 0, 0, a); };
+            auto fk = [&] { TemporalArgs a = ta; a.out = one_range((float*)bufs[b].ptr); hipLaunchKernelGGL((temporal_vec_kernel<8, 4, SRC_U8, 1>), dim3((nb + k1_wpb(8) - 1) / k1_wpb(8)), dim3(64 * k1_wpb(8)), 0, 0, a); };
             fk(); CK(hipDeviceSynchronize());
             printf(" | %5.2f\n", time_us(fk, 5) / NOUT);
             fflush(stdout);
