@@ -122,7 +122,7 @@ def main():
     es_in = 1                                          # uint8 RGB
     need = {"source clips": 2.0 * 3 * W * H * n_clip * es_in * K,
             "pyramid scratch (one batch of <= 128 frames, all levels)": 16.0 * W * H * 1.34 * min(N, 128),
-            "level-0 candidates timed at context creation (one extra level 0) + its synthetic clip": 16.0 * W * H * min(N, 128) + 2.0 * 16 * 3 * W * H,
+            "six half-size level-0 candidates at context creation (two level 0 beyond the scratch) + the synthetic clip": 2 * 16.0 * W * H * min(N, 128) + 2.0 * 16 * 3 * W * H,
             "margin": 2.0 * (1 << 30)}
     free_b, total_b = torch.cuda.mem_get_info(dev)
     if sum(need.values()) > free_b:
@@ -306,8 +306,9 @@ def main():
                    "note": "reads 6 B and writes 16 B per pixel and frame: nothing to save but the time.  How fast the 8 GB of level 0 can "
                            "be WRITTEN depends on where they lie physically (31-33 or 36-38 us per frame; a kernel that only replays the "
                            "store stream, and a plain streaming write, show the same two speeds on the same buffers; on the slow ones "
-                           "the L2's write requests wait 6-20x longer for DRAM credits): profiles/r05_k1_mode.md.  The context times N "
-                           "candidate buffers at creation and keeps the fastest (level0_alloc)."}
+                           "the L2's write requests wait 6-20x longer for DRAM credits): profiles/r05_k1_mode.md.  The context keeps level 0 "
+                           "in two ranges (even / odd frame slots) chosen at creation among half-size candidates: the pair that is written "
+                           "fastest at once, i.e. two ranges of different kinds of physical memory where there are any (level0_alloc)."}
         if k1_live is not None and (W, H, int(frames_per_launch), es, Cc, fps) == (3840, 2160, 60, 1, 3, 30):
             roof_k1["traffic"] = int(k1_live["traffic_bytes"])
             roof_k1["traffic_source"] = ("measured in this run: the same two rocprofv3 --pmc passes (FETCH_SIZE x2 + WRITE_SIZE) of the temporal "

@@ -103,9 +103,12 @@ this file is assembled from their logs by `tools/make_r5_evidence.py`.  All sess
    fast after a process that had allocated and freed 150 GiB); holding back a spacer between two halves of a buffer does not move
    the second half (`hipMemCreate` alone does not seem to place memory).  A search for the other class by allocating ahead found it
    after 29 GiB in one run and not within 100-120 GiB in three others.  Section 4.
-5. *What the library does with that.*  (a) `fvvdp_ctx_create` times K1 + the pyramid pass on N = 6 candidate buffers (chunk-mapped,
-   `hipMalloc`, uncached device memory, twice: section 5) and keeps the fastest -- it helps when the candidates differ (sessions 1 and 3: 5-7 of 13 buffers fast)
-   and costs 0.1-0.2 s when they do not; nothing happens in per-frame calls any more.  (b) K1 itself got what the replay showed
+5. *What the library does with that.*  (a) Level 0 of a large video context lives in TWO ranges -- even frame slots in one, odd slots in
+   the other -- that `fvvdp_ctx_create` chooses among N = 6 half-size candidates (chunk-mapped and `hipMalloc` in turn) by writing every
+   pair at once: the pair with the highest rate is two ranges of different classes wherever the candidates hold both (every one of 58
+   processes on 6 boxes so far: pair kept 6.9-7.2 TB/s, slowest pair 5.3-6.5), and K1 runs at 29.7-31.5 us per frame in every one of
+   them -- section 7, which also lists the one session whose pair rates were not recorded and that had two processes at 33 and 35 us.  (Before that, the context kept the best of six full-size candidates, which helps only when a whole 8 GB candidate
+   happens to span both classes: sections 5 and 6.)  0.1 s at creation; nothing happens in per-frame calls any more.  (b) K1 itself got what the replay showed
    to help on EVERY buffer: 4 waves per workgroup on adjacent pixel blocks (`k1_4w` / `rp_4w` columns: -1.2 ... -1.5 us per frame, slow
    and fast alike).  A kernel-side remedy for the slow mode does not exist: a plain streaming write has it.
 
@@ -244,6 +247,63 @@ The search is not in the product.
 ```
 %s
 ```
+
+## 7. Level 0 in two chosen ranges (sessions 20-25): the fast mode by construction
+
+What section 6 asked for, without remapping anything: frame slot s of level 0 lies at `(s & 1 ? hi : lo) + (s >> 1) * frame` (`L0Addr`,
+`csrc/device_common.hpp`; one address formula in the temporal kernels, both pyramid kernels, the planar hand-over / export and the heat-map
+colouring -- 186 GPU tests green, and the whole suite once more with EVERY context split, `FVVDP_LEVEL0_SPLIT=1`: 180 green).  At creation
+a context whose level 0 holds >= 1 GiB gives back the range it came with, takes N = 6 candidates of HALF a level 0 (chunk-mapped and
+`hipMalloc` in turn), writes every one of the 15 pairs at once with a streaming-write kernel (4 ms per pair: even workgroups into one
+range, odd ones into the other), keeps the pair with the highest rate and frees the rest: ~90 ms, N halves of level 0 held for the
+moment, no allocation / free / synchronisation in any per-frame call (`fvvdp_ctx_call_stats`, `test_level0_in_two_chosen_ranges_changes_no_bits`).
+Consecutive frames of the temporal kernel's store stream then go to different classes of memory whenever the candidates hold both.
+
+Ten pairs of bench processes on one box, the choice on / off (`FVVDP_PLACEMENT_PROBE=0`: one range as allocated); columns: ms per step,
+K1 us per frame, levels 0+1, all levels | candidates kept, TB/s of the pair kept / of the slowest pair, K1 + pyramid pass at creation
+(variant with clamps, first touch included), first step incl. creation [ms], JOD:
+
+```
+%s
+```
+
+Twelve processes in a row on another box (K1 of each of the 12 timed launches):
+
+```
+%s
+```
+
+And after six 1080p processes on a third (1080p: level 0 of 60 frames holds 2 GB, chosen the same way):
+
+```
+%s
+```
+
+Twenty more in a row on a fourth box with the card's sensors read before each (junction 46 C, memory 36-37 C, mclk 2000 MHz throughout:
+no drift with time or temperature):
+
+```
+%s
+```
+
+K1 over the 58 two-range 4K processes of sessions 20, 22, 24, 25 and 26: 29.7-31.5 us per frame; one range as allocated on the same boxes:
+30.6-32.5 (these boxes gave fast single ranges; the processes of sections 2, 4 and 5 that gave 35-37 are what the pairs are for -- in every
+process so far the slowest pair of the six candidates ran at 5.3-6.5 TB/s, i.e. both classes were among them).  The exception, for the
+record: session 23 (a fifth box; 1080p processes first, then four 4K ones whose `level0_alloc` was not printed) measured K1 at 29.8, 30.9,
+33.1 and 35.1 us in that order, levels 0+1 at 30.0-30.7 throughout.  Session 25 repeated the sequence with the pair rates printed and
+session 26 watched the sensors: neither reproduced it.  Whether those two contexts had no pair of different classes to choose from, or
+something else slowed the writes, is not known.
+
+**Uncached device memory is out.**  Round 5 first had `hipExtMallocWithFlags(hipDeviceMallocUncached)` among the candidate kinds
+(5-15 %% faster streaming writes, section 5).  With every context split and the odd slots in a fresh uncached range, 3 of 180 GPU tests
+failed and not always the same ones: the FIRST pass over a fresh range returned a few pixels that the temporal kernel had not written
+(row 0 of a three-call test differed, rows 1-2 did not), never with `hipMalloc` memory in the same place (session 21: 3 / 0 / 1 / 0 failures
+for uncached / hipMalloc / uncached after a fill / one range, twice).  The reads of a range that was cached under its previous owner are
+not safe until its lines are gone; the kind was removed from the library rather than worked around.
+
+```
+%s
+```
 """
 
 zones = rd("r5s4/zones.txt").split("\n")
@@ -268,6 +328,9 @@ out = doc % (first_table("r5s1/stream.txt", 13), corr_lines("r5s1/stream.txt"),
              "\n".join(l for l in rd("r5s13_call.log").split("\n") if l.startswith("uncached ")),
              "\n".join(rd("r5s15_call.log").split("\n")[5:19]),
              rd("r5s16/balance.txt", cut=330),
-             "\n".join(l[:330] for l in rd("r5s19/ab.txt").split("\n") if l.startswith("4K") or l.startswith("fvvdp: level write")))
+             "\n".join(l[:330] for l in rd("r5s19/ab.txt").split("\n") if l.startswith("4K") or l.startswith("fvvdp: level write")),
+             rd("r5s22/ab.txt", cut=200), rd("r5s24/k1.txt", cut=260), rd("r5s25/out.txt", cut=260),
+             "\n".join(l[:200] for l in rd("r5s26/drift.txt").split("\n") if l.startswith("run ")),
+             "\n".join(l[:200] for l in rd("r5s21_call.log").split("\n") if l.startswith("==") or l.startswith("FAILED") or " passed" in l))
 open(os.path.join(R, "profiles", "r05_k1_mode.md"), "w").write(out)
 print("written", len(out))
