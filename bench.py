@@ -216,7 +216,7 @@ def main():
             # streaming-write probe wrote fastest at once, i.e. two ranges of different classes of the box's physical memory where there are any
             "in_use": ("even frame slots: %s; odd frame slots: %s" % (kinds.get(cm_.value % 10), kinds.get((cm_.value // 10) % 10))) if two
                       else kinds.get(cm_.value, str(cm_.value)),
-            "half_size_candidates": nt_.value, "kept_indices": [kept_.value % 8, kept_.value // 8] if kept_.value >= 0 else None,
+            "half_size_candidates": nt_.value, "further_candidates_tried": int(us_[3]), "kept_indices": [kept_.value % 8, kept_.value // 8] if kept_.value >= 0 else None,
             "pair_write_rate_tbs": {"kept": round(us_[1], 2), "lowest": round(us_[2], 2)} if nt_.value else None,
             "temporal_plus_pyramid_us_per_frame_at_creation": round(us_[0], 2) if nt_.value else None, "state": st_.value,
             "per_frame_calls": {"host_syncs": int(cs_[0]), "allocations": int(cs_[1]), "frees": int(cs_[2])},

@@ -57,7 +57,9 @@ extern "C" const char* fvvdp_last_error(void) { return g_err; }
 struct CtxEnv {
     bool alloc_malloc = false;    // FVVDP_ALLOC=malloc: every scratch buffer from hipMalloc (default: large levels mapped from chunks)
     size_t vmm_chunk = 0;         // FVVDP_VMM_CHUNK_MB: chunk size of the >= 256 MB levels (default 32 MB)
-    int probe_n = -1;             // FVVDP_PLACEMENT_PROBE=n: level-0 candidates timed at creation (0 / 1 = none; default 6)
+    int probe_n = -1;             // FVVDP_PLACEMENT_PROBE=n: half-size level-0 candidates compared at creation (0 / 1 = none; default 6)
+    int probe_extra = -1;         // FVVDP_PLACEMENT_EXTRA=n: further candidates tried while no pair reaches probe_mixed (default 8)
+    float probe_mixed = 6.75f;    // FVVDP_PLACEMENT_MIXED_TBS: a pair written at once at this rate [TB/s] lies in both classes of memory
     bool inrange_off = false;     // FVVDP_BAND_INRANGE=0: always the pyramid kernels with clamps
     int fuse_mode = -1;           // FVVDP_BAND_FUSE=0 / 1: two-level pyramid kernel never / wherever valid (default: large levels)
     int band_cr = 0, band2_kr = 0, band2_kr2 = -1, band2_wpb = 0;   // FVVDP_BAND_CR, FVVDP_BAND2_KR, _KR2, _WPB: work decomposition overrides
@@ -74,6 +76,8 @@ static CtxEnv read_env() {
     if (const char* v = getenv("FVVDP_ALLOC")) e.alloc_malloc = strcmp(v, "malloc") == 0;
     e.vmm_chunk = (size_t)(num("FVVDP_VMM_CHUNK_MB", 0) > 0 ? num("FVVDP_VMM_CHUNK_MB", 0) : 0) << 20;
     e.probe_n = num("FVVDP_PLACEMENT_PROBE", -1);
+    e.probe_extra = num("FVVDP_PLACEMENT_EXTRA", -1);
+    if (const char* v = getenv("FVVDP_PLACEMENT_MIXED_TBS")) e.probe_mixed = (float)atof(v);
     if (const char* v = getenv("FVVDP_BAND_INRANGE")) e.inrange_off = v[0] == '0';
     if (const char* v = getenv("FVVDP_BAND_FUSE")) e.fuse_mode = (v[0] == '0' || v[0] == '1') ? v[0] - '0' : -1;
     e.band_cr = num("FVVDP_BAND_CR", 0);
@@ -430,6 +434,10 @@ extern "C" int fvvdp_ctx_create(fvvdp_ctx** out, int width, int height, int n_ba
         c->wave_capacity2 = (long long)per_cu2 * cus;
     }
     choose_level0(c);
+    if (!c->level[0]) {                            // the candidates and the fall-back to one range all failed to allocate
+        fvvdp_ctx_destroy(c);
+        return fail(FVVDP_ENOMEM, "no device memory for pyramid level 0");
+    }
     c->created = true;
     *out = c;
     return FVVDP_OK;
@@ -1450,8 +1458,9 @@ extern "C" int fvvdp_bands_forward_pool(fvvdp_ctx* c, int n, float* d_Q, int q_s
 // TWO ranges -- even frame slots in one, odd slots in the other (L0Addr, device_common.hpp: one address formula in every kernel that
 // touches level 0) -- and the two are CHOSEN: N half-size candidates (default 6: chunk-mapped and hipMalloc in
 // turn), every pair written at once by a streaming-write probe (4 ms per pair), the pair with the highest rate is kept, the
-// rest freed.  Two halves of different classes are the fast mode by construction; if every candidate lies in one class the best pair is
-// as good as any single buffer.  All of it happens here, before the first user call (~0.15 s, N x half a level 0 held for the moment);
+// rest freed.  Two halves of different classes are the fast mode by construction; if every candidate lies in one class (no pair above
+// 6.75 TB/s), up to 8 further candidates are taken while the first ones are held, each written together with one range of the best pair,
+// until a pair of different classes turns up; failing that the best pair is as good as any single buffer.  All of it happens here, before the first user call (~0.15 s, N x half a level 0 held for the moment);
 // per-frame calls never allocate, free or synchronise for it.  Results never depend on it.  Video contexts whose level 0 holds >= 1 GiB
 // (FVVDP_PLACEMENT_PROBE=n candidates, 0 / 1 = level 0 stays the single range it was allocated as; FVVDP_LEVEL0_SPLIT=1 splits any
 // context without probing: tests).
@@ -1537,10 +1546,40 @@ static void choose_level0(fvvdp_ctx* c) {
                 if (r > 0.0f && (r_worst == 0.0f || r < r_worst)) r_worst = r;
             }
     }
+    // No pair of different classes among them (pairs of one class: 5.3-6.5 TB/s, of two: 6.9-7.2; profiles/r05_k1_mode.md section 7 -- it
+    // happens where allocations come in runs of one class, e.g. the second and fourth of eight contexts of one process): take further
+    // candidates while HOLDING the ones there are, so that the allocator has to move on, and write each together with one range of the
+    // best pair; stop at the first pair of different classes.
+    int n_extra = 0;
+    std::vector<float*> held;
+    if (n_got >= 2 && r_best > 0.0f && r_best < c->env.probe_mixed) {
+        const int max_extra = c->env.probe_extra < 0 ? 8 : c->env.probe_extra;
+        for (int k = 0; k < max_extra; ++k) {
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (free_b < half_bytes + ((size_t)3 << 30)) break;
+            const int kd = c->env.alloc_malloc ? 0 : ((n_got + k) % 2 == 0 ? 1 : 0);
+            float* q = alloc_kind(kd, half_bytes);
+            if (!q) break;
+            ++n_extra;
+            const float r = pair_rate(cand[bi], q);
+            if (r > 0.0f && (r_worst == 0.0f || r < r_worst)) r_worst = r;
+            if (r > r_best) {
+                held.push_back(cand[bj]);
+                cand[bj] = q;
+                kind[bj] = kd;
+                r_best = r;
+            } else {
+                held.push_back(q);
+            }
+            if (r_best >= c->env.probe_mixed) break;
+        }
+    }
     (void)hipStreamSynchronize(st);
     for (auto& e : ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(st);
     (void)hipGetLastError();
+    for (float* q : held) free_any(q);
     if (n_got >= 2) {
         c->level[0] = cand[bi];
         c->level0_hi = cand[bj];
@@ -1561,9 +1600,10 @@ static void choose_level0(fvvdp_ctx* c) {
     c->sel_kept = bi + 8 * bj;
     c->sel_us[1] = r_best;
     c->sel_us[2] = r_worst;
+    c->sel_us[3] = (float)n_extra;
     if (c->env.debug_variant)
-        fprintf(stderr, "fvvdp: level 0 in two ranges: %d half-size candidates, pairs written at once at %.2f ... %.2f TB/s -> kept #%d (kind %d) + #%d (kind %d)\n",
-                n_got, r_worst, r_best, bi, kind[bi], bj, kind[bj]);
+        fprintf(stderr, "fvvdp: level 0 in two ranges: %d half-size candidates + %d further ones, pairs written at once at %.2f ... %.2f TB/s -> kept #%d (kind %d) + #%d (kind %d)\n",
+                n_got, n_extra, r_worst, r_best, bi, kind[bi], bj, kind[bj]);
     // for the record: the temporal kernel + the pyramid pass on the chosen layout, a synthetic uint8 clip as input (us per frame)
     const int SRC_FRAMES = 16, FL = 8, n = c->max_frames < 128 ? c->max_frames : 128;
     const size_t src_bytes = (size_t)SRC_FRAMES * 3 * HW;
@@ -1801,7 +1841,7 @@ extern "C" int fvvdp_ctx_alloc_info(const fvvdp_ctx* c, int* state, int* chunk_m
     *state = c->sel_phase;
     // one range: its kind (0 hipMalloc, 1 chunk-mapped); two ranges: 100 + 10 * kind of the odd slots + kind of the even slots
     *chunk_mapped = c->level0_hi ? 100 + 10 * c->level0_kind_hi + c->level0_kind : c->level0_kind;
-    for (int k = 0; k < capacity; ++k) h_us[k] = (k < 3 && c->sel_n > 0) ? c->sel_us[k] : 0.0f;
+    for (int k = 0; k < capacity; ++k) h_us[k] = (k < 4 && c->sel_n > 0) ? c->sel_us[k] : 0.0f;
     *n_timed = c->sel_n;
     *kept = c->sel_kept;
     return FVVDP_OK;

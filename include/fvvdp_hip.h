@@ -282,11 +282,14 @@ int fvvdp_ctx_timing_read(fvvdp_ctx* ctx, float* h_ms, int32_t* h_count, int cap
  * a video context that holds >= 1 GiB therefore lives in TWO ranges -- even frame slots in one, odd slots in the other -- chosen by
  * fvvdp_ctx_create among N half-size candidates (default 6: chunk-mapped and hipMalloc in turn;
  * environment FVVDP_PLACEMENT_PROBE=n, 0 / 1 = one range as allocated): every pair is written at once by a streaming-write probe and
- * the pair with the highest rate is kept.  ~0.15 s at creation, N halves of level 0 held for the moment, nothing in any per-frame
+ * the pair with the highest rate is kept; if no pair reaches the rate of two different classes (6.75 TB/s), up to 8 further candidates
+ * are taken while the first ones are held (FVVDP_PLACEMENT_EXTRA=n), each written together with one range of the best pair, until one
+ * does.  ~0.1 s at creation (0.3 s with the further candidates), the candidates' memory held for the moment, nothing in any per-frame
  * call.  Results never depend on it.
  *   *state: always 9 (settled);  *chunk_mapped: one range: its kind (0 hipMalloc, 1 mapped from physical chunks); two ranges: 100 + 10 * kind of the odd slots' range + kind of the even slots' range
  *   h_us[capacity]: [0] microseconds per frame of the temporal kernel + pyramid pass on the layout in use (a synthetic clip, timed once at
- *   creation; 0 = not timed), [1] / [2] highest / lowest streaming-write rate [TB/s] over the candidate pairs, 0 beyond
+ *   creation; 0 = not timed), [1] / [2] highest / lowest streaming-write rate [TB/s] over the candidate pairs, [3] number of further candidates
+ *   tried, 0 beyond
  *   *n_timed: number of half-size candidates (0: no choice);  *kept: index of the even slots' candidate + 8 * index of the odd slots' (-1: no choice) */
 int fvvdp_ctx_alloc_info(const fvvdp_ctx* ctx, int* state, int* chunk_mapped, float* h_us, int capacity, int* n_timed, int* kept);
 

@@ -453,7 +453,8 @@ def test_level0_in_two_chosen_ranges_changes_no_bits(tmp_path):
     the kinds of the two ranges, the highest / lowest pair rate, the layout's timing); the other candidates are freed before the first user
     call.  Per-frame calls never allocate, free or synchronise (fvvdp_ctx_call_stats: all zero from the FIRST call on -- SURVEY 8(b)
     "allocated once in ctx_create").  Same bits with one range (choice off), with hipMalloc candidates only, with 2 or 4
-    candidates; small contexts and images keep their one range."""
+    candidates, and with the further candidates that are taken while no pair reaches the rate of two different classes (forced by an
+    unreachable rate: all of them tried, the memory given back); small contexts and images keep their one range."""
     import subprocess
     import sys
     import os
@@ -488,6 +489,7 @@ def test_level0_in_two_chosen_ranges_changes_no_bits(tmp_path):
         "np.save(sys.argv[1], np.stack(out))\n" % root)
     res = {}
     modes = (("default", {}, 6), ("off", {"FVVDP_PLACEMENT_PROBE": "0"}, 0), ("malloc", {"FVVDP_ALLOC": "malloc"}, 6),
+             ("further", {"FVVDP_PLACEMENT_MIXED_TBS": "99", "FVVDP_PLACEMENT_EXTRA": "5"}, 6),      # no pair is ever good enough: all five further candidates are tried
              ("two", {"FVVDP_PLACEMENT_PROBE": "2"}, 2), ("four", {"FVVDP_PLACEMENT_PROBE": "4"}, 4))
     for mode, env, n_want in modes:
         f = str(tmp_path / ("s_%s.npy" % mode))
@@ -507,9 +509,11 @@ def test_level0_in_two_chosen_ranges_changes_no_bits(tmp_path):
             if n_want:
                 lo, hi = kept % 8, kept // 8
                 assert 0 <= lo < hi < n_want and kind >= 100, (mode, i)
-                assert us[0] > 0 and us[1] >= us[2] > 0 and all(u == 0 for u in us[3:]), (mode, i)
+                assert us[0] > 0 and us[1] >= us[2] > 0 and all(u == 0 for u in us[4:]), (mode, i)
+                assert us[3] == (5 if mode == "further" else us[3]) and 0 <= us[3] <= 8, (mode, i)
                 want = {"malloc": [0] * 6}.get(mode, [1, 0, 1, 0, 1, 0])    # candidate kinds: chunk-mapped and hipMalloc in turn
-                assert kind == 100 + 10 * want[hi] + want[lo], (mode, i)
+                if us[3] == 0:
+                    assert kind == 100 + 10 * want[hi] + want[lo], (mode, i)
             else:
                 assert kept == -1 and kind == 1
         assert infos[0] == infos[3]                                                       # settled at creation: nothing moves afterwards

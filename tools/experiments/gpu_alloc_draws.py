@@ -1,6 +1,7 @@
 """Round 4: is a fresh level-0 allocation an independent draw of the temporal kernel's "mode"?  N contexts held at the same time in one
 process (each with its own chunk-mapped or hipMalloc scratch), the same 4K x 60 pair through each, K1 / levels 0+1 us per frame from the
-library's HIP events.  FVVDP_PLACEMENT_PROBE=0 FVVDP_ALLOC=[malloc] python tools/experiments/gpu_alloc_draws.py [N]"""
+library's HIP events.  Round 5: also where each context keeps its level 0 (two chosen ranges by default).
+[FVVDP_PLACEMENT_PROBE=0] [FVVDP_ALLOC=malloc] python tools/experiments/gpu_alloc_draws.py [N]"""
 import ctypes as C
 import os
 import sys
@@ -22,6 +23,12 @@ for k in range(N):
     m.timing = True
     m.predict(t, r, frames_per_second=30)
     models.append(m)
+def layout(m):
+    st, cm, n, kept = C.c_int(0), C.c_int(0), C.c_int(0), C.c_int(-1)
+    us = (C.c_float * 8)()
+    nat.check(nat.lib().fvvdp_ctx_alloc_info(m._ctx.handle, C.byref(st), C.byref(cm), us, 8, C.byref(n), C.byref(kept)))
+    return "%d:%.2f/%.2f" % (cm.value, us[1], us[2])
+print("level 0 per context (kind code : TB/s of the pair kept / of the slowest pair; 0 = one range): %s" % "  ".join(layout(m) for m in models))
 for rnd in range(2):
     row = []
     for m in models:
