@@ -105,9 +105,11 @@ this file is assembled from their logs by `tools/make_r5_evidence.py`.  All sess
    after 29 GiB in one run and not within 100-120 GiB in three others.  Section 4.
 5. *What the library does with that.*  (a) Level 0 of a large video context lives in TWO ranges -- even frame slots in one, odd slots in
    the other -- that `fvvdp_ctx_create` chooses among N = 6 half-size candidates (chunk-mapped and `hipMalloc` in turn) by writing every
-   pair at once: the pair with the highest rate is two ranges of different classes wherever the candidates hold both (every one of 58
-   processes on 6 boxes so far: pair kept 6.9-7.2 TB/s, slowest pair 5.3-6.5), and K1 runs at 29.7-31.5 us per frame in every one of
-   them -- section 7, which also lists the one session whose pair rates were not recorded and that had two processes at 33 and 35 us.  (Before that, the context kept the best of six full-size candidates, which helps only when a whole 8 GB candidate
+   pair at once: the pair with the highest rate is two ranges of different classes wherever the candidates hold both (58 of 58
+   single-context processes on five boxes: pair kept 6.9-7.2 TB/s, slowest pair 5.3-6.5, K1 29.7-31.5 us per frame); where the six lie
+   in one class -- 2 of 8 contexts held in one process in session 27 -- up to 8 further candidates are taken while the first are held,
+   until a pair of different classes turns up (session 28: K1 29.7-31.3 us on 24 of 24 contexts of three processes) -- section 7,
+   which also lists the one session whose pair rates were not recorded and that had two processes at 33 and 35 us.  (Before that, the context kept the best of six full-size candidates, which helps only when a whole 8 GB candidate
    happens to span both classes: sections 5 and 6.)  0.1 s at creation; nothing happens in per-frame calls any more.  (b) K1 itself got what the replay showed
    to help on EVERY buffer: 4 waves per workgroup on adjacent pixel blocks (`k1_4w` / `rp_4w` columns: -1.2 ... -1.5 us per frame, slow
    and fast alike).  A kernel-side remedy for the slow mode does not exist: a plain streaming write has it.
@@ -294,6 +296,25 @@ record: session 23 (a fifth box; 1080p processes first, then four 4K ones whose 
 session 26 watched the sensors: neither reproduced it.  Whether those two contexts had no pair of different classes to choose from, or
 something else slowed the writes, is not known.
 
+**Eight contexts held in one process** (`tools/experiments/gpu_alloc_draws.py 8`, the set-up VERDICT r4 item 1 names; K1 / levels 0+1 us per
+frame per context, two rounds; the first line gives each context's layout code and the rate of the pair kept / of the slowest pair).
+Session 27, before the further candidates existed: in the first process the six candidates of the 2nd and the 4th context lay in ONE class
+(best pair 5.73 / 5.70 TB/s) and K1 ran at 35.5 / 34.6 us there; one range as allocated: 2 of 8 (chunk-mapped) and 3-4 of 8 (`hipMalloc`)
+contexts slow in every process:
+
+```
+%s
+```
+
+Hence the further candidates: while no pair reaches 6.75 TB/s (pairs of one class: 5.3-6.5, of two: 6.9-7.2), `fvvdp_ctx_create` takes up
+to 8 more half-size candidates WHILE HOLDING the first six -- so that the allocator has to move on -- and writes each together with one
+range of the best pair, until a pair of different classes turns up.  Session 28, three processes of eight contexts: one context of 24
+needed them (`+ 8 further ones`: 6.83 TB/s), K1 29.7-31.3 us on all 24 contexts in both rounds:
+
+```
+%s
+```
+
 **Uncached device memory is out.**  Round 5 first had `hipExtMallocWithFlags(hipDeviceMallocUncached)` among the candidate kinds
 (5-15 %% faster streaming writes, section 5).  With every context split and the odd slots in a fresh uncached range, 3 of 180 GPU tests
 failed and not always the same ones: the FIRST pass over a fresh range returned a few pixels that the temporal kernel had not written
@@ -331,6 +352,7 @@ out = doc % (first_table("r5s1/stream.txt", 13), corr_lines("r5s1/stream.txt"),
              "\n".join(l[:330] for l in rd("r5s19/ab.txt").split("\n") if l.startswith("4K") or l.startswith("fvvdp: level write")),
              rd("r5s22/ab.txt", cut=200), rd("r5s24/k1.txt", cut=260), rd("r5s25/out.txt", cut=260),
              "\n".join(l[:200] for l in rd("r5s26/drift.txt").split("\n") if l.startswith("run ")),
+             rd("r5s27/draws.txt", cut=260), rd("r5s28/draws.txt", cut=260),
              "\n".join(l[:200] for l in rd("r5s21_call.log").split("\n") if l.startswith("==") or l.startswith("FAILED") or " passed" in l))
 open(os.path.join(R, "profiles", "r05_k1_mode.md"), "w").write(out)
 print("written", len(out))
