@@ -548,8 +548,12 @@ class fvvdp:
 
     def _context(self, W, H, n_bands, planes, batch, rho_band):
         key = self._context_key(W, H, n_bands, planes, batch, rho_band)
-        if self._ctx is not None and self._ctx.key == key:
-            return self._ctx
+        if self._ctx is not None:
+            have = self._ctx.key
+            # a context made for a longer batch serves a shorter one (clips of different lengths in one folder: no new scratch,
+            # no second choice of the level-0 ranges); everything else it bakes in must match by value
+            if have[:4] == key[:4] and have[5:] == key[5:] and have[4] >= batch:
+                return self._ctx
         self._drop_context()
         with torch.cuda.device(self.device):
             ctx = _Context(W, H, n_bands, planes, batch, rho_band, self.native_params())

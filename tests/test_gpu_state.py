@@ -634,3 +634,29 @@ def test_ticketed_temporal_kernel_changes_no_bits(monkeypatch):
                 out[mode] = np.stack(res)
             assert np.array_equal(out["1"], out["0"]), (N, H, W, fps, gray)
             assert np.array_equal(out["1"][0], out["1"][2])
+
+
+def test_context_made_for_a_longer_clip_serves_shorter_ones(fv):
+    """Clips of different lengths through one metric object: the native context made for the longer clip (scratch for its batch, the
+    level-0 ranges chosen at its creation) serves the shorter ones -- no second context; a longer clip replaces it.  Same bits as a
+    fresh object per clip."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    t, r = synth_video_pair(24, 96, 160, device="cuda")
+    m = fv.fvvdp(display_name="standard_fhd")
+    q24, s24 = m.predict(t, r, frames_per_second=30)
+    ctx = m._ctx
+    for n in (13, 24, 7, 2):
+        q, s = m.predict(t[:, :, :n], r[:, :, :n], frames_per_second=30)              # [1, 3, F, H, W]
+        assert m._ctx is ctx, n
+        qf, sf = fv.fvvdp(display_name="standard_fhd").predict(t[:, :, :n], r[:, :, :n], frames_per_second=30)
+        assert float(q) == float(qf) and np.array_equal(s["Q_per_ch"], sf["Q_per_ch"]), n
+    t2, r2 = synth_video_pair(31, 96, 160, device="cuda")
+    q31, s31 = m.predict(t2, r2, frames_per_second=30)
+    assert m._ctx is not ctx and m._ctx.key[4] == 31
+    qf, sf = fv.fvvdp(display_name="standard_fhd").predict(t2, r2, frames_per_second=30)
+    assert float(q31) == float(qf) and np.array_equal(s31["Q_per_ch"], sf["Q_per_ch"])
+    # a different frame size never reuses it
+    t3, r3 = synth_video_pair(5, 100, 160, device="cuda")
+    c31 = m._ctx
+    m.predict(t3, r3, frames_per_second=30)
+    assert m._ctx is not c31
