@@ -50,7 +50,9 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)       # (the context settles its level-0 buffer at creation, not over calls)
+    # the context settles its level-0 ranges at creation, not over calls; what the warm-up is for: after an idle gap the clocks come up
+    # over the first 6-8 steps (~30 ms; the per-launch list in profiles/r05_final_kernel_trace.md)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--shard", default="pairs", choices=["pairs", "frames"], help="pairs: independent pairs per rank (configs[4]); "
                     "frames: ONE pair of --frames x N frames, output frames split across the ranks (weak scaling in frames)")
     ap.add_argument("--pairs-per-gpu", type=int, default=1, help="independent pairs per rank and step (BASELINE configs[4]: 8)")

@@ -161,8 +161,10 @@ Figures derived from this bundle (quoted in DESIGN.md section 0):
 
 Every launch of the dominant kernel in that process, in order, with the kernel that ran before it.  The launches behind
 `__amd_rocclr_copyBuffer` are the host-array (PCIe-inclusive) calls at the end of bench.py: the GPU idles during the 50 ms
-upload and the kernel starts on cold clocks -- these three and the first two warm-up launches are what separated the rocprof
-AVERAGE from the HIP-event median in round 2 (8 %); the medians agree:
+upload and the kernel starts on cold clocks.  After every idle gap the launches of this arithmetic-bound kernel come down over
+the first 6-8 launches (~30 ms: 2.5 -> 2.3 -> 2.2 -> 2.0 -> 1.94 -> 1.89 -> 1.85 ms) while the power controller brings the clocks up
+(`profiles/r05_power.md`: the steady state sits at 1350 W of 1400, sclk 2.1 GHz); those launches are what separates the rocprof AVERAGE
+from the steady median and from the HIP-event median of the timed steps (bench.py warms up for 10 steps by default for this reason):
 
 ```
 {dispatch_list('kernel_trace_bench.md')}
