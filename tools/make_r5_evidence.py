@@ -325,6 +325,23 @@ not safe until its lines are gone; the kind was removed from the library rather 
 ```
 %s
 ```
+
+## 8. Reads and writes in different classes (session 31, `tools/microbench/rw_classes.hip`)
+
+Eight ranges of 4 GB (chunk-mapped and `hipMalloc` in turn), classified by writing each together with range 0; then a kernel whose
+workgroups either read range A or write range B as plain streams, the workgroups split in the ratio of the bytes: read only, 1 written per 16
+read (the pyramid pass), 6 read per 16 written (the temporal kernel), 1:1.  TB/s of both streams together, two processes:
+
+```
+%s
+```
+
+(a) A write stream of 1/16 of the bytes costs a read stream 2-3 %% whichever classes the two ranges lie in: nothing to gain for the pyramid
+pass from placing its small output elsewhere.  (b) The write-dominated mix depends on the DESTINATION alone (5.5-5.9 TB/s into a range of one
+class, 6.1-6.9 into one that spans both -- ranges 2, 4 and 6 of the second process), not on where the source lies.  (c) Plain streams in
+the temporal kernel's proportions reach 6.8-6.9 TB/s on such a destination = 26.5 us per 4K frame; the kernel, and the replay of its address
+stream, take 29.7-31.5: the shape of the stream (six byte planes read 1 KB per workgroup and frame, sixty frames written 16 KB at a time
+133 MB apart) costs ~12 %% against plain streaming, and none of the replay variants of section 1 recovers it.
 """
 
 zones = rd("r5s4/zones.txt").split("\n")
@@ -353,6 +370,7 @@ out = doc % (first_table("r5s1/stream.txt", 13), corr_lines("r5s1/stream.txt"),
              rd("r5s22/ab.txt", cut=200), rd("r5s24/k1.txt", cut=260), rd("r5s25/out.txt", cut=260),
              "\n".join(l[:200] for l in rd("r5s26/drift.txt").split("\n") if l.startswith("run ")),
              rd("r5s27/draws.txt", cut=260), rd("r5s28/draws.txt", cut=260),
-             "\n".join(l[:200] for l in rd("r5s21_call.log").split("\n") if l.startswith("==") or l.startswith("FAILED") or " passed" in l))
+             "\n".join(l[:200] for l in rd("r5s21_call.log").split("\n") if l.startswith("==") or l.startswith("FAILED") or " passed" in l),
+             rd("r5s31/rw.txt", cut=200))
 open(os.path.join(R, "profiles", "r05_k1_mode.md"), "w").write(out)
 print("written", len(out))
