@@ -342,6 +342,39 @@ class, 6.1-6.9 into one that spans both -- ranges 2, 4 and 6 of the second proce
 the temporal kernel's proportions reach 6.8-6.9 TB/s on such a destination = 26.5 us per 4K frame; the kernel, and the replay of its address
 stream, take 29.7-31.5: the shape of the stream (six byte planes read 1 KB per workgroup and frame, sixty frames written 16 KB at a time
 133 MB apart) costs ~12 %% against plain streaming, and none of the replay variants of section 1 recovers it.
+
+## 9. What the temporal kernel pays for: reads MIXED into its writes (session 32, `k1_stream ... decoupled`)
+
+The replay of the kernel's stream with its loads and stores in one wave (`rp`), the loads alone (`rp_r`), the stores alone (`rp_w`), and
+the load-only and the store-only replay launched at the same time on two streams (`rp_r || rp_w`: same addresses, same instruction
+shapes; the loads are done after a quarter of the time and the stores finish alone); last column: plain streams of the same sizes.
+us per 4K frame, two processes:
+
+```
+%s
+```
+
+The stores alone run at the rate of a plain streaming write (19.3-19.5 us per frame on a range that spans both classes), the loads alone
+take 5.6-5.8 us, one after the other 25.4-25.6 us -- and interleaved, as a kernel that turns every loaded frame into a stored one has them,
+31.1-31.5 us: **the memory system charges ~6 us per frame (a fifth of the kernel) for the reads being mixed into the writes**, on slow and
+fast ranges alike.  It is not the coupling inside a wave: with the load-only kernel throttled (fewer waves per CU through its LDS
+footprint) so that its loads spread over the whole duration, the two kernels together take as long as the coupled replay again
+(first pair of numbers per footprint: when the load kernel ended / when both had ended):
+
+```
+%s
+```
+
+So the gain needs PHASES -- the chip reading for a while, then writing for a while -- and a kernel can only get them by holding a phase's
+worth of data on the chip (one 4K frame pair of sources is 50 MB) or by keeping all its waves in step.  Tried: every wave loads ten frames
+in one go and then stores ten, the loads gated into a window of the 100 MHz real-time counter that all waves see (`replay_phased`, periods
+of 28-38 us, 20-28 %% of them open for loads, stores gated out of the window or not): 42 us per frame ungated, 46-49 gated -- a wave that
+drains its loads before it stores hides no latency, and a wave that misses its window loses a period.  Not built into the kernel; the
+6 us stand as the difference between the temporal kernel (0.73-0.77 of the HBM peak) and plain streaming of its bytes.
+
+```
+%s
+```
 """
 
 zones = rd("r5s4/zones.txt").split("\n")
@@ -371,6 +404,8 @@ out = doc % (first_table("r5s1/stream.txt", 13), corr_lines("r5s1/stream.txt"),
              "\n".join(l[:200] for l in rd("r5s26/drift.txt").split("\n") if l.startswith("run ")),
              rd("r5s27/draws.txt", cut=260), rd("r5s28/draws.txt", cut=260),
              "\n".join(l[:200] for l in rd("r5s21_call.log").split("\n") if l.startswith("==") or l.startswith("FAILED") or " passed" in l),
-             rd("r5s31/rw.txt", cut=200))
+             rd("r5s31/rw.txt", cut=200),
+             rd("r5s32/decoupled.txt", cut=200), "\n".join(l[:200] for l in rd("r5s32/throttled.txt").split("\n") if l[:1].isdigit() or l.startswith("buf")),
+             "\n".join(l[:330] for l in rd("r5s32/phased.txt").split("\n") if "phased" in l or l[:1].isdigit()))
 open(os.path.join(R, "profiles", "r05_k1_mode.md"), "w").write(out)
 print("written", len(out))

@@ -136,6 +136,63 @@ __global__ __launch_bounds__(64 * WAVES) void replay(const ReplayArgs a) {
     }
 }
 
+// The same stream in chip-wide PHASES: every wave loads the source bytes of B frames in one go and then stores B output frames; with GATE
+// the loads may only be issued inside a window of the 100 MHz real-time counter that all waves see (t mod period < rwin), with GATE 2 the
+// stores only outside it -- reads and writes of the whole chip separated in time (session 32: loads first, stores after = 25 us per frame,
+// interleaved = 31).  One wave per workgroup, 7 history frames loaded in a prologue.
+struct PhaseArgs { ReplayArgs r; unsigned int period, rwin; };
+template <int B, int GATE>
+__global__ __launch_bounds__(64) void replay_phased(const PhaseArgs pa) {
+    const ReplayArgs& a = pa.r;
+    const int block = blockIdx.x;
+    if (block >= a.n_blocks) return;
+    const int lane = threadIdx.x;
+    const int p0 = block * 256;
+    const int pl = min(p0 + lane * 4, a.HW - 4);
+    unsigned int soff[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) soff[i] = (p0 + i * 64 + lane < a.HW) ? (unsigned int)(p0 + i * 64 + lane) * 16u : 0xFFFFFFFFu;
+    const unsigned int frame_bytes = (unsigned int)a.HW * 16u;
+    auto fetch = [&](int f, unsigned int (&v)[6]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int c = 0; c < 3; ++c)
+                v[s * 3 + c] = __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(a.src[s] + (size_t)f * a.frame_stride + c * a.chan_stride + pl));
+    };
+    auto in_window = [&]() { return ((unsigned int)__builtin_amdgcn_s_memrealtime() % pa.period) < pa.rwin; };
+    float hist = 0.0f;
+    {   // history
+        unsigned int h[7][6];
+        if (GATE >= 1) while (!in_window()) __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) fetch(k, h[k]);
+#pragma unroll
+        for (int k = 0; k < 7; ++k) hist = hist * 0.5f + (float)(h[k][0] & 0xFF) + (float)(h[k][3] >> 24) + (float)(h[k][5] & 0xFF00) + (float)(h[k][1] ^ h[k][2] ^ h[k][4]);
+    }
+    for (int t0 = 0; t0 < a.n_out; t0 += B) {
+        unsigned int buf[B][6];
+        if (GATE >= 1) while (!in_window()) __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+        for (int k = 0; k < B; ++k) fetch(min(7 + t0 + k, 6 + a.n_out), buf[k]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (GATE >= 2) while (in_window()) __builtin_amdgcn_s_sleep(8);
+#pragma unroll
+        for (int k = 0; k < B; ++k) {
+            int t = t0 + k;
+            if (t >= a.n_out) break;
+            const float x0 = (float)(buf[k][0] & 0xFF) + (float)(buf[k][1] >> 24) + (float)(buf[k][2] & 0xFF00);
+            const float x1 = (float)(buf[k][3] & 0xFF) + (float)(buf[k][4] >> 24) + (float)(buf[k][5] & 0xFF00);
+            hist = hist * 0.5f + x0;
+            asm volatile("" : "+s"(t));
+            const __amdgpu_buffer_rsrc_t o = level_rsrc(a.out + (size_t)t * a.HW * 4, frame_bytes);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{hist, x1, x0, (float)i}), o, soff[i], 0, 2);
+        }
+    }
+}
+
 // plain streaming write / read of the same 7.96 GB (grid-stride, 16 B per lane): is a slow buffer slow for every pattern?
 __global__ __launch_bounds__(256) void stream_write(float4* __restrict__ q, size_t n4, float v) {
     size_t i = (size_t)blockIdx.x * 1024 + threadIdx.x;
@@ -227,9 +284,9 @@ static size_t out_bytes_c(int hw) { return (size_t)NOUT * hw * 16; }
 
 int main(int argc, char** argv) {
     int n_malloc = 4, n_v32 = 4, n_v2 = 2, n_other = 0;
-    bool pmc = false, regions = false, zones = false, balanced = false, spread = false;
+    bool pmc = false, regions = false, zones = false, balanced = false, spread = false; bool decoupled = false;
     std::vector<int> nums;
-    for (int i = 1; i < argc; ++i) { if (!strcmp(argv[i], "pmc")) pmc = true; else if (!strcmp(argv[i], "regions")) regions = true; else if (!strcmp(argv[i], "zones")) zones = true; else if (!strcmp(argv[i], "balanced")) balanced = true; else if (!strcmp(argv[i], "spread")) spread = true; else nums.push_back(atoi(argv[i])); }
+    for (int i = 1; i < argc; ++i) { if (!strcmp(argv[i], "pmc")) pmc = true; else if (!strcmp(argv[i], "regions")) regions = true; else if (!strcmp(argv[i], "zones")) zones = true; else if (!strcmp(argv[i], "balanced")) balanced = true; else if (!strcmp(argv[i], "spread")) spread = true; else if (!strcmp(argv[i], "decoupled")) decoupled = true; else nums.push_back(atoi(argv[i])); }
     if (nums.size() >= 3) { n_malloc = nums[0]; n_v32 = nums[1]; n_v2 = nums[2]; }
     if (nums.size() >= 4) n_other = nums[3];
     if (zones) {
@@ -503,6 +560,75 @@ int main(int argc, char** argv) {
             auto fk = [&] { TemporalArgs a = ta; a.out = one_range((float*)bufs[b].ptr); hipLaunchKernelGGL((temporal_vec_kernel<8, 4, SRC_U8, 1>), dim3((nb + k1_wpb(8) - 1) / k1_wpb(8)), dim3(64 * k1_wpb(8)), 0, 0, a); };
             fk(); CK(hipDeviceSynchronize());
             printf(" | %5.2f\n", time_us(fk, 5) / NOUT);
+            fflush(stdout);
+        }
+        return 0;
+    }
+    if (decoupled) {
+        // Loads and stores of the temporal kernel's stream coupled in one wave (rp), each alone (rp_r, rp_w), and DECOUPLED: the load-only
+        // and the store-only replay at the same time on two streams (5 KB of LDS each: 16 + 16 waves per CU) -- same addresses, same
+        // instruction shapes, but no wave waits for its own loads before it stores.  Last: plain streams in the same proportions.
+        hipStream_t s0, s1; CK(hipStreamCreateWithFlags(&s0, hipStreamNonBlocking)); CK(hipStreamCreateWithFlags(&s1, hipStreamNonBlocking));
+        hipEvent_t e0, e1, e2; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1)); CK(hipEventCreate(&e2));
+        auto both = [&](std::function<void(hipStream_t)> fa, std::function<void(hipStream_t)> fb) {
+            std::vector<double> v;
+            for (int rep = 0; rep < 6; ++rep) {
+                CK(hipDeviceSynchronize());
+                CK(hipEventRecord(e0, s0)); CK(hipStreamWaitEvent(s1, e0, 0));
+                fa(s0); fb(s1);
+                CK(hipEventRecord(e1, s1)); CK(hipStreamWaitEvent(s0, e1, 0)); CK(hipEventRecord(e2, s0)); CK(hipEventSynchronize(e2));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e2));
+                if (rep) v.push_back(ms * 1e3);
+            }
+            std::sort(v.begin(), v.end());
+            return v[v.size() / 2] / NOUT;
+        };
+        float* sink = nullptr; CK(hipMalloc(&sink, 64));
+        const size_t src4 = (size_t)NSRC * 3 * HW / 16, out4 = (size_t)NOUT * HW;
+        printf("%-3s %-8s %10s %10s %10s %12s %12s %14s   (us per 4K frame)\n", "buf", "kind", "rp", "rp_r", "rp_w", "rp_r || rp_w", "rp_4w", "plain r || w");
+        for (size_t b = 0; b < bufs.size(); ++b) {
+            float* o = (float*)bufs[b].ptr;
+            auto one = [&](std::function<void(hipStream_t)> f) { return both(f, [](hipStream_t) {}); };
+            const double t_rp = one([&](hipStream_t st) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, true, 1, 2, 0>), dim3(nb), dim3(64), 10240, st, a); });
+            const double t_r = one([&](hipStream_t st) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, false, 1, 2, 0>), dim3(nb), dim3(64), 10240, st, a); });
+            const double t_w = one([&](hipStream_t st) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, false, true, 1, 2, 0>), dim3(nb), dim3(64), 10240, st, a); });
+            const double t_rw = both([&](hipStream_t st) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, false, 1, 2, 0>), dim3(nb), dim3(64), 5120, st, a); },
+                                     [&](hipStream_t st) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, false, true, 1, 2, 0>), dim3(nb), dim3(64), 5120, st, a); });
+            const double t_4w = one([&](hipStream_t st) { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, true, 4, 2, 0>), dim3((nb + 3) / 4), dim3(256), 40960, st, a); });
+            const double t_pl = both([&](hipStream_t st) { hipLaunchKernelGGL(stream_read, dim3(8192), dim3(256), 0, st, (const float4*)src[0], src4, sink);
+                                                           hipLaunchKernelGGL(stream_read, dim3(8192), dim3(256), 0, st, (const float4*)src[1], src4, sink); },
+                                     [&](hipStream_t st) { hipLaunchKernelGGL(stream_write, dim3(24576), dim3(256), 0, st, (float4*)o, out4, 1.0f); });
+            printf("%-3zu %-8s %10.2f %10.2f %10.2f %12.2f %12.2f %14.2f", b, bufs[b].kind.c_str(), t_rp, t_r, t_w, t_rw, t_4w, t_pl);
+            // the load-only replay throttled by its LDS footprint (fewer waves per CU): do the loads have to END early for the gain, or is it
+            // enough that no wave waits for its own loads?  per footprint: when the load kernel ended / when both had ended (us per frame)
+            static hipEvent_t er = nullptr; if (!er) CK(hipEventCreate(&er));
+            for (int kb : {20, 40, 64, 100}) {
+                std::vector<double> vt, vr;
+                for (int rep = 0; rep < 4; ++rep) {
+                    CK(hipDeviceSynchronize());
+                    CK(hipEventRecord(e0, s0)); CK(hipStreamWaitEvent(s1, e0, 0));
+                    { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, false, true, 1, 2, 0>), dim3(nb), dim3(64), 2048, s1, a); }
+                    { ReplayArgs a = ra; a.out = o; hipLaunchKernelGGL((replay<0, true, false, 1, 2, 0>), dim3(nb), dim3(64), kb * 1024, s0, a); }
+                    CK(hipEventRecord(er, s0));
+                    CK(hipEventRecord(e1, s1)); CK(hipStreamWaitEvent(s0, e1, 0)); CK(hipEventRecord(e2, s0)); CK(hipEventSynchronize(e2));
+                    float ms, mr; CK(hipEventElapsedTime(&ms, e0, e2)); CK(hipEventElapsedTime(&mr, e0, er));
+                    if (rep) { vt.push_back(ms * 1e3 / NOUT); vr.push_back(mr * 1e3 / NOUT); }
+                }
+                std::sort(vt.begin(), vt.end()); std::sort(vr.begin(), vr.end());
+                printf("  | %dK: %.1f/%.1f", kb, vr[1], vt[1]);
+            }
+            printf("\n");
+            // chip-wide phases (replay_phased): B = 10 frames per wave and period, loads gated into a window of the real-time counter
+            printf("      phased B=10: ungated %.2f", one([&](hipStream_t st) { PhaseArgs pa; pa.r = ra; pa.r.out = o; pa.period = 3000; pa.rwin = 750;
+                                                              hipLaunchKernelGGL((replay_phased<10, 0>), dim3(nb), dim3(64), 10240, st, pa); }));
+            for (unsigned int per : {2800u, 3100u, 3400u, 3800u})
+                for (unsigned int duty : {20u, 28u}) {
+                    auto go = [&](int gate) { return one([&](hipStream_t st) { PhaseArgs pa; pa.r = ra; pa.r.out = o; pa.period = per; pa.rwin = per * duty / 100;
+                        if (gate == 1) hipLaunchKernelGGL((replay_phased<10, 1>), dim3(nb), dim3(64), 10240, st, pa);
+                        else hipLaunchKernelGGL((replay_phased<10, 2>), dim3(nb), dim3(64), 10240, st, pa); }); };
+                    printf(" | %u/%u%%: %.2f %.2f", per, duty, go(1), go(2));
+                }
+            printf("   (period in 10 ns ticks / share of it open for loads: loads gated, loads and stores gated)\n");
             fflush(stdout);
         }
         return 0;
