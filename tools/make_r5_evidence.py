@@ -366,10 +366,11 @@ footprint) so that its loads spread over the whole duration, the two kernels tog
 ```
 
 So the gain needs PHASES -- the chip reading for a while, then writing for a while -- and a kernel can only get them by holding a phase's
-worth of data on the chip (one 4K frame pair of sources is 50 MB) or by keeping all its waves in step.  Tried: every wave loads ten frames
-in one go and then stores ten, the loads gated into a window of the 100 MHz real-time counter that all waves see (`replay_phased`, periods
-of 28-38 us, 20-28 %% of them open for loads, stores gated out of the window or not): 42 us per frame ungated, 46-49 gated -- a wave that
-drains its loads before it stores hides no latency, and a wave that misses its window loses a period.  Not built into the kernel; the
+worth of data on the chip (one 4K frame pair of sources is 50 MB) or by keeping all its waves in step.  Tried: every wave loads the bytes of
+ten frames in one go (60 registers) and then stores ten frames, the loads gated into a window of the 100 MHz real-time counter that all waves
+see (`replay_phased`, periods of 28-38 us, 20-28 %% of them open for loads, stores gated out of the window or not).  On a box whose four
+ranges were all of one class (coupled replay 38.2 us per frame, loads then stores 31.3): ungated 37.8, gated 38.0-40.3 -- no phase gain;
+the waves do not finish a block per period (the time does not follow the period), so the windows never line the chip up.  Not built into the kernel; the
 6 us stand as the difference between the temporal kernel (0.73-0.77 of the HBM peak) and plain streaming of its bytes.
 
 ```

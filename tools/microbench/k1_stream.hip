@@ -179,8 +179,7 @@ __global__ __launch_bounds__(64) void replay_phased(const PhaseArgs pa) {
         if (GATE >= 2) while (in_window()) __builtin_amdgcn_s_sleep(8);
 #pragma unroll
         for (int k = 0; k < B; ++k) {
-            int t = t0 + k;
-            if (t >= a.n_out) break;
+            int t = t0 + k;                      // (n_out is a multiple of B)
             const float x0 = (float)(buf[k][0] & 0xFF) + (float)(buf[k][1] >> 24) + (float)(buf[k][2] & 0xFF00);
             const float x1 = (float)(buf[k][3] & 0xFF) + (float)(buf[k][4] >> 24) + (float)(buf[k][5] & 0xFF00);
             hist = hist * 0.5f + x0;
