@@ -370,8 +370,15 @@ worth of data on the chip (one 4K frame pair of sources is 50 MB) or by keeping 
 ten frames in one go (60 registers) and then stores ten frames, the loads gated into a window of the 100 MHz real-time counter that all waves
 see (`replay_phased`, periods of 28-38 us, 20-28 %% of them open for loads, stores gated out of the window or not).  On a box whose four
 ranges were all of one class (coupled replay 38.2 us per frame, loads then stores 31.3): ungated 37.8, gated 38.0-40.3 -- no phase gain;
-the waves do not finish a block per period (the time does not follow the period), so the windows never line the chip up.  Not built into the kernel; the
-6 us stand as the difference between the temporal kernel (0.73-0.77 of the HBM peak) and plain streaming of its bytes.
+the waves do not finish a block per period (the time does not follow the period), so the windows never line the chip up.  Also tried: the frame in 8 / 16 / 32 / 64 launches of one
+round of resident waves or less, each wave first touching all source bytes of its block (a read-only phase at the start of every launch) so
+that the loop would find them in the 256 MB memory-side cache: 41-45 us per frame against 33-34 without the touch (last block below) -- the
+touch costs its 6-8 us and the loop gains nothing (a slab's sources, 104-416 MB, do not survive its 250-1000 MB of stores).  Not built
+into the kernel; the 6 us stand as the difference between the temporal kernel (0.73-0.77 of the HBM peak) and plain streaming of its bytes.
+
+```
+%s
+```
 
 ```
 %s
@@ -407,6 +414,7 @@ out = doc % (first_table("r5s1/stream.txt", 13), corr_lines("r5s1/stream.txt"),
              "\n".join(l[:200] for l in rd("r5s21_call.log").split("\n") if l.startswith("==") or l.startswith("FAILED") or " passed" in l),
              rd("r5s31/rw.txt", cut=200),
              rd("r5s32/decoupled.txt", cut=200), "\n".join(l[:200] for l in rd("r5s32/throttled.txt").split("\n") if l[:1].isdigit() or l.startswith("buf")),
-             "\n".join(l[:330] for l in rd("r5s32/phased.txt").split("\n") if "phased" in l or l[:1].isdigit()))
+             "\n".join(l[:330] for l in rd("r5s32/phased.txt").split("\n") if "phased" in l or l[:1].isdigit()),
+             "\n".join(l[:160] for l in rd("r5s32/touch.txt").split("\n") if "slabs" in l or l[:1].isdigit() or l.startswith("buf")))
 open(os.path.join(R, "profiles", "r05_k1_mode.md"), "w").write(out)
 print("written", len(out))

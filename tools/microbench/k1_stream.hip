@@ -83,7 +83,7 @@ struct ReplayArgs {
 // MAP 0 = block order of the real kernel, 1 = XCD-contiguous, 2 = runs of 16; RD / WR = with loads / stores; WAVES per workgroup;
 // dynamic LDS of 10 KB per wave holds the replay at the real kernel's 16 waves per CU (0 = as many as fit: "rp_occ8");
 // AUX = cache policy of the stores (2 = nt as in the real kernel); ALU = filler multiply-adds per step and pixel
-template <int MAP, bool RD, bool WR, int WAVES, int AUX, int ALU, bool STEP = false>
+template <int MAP, bool RD, bool WR, int WAVES, int AUX, int ALU, bool STEP = false, bool TOUCH = false>
 __global__ __launch_bounds__(64 * WAVES) void replay(const ReplayArgs a) {
     int wg = blockIdx.x + a.wg0;
     const int n_wg = (a.n_blocks + WAVES - 1) / WAVES;
@@ -102,7 +102,9 @@ __global__ __launch_bounds__(64 * WAVES) void replay(const ReplayArgs a) {
         for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int c = 0; c < 3; ++c)
-                v[s * 3 + c] = RD ? __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(a.src[s] + (size_t)f * a.frame_stride + c * a.chan_stride + pl)) : (unsigned int)(f + c);
+                v[s * 3 + c] = RD ? (TOUCH ? *reinterpret_cast<const unsigned int*>(a.src[s] + (size_t)f * a.frame_stride + c * a.chan_stride + pl)
+                                           : __builtin_nontemporal_load(reinterpret_cast<const unsigned int*>(a.src[s] + (size_t)f * a.frame_stride + c * a.chan_stride + pl)))
+                                  : (unsigned int)(f + c);
     };
     unsigned int soff[4];
 #pragma unroll
@@ -110,6 +112,18 @@ __global__ __launch_bounds__(64 * WAVES) void replay(const ReplayArgs a) {
     const unsigned int frame_bytes = (unsigned int)a.HW * 16u;
     const int total = 7 + a.n_out;
     float hist = 0.0f;
+    if (TOUCH) {
+        // a read-only phase first: every wave of the launch touches all source bytes of its block (the launch is one round of resident
+        // waves that start together), so that the loop below finds them in the memory-side cache and sends only its stores to the DRAM
+        unsigned int acc = 0;
+        for (int f = 0; f < total; ++f) {
+            unsigned int tmp[6];
+            fetch(f, tmp);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc ^= tmp[k];
+        }
+        if (acc == 0x12345678u) hist = 1.0f;
+    }
     fetch(0, nx);
     for (int v = 0; v < total; ++v) {
         unsigned int cur[6];
@@ -615,6 +629,17 @@ int main(int argc, char** argv) {
                 }
                 std::sort(vt.begin(), vt.end()); std::sort(vr.begin(), vr.end());
                 printf("  | %dK: %.1f/%.1f", kb, vr[1], vt[1]);
+            }
+            printf("\n");
+            // the frame in N launches (one round of resident waves each or less), without / with a read-only phase at the start of every launch
+            printf("      slabs, plain / touch-first:");
+            for (int ns : {8, 16, 32, 64}) {
+                const int per = (nb + ns - 1) / ns;
+                const double t0 = one([&](hipStream_t st) { for (int k = 0; k < ns; ++k) { ReplayArgs a = ra; a.out = o; a.wg0 = k * per; if (a.wg0 >= nb) break;
+                    hipLaunchKernelGGL((replay<0, true, true, 1, 2, 0>), dim3(std::min(per, nb - a.wg0)), dim3(64), 10240, st, a); } });
+                const double t1 = one([&](hipStream_t st) { for (int k = 0; k < ns; ++k) { ReplayArgs a = ra; a.out = o; a.wg0 = k * per; if (a.wg0 >= nb) break;
+                    hipLaunchKernelGGL((replay<0, true, true, 1, 2, 0, false, true>), dim3(std::min(per, nb - a.wg0)), dim3(64), 10240, st, a); } });
+                printf("  %d: %.2f / %.2f", ns, t0, t1);
             }
             printf("\n");
             // chip-wide phases (replay_phased): B = 10 frames per wave and period, loads gated into a window of the real-time counter
