@@ -151,8 +151,9 @@ def _check_bench_line(out, dims, backend, world=2):
     # value is the median step; the mean is carried beside it, and the two are consistent with their times
     tm = out["timing"]
     px = 2.0 * W * H * N * K * world
-    assert abs(out["value"] - px / (out["ms_per_step"] * 1e-3) / 1e6) <= 2e-3 * out["value"]
-    assert abs(tm["value_mean"] - px / (tm["ms_per_step_mean"] * 1e-3) / 1e6) <= 2e-3 * tm["value_mean"]
+    # (the line carries the times rounded to a microsecond: half a unit of that on a step of a few hundred microseconds counts)
+    assert abs(out["value"] - px / (out["ms_per_step"] * 1e-3) / 1e6) <= (1e-3 + 0.0006 / out["ms_per_step"]) * out["value"]
+    assert abs(tm["value_mean"] - px / (tm["ms_per_step_mean"] * 1e-3) / 1e6) <= (1e-3 + 0.0006 / tm["ms_per_step_mean"]) * tm["value_mean"]
     assert tm["ms_per_step_min"] <= out["ms_per_step"] <= tm["ms_per_step_max"]
     if world > 1:
         # what the communicator reports: backend, size, one entry per rank
