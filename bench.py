@@ -429,6 +429,7 @@ def main():
                "timing": {"statistic": "median of the %d timed steps (SURVEY 8(d)); value = pixels of a step / ms_per_step" % args.steps,
                           "ms_per_step_mean": round(dt / args.steps * 1e3, 3), "value_mean": round(mpix_mean, 1),
                           "ms_per_step_min": round(float(step_s[0]) * 1e3, 3), "ms_per_step_max": round(float(step_s[-1]) * 1e3, 3),
+                          "ms_per_step_in_order": [round(float(x) * 1e3, 3) for x in tall[1:]],
                           "timed_region_s": round(dt, 4)},
                "jod": [round(j, 6) for j in jods[:8]],
                "jod_delta_vs_reference": None if jod_delta is None else float("%.3g" % jod_delta), "roofline": roof, "cpu_baseline": cpu}
