@@ -294,7 +294,8 @@ process so far the slowest pair of the six candidates ran at 5.3-6.5 TB/s, i.e. 
 record: session 23 (a fifth box; 1080p processes first, then four 4K ones whose `level0_alloc` was not printed) measured K1 at 29.8, 30.9,
 33.1 and 35.1 us in that order, levels 0+1 at 30.0-30.7 throughout.  Session 25 repeated the sequence with the pair rates printed and
 session 26 watched the sensors: neither reproduced it.  Whether those two contexts had no pair of different classes to choose from, or
-something else slowed the writes, is not known.
+something else slowed the writes, is not known (one candidate: the episodes of a few tens of milliseconds in which the power controller
+pulls the clocks back, `profiles/r05_power.md`).
 
 **Eight contexts held in one process** (`tools/experiments/gpu_alloc_draws.py 8`, the set-up VERDICT r4 item 1 names; K1 / levels 0+1 us per
 frame per context, two rounds; the first line gives each context's layout code and the rate of the pair kept / of the slowest pair).
