@@ -155,6 +155,7 @@ def _check_bench_line(out, dims, backend, world=2):
     assert abs(out["value"] - px / (out["ms_per_step"] * 1e-3) / 1e6) <= (1e-3 + 0.0006 / out["ms_per_step"]) * out["value"]
     assert abs(tm["value_mean"] - px / (tm["ms_per_step_mean"] * 1e-3) / 1e6) <= (1e-3 + 0.0006 / tm["ms_per_step_mean"]) * tm["value_mean"]
     assert tm["ms_per_step_min"] <= out["ms_per_step"] <= tm["ms_per_step_max"]
+    assert len(tm["ms_per_step_in_order"]) == out["steps"] and max(tm["ms_per_step_in_order"]) == tm["ms_per_step_max"]
     if world > 1:
         # what the communicator reports: backend, size, one entry per rank
         cm = out["communicator"]
