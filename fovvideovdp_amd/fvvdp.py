@@ -382,6 +382,8 @@ class fvvdp:
         call: 4K x 60, 4.25 against 4.15 ms); the caller gets its own copy.  Falls back to `.cpu()` where page-locking is refused."""
         n = res.numel()
         pin = self.__dict__.get("_res_pin")
+        if pin is False:                       # page-locking was refused once: do not ask again
+            return res.detach().cpu()
         if pin is None or pin.numel() < n:
             try:
                 pin = torch.empty(max(n, 4096), dtype=torch.float32, pin_memory=True)

@@ -400,3 +400,24 @@ def test_hot_kernels_do_not_spill():
             seen["yuv_vec"] += 1
     assert seen["temporal_vec"] == 12 and seen["band2"] == 4 and seen["band"] == 8 and seen["yuv_vec"] == 48, seen
     assert seen["ring"] == 9 and seen["yuv"] == 6, seen
+
+
+def test_result_copy_survives_refused_page_locking(monkeypatch):
+    """where page-locking is refused (memlock ulimit) `_to_host` falls back to `.cpu()` -- on EVERY call, not only the
+    first (the sentinel it caches used to be fed to `.numel()` on the second call)."""
+    m = fv.fvvdp(display_name="standard_fhd", device=torch.device("cpu"))
+    real_empty = torch.empty
+    asked = []
+
+    def refusing_empty(*a, **k):
+        if k.get("pin_memory"):
+            asked.append(1)
+            raise RuntimeError("cannot page-lock")
+        return real_empty(*a, **k)
+
+    monkeypatch.setattr(torch, "empty", refusing_empty)
+    res = torch.arange(10, dtype=torch.float32)
+    for _ in range(3):
+        out = m._to_host(res)
+        assert torch.equal(out, res)
+    assert len(asked) == 1 and m._res_pin is False       # asked once, remembered
