@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cfloat>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -533,6 +534,11 @@ extern "C" int fvvdp_ctx_set_csf_3d(fvvdp_ctx* c, int tc, const float* h_S_log, 
 // ------------------------------------------------------------------------------------------------------------
 // stage 1 launchers
 // ------------------------------------------------------------------------------------------------------------
+// A caller-built table states the range of its entries in L_min / L_max (optional).  The kernels ENFORCE a stated range on every
+// entry they read (lut_entry in temporal_kernels.hpp), so what clamps_never_bind() derives from it holds for any table contents.
+static bool eotf_lut_range_stated(const fvvdp_eotf* e) {
+    return e->L_max > e->L_min && e->L_min >= 0.0f && std::isfinite(e->L_max);
+}
 static EotfDev make_eotf(const fvvdp_eotf* e) {
     EotfDev d;
     d.kind = e->kind;
@@ -543,6 +549,11 @@ static EotfDev make_eotf(const fvvdp_eotf* e) {
     d.l_min = e->L_min;
     d.l_max = e->L_max;
     d.lut = e->d_lut;
+    if (e->kind == FVVDP_EOTF_LUT && !eotf_lut_range_stated(e)) {
+        // no (usable) range stated for the table: its entries pass as they are, and luminance_range() treats level 0 as unknown
+        d.l_min = -FLT_MAX;
+        d.l_max = FLT_MAX;
+    }
     return d;
 }
 

@@ -35,7 +35,7 @@ __global__ __launch_bounds__(256) void pu21_sse_kernel(const Pu21Args a_byval) {
     __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
     __shared__ double s_red[4];
     if constexpr (SRC == SRC_U8) {
-        build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 256);
+        build_lutw(lutw, a.e, a.C, a.w, threadIdx.x, 256);
         __syncthreads();
     }
     const float w[3] = {a.C == 3 ? a.w[0] : 1.0f, a.w[1], a.w[2]};

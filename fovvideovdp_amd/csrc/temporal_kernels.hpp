@@ -149,7 +149,7 @@ struct Sampler {
                 for (int i = 0; i < PX; ++i) o[i] = __fmul_rn(eotf_f32((float)code[i] * (1.0f / 65535.0f), e, bad), wc);
             } else {
 #pragma unroll
-                for (int i = 0; i < PX; ++i) o[i] = __fmul_rn(lut16[code[i]], wc);
+                for (int i = 0; i < PX; ++i) o[i] = __fmul_rn(lut_entry(lut16, code[i], e), wc);
             }
         } else {
             const float* q = reinterpret_cast<const float*>(p) + off;
@@ -203,9 +203,17 @@ struct TemporalArgs {
                            // frames of a stream are separate allocations (fvvdp_temporal_channels_frames)
 };
 
-__device__ __forceinline__ void build_lutw(float* lutw, const float* lut, int C, const float* w, int tid, int nthreads) {
+// Entry of a caller-built code-value table.  The range the caller STATED for the table (fvvdp_eotf.L_min / L_max; the host passes
+// -FLT_MAX / FLT_MAX when none was stated) is enforced here: the pyramid pass drops clamps on the strength of that range
+// (clamps_never_bind in fvvdp_hip.hip), so it must hold whatever the table contains.  A table that keeps its word is unchanged
+// (fminf / fmaxf with a bound that does not bind are exact; a NaN entry becomes a bound).
+__device__ __forceinline__ float lut_entry(const float* lut, unsigned code, const EotfDev& e) {
+    return fminf(fmaxf(lut[code], e.l_min), e.l_max);
+}
+
+__device__ __forceinline__ void build_lutw(float* lutw, const EotfDev& e, int C, const float* w, int tid, int nthreads) {
     for (int i = tid; i < 256; i += nthreads) {
-        const float l = lut[i];
+        const float l = lut_entry(e.lut, i, e);
         if (C == 3) {
             lutw[i] = __fmul_rn(l, w[0]);
             lutw[256 + i] = __fmul_rn(l, w[1]);
@@ -321,7 +329,7 @@ __device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lu
 #else
                 if constexpr (SRC == SRC_U8) v[c][i] = lutw[c * 256 + f.ch[c].code(i)];
 #endif
-                else v[c][i] = __fmul_rn(lut16[f.ch[c].code(i)], w[c]);
+                else v[c][i] = __fmul_rn(lut_entry(lut16, f.ch[c].code(i), e), w[c]);
             }
         }
     }
@@ -360,7 +368,7 @@ template <int FL, int PX, int SRC>
 __global__ __launch_bounds__(256) void temporal_ring_kernel(const TemporalArgs a) {
     __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
     if constexpr (SRC == SRC_U8) {
-        build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 256);
+        build_lutw(lutw, a.e, a.C, a.w, threadIdx.x, 256);
         __syncthreads();
     }
     int px[PX];          // this thread's pixels (clamped for the loads; stores are predicated on `ok`)
@@ -734,7 +742,7 @@ void temporal_vec_kernel(const TemporalArgs a_byval) {
     constexpr int WPB = k1_wpb(FL);
     __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
     __shared__ float4 s_t_all[WPB][64 * (PX + 1)];  // per wave: one padded row of PX float4 per lane
-    if constexpr (SRC == SRC_U8) build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 64 * WPB);
+    if constexpr (SRC == SRC_U8) build_lutw(lutw, a.e, a.C, a.w, threadIdx.x, 64 * WPB);
     __syncthreads();
     const int wave = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
     float4* const s_t = s_t_all[wave];
@@ -1301,7 +1309,7 @@ template <int SRC, int P>
 __global__ __launch_bounds__(256) void temporal_generic_kernel(const GenericArgs a) {
     __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
     if constexpr (SRC == SRC_U8) {
-        build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 256);
+        build_lutw(lutw, a.e, a.C, a.w, threadIdx.x, 256);
         __syncthreads();
     }
     const int p = blockIdx.x * 256 + threadIdx.x;
@@ -1369,7 +1377,7 @@ template <int SRC>
 __global__ __launch_bounds__(256) void luminance_frames_kernel(const LumArgs a) {
     __shared__ float lutw[SRC == SRC_U8 ? 768 : 1];
     if constexpr (SRC == SRC_U8) {
-        build_lutw(lutw, a.e.lut, a.C, a.w, threadIdx.x, 256);
+        build_lutw(lutw, a.e, a.C, a.w, threadIdx.x, 256);
         __syncthreads();
     }
     const int p = blockIdx.x * 256 + threadIdx.x;

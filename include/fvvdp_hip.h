@@ -81,7 +81,11 @@ typedef struct fvvdp_eotf {
     float gamma;
     float L_min, L_max;      /* FVVDP_EOTF_ABSOLUTE: the clamp.  FVVDP_EOTF_LUT (optional): smallest / largest entry of the
                               * table; with it the library can prove that clamps of the pyramid pass never bind on this
-                              * content and drop them (same results); 0, 0 = not stated */
+                              * content and drop them (same results).  A stated range (L_max > L_min >= 0, finite) is
+                              * ENFORCED: the kernels clamp every table entry they read to [L_min, L_max], the identity for
+                              * a table that keeps its word, so a wrong statement yields the results of the clamped table,
+                              * never an out-of-range CSF query.  Anything else (e.g. 0, 0) = not stated: entries pass as
+                              * they are and the pyramid pass keeps its clamps */
     const float* d_lut;      /* FVVDP_EOTF_LUT: 256 (U8) or 65536 (U16) luminances per code value */
 } fvvdp_eotf;
 

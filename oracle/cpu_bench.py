@@ -18,17 +18,19 @@ def _worker(argv):
     from oracle import fvvdp_oracle as orc
     t = np.ascontiguousarray(np.load(test_npy, mmap_mode="r")[:, :, first:first + fl])
     r = np.ascontiguousarray(np.load(ref_npy, mmap_mode="r")[:, :, first:first + fl])
-    o = orc.Oracle(display)
-    o.predict(t[:, :, :1, :32, :32], r[:, :, :1, :32, :32], frames_per_second=0)          # touch the LUTs
+    gaze = os.environ.get("ORACLE_FOVEATED_GAZE")                # "x,y": foveated mode with a fixed gaze (BASELINE configs[3])
+    fix = [float(v) for v in gaze.split(",")] if gaze else None
+    o = orc.Oracle(display, foveated=fix is not None)
+    o.predict(t[:, :, :1, :32, :32], r[:, :, :1, :32, :32], frames_per_second=0, fixation_point=[16, 16] if fix else None)   # touch the LUTs
     while time.time() < start_at:
         time.sleep(0.005)
     t0 = time.perf_counter()
-    o.predict(t, r, frames_per_second=fps, frames=[fl - 1])
+    o.predict(t, r, frames_per_second=fps, frames=[fl - 1], fixation_point=fix)
     dt = time.perf_counter() - t0
     print("%.6f %.6f" % (dt, time.time()), flush=True)
 
 
-def timed_frames(test, ref, fps, display, fl, n_procs, tmp_dir, timeout=180.0):
+def timed_frames(test, ref, fps, display, fl, n_procs, tmp_dir, timeout=180.0, gaze=None):
     """Evaluates n_procs output frames of the clip (frames fl-1, fl, ...; wrapping around when there are more processes than
     full windows in the clip: every frame costs the same), one per subprocess, all at the same time.
     Returns (wall seconds from the common start to the last finish, per-frame seconds) or raises RuntimeError."""
@@ -39,6 +41,9 @@ def timed_frames(test, ref, fps, display, fl, n_procs, tmp_dir, timeout=180.0):
     np.save(rp, np.ascontiguousarray(ref[:, :, :need]))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1", PYTHONPATH=root)
+    env.pop("ORACLE_FOVEATED_GAZE", None)
+    if gaze is not None:                                     # foveated mode, one fixed gaze position (x, y) for every worker
+        env["ORACLE_FOVEATED_GAZE"] = "%g,%g" % (float(gaze[0]), float(gaze[1]))
     start_at = time.time() + 6.0 + 0.05 * n_procs           # interpreter + numpy start-up, frame loading
     procs = []
     try:

@@ -261,3 +261,62 @@ def test_clamp_free_variant_bit_identity_on_odd_sizes_and_ragged_widths(monkeypa
         out[mode] = (float(q), st["Q_per_ch"].copy(), "true>" in err, "band2_kernel<" in err)
     assert out["1"][3] and out["1"][2] and not out["0"][2], (H, W, N)
     assert out["1"][0] == out["0"][0] and np.array_equal(out["1"][1], out["0"][1]), (H, W, N)
+
+
+def test_stated_table_range_is_enforced_not_trusted(monkeypatch, capfd):
+    """VERDICT r5 #4 / ADVICE r4: a C caller states the range of its code-value table in fvvdp_eotf.L_min / L_max and the pyramid pass
+    drops clamps on the strength of it (an unclamped CSF table index among them).  The statement is now ENFORCED where the table
+    is read (lut_entry, temporal_kernels.hpp): a wrong or hostile table gives exactly the results of the table clamped to the
+    stated range -- finite, identical with and without the clamp-free variant -- and a table that keeps its word is unchanged."""
+    import ctypes as C
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd import _native as nat
+    from fovvideovdp_amd.fvvdp import window_frame_indices
+    from fovvideovdp_amd.synth import synth_video_pair
+    from lowlevel import Pipeline
+    H, W, N, fps = 128, 256, 5, 30            # even x even on every level: the parity condition of the proof holds
+    test, ref = synth_video_pair(N, H, W, device="cuda")
+    m = fv.fvvdp(display_name="standard_fhd")
+    m.filter_len = int(np.ceil(250.0 / (1000.0 / fps)))
+    F, _ = m.get_temporal_filters(fps)
+    taps, fl = F.numpy(), m.filter_len
+    idx = window_frame_indices(N, fl, "replicate")
+    w = np.asarray([0.2126, 0.7152, 0.0722], dtype=np.float32)
+    lut_true = m._code_lut(m.display_photometry, 8).clone()
+    lo_t, hi_t = float(lut_true.min()), float(lut_true.max())
+    hostile = lut_true.clone()
+    hostile[::7] = 0.0
+    hostile[3::11] = float("nan")
+    hostile[5::13] = -4.0
+    hostile[1::17] = 3e7
+    monkeypatch.setenv("FVVDP_BAND_FUSE", "1")
+    monkeypatch.setenv("FVVDP_DEBUG_VARIANT", "1")
+
+    def run(lut, lo, hi, inrange="1"):
+        monkeypatch.setenv("FVVDP_BAND_INRANGE", inrange)
+        capfd.readouterr()
+        pipe = Pipeline(m, W, H, 4, N)
+        e = nat.Eotf()
+        e.kind, e.d_lut, e.L_min, e.L_max = nat.EOTF_LUT, lut.data_ptr(), lo, hi
+        oob = torch.zeros(1, dtype=torch.int32, device="cuda")
+        pipe.temporal(test, ref, nat.FVVDP_U8, 3, N * H * W, H * W, e, w, idx, taps, fl, N, oob=oob)
+        Q = pipe.bands_forward(N)
+        torch.cuda.synchronize()
+        err = capfd.readouterr().err
+        pipe.close()
+        return Q.cpu().numpy(), ("true>" in err), ("band2_kernel<" in err)
+
+    q_true, var_true, ran2 = run(lut_true, lo_t, hi_t)
+    assert ran2 and var_true                                        # a truthful SDR table: the clamp-free variant
+    q_unstated, var_u, _ = run(lut_true, 0.0, 0.0)
+    assert not var_u and np.array_equal(q_unstated, q_true)         # nothing stated: clamps kept, same bits
+    for (lut, lo, hi) in ((lut_true, 5.0, 50.0), (hostile, 1.0, 100.0), (hostile, lo_t, hi_t)):
+        q_wrong, var_w, _ = run(lut, lo, hi)
+        assert var_w and np.all(np.isfinite(q_wrong))               # the proof goes through on the STATED range ... and holds
+        q_clamps, var_c, _ = run(lut, lo, hi, inrange="0")
+        assert not var_c and np.array_equal(q_wrong, q_clamps)      # clamp-path-equal
+        fixed = torch.clamp(torch.nan_to_num(lut, nan=lo), lo, hi)  # what the statement promised
+        q_fixed, _, _ = run(fixed, lo, hi)
+        assert np.array_equal(q_wrong, q_fixed)
+    q_liar_unstated, var_l, _ = run(hostile, 0.0, 0.0)             # a hostile table without a statement: clamps stay on, entries as they are
+    assert not var_l

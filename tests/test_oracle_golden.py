@@ -476,3 +476,50 @@ def test_cpu_baseline_helper_runs_frames_in_parallel(tmp_path):
     assert len(per) == 2 and all(p > 0 for p in per)
     assert wall >= max(per) - 1e-3 and wall < max(per) + 1.0
     assert not list(tmp_path.iterdir())                       # temporary frame files removed
+
+
+def test_foveated_4k_geometry_corner_g16():
+    """The oracle at the 4K display geometry in foveated mode (golden g16: the real reference on a 3-frame 3840x2160 pair, gaze in a
+    corner / centre / opposite corner).  End to end the restatement agrees with the reference to 1.8e-4 on Q_per_ch.  On 270x480
+    windows of S in the top-left corner of bands 0-2 the reference's own rounding noise shows: its resolution magnification is a
+    difference of fp32 tangents (fvvdp_display_model.py:475-488) with delta = 0.0066 deg, so the SAME fp32 formula evaluated with
+    numpy's tan instead of torch's lands up to 2e-2 away, and the formula in fp64 (`exact_geometry`) up to 1.3e-2 -- the facts the
+    GPU test test_foveated_4k_geometry_corner_golden builds on."""
+    z = load("g16_foveated_uhd_corner")
+    H, W = 2160, 3840
+    gaze = z["gaze"]
+    test, ref = synth_video_pair(3, H, W)
+    o = orc.Oracle("standard_hdr_pq", foveated=True)
+    q, st = o.predict(test.numpy(), ref.numpy(), frames_per_second=30, fixation_point=gaze)
+    assert abs(float(q) - float(z["jod"])) < 2e-5                                   # measured 5.7e-6
+    qq, gq = st["Q_per_ch"].astype(np.float64), z["Q_per_ch"].astype(np.float64)
+    assert np.max(np.abs(qq - gq) / (np.abs(gq) + 1e-6 * gq.max())) < 5e-4         # measured 1.8e-4
+    nb, rho_band = orc.band_frequencies(W, H, o.ppd)
+    r0, r1, c0, c1 = [int(v) for v in z["window"]]
+    _F = np.float32
+
+    def window_S(b, ff, cc, lbkg):
+        wb, hb = W, H
+        for _ in range(b):
+            wb, hb = (wb + 1) // 2, (hb + 1) // 2
+        xv = np.linspace(0.5, wb - 0.5, wb).astype(_F)[c0:c1]
+        yv = np.linspace(0.5, hb - 0.5, hb).astype(_F)[r0:r1]
+        xx, yy = np.meshgrid(xv, yv, indexing="xy")
+        vx, vy = o.geometry.pix2view_direction((wb, hb), xx, yy)
+        gx, gy = o.geometry.pix2view_direction((W, H), _F(gaze[ff][0]) + _F(0.5), _F(gaze[ff][1]) + _F(0.5))
+        ecc = np.sqrt((vx - gx) ** 2 + (vy - gy) ** 2).astype(_F)
+        rho = (_F(rho_band[b]) * o.geometry.resolution_magnification(vx, vy)).astype(_F)
+        return orc.cached_sensitivity(o.lut[cc], rho, lbkg, ecc)
+
+    w32, w64 = [0.0, 0.0], [0.0, 0.0]
+    for ff in (0, 2):
+        for b in range(3):
+            for cc in range(2):
+                gs, gl = z[f"S_f{ff}_b{b}_c{cc}"], z[f"lbkg_f{ff}_b{b}"]
+                for exact, acc in ((False, w32), (True, w64)):
+                    o.geometry.exact_geometry = exact
+                    rel = np.abs(window_S(b, ff, cc, gl) - gs) / gs
+                    acc[0], acc[1] = max(acc[0], float(rel.max())), max(acc[1], float(rel.mean()))
+    o.geometry.exact_geometry = False
+    assert 5e-3 < w32[0] < 6e-2 and 5e-4 < w32[1] < 4e-3, w32          # measured: max 2.0e-2, worst window mean 1.3e-3
+    assert 5e-3 < w64[0] < 4e-2 and 1e-3 < w64[1] < 6e-3, w64          # measured: max 1.33e-2, worst window mean 1.9e-3

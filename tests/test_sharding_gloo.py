@@ -121,9 +121,32 @@ def _worker_empty_shard(rank, world, port, out_dir):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         from fovvideovdp_amd.sharding import predict_frame_sharded
+        import logging
         out = {}
-        for n in (1, 3):                         # 1 frame on 2 ranks: rank 1 has an empty shard and still joins both collectives
+        calls = []
+        real_all_reduce = dist.all_reduce
+
+        def counting_all_reduce(*a, **k):
+            calls.append(1)
+            return real_all_reduce(*a, **k)
+        dist.all_reduce = counting_all_reduce
+        warned = []
+
+        class _H(logging.Handler):
+            def emit(self, record):
+                warned.append(record.getMessage())
+        logging.getLogger().addHandler(_H())
+        for n in (1, 3):                         # 1 frame on 2 ranks: rank 1 has an empty shard and still joins the collective
             m = _StubMetric(flag_value=1 if rank == 0 else 0)
+            before = len(calls)
+            jod, stats = predict_frame_sharded(m, _StubSource(n), rank, world)
+            assert len(calls) - before == 1, "frame sharding issues ONE collective (Q_per_ch and the range flag in one buffer)"
+            assert "range_flag" not in stats and "result_buffer" not in stats
+        dist.all_reduce = real_all_reduce
+        # rank 0's flag reaches rank 1 through the same buffer: both ranks warn, for both clips
+        out["warnings"] = sum(1 for w in warned if "outside the valid range" in w)
+        for n in (1, 3):
+            m = _StubMetric(flag_value=0)
             jod, stats = predict_frame_sharded(m, _StubSource(n), rank, world)
             out["jod%d" % n] = float(jod)
             out["Q%d" % n] = stats["Q_per_ch"]
@@ -140,12 +163,14 @@ def _worker_empty_shard(rank, world, port, out_dir):
 @pytest.mark.timeout(120)
 def test_frame_sharding_with_an_empty_shard_world2(tmp_path):
     """More ranks than frames (a still image, a short clip on 8 GPUs): the rank that computes nothing must still take part in
-    the Q_per_ch all-reduce AND in the out-of-range-flag all-reduce (collective mismatch)."""
+    the ONE all-reduce that carries Q_per_ch and the out-of-range flag (collective mismatch; VERDICT r5: one
+    collective in frame mode, as north_star states)."""
     world = 2
     mp.spawn(_worker_empty_shard, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     res = [np.load(os.path.join(str(tmp_path), f"e{k}.npz")) for k in range(world)]
     for k in range(world):
         assert res[k]["after"] == 3.0
+        assert int(res[k]["warnings"]) == 2          # the flag set on rank 0 only warns on every rank, once per clip
         assert np.array_equal(res[k]["Q1"], res[0]["Q1"]) and res[k]["Q1"].shape[2] == 1 and np.all(res[k]["Q1"] == 1.0)
         assert np.array_equal(res[k]["Q3"][0, 0], [1.0, 2.0, 3.0])
         assert res[k]["jod1"] == res[0]["jod1"] and res[k]["jod3"] == res[0]["jod3"]
@@ -195,3 +220,34 @@ def test_bench_labels_follow_the_arguments():
     assert b.baseline_label(1920, 1080, 60, 30, "standard_fhd", 1, 1, False) == "BASELINE.json configs[1]"
     assert "not a BASELINE" in b.baseline_label(960, 540, 20, 30, "standard_4k", 2, 2, False)
     assert "frame sharding" in b.baseline_label(3840, 2160, 60, 30, "standard_4k", 8, 1, True)
+
+
+def test_forced_collective_on_one_rank():
+    """bench.py at N = 1 (`--collective force`, the default where RCCL initialises): a world-size-1 process group, and the result rows
+    go through the same zero-buffer all-reduce as at N > 1 instead of the one-rank shortcut.  Here with gloo and an in-process store;
+    the values are unchanged, the collective is issued exactly once, and frame sharding on one rank behaves the same way."""
+    from fovvideovdp_amd.sharding import collective_active, predict_frame_sharded
+    assert not collective_active(force=True)                   # no process group: nothing to force
+    rows = torch.randn(3, 19)
+    assert gather_pair_results(rows, 0, 1, force_collective=True) is rows
+    dist.init_process_group("gloo", store=dist.HashStore(), rank=0, world_size=1)
+    try:
+        assert collective_active(force=True) and not collective_active(force=False)
+        calls = []
+        real = dist.all_reduce
+
+        def counting(*a, **k):
+            calls.append(1)
+            return real(*a, **k)
+        dist.all_reduce = counting
+        try:
+            out = gather_pair_results(rows, 0, 1, force_collective=True)
+            assert out is not rows and torch.equal(out, rows) and len(calls) == 1
+            assert gather_pair_results(rows, 0, 1) is rows and len(calls) == 1          # not forced: the shortcut
+            m = _StubMetric(flag_value=0)
+            jod, stats = predict_frame_sharded(m, _StubSource(3), 0, 1, force_collective=True)
+            assert len(calls) == 2 and np.array_equal(stats["Q_per_ch"][0, 0], [1.0, 2.0, 3.0])
+        finally:
+            dist.all_reduce = real
+    finally:
+        dist.destroy_process_group()

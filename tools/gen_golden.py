@@ -617,6 +617,37 @@ def g15(pyfvvdp):
     save("g15_bt2020", out)
 
 
+def g16(pyfvvdp):
+    """Foveated mode at the 4K display geometry (BASELINE configs[3]'s geometry: standard_hdr_pq, 75 ppd, delta = 0.0066 deg, where the
+    reference's fp32 tangent difference cancels hardest): a 3-frame 3840x2160 pair with the gaze in a corner, at the centre and in the
+    opposite corner.  Kept: JOD, Q_per_ch, dsum, and 270x480 windows of L_bkg and S cut from the top-left CORNER of bands 0-2 of the
+    first and the last frame (largest viewing angle -> largest resolution magnification; frame 0 has the gaze inside the window,
+    frame 2 at the far corner).  VERDICT r5 item 2: the 2e-3 foveated tolerance at 4K shown, not assumed."""
+    from fovvideovdp_amd.synth import synth_video_pair
+    N, H, W = 3, 2160, 3840
+    test, ref = synth_video_pair(N, H, W)
+    gaze = torch.tensor([[40.0, 30.0], [1900.0, 1000.0], [3800.0, 2130.0]], dtype=torch.float32)
+    fv = pyfvvdp.fvvdp(display_name="standard_hdr_pq", heatmap=None, device=torch.device("cpu"), foveated=True, quiet=True)
+    frames = (0, N - 1)
+    cap = Capture(fv, frames=frames, keep_maps=True)
+    t0 = time.time()
+    with torch.no_grad():
+        q, stats = fv.predict(test, ref, dim_order="BCFHW", frames_per_second=30, fixation_point=gaze)
+    out = {"jod": np.float32(q.item()), "Q_per_ch": stats["Q_per_ch"], "rho_band": np.asarray(stats["rho_band"]),
+           "seconds": np.float64(time.time() - t0), "gaze": gaze.numpy(), "F": fv.F.numpy(),
+           "window": np.asarray([0, 270, 0, 480], dtype=np.int64)}
+    nb = stats["Q_per_ch"].shape[0]
+    for ff in frames:
+        for b in range(3):
+            out[f"lbkg_f{ff}_b{b}"] = cap.lbkg[ff][b][:270, :480].copy()
+            for cc in range(2):
+                out[f"S_f{ff}_b{b}_c{cc}"] = cap.S[ff][cc * nb + b][:270, :480].copy()
+    fr = sorted(cap.dsum)
+    out["dsum"] = np.array([cap.dsum[f] for f in fr], dtype=np.float64)
+    print("g16 JOD", out["jod"], "seconds", out["seconds"])
+    save("g16_foveated_uhd_corner", out)
+
+
 def main():
     which = sys.argv[1:] or ["g0", "g1", "g2", "g5"]
     torch.set_num_threads(int(os.environ.get("GOLDEN_THREADS", "8")))
@@ -659,6 +690,8 @@ def main():
             g14(pyfvvdp)
         elif w == "g15":
             g15(pyfvvdp)
+        elif w == "g16":
+            g16(pyfvvdp)
         else:
             raise SystemExit("unknown case " + w)
         print(w, "done in %.1f s" % (time.time() - t0), flush=True)
