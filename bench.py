@@ -84,6 +84,12 @@ def main():
                     help="BASELINE.json configs[] index: 1 = 1920x1080 x60 standard_fhd, 2 = 3840x2160 x60 standard_4k (the default "
                          "arguments), 3 = 3840x2160 x120 foveated with moving gaze on standard_hdr_pq (adds `roofline_fov`)")
     args = ap.parse_args()
+    # stdout carries ONE JSON line and nothing else: librccl prints a version banner on the C stdout of rank 0 when a communicator is
+    # created (5 lines, flushed at exit), other libraries may follow.  File descriptor 1 is pointed at stderr for the life of the
+    # process and the line is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     foveated = False
     if args.config == 1:
         args.width, args.height, args.frames, args.fps, args.display = 1920, 1080, 60, 30, "standard_fhd"
@@ -568,14 +574,15 @@ def main():
                           "ms_per_step_min": round(float(step_s[0]) * 1e3, 3), "ms_per_step_max": round(float(step_s[-1]) * 1e3, 3),
                           "ms_per_step_in_order": [round(float(x) * 1e3, 3) for x in tall[1:]],
                           "timed_region_s": round(dt, 4)},
-               "jod": [round(j, 6) for j in jods[:8]],
+               "jod": [round(j, 6) for j in jods[:8]], "jod_exact": [float(j).hex() for j in jods[:8]],
                "jod_delta_vs_reference": None if jod_delta is None else float("%.3g" % jod_delta), "roofline": roof, "cpu_baseline": cpu}
         out.update(extra)
         if comm is not None:
             out["communicator"] = comm
         if coll is not None:
             out["collective"] = coll
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()             # rank 0 ran the per-kernel timing, the PCIe leg and the CPU baseline alone: leave together
         dist.destroy_process_group()

@@ -664,6 +664,9 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
                 }
             }
         }
+#if defined(FOV_PRIO)       // A/B build (profiles/r06_fov_floor.md): the memory-issuing head of a step at raised wave priority
+        if constexpr (FOV) __builtin_amdgcn_s_setprio(FOV_PRIO);
+#endif
         if constexpr (FOV) __builtin_amdgcn_sched_barrier(0);
         load_row(2 * c + 5, R[(s0 + 5) & 7][0], R[(s0 + 5) & 7][1]);
         load_row(2 * c + 6, R[(s0 + 6) & 7][0], R[(s0 + 6) & 7][1]);
@@ -695,6 +698,12 @@ __device__ __forceinline__ void band_item(const BandArgs& a, const int strip, co
             dpp_expand_taps(evO.h[k], el, er, orr, x10.h[k], x11.h[k]);
         }
         const bool row1_ok = (2 * c + 1) < h;
+#if defined(FOV_PRIO)
+#if !defined(FOV_TAILPRIO)
+#define FOV_TAILPRIO 0      // (the reverse experiment: the arithmetic tail at raised priority)
+#endif
+        if constexpr (FOV) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(FOV_TAILPRIO); }
+#endif
 #if defined(BAND_ABLATE) && BAND_ABLATE >= 1      // profiling ablation: no per-pixel tail, keep the data flow alive
         acc[0] += x00.h[0].x + x01.h[0].x + x10.h[0].x + x11.h[0].x + W0[0].h[0].x + W0[1].h[0].x + W1[0].h[0].x + W1[1].h[0].x;
         if (false)

@@ -1002,7 +1002,10 @@ __device__ __forceinline__ v2f pfma_clamp01(v2f a, float s, v2f c) {
     return r;
 }
 
-template <typename T, bool C420>
+// STDM: the colour matrix has the shape of every ITU YCbCr matrix -- R = Y + m2 Cr, G = Y + m4 Cb + m5 Cr, B = Y + m7 Cb (unit luma
+// column, no Cb in red, no Cr in blue; the host checks the nine numbers, yuv_matrix_is_standard).  Multiplying by 1 and adding 0 * x
+// are exact, so the four multiply-adds left per pixel give the same bits as the nine of the general form.
+template <typename T, bool C420, bool STDM>
 __device__ __forceinline__ void yuv_pair_rgb(const YuvRaw<T, C420>& r0, const YuvRaw<T, C420>& r1, const YuvArgs& a,
                                              const YuvGeom& g, float fy, float gy, float fx0, float gx0, v2f (&rgb)[12]) {
     auto cf = [&](float c0, float c1) { return clamp2(pfma(v2f{c0, c1}, a.wc, splat(-(128.0f / 224.0f))), -0.5f, 0.5f); };
@@ -1043,11 +1046,17 @@ __device__ __forceinline__ void yuv_pair_rgb(const YuvRaw<T, C420>& r0, const Yu
     for (int i = 0; i < 4; ++i) {
         // the [0,1] clips ride on the multiply-add that produces the value (VOP3P clamp bit): one instruction instead of three
         const v2f Yf = pfma_clamp01(v2f{r0.ysample(i), r1.ysample(i)}, a.wy, splat(-(16.0f / 219.0f)));
+        if constexpr (STDM) {
+            rgb[3 * i + 0] = pfma_clamp01(uv[1][i], a.m[2], Yf);
+            rgb[3 * i + 1] = pfma_clamp01(uv[1][i], a.m[5], pfma(uv[0][i], a.m[4], Yf));
+            rgb[3 * i + 2] = pfma_clamp01(uv[0][i], a.m[7], Yf);
+        } else {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            v2f v = Yf * a.m[3 * c];
-            v = pfma(uv[0][i], a.m[3 * c + 1], v);
-            rgb[3 * i + c] = pfma_clamp01(uv[1][i], a.m[3 * c + 2], v);
+            for (int c = 0; c < 3; ++c) {
+                v2f v = Yf * a.m[3 * c];
+                v = pfma(uv[0][i], a.m[3 * c + 1], v);
+                rgb[3 * i + c] = pfma_clamp01(uv[1][i], a.m[3 * c + 2], v);
+            }
         }
     }
 }
@@ -1060,13 +1069,29 @@ __device__ __forceinline__ void eotf_apply_pairs(v2f (&V)[N], const EotfDev& e) 
     bool bad = false;
     switch (KIND) {                                  // compile-time: one case survives, the loop body stays branch-free
         case FVVDP_EOTF_SRGB: {
+            // The linear toe (V <= 0.04045, i.e. 8-bit codes <= 10) costs a compare, a select and half a multiply per value: 5 of 14
+            // vector instructions per (test, reference) pair.  One wave-uniform branch on the smallest of the 2N values (N/2 + N/4 + ...
+            // v_min3) takes the power branch alone where no lane needs the toe -- the same expression for those values, same bits.
+            float mn;
+            asm("v_min_f32 %0, %1, %2" : "=v"(mn) : "v"(V[0].x), "v"(V[0].y));
 #pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const v2f t = (V[i] + 0.055f) * (1.0f / 1.055f);
-                const v2f ex = v2f{fast_log2(t.x), fast_log2(t.y)} * 2.4f;
-                const v2f lo = V[i] * (1.0f / 12.92f);
-                const v2f lin = v2f{V[i].x > 0.04045f ? fast_exp2(ex.x) : lo.x, V[i].y > 0.04045f ? fast_exp2(ex.y) : lo.y};
-                V[i] = lin * e.scale + e.y_black;
+            for (int i = 1; i < N; ++i) asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn) : "v"(V[i].x), "v"(V[i].y));
+            if (__builtin_amdgcn_ballot_w64(!(mn > 0.04045f)) == 0) {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const v2f t = (V[i] + 0.055f) * (1.0f / 1.055f);
+                    const v2f ex = v2f{fast_log2(t.x), fast_log2(t.y)} * 2.4f;
+                    V[i] = v2f{fast_exp2(ex.x), fast_exp2(ex.y)} * e.scale + e.y_black;
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < N; ++i) {
+                    const v2f t = (V[i] + 0.055f) * (1.0f / 1.055f);
+                    const v2f ex = v2f{fast_log2(t.x), fast_log2(t.y)} * 2.4f;
+                    const v2f lo = V[i] * (1.0f / 12.92f);
+                    const v2f lin = v2f{V[i].x > 0.04045f ? fast_exp2(ex.x) : lo.x, V[i].y > 0.04045f ? fast_exp2(ex.y) : lo.y};
+                    V[i] = lin * e.scale + e.y_black;
+                }
             }
             break;
         }
@@ -1155,7 +1180,7 @@ __device__ __forceinline__ void yuv_window_dispatch(int slot, v2f (&win)[FL][4],
 // drains).  The conversion of a frame is a few hundred instructions and exists once; the window of the last FL luminance
 // pairs stays where it is (yuv_window_step above) and only the short FIR exists FL times.
 // The FIR also runs during the history frames (its result is dropped by an out-of-range store offset).
-template <int FL, typename T, bool C420, int KIND>
+template <int FL, typename T, bool C420, int KIND, bool STDM>
 __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* s_t) {
     constexpr int PX = 4;
     constexpr int TD = FL <= 8 ? YUV_TD8 : YUV_TD16;
@@ -1234,7 +1259,7 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
             const YuvRaw<T, C420> cur0 = nx[d][0], cur1 = nx[d][1];
             prefetch(v + TD, nx[d][0], nx[d][1]);
             v2f rgb[12];
-            yuv_pair_rgb<T, C420>(cur0, cur1, a, g, g_fy, g_gy, g_fx0, g_gx0, rgb);
+            yuv_pair_rgb<T, C420, STDM>(cur0, cur1, a, g, g_fy, g_gy, g_fx0, g_gx0, rgb);
             eotf_apply_pairs<12, KIND>(rgb, a.e);
             v2f lum[PX];
 #pragma unroll
@@ -1277,13 +1302,13 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
 // KIND = display model (compile-time: the host picks the instantiation): one loop body per kernel.  With a switch over the six
 // bodies inside one kernel, scalar values of the prologue stayed alive across all of them and spilled (8 SGPRs in the 16-slot
 // 4:2:0 kernels).
-template <int FL, typename T, bool C420, int KIND>
+template <int FL, typename T, bool C420, int KIND, bool STDM>
 __global__ __launch_bounds__(64, (FL == 8 ? (((sizeof(T) == 2 && !C420) || KIND == FVVDP_EOTF_PQ) ? 2 : YUV_WAVES8) : YUV_WAVES16))     // 16-bit 4:4:4: 8 raw dwords per frame pair more; PQ: the longest display model
 void temporal_yuv_vec_kernel(const YuvArgs a_byval) {
     const YuvArgs& a = *(const YuvArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // see temporal_vec_kernel
     (void)a_byval;
     __shared__ float4 s_t[64 * (4 + 1)];
-    temporal_yuv_vec_body<FL, T, C420, KIND>(a, s_t);
+    temporal_yuv_vec_body<FL, T, C420, KIND, STDM>(a, s_t);
 }
 
 // Generic (any fl, any frame size) version: one thread per pixel per output frame, the window is re-read from

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <cstddef>
+#include <cstdlib>
 #include <cstdint>
 #include <type_traits>
 
@@ -128,17 +129,26 @@ static void launch_yuv(int bytes, const YuvArgs& a, hipStream_t st) {
     if (bytes == 1) hipLaunchKernelGGL((temporal_yuv_kernel<FL, PX, unsigned char>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((temporal_yuv_kernel<FL, PX, unsigned short>), grid, block, 0, st, a);
 }
-template <int FL, typename T, bool C420>
+// the colour matrix has the shape of the ITU YCbCr matrices (temporal_kernels.hpp, yuv_pair_rgb<.., STDM>)
+static bool yuv_matrix_is_standard(const YuvArgs& a) {
+    return a.m[0] == 1.0f && a.m[3] == 1.0f && a.m[6] == 1.0f && a.m[1] == 0.0f && a.m[8] == 0.0f;
+}
+template <int FL, typename T, bool C420, bool STDM>
 static void launch_yuv_vec_kind(const YuvArgs& a, dim3 grid, hipStream_t st) {
     const dim3 block(64);
     switch (a.e.kind) {          // the display model is a template constant of the kernel
-        case FVVDP_EOTF_SRGB: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_SRGB>), grid, block, 0, st, a); break;
-        case FVVDP_EOTF_GAMMA: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_GAMMA>), grid, block, 0, st, a); break;
-        case FVVDP_EOTF_PQ: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_PQ>), grid, block, 0, st, a); break;
-        case FVVDP_EOTF_LINEAR: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_LINEAR>), grid, block, 0, st, a); break;
-        case FVVDP_EOTF_ABSOLUTE: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_ABSOLUTE>), grid, block, 0, st, a); break;
-        default: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_NONE>), grid, block, 0, st, a); break;
+        case FVVDP_EOTF_SRGB: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_SRGB, STDM>), grid, block, 0, st, a); break;
+        case FVVDP_EOTF_GAMMA: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_GAMMA, STDM>), grid, block, 0, st, a); break;
+        case FVVDP_EOTF_PQ: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_PQ, STDM>), grid, block, 0, st, a); break;
+        case FVVDP_EOTF_LINEAR: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_LINEAR, STDM>), grid, block, 0, st, a); break;
+        case FVVDP_EOTF_ABSOLUTE: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_ABSOLUTE, STDM>), grid, block, 0, st, a); break;
+        default: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_NONE, STDM>), grid, block, 0, st, a); break;
     }
+}
+template <int FL, typename T, bool C420>
+static void launch_yuv_vec_kind(const YuvArgs& a, dim3 grid, hipStream_t st) {
+    if (yuv_matrix_is_standard(a) && !getenv("FVVDP_YUV_GENERAL_MATRIX")) launch_yuv_vec_kind<FL, T, C420, true>(a, grid, st);
+    else launch_yuv_vec_kind<FL, T, C420, false>(a, grid, st);
 }
 template <int FL>
 static void launch_yuv_vec(int bytes, bool c420, const YuvArgs& a, hipStream_t st) {

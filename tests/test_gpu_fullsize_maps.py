@@ -107,11 +107,13 @@ def test_full_size_difference_maps_golden(tag, H, W, disp, batch):
     qdev = float(np.max(np.abs(Q - stats["Q_per_ch"]) / (np.abs(stats["Q_per_ch"]) + 1e-6 * stats["Q_per_ch"].max())))
     _record("g3_" + tag, {"sum": dev[0], "sum_sq": dev[1], "max": dev[2], "Q_maps_pass_vs_product_pass": qdev})
     assert dev[0] < DSUM_TOL[tag][0] and dev[1] < DSUM_TOL[tag][1] and dev[2] < DSUM_TOL[tag][2], dev
-    assert qdev < 2e-5
+    assert qdev < 1e-6            # measured 1.2e-7: the map-writing one-level kernels pool the same values as the two-level pass
 
 
-# (sum, sum of squares, max): measured on MI355X, see gpurun_out/fullsize_maps_*.json of the round-6 bundle, quoted in profiles/r06_parity.md
-DSUM_TOL = {"fhd": (2e-3, 5e-3, 1e-2), "uhd": (2e-3, 5e-3, 1e-2), "fov": (2e-2, 5e-2, 1e-1)}
+# worst relative deviation of (sum, sum of squares, max) over all frames, bands and channels.  Measured on MI355X (round 6, session 1;
+# profiles/r06_parity.md): fhd 8.5e-5 / 2.4e-4 / 6.1e-4, uhd 9.9e-5 / 2.4e-4 / 1.4e-3 (the maximum is ONE pixel of D ~ contrast^2.4),
+# foveated 4.9e-3 / 1.03e-2 / 1.28e-2 (the reference's rho noise, amplified by D ~ S^2.4; Q_per_ch of the same pass 7.1e-4)
+DSUM_TOL = {"fhd": (2.5e-4, 7e-4, 1.8e-3), "uhd": (3e-4, 7e-4, 4e-3), "fov": (1.5e-2, 3e-2, 3.8e-2)}
 
 
 @pytest.mark.timeout(1200)
@@ -225,18 +227,21 @@ def test_foveated_4k_geometry_corner_golden():
     pipe.close()
     _record("g16_corner", dict(worst, Q_hip_vs_ref=q_vs_ref, Q_hip_vs_exact=q_vs_exact, Q_exact_vs_ref=exact_vs_ref,
                                jod_delta_ref=abs(float(q) - float(z["jod"])), jod_delta_exact=abs(float(q) - float(oq))))
-    assert worst["lbkg"] < 2e-6
+    # measured on MI355X (round 6, session 1): hip_vs_ref max 1.33e-2 / mean 1.90e-3, ref_vs_exact 1.31e-2 / 1.89e-3, hip_vs_exact
+    # 8.8e-4 / 3.2e-6, numpy32_vs_ref 2.0e-2 / 1.3e-3, lbkg 3.9e-7; Q_per_ch: hip vs ref 6.66e-4, exact vs ref 6.67e-4, hip vs exact 2.5e-5;
+    # JOD: 2.4e-5 from the reference, 1.9e-6 from the fp64-geometry oracle
+    assert worst["lbkg"] < 1.2e-6
     # (1) + (2): the reference against its own formula in fp64 (here: max 1.33e-2, mean 1.9e-3) and in fp32 with another libm
     # (max 2.0e-2, mean 1.3e-3) -- measured in the build container against g16, independent of the GPU
     assert worst["ref_vs_exact"][0] > 5e-3 and worst["ref_vs_exact"][1] > 1e-3
     assert worst["numpy32_vs_ref"][0] > 5e-3 and worst["numpy32_vs_ref"][1] > 5e-4
     # the kernel against the reference: the same distance as (1) ...
-    assert worst["hip_vs_ref"][0] < 3 * worst["ref_vs_exact"][0] and worst["hip_vs_ref"][1] < 1.5 * worst["ref_vs_exact"][1]
+    assert worst["hip_vs_ref"][0] < 1.5 * worst["ref_vs_exact"][0] and worst["hip_vs_ref"][1] < 1.1 * worst["ref_vs_exact"][1]
     # (3) ... and against the fp64-geometry evaluation an order of magnitude closer on average (the maximum is the pixel under the
     # gaze, where sqrt(ecc) amplifies a 1e-6 deg rounding difference)
-    assert worst["hip_vs_exact"][1] < 0.1 * worst["ref_vs_exact"][1], worst
-    assert worst["hip_vs_exact"][0] < 6e-3, worst
+    assert worst["hip_vs_exact"][1] < 1e-5 and worst["hip_vs_exact"][1] < 0.01 * worst["ref_vs_exact"][1], worst      # 600x closer on average
+    assert worst["hip_vs_exact"][0] < 2.6e-3, worst
     # (4) end to end
-    assert abs(float(q) - float(z["jod"])) < 1e-4 and abs(float(q) - float(oq)) < 2e-5
+    assert abs(float(q) - float(z["jod"])) < 7e-5 and abs(float(q) - float(oq)) < 6e-6
     assert q_vs_ref < 2e-3 and exact_vs_ref > 3e-4          # reference vs its own formula in fp64: 6.7e-4 (build container)
-    assert q_vs_exact < 0.35 * exact_vs_ref, (q_vs_exact, exact_vs_ref)
+    assert q_vs_exact < 8e-5 and q_vs_exact < 0.12 * exact_vs_ref, (q_vs_exact, exact_vs_ref)      # 26x closer to the fp64 evaluation

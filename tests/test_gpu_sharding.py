@@ -111,7 +111,7 @@ def test_use_checkpoints_flag_is_accepted_and_gradients_are_refused():
         m.predict(t, ref.to(torch.float32) / 255, frames_per_second=FPS)
 
 
-def _run_bench(backend, world, extra=(), dims=(960, 540, 20, 2)):
+def _run_bench(backend, world, extra=(), dims=(960, 540, 20, 2), torchrun=None):
     """bench.py launched the way the driver launches it (torch.distributed.run, one process per rank; a plain process for one rank);
     returns the JSON line."""
     import json
@@ -122,7 +122,7 @@ def _run_bench(backend, world, extra=(), dims=(960, 540, 20, 2)):
     args = [os.path.join(root, "bench.py"), "--gpus", str(world), "--backend", backend,
             "--pairs-per-gpu", str(K), "--width", str(W), "--height", str(H), "--frames", str(N), "--steps", "3", "--warmup", "1",
             "--no-cpu-baseline", "--no-h2d", "--no-measure-traffic"] + list(extra)
-    if world > 1:
+    if world > 1 or torchrun:
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port())] + args
     else:
@@ -167,7 +167,13 @@ def _check_bench_line(out, dims, backend, world=2):
             assert cm["distinct_devices"] == min(world, torch.cuda.device_count())      # dry run: the ranks share the GPUs there are
         assert out["predict_call_ms"] is None
     else:
-        assert "communicator" not in out and out["predict_call_ms"] > 0
+        assert (out["predict_call_ms"] > 0) if K == 1 else (out["predict_call_ms"] is None)     # the reference-style call beside a one-pair step
+        cm = out.get("communicator")
+        if cm is not None and cm.get("backend"):            # --collective auto / force: a world-size-1 group of the backend
+            assert cm["backend"] == backend and cm["world_size"] == 1 and "forced" in cm["collective_on_one_rank"]
+            assert "world-size-1 %s group" % backend in out["step_path"] and out["collective"]["us_per_call_back_to_back"] > 0
+        else:                                               # --collective off, or no communicator on this box (reason in the line)
+            assert "skipped" in out["step_path"] and "collective" not in out
     assert len(out["jod"]) == min(8, world * K)
     m = fv.fvvdp(display_name="standard_4k")
     for pidx in range(len(out["jod"])):
@@ -192,6 +198,31 @@ def test_bench_one_rank_takes_the_same_step_path():
     compares like with like -- and reports the reference-style synchronous predict() once beside it (`predict_call_ms`)."""
     out, dims = _run_bench("nccl", 1, dims=(960, 540, 20, 1))
     _check_bench_line(out, dims, "nccl", world=1)
+
+
+@pytest.mark.timeout(900)
+def test_rccl_executes_on_one_rank_through_the_step_path():
+    """RCCL on hardware through the product's own step.  bench.py launched the way the driver launches a multi-rank
+    run (torch.distributed.run, here --nproc-per-node 1) with `--collective force`: init_process_group("nccl", world_size=1, device_id),
+    every step's result rows (written by the library's kernels on the caller's stream) go through the zero-buffer all-reduce
+    WITHOUT the one-rank shortcut, and the line carries what the communicator reports.  The JODs are bit-equal to the same run
+    with `--collective off` (the shortcut), `--collective auto` (the default of a plain `python bench.py`) takes the forced path
+    on a box where RCCL initialises, and frame sharding issues its one collective the same way."""
+    dims = (960, 540, 20, 2)
+    forced, _ = _run_bench("nccl", 1, extra=("--collective", "force"), dims=dims, torchrun=True)
+    cm = forced["communicator"]
+    assert cm["backend"] == "nccl" and cm["world_size"] == 1 and cm["rccl_version"] and cm["distinct_devices"] == 1
+    assert cm["ranks"][0]["device_uuid"] and "forced" in cm["collective_on_one_rank"]
+    assert forced["collective"]["backend"] == "nccl" and 0 < forced["collective"]["us_per_call_back_to_back"] < 2000
+    _check_bench_line(forced, dims, "nccl", world=1)
+    off, _ = _run_bench("nccl", 1, extra=("--collective", "off"), dims=dims)
+    assert "communicator" not in off and "collective" not in off
+    assert forced["jod_exact"] == off["jod_exact"] and len(off["jod_exact"]) == 2          # bit-equal, both pairs
+    auto, _ = _run_bench("nccl", 1, dims=dims)                                          # what the driver's N = 1 run does
+    assert auto["communicator"]["backend"] == "nccl" and auto["jod_exact"] == off["jod_exact"]
+    fr_forced, _ = _run_bench("nccl", 1, extra=("--shard", "frames", "--collective", "force"), dims=(960, 540, 12, 1), torchrun=True)
+    fr_off, _ = _run_bench("nccl", 1, extra=("--shard", "frames", "--collective", "off"), dims=(960, 540, 12, 1))
+    assert fr_forced["communicator"]["backend"] == "nccl" and fr_forced["jod_exact"] == fr_off["jod_exact"]
 
 
 @pytest.mark.timeout(900)
