@@ -173,7 +173,7 @@ def main():
     es_in = 1                                          # uint8 RGB
     need = {"source clips": 2.0 * 3 * W * H * n_clip * es_in * K,
             "pyramid scratch (one batch of <= 128 frames, all levels)": 16.0 * W * H * 1.34 * min(N, 128),
-            "six half-size level-0 candidates at context creation (two level 0 beyond the scratch) + the synthetic clip": 2 * 16.0 * W * H * min(N, 128) + 2.0 * 16 * 3 * W * H,
+            "six half-size level-0 candidates at context creation (two level 0 beyond the scratch)": 2 * 16.0 * W * H * min(N, 128),
             "margin": 2.0 * (1 << 30)}
     free_b, total_b = torch.cuda.mem_get_info(dev)
     if sum(need.values()) > free_b:
@@ -299,7 +299,7 @@ def main():
                       else kinds.get(cm_.value, str(cm_.value)),
             "half_size_candidates": nt_.value, "further_candidates_tried": int(us_[3]), "kept_indices": [kept_.value % 8, kept_.value // 8] if kept_.value >= 0 else None,
             "pair_write_rate_tbs": {"kept": round(us_[1], 2), "lowest": round(us_[2], 2)} if nt_.value else None,
-            "temporal_plus_pyramid_us_per_frame_at_creation": round(us_[0], 2) if nt_.value else None, "state": st_.value,
+            "state": st_.value,
             "per_frame_calls": {"host_syncs": int(cs_[0]), "allocations": int(cs_[1]), "frees": int(cs_[2])},
             "first_step_ms_incl_context_creation": round(t_first * 1e3, 1) if args.warmup > 0 else None,
             "evidence": "profiles/r05_k1_mode.md"}

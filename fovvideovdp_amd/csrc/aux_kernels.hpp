@@ -285,15 +285,6 @@ __global__ __launch_bounds__(256) void colour_map_kernel(const ColourArgs a) {
     }
 }
 
-// counter-hash fill (32-bit words): the synthetic uint8 clip behind the creation-time timing of level-0 candidates (choose_level0)
-__global__ __launch_bounds__(256) void hash_fill_kernel(unsigned int* __restrict__ p, size_t n_words, unsigned int seed) {
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
-        unsigned int x = (unsigned int)i * 2654435761u + seed;
-        x ^= x >> 15; x *= 2246822519u; x ^= x >> 13;
-        p[i] = x;
-    }
-}
-
 // Streaming write of n4 float4 into each of q0 and q1 at once (even workgroups -> q0, odd -> q1): the probe of choose_level0.  Two ranges
 // of different classes of physical memory take ~7 TB/s together, two of the same class ~5.5.  Grid-stride, 16 B per lane, non-temporal.
 __global__ __launch_bounds__(256) void stream_write_probe_kernel(float4* __restrict__ q0, float4* __restrict__ q1, size_t n4, float v) {

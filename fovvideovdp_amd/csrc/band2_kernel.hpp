@@ -460,7 +460,11 @@ __global__ __launch_bounds__(64 * BAND2_WPB_MAX, BAND2_LB) void band2_kernel(con
     bool tall;
     if (a.tickets) {
         if (threadIdx.x == 0) {
-            const int x = (int)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7;       // XCC_ID: the XCD this workgroup runs on
+#if defined(__gfx942__) || defined(__gfx950__)
+            const int x = (int)__builtin_amdgcn_s_getreg((4 - 1) << 11 | 20) & 7;       // XCC_ID: the XCD this workgroup runs on (hwreg 20 exists on gfx942 / gfx950 only; 8 XCDs assumed, any value 0..7 is correct)
+#else
+            const int x = (int)(blockIdx.x & 7);                                        // other targets: the hardware's round-robin placement as the estimate
+#endif
             const int nbp[2] = {first, a.n_items - first};
             int item = -1, ph_found = 0;
             for (int k = 0; k < 16 && item < 0; ++k) {

@@ -1014,25 +1014,26 @@ __device__ __forceinline__ void yuv_pair_rgb(const YuvRaw<T, C420>& r0, const Yu
     for (int pl = 0; pl < 2; ++pl) {
         if constexpr (C420) {
             using R = YuvRaw<T, C420>;
-            v2f rowv[4][2];
+            // A lane converts ONLY its own two chroma columns (2j, 2j+1: the pair word) of the two source rows and blends them
+            // vertically; the neighbour columns 2j-1 / 2j+2 are the finished values of the adjacent lanes (their column 1 / 0, same
+            // image row, hence the same vertical weights) and arrive through DPP -- half the conversions, clamps and vertical blends
+            // of fetching the neighbours' raw words and converting all four columns in every lane (round 6: 160 -> 80 vector
+            // instructions per lane and frame for the chroma of 4 pixels x 2 streams; the same values, bit for bit).  At a row
+            // start / end the clamped neighbour column is one of the lane's own.
+            v2f own[2];
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                const unsigned int w0 = r0.cp[pl][rr], w1 = r1.cp[pl][rr];
-                // neighbour columns: the adjacent lane's pair word or (image edge) an own column
-                const unsigned int l0 = lane_left_u32(w0), l1 = lane_left_u32(w1);
-                const unsigned int n0 = lane_right_u32(w0), n1 = lane_right_u32(w1);
-                const float lf0 = g.left_own ? R::lo(w0) : R::hi(l0);
-                const float lf1 = g.left_own ? R::lo(w1) : R::hi(l1);
-                const float rt0 = g.right_own ? R::hi(w0) : R::lo(n0);
-                const float rt1 = g.right_own ? R::hi(w1) : R::lo(n1);
-                rowv[0][rr] = cf(lf0, lf1);
-                rowv[1][rr] = cf(R::lo(w0), R::lo(w1));
-                rowv[2][rr] = cf(R::hi(w0), R::hi(w1));
-                rowv[3][rr] = cf(rt0, rt1);
+            for (int k = 0; k < 2; ++k) {
+                const v2f a0 = k == 0 ? cf(R::lo(r0.cp[pl][0]), R::lo(r1.cp[pl][0])) : cf(R::hi(r0.cp[pl][0]), R::hi(r1.cp[pl][0]));
+                const v2f a1 = k == 0 ? cf(R::lo(r0.cp[pl][1]), R::lo(r1.cp[pl][1])) : cf(R::hi(r0.cp[pl][1]), R::hi(r1.cp[pl][1]));
+                own[k] = pfma(a1, fy, a0 * gy);
             }
+            const v2f nl = v2f{__uint_as_float(lane_left_u32(__float_as_uint(own[1].x))), __uint_as_float(lane_left_u32(__float_as_uint(own[1].y)))};
+            const v2f nr = v2f{__uint_as_float(lane_right_u32(__float_as_uint(own[0].x))), __uint_as_float(lane_right_u32(__float_as_uint(own[0].y)))};
             v2f col[4];
-#pragma unroll
-            for (int k = 0; k < 4; ++k) col[k] = pfma(rowv[k][1], fy, rowv[k][0] * gy);
+            col[0] = g.left_own ? own[0] : nl;
+            col[1] = own[0];
+            col[2] = own[1];
+            col[3] = g.right_own ? own[1] : nr;
             uv[pl][0] = pfma(col[1], fx0, col[0] * gx0);
             uv[pl][1] = pfma(col[2], 0.25f, col[1] * 0.75f);
             uv[pl][2] = pfma(col[2], 0.75f, col[1] * 0.25f);
@@ -1062,10 +1063,12 @@ __device__ __forceinline__ void yuv_pair_rgb(const YuvRaw<T, C420>& r0, const Yu
 }
 
 // Display model on N (test, reference) pairs whose values are already inside [0,1]; one wave-uniform branch.
-// The affine parts run packed; scale*lin and +y_black keep their separate roundings (fvvdp_display_model.py:160-165).
+// The affine parts run packed and fused (one multiply-add where fvvdp_display_model.py:160-165 rounds twice): the power itself goes
+// through the hardware's log2 / exp2 (relative error up to ~1e-6 on the dark end), an order of magnitude above what a rounding of an
+// affine step moves, so mimicking the reference's separate roundings bought nothing here (round 6: -32 of 448 vector instructions per
+// lane and frame; the 8-bit RGB path, which is table-exact, is a different kernel).
 template <int N, int KIND>
 __device__ __forceinline__ void eotf_apply_pairs(v2f (&V)[N], const EotfDev& e) {
-#pragma clang fp contract(off)
     bool bad = false;
     switch (KIND) {                                  // compile-time: one case survives, the loop body stays branch-free
         case FVVDP_EOTF_SRGB: {
@@ -1079,18 +1082,18 @@ __device__ __forceinline__ void eotf_apply_pairs(v2f (&V)[N], const EotfDev& e) 
             if (__builtin_amdgcn_ballot_w64(!(mn > 0.04045f)) == 0) {
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    const v2f t = (V[i] + 0.055f) * (1.0f / 1.055f);
+                    const v2f t = pfma(V[i], 1.0f / 1.055f, splat(0.055f / 1.055f));
                     const v2f ex = v2f{fast_log2(t.x), fast_log2(t.y)} * 2.4f;
-                    V[i] = v2f{fast_exp2(ex.x), fast_exp2(ex.y)} * e.scale + e.y_black;
+                    V[i] = pfma(v2f{fast_exp2(ex.x), fast_exp2(ex.y)}, e.scale, splat(e.y_black));
                 }
             } else {
 #pragma unroll
                 for (int i = 0; i < N; ++i) {
-                    const v2f t = (V[i] + 0.055f) * (1.0f / 1.055f);
+                    const v2f t = pfma(V[i], 1.0f / 1.055f, splat(0.055f / 1.055f));
                     const v2f ex = v2f{fast_log2(t.x), fast_log2(t.y)} * 2.4f;
                     const v2f lo = V[i] * (1.0f / 12.92f);
                     const v2f lin = v2f{V[i].x > 0.04045f ? fast_exp2(ex.x) : lo.x, V[i].y > 0.04045f ? fast_exp2(ex.y) : lo.y};
-                    V[i] = lin * e.scale + e.y_black;
+                    V[i] = pfma(lin, e.scale, splat(e.y_black));
                 }
             }
             break;
@@ -1100,7 +1103,7 @@ __device__ __forceinline__ void eotf_apply_pairs(v2f (&V)[N], const EotfDev& e) 
             for (int i = 0; i < N; ++i) {
                 const v2f ex = v2f{fast_log2(V[i].x), fast_log2(V[i].y)} * e.gamma;
                 const v2f lin = v2f{V[i].x > 0.0f ? fast_exp2(ex.x) : 0.0f, V[i].y > 0.0f ? fast_exp2(ex.y) : 0.0f};
-                V[i] = lin * e.scale + e.y_black;
+                V[i] = pfma(lin, e.scale, splat(e.y_black));
             }
             break;
         }
@@ -1123,10 +1126,9 @@ __device__ __forceinline__ void eotf_apply_pairs(v2f (&V)[N], const EotfDev& e) 
     }
 }
 
-// luminance (R*w0 + G*w1) + B*w2 with the reference's separate roundings (video_source.py:206)
+// luminance R*w0 + G*w1 + B*w2 (video_source.py:206) as one multiply and two multiply-adds (see eotf_apply_pairs)
 __device__ __forceinline__ v2f lum_pair(v2f r, v2f g, v2f b, float w0, float w1, float w2) {
-#pragma clang fp contract(off)
-    return (r * w0 + g * w1) + b * w2;
+    return pfma(b, w2, pfma(g, w1, r * w0));
 }
 
 // Window of the last FL luminance pairs of a lane's 4 pixels, kept in registers WITHOUT moving it: frame v goes to slot

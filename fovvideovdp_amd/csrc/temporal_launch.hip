@@ -2,7 +2,6 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <cstddef>
-#include <cstdlib>
 #include <cstdint>
 #include <type_traits>
 
@@ -146,25 +145,25 @@ static void launch_yuv_vec_kind(const YuvArgs& a, dim3 grid, hipStream_t st) {
     }
 }
 template <int FL, typename T, bool C420>
-static void launch_yuv_vec_kind(const YuvArgs& a, dim3 grid, hipStream_t st) {
-    if (yuv_matrix_is_standard(a) && !getenv("FVVDP_YUV_GENERAL_MATRIX")) launch_yuv_vec_kind<FL, T, C420, true>(a, grid, st);
+static void launch_yuv_vec_kind(bool general, const YuvArgs& a, dim3 grid, hipStream_t st) {
+    if (yuv_matrix_is_standard(a) && !general) launch_yuv_vec_kind<FL, T, C420, true>(a, grid, st);
     else launch_yuv_vec_kind<FL, T, C420, false>(a, grid, st);
 }
 template <int FL>
-static void launch_yuv_vec(int bytes, bool c420, const YuvArgs& a, hipStream_t st) {
+static void launch_yuv_vec(int bytes, bool c420, bool general, const YuvArgs& a, hipStream_t st) {
     const int HW = a.W * a.H;
     dim3 grid((HW / 4 + YUV_QUADS - 1) / YUV_QUADS);
     if (bytes == 1) {
-        if (c420) launch_yuv_vec_kind<FL, unsigned char, true>(a, grid, st);
-        else launch_yuv_vec_kind<FL, unsigned char, false>(a, grid, st);
+        if (c420) launch_yuv_vec_kind<FL, unsigned char, true>(general, a, grid, st);
+        else launch_yuv_vec_kind<FL, unsigned char, false>(general, a, grid, st);
     } else {
-        if (c420) launch_yuv_vec_kind<FL, unsigned short, true>(a, grid, st);
-        else launch_yuv_vec_kind<FL, unsigned short, false>(a, grid, st);
+        if (c420) launch_yuv_vec_kind<FL, unsigned short, true>(general, a, grid, st);
+        else launch_yuv_vec_kind<FL, unsigned short, false>(general, a, grid, st);
     }
 }
-void k1_launch_yuv_vec(int FL, int bytes, bool c420, const YuvArgs& a, hipStream_t st) {
-    if (FL == 8) launch_yuv_vec<8>(bytes, c420, a, st);
-    else launch_yuv_vec<16>(bytes, c420, a, st);
+void k1_launch_yuv_vec(int FL, int bytes, bool c420, bool general_matrix, const YuvArgs& a, hipStream_t st) {
+    if (FL == 8) launch_yuv_vec<8>(bytes, c420, general_matrix, a, st);
+    else launch_yuv_vec<16>(bytes, c420, general_matrix, a, st);
 }
 void k1_launch_yuv_luminance(int bytes, const YuvLumArgs& a, hipStream_t st) {
     dim3 grid((a.y.W * a.y.H + 255) / 256, a.n_frames), block(256);

@@ -43,6 +43,6 @@ void k1_launch_vec(int FL, int dtype, const TemporalArgs& a, hipStream_t st);   
 void k1_launch_ring(int FL, int dtype, const TemporalArgs& a, hipStream_t st);    // any size
 void k1_launch_generic(int planes, int dtype, const GenericArgs& a, hipStream_t st);
 void k1_launch_luminance(int dtype, const LumArgs& a, hipStream_t st);     // source frames -> fp32 luminance frames (two-pass path)
-void k1_launch_yuv_vec(int FL, int bytes, bool c420, const YuvArgs& a, hipStream_t st);   // FL in {8, 16}
+void k1_launch_yuv_vec(int FL, int bytes, bool c420, bool general_matrix, const YuvArgs& a, hipStream_t st);   // FL in {8, 16}
 void k1_launch_yuv(int FL, int bytes, const YuvArgs& a, hipStream_t st);
 void k1_launch_yuv_luminance(int bytes, const YuvLumArgs& a, hipStream_t st);   // planar YUV frames -> fp32 luminance frames (two-pass path)

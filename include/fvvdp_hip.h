@@ -291,9 +291,10 @@ int fvvdp_ctx_timing_read(fvvdp_ctx* ctx, float* h_ms, int32_t* h_count, int cap
  * does.  ~0.1 s at creation (0.3 s with the further candidates), the candidates' memory held for the moment, nothing in any per-frame
  * call.  Results never depend on it.
  *   *state: always 9 (settled);  *chunk_mapped: one range: its kind (0 hipMalloc, 1 mapped from physical chunks); two ranges: 100 + 10 * kind of the odd slots' range + kind of the even slots' range
- *   h_us[capacity]: [0] microseconds per frame of the temporal kernel + pyramid pass on the layout in use (a synthetic clip, timed once at
- *   creation; 0 = not timed), [1] / [2] highest / lowest streaming-write rate [TB/s] over the candidate pairs, [3] number of further candidates
- *   tried, 0 beyond
+ *   h_us[capacity]: [0] always 0 (until round 5: a timing of the layout on a synthetic clip at creation; dropped, it had to borrow the
+ *   context's tables), [1] / [2] highest / lowest streaming-write rate [TB/s] over the candidate pairs, [3] number of further candidates
+ *   tried, 0 beyond.  The original range is given back only once two candidates are in hand: a probe that cannot allocate leaves the
+ *   context with the range it came with.
  *   *n_timed: number of half-size candidates (0: no choice);  *kept: index of the even slots' candidate + 8 * index of the odd slots' (-1: no choice) */
 int fvvdp_ctx_alloc_info(const fvvdp_ctx* ctx, int* state, int* chunk_mapped, float* h_us, int capacity, int* n_timed, int* kept);
 

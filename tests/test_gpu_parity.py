@@ -1044,3 +1044,54 @@ def test_config5_per_gpu_share_8_pairs_golden(fv):
     q0, st0 = m.predict(pairs[3][0], pairs[3][1], frames_per_second=30)
     assert abs(float(q0) - jods[3]) < 2e-6
     assert np.allclose(st0["Q_per_ch"], qh[3], rtol=2e-6, atol=0)
+
+
+@pytest.mark.parametrize("bd,css,fps", [(8, "420", 30), (10, "420", 60), (8, "444", 30)])
+def test_yuv_ingest_dark_and_mixed_content(fv, bd, css, fps, monkeypatch):
+    """Round 6: the vector YUV ingest takes the sRGB power branch alone for a wave none of whose values lies on the linear toe
+    (V <= 0.04045) and the ITU-shaped colour matrix in four multiply-adds.  The synthetic clips of the other tests are bright
+    everywhere (the fast path throughout); here (a) a dark clip (every pixel on the toe), (b) a clip that is dark in its left half only
+    (waves of both kinds, and waves with both kinds of lanes) and (c) chroma codes outside the legal range (the +-0.5 clamps) against
+    the oracle's restatement of the reference's unpack pipeline; and the nine-term matrix (FVVDP_YUV_GENERAL_MATRIX=1) gives the same
+    bits as the four-term one."""
+    from fovvideovdp_amd.synth import synth_yuv_pair
+    from oracle import fvvdp_oracle as orc
+    N, H, W = 2 * (int(np.ceil(250.0 / (1000.0 / fps)))) + 1, 72, 248 * 2     # two waves per row (62 quads each): a dark one and a bright one
+    ty, ry = synth_yuv_pair(N, H, W, bit_depth=bd, chroma_ss=css)
+    sc = 1 << (bd - 8)
+
+    def darken(a, cols):
+        a = a.clone()
+        Y = a[:, :H * W].view(N, H, W)
+        Y[:, :, cols] = (16 * sc + (Y[:, :, cols].to(torch.int64) - 16 * sc) // 24).to(a.dtype)      # luma just above black
+        return a
+
+    def wild_chroma(a):
+        a = a.clone()
+        n_c = (a.shape[1] - H * W) // 2
+        U = a[:, H * W:H * W + n_c]
+        U[:, ::7] = 3 * sc                   # below 16: clamps to -0.5
+        U[:, 3::11] = 253 * sc               # above 240: clamps to +0.5
+        return a
+
+    cases = {"dark": (darken(ty, slice(0, W)), darken(ry, slice(0, W))),
+             "half dark": (darken(ty, slice(0, W // 2 + 6)), darken(ry, slice(0, W // 2 + 6))),
+             "chroma clamps": (wild_chroma(ty), wild_chroma(darken(ry, slice(W // 2, W))))}
+    o = orc.Oracle("standard_fhd")
+    for tag, (t, r) in cases.items():
+        res = {}
+        for general in (False, True):
+            if general:
+                monkeypatch.setenv("FVVDP_YUV_GENERAL_MATRIX", "1")
+            else:
+                monkeypatch.delenv("FVVDP_YUV_GENERAL_MATRIX", raising=False)
+            m = fv.fvvdp(display_name="standard_fhd")
+            tt, rr = (t, r) if bd == 8 else (t.to(torch.int16), r.to(torch.int16))
+            vs = fv.fvvdp_video_source_yuv_frames(tt, rr, fps, W, H, bit_depth=bd, chroma_ss=css, color_space="bt709",
+                                                  display_photometry=m.display_photometry)
+            q, st = m.predict_video_source(vs)
+            res[general] = (float(q), st["Q_per_ch"].copy())
+        assert res[False][0] == res[True][0] and np.array_equal(res[False][1], res[True][1]), tag      # four terms == nine terms, bit for bit
+        oq, ost = o.predict_yuv(t.numpy(), r.numpy(), fps, W, H, bit_depth=bd, chroma_ss=css, color_space="bt709")
+        assert abs(res[False][0] - float(oq)) < 1e-4, (tag, res[False][0], float(oq))
+        check_q(res[False][1], ost["Q_per_ch"], coarse=2e-3, fine=3e-4)

@@ -398,7 +398,7 @@ def test_hot_kernels_do_not_spill():
             assert m["vgpr_spill_count"] == 0 and m["private_segment_fixed_size"] == 0, (nice, spills)
             assert m["sgpr_spill_count"] <= 2, (nice, spills)     # 16-bit 4:4:4 behind PQ with the 16-slot window: one pointer pair
             seen["yuv_vec"] += 1
-    assert seen["temporal_vec"] == 12 and seen["band2"] == 4 and seen["band"] == 8 and seen["yuv_vec"] == 48, seen
+    assert seen["temporal_vec"] == 12 and seen["band2"] == 4 and seen["band"] == 8 and seen["yuv_vec"] == 96, seen      # (yuv_vec: x2 since round 6, ITU-shaped and general colour matrix)
     assert seen["ring"] == 9 and seen["yuv"] == 6, seen
 
 

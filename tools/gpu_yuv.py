@@ -15,6 +15,10 @@ for sp in specs:
     css = parts[2] if len(parts) > 2 else "420"
     fps = int(parts[3]) if len(parts) > 3 else 30
     ty, ry = synth_yuv_pair(N, H, W, bit_depth=bd, chroma_ss=css, device="cuda")
+    if os.environ.get("YUV_DARK"):          # luma just above black: every value on the sRGB toe (the slow branch of the display model)
+        for a in (ty, ry):
+            Y = a[:, :H * W]
+            Y.copy_((16 * (1 << (bd - 8)) + (Y.to(torch.int64) - 16 * (1 << (bd - 8))) // 24).to(a.dtype))
     if bd > 8:
         ty, ry = ty.to(torch.int16), ry.to(torch.int16)
     m = fv.fvvdp(display_name="standard_4k")

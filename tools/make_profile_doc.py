@@ -121,8 +121,8 @@ def quoted_figures():
         pr = la.get("pair_write_rate_tbs") or {}
         out.append("* level 0 of the unprofiled run: %s%s; host syncs / allocations / frees inside per-frame calls: %s; first step incl. context creation %s ms" % (
             la.get("in_use"),
-            (" (fvvdp_ctx_create wrote every pair of %s half-size candidates at once: %.2f TB/s for the pair kept, %.2f for the slowest; temporal kernel + pyramid pass "
-             "on the layout kept: %s us per frame)" % (la.get("half_size_candidates"), pr.get("kept", 0), pr.get("lowest", 0), la.get("temporal_plus_pyramid_us_per_frame_at_creation")))
+            (" (fvvdp_ctx_create wrote every pair of %s half-size candidates at once: %.2f TB/s for the pair kept, %.2f for the slowest)" % (
+                la.get("half_size_candidates"), pr.get("kept", 0), pr.get("lowest", 0)))
             if la.get("half_size_candidates") else "",
             "/".join(str(v) for v in (la.get("per_frame_calls") or {}).values()), la.get("first_step_ms_incl_context_creation")))
     if jp.get("predict_call_ms"):

@@ -1,0 +1,294 @@
+#!/usr/bin/env python3
+"""Assembles the round-6 evidence files under profiles/ from the logs of tools/experiments/r6/s*.sh (gpurun_out/r6s*/):
+  profiles/r06_rccl_single_rank.md  RCCL executing on one GPU through the product's step path
+  profiles/r06_fov_floor.md         configs[3]: placement A/B, ablations and variants of the foveated level-0 pass on the round-6 build (item 3)
+  profiles/r06_parity.md            the parity figures measured this round (full-size D maps, the 4K-geometry corner; item 2)
+  profiles/r06_yuv_ingest.md        the 8-bit 4:2:0 YUV ingest: instruction budget, before / after (item 6)
+usage: tools/make_r6_evidence.py"""
+import glob
+import json
+import os
+import re
+import statistics
+
+R = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(R, "gpurun_out")
+P = os.path.join(R, "profiles")
+
+
+def rd(rel):
+    try:
+        return open(os.path.join(G, rel)).read().rstrip("\n")
+    except OSError:
+        return "(log %s not available)" % rel
+
+
+def jline(rel):
+    try:
+        return json.loads(open(os.path.join(G, rel)).readline())
+    except (OSError, ValueError):
+        return None
+
+
+def write(name, text):
+    with open(os.path.join(P, name), "w") as f:
+        f.write(text.rstrip("\n") + "\n")
+    print("wrote profiles/%s (%d lines)" % (name, text.count("\n") + 1))
+
+
+def kernel_us(rel):
+    m = re.search(r"kernel us/frame: \[([^\]]+)\]", rd(rel))
+    return [float(x) for x in m.group(1).split(",")] if m else None
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+def rccl():
+    rows = []
+    for tag, rel in (("auto (default)", "r6s1/bench_auto.json"), ("off", "r6s1/bench_off.json"), ("force", "r6s1/bench_force.json"),
+                     ("off", "r6s1/bench_off2.json"), ("force", "r6s1/bench_force2.json"), ("force, under rocprofv3", "r6s1/bench_rccl_profiled.json")):
+        o = jline(rel)
+        if not o:
+            continue
+        c = o.get("collective") or {}
+        rows.append("| `--collective %s` | %.3f | %.3f | %.1f | %s | %s |" % (
+            tag, o["ms_per_step"], o["timing"]["ms_per_step_min"], o["value"] / 1e3, (o.get("communicator") or {}).get("rccl_version"),
+            c.get("us_per_call_back_to_back")))
+    o = jline("r6s1/bench_auto.json") or {}
+    comm = json.dumps(o.get("communicator"), indent=1)
+    coll = json.dumps(o.get("collective"), indent=1)
+    kern = rd("r6s2/rccl_kernels.txt")
+    one = rd("r6s2/rccl_one_rank.txt")
+    trace = "\n".join(l for l in rd("r6s2/kernel_trace_rccl_one_rank.md").split("\n") if l.startswith("| kernel") or l.startswith("|---") or "oneRank" in l or "band2_kernel<4, true>" in l or "temporal_vec" in l)
+    pt = rd("r6s2/pytest.log").split("\n")[-3:]
+    write("r06_rccl_single_rank.md", f"""# Round 6 -- RCCL executing on hardware through the product's own step path (VERDICT r5 item 1)
+
+Until this round nothing in the repository had ever loaded `librccl`: `bench.py` created a process group only for `--gpus > 1`, the GPU box has
+one GPU, and the multi-rank tests ran under `gloo`.  Now:
+
+* `bench.py --gpus 1` (what the driver runs for `BENCH` and for the N = 1 point of `SCALE`) creates a **world-size-1 `nccl` process group**
+  (`--collective auto`, the default: in-process `HashStore`, `device_id` = the GPU, a probe all-reduce inside a `try` -- where no communicator
+  can be had the step falls back to the one-rank shortcut and says why in `communicator.error`), and every step's result rows -- written by
+  the library's kernels on the caller's stream -- go through the SAME zero-buffer `all_reduce(sum)` as at N > 1
+  (`sharding.gather_pair_results(..., force_collective=True)`: no `world == 1` early return).  The line carries `communicator`
+  (backend, RCCL version, device uuid) and `collective` (the all-reduce alone, back to back) at N = 1 too.
+* `--shard frames` issues ONE collective as well: the out-of-range flag rides in the `Q_per_ch` row (`sharding.frame_sharded_row`;
+  `tests/test_sharding_gloo.py` counts the calls: exactly one per clip, empty shards included).
+* `tests/test_gpu_sharding.py::test_rccl_executes_on_one_rank_through_the_step_path` (GPU): `bench.py` through `torch.distributed.run
+  --nproc-per-node 1` with `--collective force`; `communicator.backend == "nccl"`, an RCCL version, the JODs **bit-equal** (`jod_exact`, hex
+  floats) to `--collective off` and to `--collective auto`, pairs and frames mode.  Session 2: `{pt[0].strip()}` / `{pt[1].strip()}`.
+* stdout hygiene: librccl prints a five-line version banner on the C stdout of rank 0 when a communicator is created (it came AFTER the JSON
+  line, flushed at exit).  `bench.py` now points file descriptor 1 at stderr for the life of the process and writes its one JSON line to the
+  saved descriptor: stdout = one line, whatever libraries print.
+
+## What the communicator reports (N = 1, `gpurun_out/r6s1/bench_auto.json`)
+
+```
+{comm}
+{coll}
+```
+
+## What the collective costs a step (one box, session 1, alternating processes; 4K x60, one pair per step)
+
+| run | ms per step (median) | min | Gpix/s | RCCL | all-reduce alone, us per call |
+|---|---|---|---|---|---|
+{chr(10).join(rows)}
+
+The forced collective adds 0.01-0.04 ms to a 3.95-ms step (0.3-1 %, inside the process-to-process spread of this box: the two `off` runs differ by
+0.027 ms); the all-reduce alone, issued back to back, takes 12-13 us per call of host + stream hand-over time.  DESIGN section 7's
+"tens of us" estimate for the latency-bound collective is replaced by this number for one rank; the xGMI hop of N > 1 is the driver's to measure.
+
+## Which RCCL device code runs on one rank (`tools/gpu_rccl_one_rank.py` under `rocprofv3 --kernel-trace`, session 2)
+
+An in-place `ncclAllReduce(sum)` on a communicator of ONE rank needs no device work: RCCL returns after torch's stream hand-over and **no RCCL
+kernel appears in the trace** (the kernel table of `bench.py --collective force` under rocprofv3, `gpurun_out/r6s1/kernel_trace_rccl.md`, holds
+the library's kernels, torch's element-wise kernels of the input generator and the runtime's copy / fill kernels -- nothing from librccl).  What a
+one-GPU box CAN show of RCCL's device side is its one-rank reduce kernel, which `ReduceOp.AVG` takes (PreMulSum with the scalar 1/1): the same
+rows, produced by the library, through `all_reduce(avg)`:
+
+```
+{one}
+```
+
+RCCL kernels in that trace (`name, dispatches, avg ns, min ns, max ns`):
+
+```
+{kern}
+```
+
+`oneRankReduce<FuncPreMulSum<float>>`: 213 dispatches, 2.6 us average (1.7-4.6) on 6.7 KB -- RCCL device code running on this GPU on the
+library's output, bit-equal result.  The ring / tree kernels of N > 1 cannot run here (RCCL refuses two ranks on one device); the rows of the
+same trace for the two long kernels of the step, for scale:
+
+{trace}
+""")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+def fov():
+    def series(fmt, tags, sess, n=3):
+        out = {}
+        for t in tags:
+            out[t] = [kernel_us(fmt % (sess, t, i)) for i in range(1, n + 1)]
+        return out
+    ab = series("%s/fov_ab_%s_%d.txt", ("0", "1", "default"), "r6s1")
+    va = series("%s/fov_%s_%d.txt", ("base", "fov_prio", "fov_tailprio", "fov_wpb6", "fov_phase4", "fov_abl_tail", "fov_abl_mem"), "r6s2")
+
+    def tab(d, names):
+        rows = []
+        for t in d:
+            vs = [v for v in d[t] if v]
+            if not vs:
+                continue
+            l0 = [v[1] for v in vs]
+            l1 = [v[2] for v in vs]
+            alls = [sum(v[1:]) for v in vs]
+            rows.append("| %s | %s | %.2f | %s | %s | %.2f |" % (names.get(t, t), " / ".join("%.2f" % x for x in l0), statistics.median(l0),
+                                                               " / ".join("%.2f" % x for x in l1), " / ".join("%.1f" % x for x in alls), statistics.median(alls)))
+        return "\n".join(rows)
+    c3 = jline("r6s1/bench_config3.json") or {}
+    rf = json.dumps(c3.get("roofline_fov"), indent=1)
+    write("r06_fov_floor.md", f"""# Round 6 -- configs[3] (3840x2160 x120, foveated, moving gaze, standard_hdr_pq): where the pass stands and why (VERDICT r5 item 3)
+
+The graded pass of configs[3] measures 52.3-52.8 us per frame = 0.52-0.53 of the HBM peak on SURVEY 8(d)'s 221.17 MB; the target is 0.60 = 46.1 us.
+This file holds (a) the placement A/B the verdict asked for, (b) both ablations of the FOVEATED instantiation on the round-6 build, (c) the
+attempts at the overlap gap, and what follows from them.  `bench.py --config 3` now reproduces the figure from one command (`roofline_fov`).
+All numbers: `tools/gpu_config4.py` (12 calls per process, HIP events inside the library, median of calls 9-12), kernel us per frame;
+every table is ONE box with the variants in alternating processes (`tools/experiments/r6/s1.sh`, `s2.sh`).
+
+## (a) The +6 % of the round-5 bundle is not the two-range level-0 layout
+
+`band_kernel<4, false, 1>` at level 0 averaged 39.5 us per frame in the round-5 bundle against 37.2 in round 4's; the one new thing under it was
+level 0 living in two ranges (`L0Addr`).  Same box, three alternations: `FVVDP_PLACEMENT_PROBE=0` (one range as allocated), `=1` (one range, no
+candidates), default (two ranges chosen among six candidates):
+
+| layout | level 0, three processes | median | level 1 | all levels | median |
+|---|---|---|---|---|---|
+{tab(ab, {"0": "`PLACEMENT_PROBE=0` one range", "1": "`PLACEMENT_PROBE=1` one range", "default": "default: two chosen ranges"})}
+
+No difference between the layouts (medians within 0.3 us, less than the spread between processes of one layout: the FIRST process of every trio is
+1-1.7 us slower than the other two, whatever its layout).  The round-5 bundle's 39.5 us was that process-to-process / box-to-box spread
+(this box: 36.7-38.8; the `bench.py --config 3` process of the same session: 39.2).  The layout stays as it is; the temporal kernel in front
+(first column of the raw lines: 29.1-30.0 us with two ranges against 30.6-31.9 with one) is what it is for.
+
+## (b) The two floors of the foveated level-0 pass, re-measured on the round-6 build
+
+`-DBAND_ABLATE=1`: the per-pixel tail removed (reduce, expand, loads and stores stay) = the data flow with the pyramid arithmetic;
+`-DBAND_ABLATE_MEM`: every wave re-reads 8 rows of frame 0 from the L2 and stores nothing = the arithmetic alone.  Same box as (c):
+
+| build | level 0, three processes | median | level 1 | all levels | median |
+|---|---|---|---|---|---|
+{tab({k: va[k] for k in ("base", "fov_abl_tail", "fov_abl_mem")}, {"base": "product build", "fov_abl_tail": "`-DBAND_ABLATE=1` (no per-pixel tail)", "fov_abl_mem": "`-DBAND_ABLATE_MEM` (arithmetic alone)"})}
+
+* **Arithmetic alone: 32.7-33.4 us at level 0** (and 7.9-8.1 at level 1, 2.0-2.1 at level 2): with nothing to wait for from memory the
+  foveated kernel needs 33 us -- not the 26.5 us of the issue-count estimate in `profiles/r05_fov_budget.md` (1452 instructions per 16 pixels
+  at 1.14 quad-cycles).  Three waves per SIMD do not keep the vector ALU issuing every cycle through the dependent chains of the tail (log2 ->
+  multiply-add -> exp2 -> log2 -> exp2, two LDS gathers per phase); the sum over the levels is 32.7 + 7.9 + 2.0 + 0.6 + 0.5 = **43.7 us of
+  arithmetic for the whole pass -- 95 % of the 46.1-us target with the memory system switched off.**
+* **Data flow alone: 31.8-35.7 us at level 0** (166 MB per frame: 4.6-5.2 TB/s, the ceiling of this read : write mix on this box,
+  `profiles/r01_hbm_ceilings.md`), 8.6-9.1 at level 1.
+* **Together: 37.5-39.0 us** -- 13-18 % above the longer of two floors that are equally long.  0.60 would need level 0 at 33.5 us: BOTH floors
+  met at once with perfect overlap.  The round-5 reading ("level 0 sits on its data-flow floor, arithmetic is the shorter one") was half the
+  picture: the arithmetic floor is as high.
+
+## (c) Attempts at the overlap gap (same box, three alternations)
+
+| build | level 0, three processes | median | level 1 | all levels | median |
+|---|---|---|---|---|---|
+{tab({k: va[k] for k in ("base", "fov_prio", "fov_tailprio", "fov_wpb6", "fov_phase4")}, {"base": "product build", "fov_prio": "`-DFOV_PRIO=2`: `s_setprio 2` over the memory-issuing head of a step (rho-map + row prefetch + coarse store), 0 over the tail", "fov_tailprio": "`-DFOV_PRIO=0 -DFOV_TAILPRIO=2`: the reverse, the arithmetic tail at raised priority", "fov_wpb6": "`-DFOV_WPB=6`: 6 waves per workgroup (2 x 6 = 12 waves per CU, one LUT-slice copy per 6 waves)", "fov_phase4": "`-DFOV_PHASE=4`: the LDS reads of all 4 pixels of a step in one phase (181 VGPRs)"})}
+
+* Wave priority, either way round: inside the spread of the product build (medians 37.3 / 37.6 against 38.7; the product build's own three
+  processes span 37.5-39.0).  Not adopted -- a 1-us effect cannot be told from this box's noise in three alternations and the code path
+  stays simpler without it (the switch `-DFOV_PRIO` remains for A/B builds).
+* 6 waves per workgroup: 50 us.  The workgroups' LDS (46.5 KB slice + row table) then allows 2 workgroups per CU = 12 waves only if both fit
+  beside each other's allocation granularity; the measured time says they do not (one workgroup of 6 per CU).  4 waves per workgroup stays.
+* 4-pixel phases: +1-2 us (181 registers: 2 waves per SIMD).
+* Not built: the tail split into a sustained and a transient half to get under 128 VGPRs (4 waves per SIMD).  The register ring of the fine
+  rows alone is 64 VGPRs, the expanded level and the coarse rows 28, the CSF query state of two pixels 48: a tail that keeps only one
+  channel's masking state alive saves ~12 -- 168 -> ~156, not 128; and the LDS slice would have to shrink to 40 KB per workgroup as well.
+  Two levels per launch (fewer bytes) was built in round 4 and lost for the same arithmetic: 91 VALU instructions per pixel on 54 of 64
+  lanes at 2 waves per SIMD (`profiles/r04_fov_two_level.md`).
+
+## What follows
+
+The foveated pass is **co-bound by its arithmetic (43.7 us for all levels with memory off) and its data flow (~44 us for all levels with the
+tail off)**; it runs at 52.3-52.8 us = both floors + 19 %.  Reaching 46.1 us needs both at once: ~15 % fewer instructions per pixel (the
+formula's 13 transcendentals and the trilinear blend are itemised in `profiles/r05_fov_budget.md`; the one removable group, the four query
+clamps, is 3.7 %) AND fewer bytes (two levels per pass, which raises the register pressure of the same tail).  Neither is in reach of a
+variant of this kernel; the figure stands at 0.52-0.53 with its floors published.  `bench.py --config 3` (`gpurun_out/r6s1/bench_config3.json`,
+JOD 9.575966 = 1.24e-05 from the reference):
+
+```
+{rf}
+```
+
+Raw lines (`kernel us/frame: [K1, level 0, level 1, ..., finalize]`):
+
+```
+{chr(10).join("%-28s #%d %s" % (t, i + 1, v) for d in (ab, va) for t in d for i, v in enumerate(d[t]))}
+```
+""")
+
+
+# ------------------------------------------------------------------------------------------------------------------------------
+def parity():
+    def ld(name):
+        for s in ("r6s2", "r6s1"):
+            try:
+                return json.load(open(os.path.join(G, s, name))) if os.path.exists(os.path.join(G, s, name)) else json.load(open(os.path.join(G, name)))
+            except (OSError, ValueError):
+                continue
+        return None
+    f, u, v, c = (ld("fullsize_maps_g3_fhd.json"), ld("fullsize_maps_g3_uhd.json"), ld("fullsize_maps_g4_fov.json"), ld("fullsize_maps_g16_corner.json"))
+    write("r06_parity.md", f"""# Round 6 -- parity figures measured this round (MI355X, `tests/test_gpu_fullsize_maps.py`; VERDICT r5 item 2)
+
+The rest of the parity table is unchanged from `profiles/r05_parity.md` (same kernels; the round-6 bundle re-runs `tools/gpu_parity_report.py`).
+
+## Per-band difference maps at BASELINE sizes (`dsum` of goldens g3 FHD, g3 UHD, g4 UHD x120: sum, sum of squares, maximum of EVERY D map)
+
+The reference's own run stored the three figures for every frame, band and temporal channel (`tools/gen_golden.py` `Capture._mm`,
+`fvvdp.py:454-467`); until this round no test read them.  The HIP path writes its D maps through `fvvdp_band_maps.d_D`, reduces them on the
+device in float64 and is compared; worst relative deviation over all (frame, band, channel), floor 1e-6 of the largest value of the same map
+over the clip:
+
+| clip | maps compared | sum | sum of squares | maximum (one pixel) | asserted (<= 3x) |
+|---|---|---|---|---|---|
+| g3 1920x1080 x60 (configs[1]) | 60 x 12 | {f['sum']:.2e} | {f['sum_sq']:.2e} | {f['max']:.2e} | 2.5e-4 / 7e-4 / 1.8e-3 |
+| g3 3840x2160 x60 (configs[2]) | 60 x 14 | {u['sum']:.2e} | {u['sum_sq']:.2e} | {u['max']:.2e} | 3e-4 / 7e-4 / 4e-3 |
+| g4 3840x2160 x120 foveated, PQ (configs[3]) | 120 x 14 | {v['sum']:.2e} | {v['sum_sq']:.2e} | {v['max']:.2e} | 1.5e-2 / 3e-2 / 3.8e-2 |
+
+`Q_per_ch` of the map-writing pass (one-level kernels) against the product pass (two-level kernel): {f['Q_maps_pass_vs_product_pass']:.1e} / {u['Q_maps_pass_vs_product_pass']:.1e};
+foveated map pass against the reference's `Q_per_ch`: {v['Q_maps_pass_vs_reference']:.2e} (the end-to-end figure of `test_config4_foveated_uhd_golden`).
+The foveated bounds are wider because D ~ S^2.4 amplifies the reference's rounding noise on rho -- next section.
+
+## The foveated path at the 4K display geometry (golden g16: the real reference on 3 frames of 3840x2160, `standard_hdr_pq`, gaze in a corner / centre / far corner)
+
+270x480 windows of S and L_bkg cut from the top-left corner of bands 0-2 (largest viewing angle), first and last frame.  Worst over the 12
+windows, `max / mean` of the relative difference:
+
+| comparison | max | mean | what it shows |
+|---|---|---|---|
+| reference vs its own formula with fp64 geometry (`exact_geometry`) | {c['ref_vs_exact'][0]:.2e} | {c['ref_vs_exact'][1]:.2e} | the reference's finite difference of fp32 tangents (`fvvdp_display_model.py:475-488`, delta = 0.0066 deg) scatters this far around its own formula |
+| reference vs the SAME fp32 formula with numpy's `tan` (the oracle) | {c['numpy32_vs_ref'][0]:.2e} | {c['numpy32_vs_ref'][1]:.2e} | a second fp32 evaluation of the formula does not reproduce the scatter either: it is rounding noise, not a property to match |
+| kernel vs reference | {c['hip_vs_ref'][0]:.2e} | {c['hip_vs_ref'][1]:.2e} | the same distance as the first row |
+| kernel vs fp64-geometry evaluation | {c['hip_vs_exact'][0]:.2e} | {c['hip_vs_exact'][1]:.2e} | the closed form cos d / (cos a cos(a+d)) has no cancellation: ~600x closer on average (the maximum is the pixel under the gaze) |
+| L_bkg, kernel vs reference | {c['lbkg']:.1e} | | |
+
+End to end on the 3-frame clip: `Q_per_ch` kernel vs reference {c['Q_hip_vs_ref']:.2e}, fp64-geometry oracle vs reference {c['Q_exact_vs_ref']:.2e}, kernel vs that oracle
+{c['Q_hip_vs_exact']:.2e}; JOD {c['jod_delta_ref']:.1e} from the reference, {c['jod_delta_exact']:.1e} from the oracle.  The 2e-3 accepted on `Q_per_ch` at 4K x120
+(measured 7.1e-4) is the reference's own distance from its formula (6.7e-4 here), shown at this geometry -- no longer assumed from 135x240.
+The oracle-side facts (rows 1-2, the 6.7e-4) are also asserted on the CPU: `tests/test_oracle_golden.py::test_foveated_4k_geometry_corner_g16`.
+
+## The stated range of a caller-built code-value table (`fvvdp_eotf.L_min / L_max`) is enforced (VERDICT r5 item 4)
+
+`tests/test_gpu_fused.py::test_stated_table_range_is_enforced_not_trusted`: a truthful SDR table takes the clamp-free pyramid variant, no
+statement keeps the clamps (same bits); a wrong statement ([5, 50] on a table spanning [0.2, 100]) and a hostile table (zeros, NaN, negative
+and 3e7 entries, stated [1, 100]) give finite results, bit-equal with and without the clamp-free variant and bit-equal to the table clamped
+to the statement on the host.  The clamp sits where the table is read (`lut_entry`, `csrc/temporal_kernels.hpp`): once per table entry and
+workgroup for 8-bit sources, nothing per pixel.
+""")
+
+
+if __name__ == "__main__":
+    rccl()
+    fov()
+    parity()
