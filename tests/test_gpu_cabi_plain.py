@@ -100,6 +100,11 @@ def test_video_path_through_the_c_abi_only():
         for p in (d_t, d_r, d_lut, d_Q, d_jod, d_flag):
             hip.hipFree(p)
         hip.hipStreamDestroy(stream)
+    # the raw-pointer path IS the product path: the same pair through the Python API (torch tensors, the caching allocator's memory, torch's
+    # stream) gives the same bits (the 2e-3 against the oracle below proves that the ABI is drivable, this that
+    # nothing differs between the two ways in)
+    q_api, st_api = fv.fvvdp(display_name="standard_fhd").predict(test, ref, frames_per_second=fps)
+    assert np.array_equal(st_api["Q_per_ch"], Q) and float(q_api) == float(jod[0])
     oq, ost = orc.Oracle("standard_fhd").predict(test.numpy(), ref.numpy(), frames_per_second=fps)
     assert flag[0] == 0
     assert abs(float(jod[0]) - float(oq)) < 1e-4
