@@ -3,21 +3,27 @@
 
 A "step" is one full pass of the hot path over `--pairs-per-gpu` (default 1) synthetic 3840x2160 x 60-frame video pairs
 per GPU (BASELINE.json configs[2]: uint8 RGB, standard_4k, 30 fps -> 8-tap temporal filter, foveated off; configs[4] is
-`--gpus 8 --pairs-per-gpu 8`), inputs already resident in HBM: unpack + sRGB display model + luminance + temporal
-filtering + pyramid + CSF + masking + pooling + JOD regression.  ONE step path for every N (`step_path` in the line): the pairs of
-a step are queued back to back without host synchronisation (`predict_batch`; every pair's pooling + JOD regression run in the
-library on the device), the per-pair result rows (Q_per_ch | range flag | JOD) of all ranks are combined by ONE all-reduce of
-the device buffer (a no-op on one rank) and ONE device -> host copy ends the step.  `--shard frames` measures the other
-decomposition of north_star: ONE pair of `--frames` x N frames whose output frames are split across the ranks
-(`predict_frame_sharded`: every rank reads its own fl-1 frames of temporal halo, one all-reduce of Q_per_ch, pooling on every rank).
+`--gpus 8 --pairs-per-gpu 8`; `--config 1` / `--config 3` run configs[1] / configs[3]), inputs already resident in HBM: unpack + sRGB
+display model + luminance + temporal filtering + pyramid + CSF + masking + pooling + JOD regression.  ONE step path for every N
+(`step_path` in the line): the pairs of a step are queued back to back without host synchronisation (`predict_batch`; every pair's
+pooling + JOD regression run in the library on the device), the per-pair result rows (Q_per_ch | range flag | JOD) of all ranks are
+combined by ONE all-reduce of the device buffer and ONE device -> host copy ends the step.  Since round 6 the all-reduce is issued on ONE
+rank too (`--collective auto`: a world-size-1 `nccl` group, RCCL initialised, `communicator` / `collective` in the line; `--collective
+off` = the one-rank shortcut), so the N = 1 point of a scaling curve carries the collective's fixed cost.  `--shard frames` measures the
+other decomposition of north_star: ONE pair of `--frames` x N frames whose output frames are split across the ranks
+(`predict_frame_sharded`: every rank reads its own fl-1 frames of temporal halo, ONE all-reduce of Q_per_ch + range flag, pooling on every rank).
 value = Mpixels/s (test+ref) = 2*W*H*frames of a step / median step seconds.
 
-  python bench.py [--gpus N --steps K --warmup W --pairs-per-gpu P --shard pairs|frames]   (N>1: launched by torch.distributed.run)
+  python bench.py [--gpus N --steps K --warmup W --pairs-per-gpu P --shard pairs|frames --config 1|2|3 --collective auto|off|force]
+  (N>1: launched by torch.distributed.run)
 
-One JSON line on rank 0.  `roofline`: the dominant kernel (two-level pyramid kernel, levels 0+1), timed per launch
-with HIP events inside the library on the kernels' stream (median/min/max over >= 10 launches); `graded_pass`: all
-pyramid levels + finalize against SURVEY 8(d)'s 221.2 MB per 4K frame; `roofline.traffic`: HBM bytes per launch of that
-kernel from two rocprofv3 --pmc passes run from here (fallback: the committed profile); `cpu_baseline`: the numpy oracle on a bounded
+ONE JSON line on rank 0's stdout and nothing else (file descriptor 1 is pointed at stderr while the process runs: librccl prints a banner).
+`roofline`: the dominant kernel (two-level pyramid kernel, levels 0+1), timed per launch with HIP events inside the library on the kernels'
+stream (median/min/max over >= 10 launches); `roofline.frac_rocprof_avg`: the same bytes over the rocprofv3 AVERAGE duration of the kernel
+in a kernel trace run from here (cold launches included); `roofline.frac_bmin`: SURVEY 8(d)'s conservative figure (level 0 read once, over the
+whole graded pass); `roofline.with_clamps`: the variant of the kernel that HDR displays take; `graded_pass`: all pyramid levels + finalize
+against SURVEY 8(d)'s 221.2 MB per 4K frame; `roofline.traffic`: HBM bytes per launch of that kernel from two rocprofv3 --pmc passes run from
+here (fallback: the committed profile); `roofline_fov` (`--config 3`): the foveated pass; `cpu_baseline`: the numpy oracle on a bounded
 sample of the same workload; `value_h2d_inclusive`: the same call on pageable host arrays (never `value`).
 """
 import argparse
@@ -431,7 +437,9 @@ def main():
                                   "credited) / the time of ALL pyramid levels + finalize (%.2f us per frame) / peak" % (b_min / 1e6, float(np.median(tot))))
         if foveated:
             # configs[3]: the whole graded pass of the foveated path (one-level kernels with per-pixel geometry) against SURVEY 8(d)'s bytes
-            extra["roofline_fov"] = {"bound": "hbm (target) -- in fact co-bound by VALU issue: profiles/r06_fov_floor.md",
+            extra["roofline_fov"] = {"bound": "hbm",
+                                     "note": "priced against the HBM peak as SURVEY 8(d) asks; the pass is in fact co-bound -- its arithmetic alone takes "
+                                             "43.7 us per frame for all levels, its data flow alone ~44: profiles/r06_fov_floor.md",
                                      "kernel": "band_kernel<4, false, 1> x %d levels + finalize" % n_bands,
                                      "us_per_frame_levels": extra["graded_pass"]["levels_us_per_frame_median"],
                                      "us_per_frame_all_levels": extra["graded_pass"]["us_per_frame_all_levels"],
