@@ -82,6 +82,35 @@ __device__ __forceinline__ float eotf_f32(float V, const EotfDev& e, B& bad) {
 // KIND >= 0: the display model is known at compile time (straight-line code, no branch at all).
 template <int N, int KIND = -1, typename B = bool>
 __device__ __forceinline__ void eotf_apply(float (&V)[N], const EotfDev& e, B& bad) {
+    if constexpr (KIND == FVVDP_EOTF_SRGB && N >= 4) {
+        // sRGB on N samples of a wave (16-bit / float sources in closed form): the linear toe (V <= 0.04045) costs a multiply, a
+        // compare and a select per sample.  One wave-uniform branch on the smallest clipped sample takes the power branch alone where
+        // no lane needs the toe: the same expression as eotf_one for those samples, the same bits (round 6).
+        float mn = 1.0f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            note_oob(bad, V[i]);
+            V[i] = fminf(fmaxf(V[i], 0.0f), 1.0f);
+        }
+#pragma unroll
+        for (int i = 0; i + 1 < N; i += 2) asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn) : "v"(V[i]), "v"(V[i + 1]));
+        if constexpr (N & 1) mn = fminf(mn, V[N - 1]);
+        if (__builtin_amdgcn_ballot_w64(!(mn > 0.04045f)) == 0) {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const float hi = fast_exp2(2.4f * fast_log2((V[i] + 0.055f) * (1.0f / 1.055f)));
+                V[i] = __fadd_rn(__fmul_rn(e.scale, hi), e.y_black);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < N; ++i) {
+                const float hi = fast_exp2(2.4f * fast_log2((V[i] + 0.055f) * (1.0f / 1.055f)));
+                const float lin = V[i] > 0.04045f ? hi : V[i] * (1.0f / 12.92f);
+                V[i] = __fadd_rn(__fmul_rn(e.scale, lin), e.y_black);
+            }
+        }
+        return;
+    }
     if constexpr (KIND >= 0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) V[i] = eotf_one<KIND>(V[i], e, bad);
@@ -1183,23 +1212,22 @@ __device__ __forceinline__ void yuv_window_dispatch(int slot, v2f (&win)[FL][4],
 // pairs stays where it is (yuv_window_step above) and only the short FIR exists FL times.
 // The FIR also runs during the history frames (its result is dropped by an out-of-range store offset).
 template <int FL, typename T, bool C420, int KIND, bool STDM>
-__device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* s_t) {
+__device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* s_t, const int lane, const int block) {
     constexpr int PX = 4;
     constexpr int TD = FL <= 8 ? YUV_TD8 : YUV_TD16;
     typedef const int __attribute__((address_space(4)))* karg_int_p;
     typedef const char __attribute__((address_space(4)))* karg_p;
     const karg_int_p idx = (karg_int_p)((karg_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(YuvArgs, idx));
-    const int lane = threadIdx.x;
     const int HW = a.W * a.H;
     const int uvplane = a.uvw * a.uvh;
     // lanes 1..62 own the wave's 62 pixel quads; lanes 0 and 63 convert the quads next to them, only to hand their
     // chroma columns to lanes 1 and 62 (quads are clamped to the frame: a clamped lane duplicates its neighbour,
     // which then sits at a row start / end and does not look at it)
-    const int p0 = blockIdx.x * (YUV_QUADS * PX);
+    const int p0 = block * (YUV_QUADS * PX);
 #ifdef YUV_ABLATE_MEM      // profiling ablation: every wave converts the same 64 quads of source frame 0 (cache hits), nothing is stored
     const int quad = lane;
 #else
-    const int quad = min(max(blockIdx.x * YUV_QUADS - 1 + lane, 0), HW / PX - 1);
+    const int quad = min(max(block * YUV_QUADS - 1 + lane, 0), HW / PX - 1);
 #endif
     const int pl = quad * PX;
     YuvGeom g;
@@ -1304,13 +1332,25 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
 // KIND = display model (compile-time: the host picks the instantiation): one loop body per kernel.  With a switch over the six
 // bodies inside one kernel, scalar values of the prologue stayed alive across all of them and spilled (8 SGPRs in the 16-slot
 // 4:2:0 kernels).
+// Waves per workgroup, as temporal_vec_kernel (K1_WPB8): the 8-slot window runs YUV_WPB8 waves per workgroup on adjacent runs of pixel
+// quads -- they share nothing (no table, no barrier) but start together, so the memory system sees 4 x longer contiguous runs per frame.
+#ifndef YUV_WPB8
+#define YUV_WPB8 4
+#endif
+constexpr int yuv_wpb(int FL) { return FL == 8 ? YUV_WPB8 : 1; }
 template <int FL, typename T, bool C420, int KIND, bool STDM>
-__global__ __launch_bounds__(64, (FL == 8 ? (((sizeof(T) == 2 && !C420) || KIND == FVVDP_EOTF_PQ) ? 2 : YUV_WAVES8) : YUV_WAVES16))     // 16-bit 4:4:4: 8 raw dwords per frame pair more; PQ: the longest display model
+__global__ __launch_bounds__(64 * yuv_wpb(FL), (FL == 8 ? (((sizeof(T) == 2 && !C420) || KIND == FVVDP_EOTF_PQ) ? 2 : YUV_WAVES8) : YUV_WAVES16))     // 16-bit 4:4:4: 8 raw dwords per frame pair more; PQ: the longest display model
 void temporal_yuv_vec_kernel(const YuvArgs a_byval) {
     const YuvArgs& a = *(const YuvArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // see temporal_vec_kernel
     (void)a_byval;
-    __shared__ float4 s_t[64 * (4 + 1)];
-    temporal_yuv_vec_body<FL, T, C420, KIND, STDM>(a, s_t);
+    constexpr int WPB = yuv_wpb(FL);
+    __shared__ float4 s_t_all[WPB][64 * (4 + 1)];
+    const int wave = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+    const int block = (int)blockIdx.x * WPB + wave;           // this wave's run of 62 pixel quads
+    if constexpr (WPB > 1) {
+        if (block * (YUV_QUADS * 4) >= a.W * a.H) return;      // the last workgroup of a frame whose block count is not a multiple
+    }
+    temporal_yuv_vec_body<FL, T, C420, KIND, STDM>(a, s_t_all[wave], (int)(threadIdx.x & 63), block);
 }
 
 // Generic (any fl, any frame size) version: one thread per pixel per output frame, the window is re-read from

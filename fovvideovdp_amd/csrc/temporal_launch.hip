@@ -134,7 +134,9 @@ static bool yuv_matrix_is_standard(const YuvArgs& a) {
 }
 template <int FL, typename T, bool C420, bool STDM>
 static void launch_yuv_vec_kind(const YuvArgs& a, dim3 grid, hipStream_t st) {
-    const dim3 block(64);
+    constexpr int WPB = yuv_wpb(FL);                       // waves per workgroup, one run of 62 pixel quads each
+    const dim3 block(64 * WPB);
+    grid.x = (grid.x + WPB - 1) / WPB;
     switch (a.e.kind) {          // the display model is a template constant of the kernel
         case FVVDP_EOTF_SRGB: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_SRGB, STDM>), grid, block, 0, st, a); break;
         case FVVDP_EOTF_GAMMA: hipLaunchKernelGGL((temporal_yuv_vec_kernel<FL, T, C420, FVVDP_EOTF_GAMMA, STDM>), grid, block, 0, st, a); break;

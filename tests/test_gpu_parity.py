@@ -1095,3 +1095,47 @@ def test_yuv_ingest_dark_and_mixed_content(fv, bd, css, fps, monkeypatch):
         oq, ost = o.predict_yuv(t.numpy(), r.numpy(), fps, W, H, bit_depth=bd, chroma_ss=css, color_space="bt709")
         assert abs(res[False][0] - float(oq)) < 1e-4, (tag, res[False][0], float(oq))
         check_q(res[False][1], ost["Q_per_ch"], coarse=2e-3, fine=3e-4)
+
+
+@pytest.mark.parametrize("kind", ["u16", "f32"])
+def test_closed_form_srgb_dark_and_mixed_content(fv, kind):
+    """Round 6: the temporal kernels evaluate sRGB in closed form for 16-bit and float sources and take the power branch alone for a
+    wave none of whose samples lies on the linear toe (V <= 0.04045).  The synthetic clips are bright everywhere; here a clip that is
+    dark in its left half (waves of both kinds, and waves with both kinds of lanes) and one that is dark throughout, against the
+    oracle -- and the out-of-range flag still fires from either branch."""
+    import logging
+    from fovvideovdp_amd.synth import synth_video_pair
+    from oracle import fvvdp_oracle as orc
+    N, H, W, fps = 12, 64, 1024, 30                     # 1024 columns = 4 waves of 256 pixels per row
+    test, ref = synth_video_pair(N, H, W)
+    o = orc.Oracle("standard_fhd")
+    m = fv.fvvdp(display_name="standard_fhd")
+    for cols in (slice(0, W // 2 + 40), slice(0, W)):
+        t, r = test.clone(), ref.clone()
+        t[..., cols] = t[..., cols] // 24               # codes 0..10: on the toe
+        r[..., cols] = r[..., cols] // 24
+        if kind == "u16":
+            tt, rr = (t.numpy().astype(np.uint16) * 257), (r.numpy().astype(np.uint16) * 257)
+        else:
+            tt, rr = (t.to(torch.float32) / 255).numpy(), (r.to(torch.float32) / 255).numpy()
+        q, st = m.predict(tt, rr, dim_order="BCFHW", frames_per_second=fps)
+        oq, ost = o.predict(tt, rr, dim_order="BCFHW", frames_per_second=fps)
+        assert abs(float(q) - float(oq)) < 1e-4, (kind, cols, float(q), float(oq))
+        check_q(st["Q_per_ch"], ost["Q_per_ch"], coarse=2e-3, fine=3e-4)
+    if kind == "f32":                                   # out of range in a bright wave (fast branch) and in a dark one
+        t, r = test.clone(), ref.clone()
+        t[..., :W // 2] = t[..., :W // 2] // 24
+        r[..., :W // 2] = r[..., :W // 2] // 24
+        for x in (W - 8, 8):
+            bad = (t.to(torch.float32) / 255).clone()
+            bad[0, 1, 3, 5, x] = 1.25
+            import io
+            logger = logging.getLogger()
+            buf = io.StringIO()
+            hnd = logging.StreamHandler(buf)
+            logger.addHandler(hnd)
+            try:
+                m.predict(bad.numpy(), (r.to(torch.float32) / 255).numpy(), dim_order="BCFHW", frames_per_second=fps)
+            finally:
+                logger.removeHandler(hnd)
+            assert "outside the valid range" in buf.getvalue(), x

@@ -509,7 +509,7 @@ def test_level0_in_two_chosen_ranges_changes_no_bits(tmp_path):
             if n_want:
                 lo, hi = kept % 8, kept // 8
                 assert 0 <= lo < hi < n_want and kind >= 100, (mode, i)
-                assert us[0] > 0 and us[1] >= us[2] > 0 and all(u == 0 for u in us[4:]), (mode, i)
+                assert us[0] == 0 and us[1] >= us[2] > 0 and all(u == 0 for u in us[4:]), (mode, i)      # us[0]: the creation-time timing pass of round 5 is gone
                 assert us[3] == (5 if mode == "further" else us[3]) and 0 <= us[3] <= 8, (mode, i)
                 want = {"malloc": [0] * 6}.get(mode, [1, 0, 1, 0, 1, 0])    # candidate kinds: chunk-mapped and hipMalloc in turn
                 if us[3] == 0:

@@ -288,7 +288,98 @@ workgroup for 8-bit sources, nothing per pixel.
 """)
 
 
+# ------------------------------------------------------------------------------------------------------------------------------
+def yuv():
+    def med(rel):
+        out = {}
+        for l in rd(rel).split("\n"):
+            m = re.match(r"\S+ (\S+) best ([\d.]+) ms .* JOD ([\d.]+) \| temporal ([\d.]+) us/frame", l)
+            if m:
+                out.setdefault(m.group(1), []).append((float(m.group(4)), float(m.group(2)), m.group(3)))
+        return out
+    builds = [("round 5 (`build_variants/r6_pre_yuv.so`)", med("r6s4/yuv_r5.txt")),
+              ("+ ITU-shaped matrix in 4 multiply-adds, sRGB power branch alone where no lane needs the toe", med("r6s4/yuv_step1.txt")),
+              ("+ chroma columns converted once and exchanged through DPP, affine steps fused", med("r6s4/yuv_step2.txt"))]
+    if os.path.exists(os.path.join(G, "r6s5/yuv_wpb.txt")):
+        builds.append(("+ 4 waves per workgroup (8-slot window)", med("r6s5/yuv_wpb.txt")))
+    specs = [k for k in builds[0][1]]
+    names = {"2160x3840x60:8:420": "4K x60, 8-bit 4:2:0, 30 fps (19 B per pixel: 157.6 MB per frame)", "2160x3840x60:10:420:60": "4K x60, 10-bit 4:2:0, 60 fps (15 taps)",
+             "2160x3840x60:8:444": "4K x60, 8-bit 4:4:4, 30 fps", "2160x3840x60:10:420": "4K x60, 10-bit 4:2:0, 30 fps", "1080x1920x60:8:420": "1080p x60, 8-bit 4:2:0, 30 fps"}
+    hdr = "| clip | " + " | ".join(b[0] for b in builds) + " |\n|---|" + "---|" * len(builds)
+    rows = []
+    for sp in specs:
+        cells = []
+        for _, d in builds:
+            v = d.get(sp)
+            cells.append("%s (median %.1f)" % (" / ".join("%.1f" % x[0] for x in v), statistics.median(x[0] for x in v)) if v else "-")
+        rows.append("| %s | %s |" % (names.get(sp, sp), " | ".join(cells)))
+    jods = sorted(set(x[2] for _, d in builds for v in d.get("2160x3840x60:8:420", []) for x in [v]))
+
+    def cnt(rel, kern):
+        txt = rd(rel)
+        i = txt.find(kern)
+        if i < 0:
+            return None
+        m = re.search(r"SQ_INSTS_VALU \| ([\d.e+]+)", txt[i:])
+        w = re.search(r"SQ_WAVES \| ([\d.e+]+)", txt[i:])
+        sh = re.search(r"shares of the waves' resident time: ([^\n]+)", txt[i:])
+        return (float(m.group(1)), float(w.group(1)), sh.group(1)) if m and w else None
+    c0 = cnt("r6s3/pmc_sq_yuv_before.md", "temporal_yuv_vec_kernel<8, unsigned char, true, 1>")
+    c1 = cnt("r6s3/pmc_sq_yuv_after.md", "temporal_yuv_vec_kernel<8, unsigned char, true, 1, true>")
+    c2 = cnt("r6s4/pmc_sq_yuv_step2.md", "temporal_yuv_vec_kernel<8, unsigned char, true, 1, true>")
+    crow = []
+    for tag, c in (("round 5", c0), ("matrix + sRGB branch", c1), ("+ DPP-exchanged chroma, fused affine steps", c2)):
+        if c:
+            crow.append("| %s | %.3e | %.1f | %s |" % (tag, c[0], c[0] / c[1] / 67.0, c[2]))
+    dark = (rd("r6s3/yuv_dark_before.txt"), rd("r6s3/yuv_dark_after.txt"), rd("r6s4/yuv_dark_step2.txt"))
+    write("r06_yuv_ingest.md", f"""# Round 6 -- the planar-YUV ingest kernels (`temporal_yuv_vec_kernel`): instruction budget of the 8-bit 4:2:0 instantiation, what was cut (VERDICT r5 item 6)
+
+`fvvdp_temporal_channels_yuv` replaces the reference's default decode path for files (`video_reader_yuv_pytorch.unpack`,
+`video_source_file.py:219-276,288` + `_prepare_frame` :355-363) fused with the temporal filter.  Round 5: 46.5 us per 4K frame on 8-bit 4:2:0 =
+0.42 of the HBM peak on its 19 B per pixel; the verdict asked for >= 0.55 (<= 35 us).  All timings: `tools/gpu_yuv.py` (HIP events inside the
+library), one box, the builds in alternating processes, three processes each (`tools/experiments/r6/s4.sh`); kernel us per frame:
+
+{hdr}
+{chr(10).join(rows)}
+
+JOD of the 8-bit 4:2:0 clip with every build: {", ".join(jods)} (golden g7 and the oracle tests unchanged and green; new:
+`tests/test_gpu_parity.py::test_yuv_ingest_dark_and_mixed_content` -- dark, half-dark and out-of-range-chroma clips against the oracle, and the
+four-term colour matrix bit-equal to the nine-term one).  A clip whose luma sits just above black (every value on the sRGB toe, the branch the
+fast path skips; `YUV_DARK=1`): round 5 `{dark[0].split("temporal")[-1].strip()}`, first step `{dark[1].split("temporal")[-1].strip()}`, second step `{dark[2].split("temporal")[-1].strip()}`.
+
+## Dynamic instruction counts (`rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES ...`, 8-bit 4:2:0, FL = 8; 33 450 waves, 67 source frames per launch)
+
+| build | vector instructions per dispatch | per wave and source frame (4 pixels x 2 streams per lane) | shares of the waves' resident time |
+|---|---|---|---|
+{chr(10).join(crow)}
+
+## The budget per wave and source frame, and what went
+
+Round 5, 514 vector instructions (48 of them transcendental), by part (`csrc/temporal_kernels.hpp`, `temporal_yuv_vec_body`):
+
+| part | round 5 | now | what changed |
+|---|---|---|---|
+| luma: 8 byte->float converts, 4 packed multiply-adds with the [0,1] clip riding on them | 12 | 12 | -- |
+| chroma fetch: the neighbour lanes' pair words through DPP, byte extraction, edge selects | 48 | 16 + 8 | a lane converts only its OWN two columns; the neighbour columns 2j-1 / 2j+2 are the adjacent lanes' finished (vertically blended) values: 8 DPP moves and 8 edge selects on floats instead of 16 + 16 + 16 on raw words |
+| chroma convert: 32 converts, 16 packed multiply-adds, 32 clamps (+-0.5) | 80 | 40 | half the columns |
+| chroma bilinear x2: vertical 16, horizontal 16 | 32 | 8 + 16 | vertical blend of two columns instead of four |
+| YCbCr -> RGB: 9 packed operations per pixel | 36 | 16 | every ITU matrix is R = Y + m2 Cr, G = Y + m4 Cb + m5 Cr, B = Y + m7 Cb: four multiply-adds give the same bits (x 1 and + 0 x are exact); the host checks the nine numbers, other matrices keep the general form |
+| display model (sRGB), 12 (test, reference) pairs: add, multiply, 2 log2, multiply, 2 exp2, toe multiply, 2 compares, 2 selects, scale, black level | 168 | 84 + 13 | one wave-uniform branch on the smallest of the 24 values (12 `v_min3`) takes the power branch alone where no lane is on the toe (V <= 0.04045, 8-bit codes <= 10): same expression, same bits; `(V + 0.055) / 1.055` and `scale * lin + black` as ONE multiply-add each (the hardware log2 / exp2 carry ~1e-6 on the dark end, an order above the rounding of an affine step) |
+| luminance (R w0 + G w1) + B w2 | 20 | 12 | one multiply + two multiply-adds |
+| the two 8-tap filters on (test, reference) pairs, window copy, accumulator set-up | 76 | 76 | -- |
+| LDS transpose, stores, addressing, moves | ~40 | ~40 | -- |
+| **sum** | **~514** | **~326** | measured 513.6 -> 325.6 |
+
+-37 % instructions buy -17 % time (45.7 -> 38.0 us): the kernel was bound by the vector ALU (0.97 of a SIMD's issue slots taken in round 5) and
+is not any more -- at 326 instructions per wave and frame the ALU floor is ~25 us per frame at the 2.1 GHz the card sustains, the bytes ask for
+26 us at the 6 TB/s the 8-bit RGB kernel reaches on the same write stream; the waves now wait on memory 0.24 of their resident time with 3 waves
+per SIMD (4 waves per SIMD spill: 128 registers against 166; 3 frames of raw samples in flight spill as well).  157.6 MB / 38.0 us = 4.15 TB/s =
+**0.52 of the peak** (round 5: 0.42); the target of 0.55 is not reached.
+""")
+
+
 if __name__ == "__main__":
     rccl()
     fov()
     parity()
+    yuv()
