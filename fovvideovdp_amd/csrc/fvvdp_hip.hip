@@ -1581,8 +1581,9 @@ static void choose_level0(fvvdp_ctx* c) {
     int n_extra = 0;
     std::vector<float*> held;
     // (probe_mixed is an MI355X figure: one class of its memory takes ~5.5 TB/s of streaming writes, both at once 7.0.  A part whose best
-    // pair stays below 0.7 x that rate -- MI300X: 5.3 TB/s peak -- cannot reach it with any pair: no further candidates there.)
-    if (n_got >= 2 && r_best >= 0.7f * c->env.probe_mixed && r_best < c->env.probe_mixed) {
+    // pair stays below 0.7 x that rate (4.7 TB/s) -- MI300X: 5.3 TB/s peak -- cannot reach it with any pair: no further candidates there.)
+    const float reachable = 0.7f * 6.75f;      // (of the MI355X figure itself, not of an overridden FVVDP_PLACEMENT_MIXED_TBS)
+    if (n_got >= 2 && r_best >= reachable && r_best < c->env.probe_mixed) {
         const int max_extra = c->env.probe_extra < 0 ? 8 : c->env.probe_extra;
         for (int k = 0; k < max_extra; ++k) {
             size_t free_b = 0, total_b = 0;

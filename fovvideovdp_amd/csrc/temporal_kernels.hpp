@@ -82,35 +82,9 @@ __device__ __forceinline__ float eotf_f32(float V, const EotfDev& e, B& bad) {
 // KIND >= 0: the display model is known at compile time (straight-line code, no branch at all).
 template <int N, int KIND = -1, typename B = bool>
 __device__ __forceinline__ void eotf_apply(float (&V)[N], const EotfDev& e, B& bad) {
-    if constexpr (KIND == FVVDP_EOTF_SRGB && N >= 4) {
-        // sRGB on N samples of a wave (16-bit / float sources in closed form): the linear toe (V <= 0.04045) costs a multiply, a
-        // compare and a select per sample.  One wave-uniform branch on the smallest clipped sample takes the power branch alone where
-        // no lane needs the toe: the same expression as eotf_one for those samples, the same bits (round 6).
-        float mn = 1.0f;
-#pragma unroll
-        for (int i = 0; i < N; ++i) {
-            note_oob(bad, V[i]);
-            V[i] = fminf(fmaxf(V[i], 0.0f), 1.0f);
-        }
-#pragma unroll
-        for (int i = 0; i + 1 < N; i += 2) asm("v_min3_f32 %0, %0, %1, %2" : "+v"(mn) : "v"(V[i]), "v"(V[i + 1]));
-        if constexpr (N & 1) mn = fminf(mn, V[N - 1]);
-        if (__builtin_amdgcn_ballot_w64(!(mn > 0.04045f)) == 0) {
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const float hi = fast_exp2(2.4f * fast_log2((V[i] + 0.055f) * (1.0f / 1.055f)));
-                V[i] = __fadd_rn(__fmul_rn(e.scale, hi), e.y_black);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < N; ++i) {
-                const float hi = fast_exp2(2.4f * fast_log2((V[i] + 0.055f) * (1.0f / 1.055f)));
-                const float lin = V[i] > 0.04045f ? hi : V[i] * (1.0f / 12.92f);
-                V[i] = __fadd_rn(__fmul_rn(e.scale, lin), e.y_black);
-            }
-        }
-        return;
-    }
+    // (round 6: a wave-uniform branch that skips the sRGB toe, as in the YUV kernel, was measured here for 16-bit / float sources:
+    // 47.2 -> 46.7 us per 4K frame on uint16 RGB, nothing on float RGB (tools/experiments/r6/s5.sh) -- these kernels wait on memory, not on
+    // the toe's three instructions per sample; not kept)
     if constexpr (KIND >= 0) {
 #pragma unroll
         for (int i = 0; i < N; ++i) V[i] = eotf_one<KIND>(V[i], e, bad);
@@ -1332,10 +1306,11 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
 // KIND = display model (compile-time: the host picks the instantiation): one loop body per kernel.  With a switch over the six
 // bodies inside one kernel, scalar values of the prologue stayed alive across all of them and spilled (8 SGPRs in the 16-slot
 // 4:2:0 kernels).
-// Waves per workgroup, as temporal_vec_kernel (K1_WPB8): the 8-slot window runs YUV_WPB8 waves per workgroup on adjacent runs of pixel
-// quads -- they share nothing (no table, no barrier) but start together, so the memory system sees 4 x longer contiguous runs per frame.
+// Waves per workgroup (A/B switch): temporal_vec_kernel gains 4 % from 4 waves per workgroup on adjacent pixel blocks (K1_WPB8); this kernel
+// does not -- 37.5-38.1 against 37.7-38.2 us per 4K frame, 1080p 10.5-11.2 against 10.2-10.4 (tools/experiments/r6/s5.sh), and the
+// 8-bit 4:2:0 sRGB instantiation then spills one register -- so it stays at one wave per workgroup.
 #ifndef YUV_WPB8
-#define YUV_WPB8 4
+#define YUV_WPB8 1
 #endif
 constexpr int yuv_wpb(int FL) { return FL == 8 ? YUV_WPB8 : 1; }
 template <int FL, typename T, bool C420, int KIND, bool STDM>

@@ -70,4 +70,9 @@ FVVDP_BAND_INRANGE=0 python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-
 [ -f $R/build_variants/k1wpb1.so ] && FVVDP_LIB=$R/build_variants/k1wpb1.so python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_k1wpb1.json 2>/dev/null
 FVVDP_BAND2_TICKET=0 python $R/bench.py --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_noticket.json 2>/dev/null
 python $R/bench.py --shard frames --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_frames.json 2>/dev/null
+# round 6: the one-rank collective off / forced (the default is auto = forced where RCCL initialises), configs[3] with its roofline_fov block
+python $R/bench.py --collective off --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_collective_off.json 2>/dev/null
+python $R/bench.py --collective force --no-cpu-baseline --no-h2d --no-measure-traffic > $OUT/bench_collective_force.json 2>/dev/null
+python $R/bench.py --config 3 --no-cpu-baseline --no-h2d > $OUT/bench_config3.json 2>/dev/null
+python $R/tools/gpu_rccl_one_rank.py > $OUT/rccl_one_rank.txt 2>/dev/null
 ls -la $OUT

@@ -86,19 +86,33 @@ def quoted_figures():
         if "band2_kernel" in label and "levels 0+1" in label:
             b = r["bytes_per_launch"]
             if "false" in label and jp["roofline"]["kernel"].startswith("band2_kernel<4, true>"):
-                out.append("* `%s`: %d launches, rocprof AVERAGE %.1f us -- not the timed steps: `fvvdp_ctx_create` times the layout it chose once (3 passes of the variant "
-                           "WITH clamps on a synthetic clip, the first touch included)" % (label.strip("`"), calls, avg))
+                out.append("* `%s`: %d launches, rocprof AVERAGE %.1f us -- not the timed steps: the `roofline.with_clamps` leg of bench.py (the same launch with the four clamps "
+                           "kept, a second context, its first touch included)" % (label.strip("`"), calls, avg))
                 continue
             out.append("* `%s`: %.4f GB algorithmic per launch / rocprof AVERAGE %.1f us = %.2f TB/s = %.3f of 8 TB/s; / steady median %.1f us = %.3f; unprofiled HIP-event median %.1f us = %.4f" % (
                 label.strip("`"), b / 1e9, avg, b / avg / 1e6, b / avg / 1e6 / 8.0, steady, b / steady / 1e6 / 8.0, r["median_launch_ms"] * 1e3, r["frac"]))
         if "temporal_vec_kernel" in label:
             b = k1["bytes_per_launch"]
             n = k1["frames_per_launch"]
-            out.append("* `%s`: %.1f MB per frame; %d launches, rocprof AVERAGE %.1f us per %d frames = %.1f us per frame = %.2f TB/s = %.3f (the average includes the 3 launches "
-                       "on a synthetic clip at context creation, first touch included); rocprof MEDIAN %.1f us = %.1f us per frame = %.3f; "
+            out.append("* `%s`: %.1f MB per frame; %d launches, rocprof AVERAGE %.1f us per %d frames = %.1f us per frame = %.2f TB/s = %.3f (all launches of the process, the first touch of a fresh context included); rocprof MEDIAN %.1f us = %.1f us per frame = %.3f; "
                        "unprofiled HIP events %.2f us per frame = %.4f" % (
                 label.strip("`"), b / n / 1e6, calls, avg, n, avg / n, b / avg / 1e6, b / avg / 1e6 / 8.0, med, med / n, b / med / 1e6 / 8.0,
                 g["temporal_us_per_frame_median"], k1["frac"]))
+    if r.get("frac_rocprof_avg"):
+        out.append("* `roofline` of the unprofiled line: frac %.4f (HIP-event median), frac_rocprof_avg %.4f (kernel trace run from bench.py, %.4f ms average), frac_bmin %.4f; "
+                   "with_clamps (`band2_kernel<4, false>`): %s" % (r["frac"], r["frac_rocprof_avg"], r.get("rocprof_avg_launch_ms", 0), r.get("frac_bmin", 0),
+                                                                      ("frac %.4f, all levels %.2f us per frame" % (r["with_clamps"]["frac"], r["with_clamps"]["us_per_frame_all_levels"])) if r.get("with_clamps") else "-"))
+    if jp.get("collective"):
+        out.append("* one-rank collective of the unprofiled line: %s, %.1f us per call back to back (RCCL %s)" % (
+            jp["collective"].get("backend"), jp["collective"].get("us_per_call_back_to_back", 0), (jp.get("communicator") or {}).get("rccl_version")))
+    try:
+        j3 = json.loads(rd("bench_config3.json").split("\n")[-1])
+        rf = j3["roofline_fov"]
+        out.append("* `bench.py --config 3` (3840x2160 x120 foveated, PQ): %.3f ms per pair = %.1f Gpix/s; roofline_fov: levels %s us per frame, all levels %.2f = %.4f of the peak "
+                   "(target 0.60 = %.2f us), frac_bmin %.4f; JOD delta to the reference %.3g" % (j3["ms_per_step"], j3["value"] / 1e3, rf["us_per_frame_levels"], rf["us_per_frame_all_levels"],
+                                                                                                   rf["frac"], rf["target_us_per_frame"], rf["frac_bmin"], j3.get("jod_delta_vs_reference") or 0.0))
+    except Exception:
+        pass
     if r.get("traffic"):
         out.append("* real traffic of the dominant kernel: %.2f GB per launch = %.3f of the algorithmic bytes; %.2f TB/s = %.3f of the peak" % (
             r["traffic"] / 1e9, r["traffic_over_algorithmic"], r["achieved_traffic"] / 1e3, r["frac_traffic"]))
@@ -108,7 +122,7 @@ def quoted_figures():
     out.append("* whole step: %.2f GB per pair, %.2f TB/s = %.3f; kernels back to back %.3f ms of %.3f ms" % (
         rs["bytes_per_step"] / 1e9, rs["achieved"] / 1e3, rs["frac"], rs["kernels_back_to_back_ms"], rs["ms_per_step"]))
     for name in ("bench_malloc.json", "bench_chunks.json", "bench_clamps.json", "bench_k1wpb1.json", "bench_noticket.json", "bench_pairs8.json", "bench_frames.json",
-                 "bench_fhd.json", "bench_fhd_plain.json"):
+                 "bench_fhd.json", "bench_fhd_plain.json", "bench_collective_off.json", "bench_collective_force.json"):
         try:
             j = json.loads(rd(name).split("\n")[-1])
             gg = j["graded_pass"]

@@ -300,8 +300,7 @@ def yuv():
     builds = [("round 5 (`build_variants/r6_pre_yuv.so`)", med("r6s4/yuv_r5.txt")),
               ("+ ITU-shaped matrix in 4 multiply-adds, sRGB power branch alone where no lane needs the toe", med("r6s4/yuv_step1.txt")),
               ("+ chroma columns converted once and exchanged through DPP, affine steps fused", med("r6s4/yuv_step2.txt"))]
-    if os.path.exists(os.path.join(G, "r6s5/yuv_wpb.txt")):
-        builds.append(("+ 4 waves per workgroup (8-slot window)", med("r6s5/yuv_wpb.txt")))
+
     specs = [k for k in builds[0][1]]
     names = {"2160x3840x60:8:420": "4K x60, 8-bit 4:2:0, 30 fps (19 B per pixel: 157.6 MB per frame)", "2160x3840x60:10:420:60": "4K x60, 10-bit 4:2:0, 60 fps (15 taps)",
              "2160x3840x60:8:444": "4K x60, 8-bit 4:4:4, 30 fps", "2160x3840x60:10:420": "4K x60, 10-bit 4:2:0, 30 fps", "1080x1920x60:8:420": "1080p x60, 8-bit 4:2:0, 30 fps"}
@@ -332,6 +331,21 @@ def yuv():
         if c:
             crow.append("| %s | %.3e | %.1f | %s |" % (tag, c[0], c[0] / c[1] / 67.0, c[2]))
     dark = (rd("r6s3/yuv_dark_before.txt"), rd("r6s3/yuv_dark_after.txt"), rd("r6s4/yuv_dark_step2.txt"))
+    w0, w1 = med("r6s5/yuv_step2.txt"), med("r6s5/yuv_wpb.txt")
+
+    def rng(d, sp):
+        v = [x[0] for x in d.get(sp, [])]
+        return "%.1f-%.1f" % (min(v), max(v)) if v else "-"
+    wpb_line = "8-bit 4:2:0 %s us per 4K frame against %s with one, 1080p %s against %s, 10-bit 60 fps %s against %s" % (
+        rng(w1, "2160x3840x60:8:420"), rng(w0, "2160x3840x60:8:420"), rng(w1, "1080x1920x60:8:420"), rng(w0, "1080x1920x60:8:420"),
+        rng(w1, "2160x3840x60:10:420:60"), rng(w0, "2160x3840x60:10:420:60"))
+
+    def k1(rel, pat):
+        v = [float(m.group(1)) for m in re.finditer(pat + r": [\d.]+ ms  K1 ([\d.]+) us/frame", rd(rel))]
+        return "%.1f" % statistics.median(v) if v else "-"
+    k1_line = "uint16 RGB at 30 fps %s -> %s us per 4K frame (median of three processes), at 60 fps %s -> %s, float RGB %s -> %s" % (
+        k1("r6s5/k1_before.txt", "@30 fps u16"), k1("r6s5/k1_after.txt", "@30 fps u16"), k1("r6s5/k1_before.txt", "@60 fps u16"),
+        k1("r6s5/k1_after.txt", "@60 fps u16"), k1("r6s5/k1_before.txt", "@30 fps f32rgb"), k1("r6s5/k1_after.txt", "@30 fps f32rgb"))
     write("r06_yuv_ingest.md", f"""# Round 6 -- the planar-YUV ingest kernels (`temporal_yuv_vec_kernel`): instruction budget of the 8-bit 4:2:0 instantiation, what was cut (VERDICT r5 item 6)
 
 `fvvdp_temporal_channels_yuv` replaces the reference's default decode path for files (`video_reader_yuv_pytorch.unpack`,
@@ -370,11 +384,18 @@ Round 5, 514 vector instructions (48 of them transcendental), by part (`csrc/tem
 | LDS transpose, stores, addressing, moves | ~40 | ~40 | -- |
 | **sum** | **~514** | **~326** | measured 513.6 -> 325.6 |
 
--37 % instructions buy -17 % time (45.7 -> 38.0 us): the kernel was bound by the vector ALU (0.97 of a SIMD's issue slots taken in round 5) and
-is not any more -- at 326 instructions per wave and frame the ALU floor is ~25 us per frame at the 2.1 GHz the card sustains, the bytes ask for
+-37 % instructions buy -17 % time (45.7 -> 38.0 us): the kernel was bound by the vector ALU (the vector instructions of its three waves per SIMD
+filled ~0.8 of the launch in round 5: 514 x 1.09 quad-cycles x 32.7 waves per SIMD and frame = 35 of 45.7 us at 2.1 GHz) and is not any more -- at 326 instructions per wave and frame the ALU floor is ~25 us per frame at the 2.1 GHz the card sustains, the bytes ask for
 26 us at the 6 TB/s the 8-bit RGB kernel reaches on the same write stream; the waves now wait on memory 0.24 of their resident time with 3 waves
 per SIMD (4 waves per SIMD spill: 128 registers against 166; 3 frames of raw samples in flight spill as well).  157.6 MB / 38.0 us = 4.15 TB/s =
 **0.52 of the peak** (round 5: 0.42); the target of 0.55 is not reached.
+
+## Measured and not kept (`tools/experiments/r6/s5.sh`, same box, three alternations)
+
+* **4 waves per workgroup on adjacent runs of pixel quads** (what gained 4 % in the 8-bit RGB kernel): {wpb_line}; the 8-bit 4:2:0 sRGB
+  instantiation then spills one register.  `-DYUV_WPB8=4` remains as a build switch.
+* **The same wave-uniform toe skip in the closed-form display model of the 16-bit / float RGB temporal kernels**: {k1_line} -- those kernels wait
+  on memory, not on the toe's three instructions per sample.
 """)
 
 
