@@ -200,6 +200,25 @@ def main():
                                                       else ("one rank: skipped" if world == 1 else "%d ranks" % world)))
 
     jods_rowlen = []            # length of a result row (Q_per_ch | flag | JOD), noted by the first step
+    pin = {}
+
+    def rows_to_host(g):
+        """the one device -> host copy of a step, through a page-locked staging buffer like `fvvdp._to_host` (an asynchronous copy + one
+        stream synchronisation instead of a pageable `.cpu()`); falls back to `.cpu()` where page-locking is refused"""
+        buf = pin.get("buf")
+        if buf is False:
+            return g.cpu()
+        if buf is None or buf.shape != g.shape:
+            try:
+                buf = torch.empty(g.shape, dtype=g.dtype, pin_memory=True)
+            except RuntimeError:
+                buf = False
+            pin["buf"] = buf
+        if buf is False:
+            return g.cpu()
+        buf.copy_(g, non_blocking=True)
+        torch.cuda.current_stream(dev).synchronize()
+        return buf
 
     def step():
         if frames_mode:
@@ -213,7 +232,7 @@ def main():
         rows = outs[0][1]["result_buffer"].unsqueeze(0) if K == 1 else torch.stack([st["result_buffer"] for (_, st) in outs])
         if not jods_rowlen:
             jods_rowlen.append(rows.shape[1])
-        return gather_pair_results(rows, rank, world, force_collective=force_collective).cpu()[:, -1].tolist()
+        return rows_to_host(gather_pair_results(rows, rank, world, force_collective=force_collective))[:, -1].tolist()
 
     def step_reference_call():
         q, _ = m.predict(pairs[0][0], pairs[0][1], dim_order="BCFHW", frames_per_second=fps, fixation_point=gaze)
