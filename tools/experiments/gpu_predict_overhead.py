@@ -30,3 +30,36 @@ def e():
 for name, f in (("predict(sync=True)", a), ("predict(sync=True) + float(q)", b), ("predict(sync=False) + synchronize", c),
                 ("predict(sync=False) + result_buffer.cpu()", d), ("bench step (one pair)", e)):
     print("%-45s %.3f ms" % (name, med(f)))
+
+
+# round 6: which way of waiting for the result costs what (the step path of bench.py against the synchronous predict())
+pin = torch.empty(4096, dtype=torch.float32, pin_memory=True)
+ev = torch.cuda.Event()
+
+
+def f():
+    q, st = m.predict(t, r, frames_per_second=30, sync=False)
+    rb = st["result_buffer"]; pin[:rb.numel()].copy_(rb, non_blocking=True); torch.cuda.current_stream().synchronize()
+def g():
+    q, st = m.predict(t, r, frames_per_second=30, sync=False)
+    rb = st["result_buffer"]; pin[:rb.numel()].copy_(rb, non_blocking=True); ev.record(); ev.synchronize()
+def h():
+    q, st = m.predict(t, r, frames_per_second=30, sync=False)
+    rb = st["result_buffer"]; pin[:rb.numel()].copy_(rb, non_blocking=True); ev.record()
+    while not ev.query():
+        pass
+def i():
+    q, st = m.predict(t, r, frames_per_second=30, sync=False); fv.fvvdp.finish(st)
+for name, fn in (("sync=False + pinned copy + stream.synchronize()", f), ("sync=False + pinned copy + event.synchronize()", g),
+                 ("sync=False + pinned copy + event.query() spin", h), ("sync=False + fvvdp.finish(stats)", i),
+                 ("predict(sync=True) again", a), ("bench step (one pair) again", e)):
+    print("%-50s %.3f ms" % (name, med(fn)))
+import cProfile, pstats, io
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(10):
+    a()
+pr.disable()
+sio = io.StringIO()
+pstats.Stats(pr, stream=sio).sort_stats("cumulative").print_stats(18)
+print(sio.getvalue()[:3500])
