@@ -290,8 +290,13 @@ def main():
     # the reference-style synchronous call next to the step path, once (one rank, one pair): the same kernels, the same single sync
     predict_ms = None
     if world == 1 and K == 1 and not frames_mode:
+        # (the legs between the timed region and here leave the GPU idle for a few milliseconds; the launches after an idle gap run on clocks
+        # that are still coming up -- profiles/r05_power.md -- and until round 6 this figure, taken on five such calls, read 0.4 ms above
+        # the step although a back-to-back comparison shows none: tools/experiments/gpu_predict_overhead.py.  Warm up, then time.)
+        for _ in range(8):
+            step_reference_call()
         tp = []
-        for _ in range(max(3, args.steps // 2)):
+        for _ in range(max(7, args.steps)):
             t1 = time.perf_counter()
             step_reference_call()
             tp.append(time.perf_counter() - t1)

@@ -236,6 +236,16 @@ def test_rccl_executes_on_one_rank_through_the_step_path():
     assert fr_forced["communicator"]["backend"] == "nccl" and fr_forced["jod_exact"] == fr_off["jod_exact"]
 
 
+@pytest.mark.timeout(600)
+def test_bench_one_rank_without_a_communicator_falls_back_and_says_so():
+    """`--collective auto` (the default) on a box where the backend cannot create a communicator (here: a backend name that does not
+    exist): the step takes the one-rank shortcut, the line says why (`communicator.error`) and the benchmark still completes."""
+    out, dims = _run_bench("no_such_backend", 1, dims=(960, 540, 20, 1))
+    cm = out["communicator"]
+    assert cm["backend"] is None and cm["error"] and "shortcut" in cm["collective_on_one_rank"]
+    _check_bench_line(out, dims, "no_such_backend", world=1)
+
+
 @pytest.mark.timeout(900)
 def test_bench_eight_ranks_dry_run_under_gloo():
     """The 8-rank launch of the round-end scaling run, dry: 8 gloo ranks sharing this box's GPU(s) at reduced size, one pair each."""
