@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Turn gpurun_out/prof_bundle/ (written by tools/collect_profiles.sh on the GPU box, ONE gpurun call = one box) into the
-tracked files profiles/<round>_final_kernel_trace.md, profiles/<round>_pmc_level0.json, profiles/<round>_parity.md.
+tracked files profiles/<round>_final_kernel_trace.md, profiles/<round>_pmc_level0.json, profiles/<round>_parity_stages.md (round 6 on: `<round>_parity.md` is the evidence file of tools/make_r6_evidence.py).
 usage: make_profile_doc.py r02"""
 import json, os, shutil, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -391,7 +391,7 @@ Notes.
   ~10x better (end to end 1.3e-4 on Q_per_ch, 2e-6 on JOD).  The remaining 1.3e-3 maximum on S is the single pixel under the
   gaze, where sqrt(ecc) amplifies a 1e-6 deg rounding difference of the eccentricity.
 """
-    open(os.path.join(ROOT, "profiles", f"{tag}_parity.md"), "w").write(par)
+    open(os.path.join(ROOT, "profiles", f"{tag}_parity_stages.md"), "w").write(par)
 print("wrote profiles/%s_final_kernel_trace.md (%d bytes)" % (tag, len(doc)))
 # DESIGN.md section 0 quotes exactly these figures: splice them in between the markers
 dpath = os.path.join(ROOT, "DESIGN.md")
