@@ -350,6 +350,13 @@ __device__ __forceinline__ void fir_tap(v2f& accS, v2f& accT, v2f x, v2f f) {
         "v_pk_fma_f32 %1, %2, %3, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"
         : "+v"(accS), "+v"(accT) : "v"(x), "s"(f));
 }
+// The first tap of a sum: accS = x * f.x, accT = x * f.y -- the bits of fir_tap on zeroed accumulators (round(x*f + 0) = round(x*f)),
+// without the 2*PX register clears per frame.
+__device__ __forceinline__ void fir_tap_first(v2f& accS, v2f& accT, v2f x, v2f f) {
+    asm("v_pk_mul_f32 %0, %2, %3 op_sel_hi:[1,0]\n\t"
+        "v_pk_mul_f32 %1, %2, %3 op_sel:[0,1] op_sel_hi:[1,1]"
+        : "=&v"(accS), "=&v"(accT) : "v"(x), "s"(f));
+}
 // TAPC taps = 2*TAPC floats of TemporalArgs::taps2 / YuvArgs::taps2, read from the kernel-argument segment with one scalar load
 #ifndef K1_TAPC
 #define K1_TAPC 4
@@ -611,6 +618,13 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
 #pragma unroll
     for (int i = 0; i < PX; ++i) soff[i] = (p0 + i * 64 + lane < a.HW) ? (unsigned int)(p0 + i * 64 + lane) * 16u : FVVDP_NO_STORE;
     const unsigned int frame_bytes = (unsigned int)a.HW * 16u;      // <= 531 MB (8K)
+#ifndef K1_NO_ENTRY_DRAIN
+    // One drain on the way in: the loop header joins the history (whose last batch requested the first output frames: loads pending, the
+    // first step's registers among the youngest) and the back edge (a step's stores behind the prefetch).  Served by one wait, that
+    // came out as vmcnt(1) / vmcnt(0) at the top of every FL frames -- the stores just issued and the prefetch drained.  With nothing
+    // pending on the entry path the wait at the header is the back edge's own: counted, stores in flight.
+    __builtin_amdgcn_s_waitcnt(0x0F70);                             // vmcnt(0) (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
+#endif
     for (int t0 = 0; t0 < a.n_out; t0 += FL) {
 #pragma unroll
         for (int j = 0; j < FL; ++j) {
@@ -629,9 +643,8 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
                 prefetch(FL - 1 + t + TD, nx[u % TD][0], nx[u % TD][1]);
             }
             __builtin_amdgcn_sched_barrier(0);
-            v2f accS[PX], accT[PX];                  // (test, reference) of the sustained / the transient channel
-#pragma unroll
-            for (int i = 0; i < PX; ++i) accS[i] = accT[i] = v2f{0.0f, 0.0f};
+            v2f accS[PX], accT[PX];                  // (test, reference) of the sustained / the transient channel: set by the first tap
+            bool first_tap = true;                   // compile-time after unrolling
             // Taps: TAPC at a time from the kernel-argument segment (scalar cache), oldest first like the reference's sum over the
             // window.  Long filters reload them in every step -- the pointer is laundered so that the loads cannot be hoisted out
             // of the frame loop, where 2*FL scalar values would have to stay alive next to everything else (spills).
@@ -651,7 +664,11 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
                     const int sl = (u - k + 2 * FL) % FL;
                     const v2f f = v2f{tc[2 * kk], tc[2 * kk + 1]};
 #pragma unroll
-                    for (int i = 0; i < PX; ++i) fir_tap(accS[i], accT[i], ring[sl][i], f);
+                    for (int i = 0; i < PX; ++i) {
+                        if (first_tap) fir_tap_first(accS[i], accT[i], ring[sl][i], f);
+                        else fir_tap(accS[i], accT[i], ring[sl][i], f);
+                    }
+                    first_tap = false;
                 }
             }
             // transpose through LDS: lane l holds pixels l*PX..l*PX+PX-1, store i writes pixels i*64+l
@@ -1155,7 +1172,10 @@ __device__ __forceinline__ void yuv_window_step(v2f (&win)[FL][4], const v2f (&l
             const int k = c * 2 + kk;
             const v2f f = v2f{tc[2 * kk], tc[2 * kk + 1]};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fir_tap(acc_s[i], acc_t[i], win[(S - k + FL) % FL][i], f);
+            for (int i = 0; i < 4; ++i) {
+                if (k == FL - 1) fir_tap_first(acc_s[i], acc_t[i], win[(S - k + FL) % FL][i], f);      // oldest tap first: it sets the sums
+                else fir_tap(acc_s[i], acc_t[i], win[(S - k + FL) % FL][i], f);
+            }
         }
     }
 }
@@ -1256,6 +1276,14 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
         soff[i] = (q < YUV_QUADS * PX && p0 + q < HW) ? (unsigned int)(p0 + q) * 16u : FVVDP_NO_STORE;
     }
     const unsigned int frame_bytes = (unsigned int)HW * 16u;
+#ifndef YUV_NO_ENTRY_DRAIN
+    // The loop header joins the entry path (TD frames of loads pending, the registers the first step reads among the LAST requested) and
+    // the back edge (the same registers requested two steps ago, with a step's stores and the other slot's loads behind them): the
+    // compiler's wait at the top of the loop has to serve both and came out as vmcnt(1) / vmcnt(0) -- a drain of the stores just issued
+    // and of the prefetch one step old, every TD frames.  Draining ONCE here leaves the back edge as the only path with loads pending,
+    // and the wait inside the loop becomes a counted one (stores and the younger prefetch stay in flight).
+    __builtin_amdgcn_s_waitcnt(0x0F70);                   // vmcnt(0) (gfx9 encoding: expcnt 7, lgkmcnt 15 = no wait)
+#endif
     for (int v0 = 0; v0 < total; v0 += TD) {
 #pragma unroll
         for (int d = 0; d < TD; ++d) {
@@ -1268,9 +1296,7 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
             v2f lum[PX];
 #pragma unroll
             for (int i = 0; i < PX; ++i) lum[i] = lum_pair(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], a.w[0], a.w[1], a.w[2]);
-            v2f acc_s[PX], acc_t[PX];                     // sustained / transient channel of (test, reference)
-#pragma unroll
-            for (int i = 0; i < PX; ++i) acc_s[i] = acc_t[i] = splat(0.0f);
+            v2f acc_s[PX], acc_t[PX];                     // sustained / transient channel of (test, reference): set by the first tap
             karg_p tp = (karg_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(YuvArgs, taps2);
             if constexpr (FL > 8) asm volatile("" : "+s"(tp));      // reloaded per frame, see temporal_vec_body
             yuv_window_dispatch<FL>(v & (FL - 1), win, lum, tp, acc_s, acc_t);
