@@ -945,21 +945,23 @@ __global__ __launch_bounds__(256) void temporal_yuv_kernel(const YuvArgs a) {
 }
 
 // ---- vector variant of the YUV ingest (the fast path for W % 4 == 0) -----------------------------------------------
-// Single-wave workgroups, a lane owns 4 CONSECUTIVE pixels of one image row (x0 = 4j).  Everything that depends only
-// on the pixel position (plane offsets, the bilinear weights of the 4:2:0 chroma upsampling) is computed once per
-// lane; per frame a lane issues one Y load (4 samples) and, per chroma plane and source row, one aligned pair load
-// (columns 2j, 2j+1); the two neighbour columns (2j-1, 2j+2, clamped) come from the adjacent lanes through DPP
+// Single-wave workgroups, a lane owns PX CONSECUTIVE pixels of one image row (x0 = PX*j; PX = 4 or 2).  Everything that depends
+// only on the pixel position (plane offsets, the bilinear weights of the 4:2:0 chroma upsampling) is computed once per
+// lane; per frame a lane issues one Y load (PX samples) and, per chroma plane and source row, one load of its own PX/2 chroma
+// columns; the two neighbour columns (clamped) come from the adjacent lanes through DPP
 // (5 loads per lane, frame and stream instead of 13, and no edge-lane branches).
 // Test and reference stream are converted together as packed (test, reference) pairs (v_pk_* instructions); the
 // result agrees with yuv_lum above to rounding order.  Raw samples of the next frame are prefetched while the
 // current one is converted, and the finished float4 pixels go through the same LDS transpose as temporal_vec_kernel.
-template <typename T, bool C420>
+// PX = 2 halves the registers of the window (2*FL*PX) and of everything per pixel: more waves per SIMD where the window is what
+// limits them (the 16-slot window above all), at the price of twice the per-lane work (loads, stores, branches) per pixel.
+template <typename T, bool C420, int PX>
 struct YuvRaw {
-    static constexpr int YW = (int)sizeof(T);          // dwords holding 4 samples: 1 (8 bit) or 2 (10..16 bit)
+    static constexpr int YW = (PX * (int)sizeof(T) + 3) / 4;      // dwords holding PX samples (PX = 2, 8 bit: half a dword)
     unsigned int y[YW];
-    // 4:2:0: cp[plane][row] = chroma columns 2j, 2j+1 packed; the neighbour columns 2j-1 / 2j+2 are the pair words of
-    // the adjacent lanes (DPP; lanes 0 and 63 of a wave are halo lanes that only supply them).
-    // 4:4:4: cp[plane][0..YW-1] = 4 samples.
+    // 4:2:0: cp[plane][row] = the lane's own chroma columns (PX = 4: columns 2j, 2j+1 packed; PX = 2: column j); the neighbour
+    // columns are the finished values of the adjacent lanes (DPP; lanes 0 and 63 of a wave are halo lanes that only supply them).
+    // 4:4:4: cp[plane][0..YW-1] = PX samples.
     unsigned int cp[2][2];
     __device__ __forceinline__ float ysample(int i) const {
         if constexpr (sizeof(T) == 1) return (float)((y[0] >> (8 * i)) & 0xFFu);
@@ -976,43 +978,43 @@ struct YuvRaw {
 };
 
 struct YuvGeom {           // per-lane constants
-    int oy;                // element offset of the 4 luma samples inside a frame
-    int opair[2];          // offsets (from the start of a chroma plane) of the pair in the two source rows
-    bool left_own, right_own;   // the clamped neighbour column is one of the lane's own pair (image edges)
+    int oy;                // element offset of the PX luma samples inside a frame
+    int opair[2];          // offsets (from the start of a chroma plane) of the lane's own columns in the two source rows
+    bool left_own, right_own;   // the clamped neighbour column is one of the lane's own (image edges)
 };
 
-template <typename T, bool C420>
-__device__ __forceinline__ YuvRaw<T, C420> yuv_fetch(const T* __restrict__ f, const YuvGeom& g, int HW, int uvplane) {
-    YuvRaw<T, C420> r;
-    if constexpr (sizeof(T) == 1) {
-        r.y[0] = *reinterpret_cast<const unsigned int*>(f + g.oy);
-    } else {
-        const uint2 t = *reinterpret_cast<const uint2*>(f + g.oy);
-        r.y[0] = t.x; r.y[1] = t.y;
+// BYTES consecutive bytes at p (aligned to BYTES) into the low bits of dwords
+template <int BYTES>
+__device__ __forceinline__ void yuv_load_bytes(const void* p, unsigned int* out) {
+    if constexpr (BYTES == 1) out[0] = *reinterpret_cast<const unsigned char*>(p);
+    else if constexpr (BYTES == 2) out[0] = *reinterpret_cast<const unsigned short*>(p);
+    else if constexpr (BYTES == 4) out[0] = *reinterpret_cast<const unsigned int*>(p);
+    else {
+        static_assert(BYTES == 8, "1, 2, 4 or 8 bytes");
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        out[0] = t.x; out[1] = t.y;
     }
+}
+
+template <typename T, bool C420, int PX>
+__device__ __forceinline__ YuvRaw<T, C420, PX> yuv_fetch(const T* __restrict__ f, const YuvGeom& g, int HW, int uvplane) {
+    YuvRaw<T, C420, PX> r;
+    yuv_load_bytes<PX * (int)sizeof(T)>(f + g.oy, r.y);
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
         const T* P = f + HW + pl * uvplane;
         if constexpr (C420) {
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) {
-                if constexpr (sizeof(T) == 1) r.cp[pl][rr] = *reinterpret_cast<const unsigned short*>(P + g.opair[rr]);
-                else r.cp[pl][rr] = *reinterpret_cast<const unsigned int*>(P + g.opair[rr]);
-            }
+            for (int rr = 0; rr < 2; ++rr) yuv_load_bytes<(PX / 2) * (int)sizeof(T)>(P + g.opair[rr], &r.cp[pl][rr]);
         } else {
-            if constexpr (sizeof(T) == 1) {
-                r.cp[pl][0] = *reinterpret_cast<const unsigned int*>(P + g.oy);
-            } else {
-                const uint2 t = *reinterpret_cast<const uint2*>(P + g.oy);
-                r.cp[pl][0] = t.x; r.cp[pl][1] = t.y;
-            }
+            yuv_load_bytes<PX * (int)sizeof(T)>(P + g.oy, r.cp[pl]);
         }
     }
     return r;
 }
 
-// RGB (clipped to [0,1]) of the lane's 4 pixels for both streams at once: rgb[3*i+c] = (test, reference).
-// 4:2:0 chroma: the four source columns are blended vertically first, then horizontally (2 x fewer products than the
+// RGB (clipped to [0,1]) of the lane's PX pixels for both streams at once: rgb[3*i+c] = (test, reference).
+// 4:2:0 chroma: the source columns are blended vertically first, then horizontally (2 x fewer products than the
 // per-pixel form; the result differs from it by rounding order only).
 // a * s + c clipped to [0, 1], both components: v_pk_fma_f32 with the clamp modifier
 __device__ __forceinline__ v2f pfma_clamp01(v2f a, float s, v2f c) {
@@ -1025,46 +1027,62 @@ __device__ __forceinline__ v2f pfma_clamp01(v2f a, float s, v2f c) {
 // STDM: the colour matrix has the shape of every ITU YCbCr matrix -- R = Y + m2 Cr, G = Y + m4 Cb + m5 Cr, B = Y + m7 Cb (unit luma
 // column, no Cb in red, no Cr in blue; the host checks the nine numbers, yuv_matrix_is_standard).  Multiplying by 1 and adding 0 * x
 // are exact, so the four multiply-adds left per pixel give the same bits as the nine of the general form.
-template <typename T, bool C420, bool STDM>
-__device__ __forceinline__ void yuv_pair_rgb(const YuvRaw<T, C420>& r0, const YuvRaw<T, C420>& r1, const YuvArgs& a,
-                                             const YuvGeom& g, float fy, float gy, float fx0, float gx0, v2f (&rgb)[12]) {
+template <typename T, bool C420, bool STDM, int PX>
+__device__ __forceinline__ void yuv_pair_rgb(const YuvRaw<T, C420, PX>& r0, const YuvRaw<T, C420, PX>& r1, const YuvArgs& a,
+                                             const YuvGeom& g, float fy, float gy, float fx0, float gx0, v2f (&rgb)[3 * PX]) {
     auto cf = [&](float c0, float c1) { return clamp2(pfma(v2f{c0, c1}, a.wc, splat(-(128.0f / 224.0f))), -0.5f, 0.5f); };
-    v2f uv[2][4];
+    auto from_left = [](v2f v) { return v2f{__uint_as_float(lane_left_u32(__float_as_uint(v.x))), __uint_as_float(lane_left_u32(__float_as_uint(v.y)))}; };
+    auto from_right = [](v2f v) { return v2f{__uint_as_float(lane_right_u32(__float_as_uint(v.x))), __uint_as_float(lane_right_u32(__float_as_uint(v.y)))}; };
+    v2f uv[2][PX];
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
         if constexpr (C420) {
-            using R = YuvRaw<T, C420>;
-            // A lane converts ONLY its own two chroma columns (2j, 2j+1: the pair word) of the two source rows and blends them
-            // vertically; the neighbour columns 2j-1 / 2j+2 are the finished values of the adjacent lanes (their column 1 / 0, same
-            // image row, hence the same vertical weights) and arrive through DPP -- half the conversions, clamps and vertical blends
-            // of fetching the neighbours' raw words and converting all four columns in every lane (round 6: 160 -> 80 vector
-            // instructions per lane and frame for the chroma of 4 pixels x 2 streams; the same values, bit for bit).  At a row
-            // start / end the clamped neighbour column is one of the lane's own.
-            v2f own[2];
+            using R = YuvRaw<T, C420, PX>;
+            // A lane converts ONLY its own chroma columns of the two source rows and blends them vertically; the neighbour columns
+            // are the finished values of the adjacent lanes (same image row, hence the same vertical weights) and arrive through
+            // DPP -- half the conversions, clamps and vertical blends of fetching the neighbours' raw words and converting all four
+            // columns in every lane (round 6: 160 -> 80 vector instructions per lane and frame for the chroma of 4 pixels x 2
+            // streams; the same values, bit for bit).  At a row start / end the clamped neighbour column is one of the lane's own.
+            // An even pixel 2c blends column c (weight fx = .75, or 0 at x = 0) with column c-1, an odd pixel 2c+1 column c (.75)
+            // with column c+1 (.25) -- torch's bilinear x2, align_corners=False.
+            if constexpr (PX == 4) {
+                v2f own[2];
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const v2f a0 = k == 0 ? cf(R::lo(r0.cp[pl][0]), R::lo(r1.cp[pl][0])) : cf(R::hi(r0.cp[pl][0]), R::hi(r1.cp[pl][0]));
-                const v2f a1 = k == 0 ? cf(R::lo(r0.cp[pl][1]), R::lo(r1.cp[pl][1])) : cf(R::hi(r0.cp[pl][1]), R::hi(r1.cp[pl][1]));
-                own[k] = pfma(a1, fy, a0 * gy);
+                for (int k = 0; k < 2; ++k) {
+                    const v2f a0 = k == 0 ? cf(R::lo(r0.cp[pl][0]), R::lo(r1.cp[pl][0])) : cf(R::hi(r0.cp[pl][0]), R::hi(r1.cp[pl][0]));
+                    const v2f a1 = k == 0 ? cf(R::lo(r0.cp[pl][1]), R::lo(r1.cp[pl][1])) : cf(R::hi(r0.cp[pl][1]), R::hi(r1.cp[pl][1]));
+                    own[k] = pfma(a1, fy, a0 * gy);
+                }
+                const v2f nl = from_left(own[1]);
+                const v2f nr = from_right(own[0]);
+                v2f col[4];
+                col[0] = g.left_own ? own[0] : nl;
+                col[1] = own[0];
+                col[2] = own[1];
+                col[3] = g.right_own ? own[1] : nr;
+                uv[pl][0] = pfma(col[1], fx0, col[0] * gx0);
+                uv[pl][1] = pfma(col[2], 0.25f, col[1] * 0.75f);
+                uv[pl][2] = pfma(col[2], 0.75f, col[1] * 0.25f);
+                uv[pl][3] = pfma(col[3], 0.25f, col[2] * 0.75f);
+            } else {
+                static_assert(PX == 2, "4 or 2 pixels per lane");
+                const v2f a0 = cf(R::lo(r0.cp[pl][0]), R::lo(r1.cp[pl][0]));
+                const v2f a1 = cf(R::lo(r0.cp[pl][1]), R::lo(r1.cp[pl][1]));
+                const v2f own = pfma(a1, fy, a0 * gy);
+                const v2f nl = from_left(own);
+                const v2f nr = from_right(own);
+                const v2f cl = g.left_own ? own : nl;
+                const v2f cr = g.right_own ? own : nr;
+                uv[pl][0] = pfma(own, fx0, cl * gx0);
+                uv[pl][1] = pfma(cr, 0.25f, own * 0.75f);
             }
-            const v2f nl = v2f{__uint_as_float(lane_left_u32(__float_as_uint(own[1].x))), __uint_as_float(lane_left_u32(__float_as_uint(own[1].y)))};
-            const v2f nr = v2f{__uint_as_float(lane_right_u32(__float_as_uint(own[0].x))), __uint_as_float(lane_right_u32(__float_as_uint(own[0].y)))};
-            v2f col[4];
-            col[0] = g.left_own ? own[0] : nl;
-            col[1] = own[0];
-            col[2] = own[1];
-            col[3] = g.right_own ? own[1] : nr;
-            uv[pl][0] = pfma(col[1], fx0, col[0] * gx0);
-            uv[pl][1] = pfma(col[2], 0.25f, col[1] * 0.75f);
-            uv[pl][2] = pfma(col[2], 0.75f, col[1] * 0.25f);
-            uv[pl][3] = pfma(col[3], 0.25f, col[2] * 0.75f);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) uv[pl][i] = cf(r0.c444(pl, i), r1.c444(pl, i));
+            for (int i = 0; i < PX; ++i) uv[pl][i] = cf(r0.c444(pl, i), r1.c444(pl, i));
         }
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PX; ++i) {
         // the [0,1] clips ride on the multiply-add that produces the value (VOP3P clamp bit): one instruction instead of three
         const v2f Yf = pfma_clamp01(v2f{r0.ysample(i), r1.ysample(i)}, a.wy, splat(-(16.0f / 219.0f)));
         if constexpr (STDM) {
@@ -1151,19 +1169,19 @@ __device__ __forceinline__ v2f lum_pair(v2f r, v2f g, v2f b, float w0, float w1,
     return pfma(b, w2, pfma(g, w1, r * w0));
 }
 
-// Window of the last FL luminance pairs of a lane's 4 pixels, kept in registers WITHOUT moving it: frame v goes to slot
+// Window of the last FL luminance pairs of a lane's PX pixels, kept in registers WITHOUT moving it: frame v goes to slot
 // v mod FL and the FIR of that frame is one of FL straight-line variants (a wave-uniform switch over v mod FL), each with
 // compile-time slots and taps: age k sits in slot (S - k) mod FL.  (Shifting the window by one slot per frame instead cost
 // FL*8-8 register moves per frame, a quarter of the 16-slot kernel's VALU instructions.)  Oldest tap first, like the
 // reference's sum over the window; two taps per scalar load: this kernel has the colour matrix, the display model and the
 // chroma weights in scalar registers next to the taps.
-template <int FL, int S>
-__device__ __forceinline__ void yuv_window_step(v2f (&win)[FL][4], const v2f (&lum)[4],
-                                                const char __attribute__((address_space(4)))* tp, v2f (&acc_s)[4], v2f (&acc_t)[4]) {
+template <int FL, int S, int PX>
+__device__ __forceinline__ void yuv_window_step(v2f (&win)[FL][PX], const v2f (&lum)[PX],
+                                                const char __attribute__((address_space(4)))* tp, v2f (&acc_s)[PX], v2f (&acc_t)[PX]) {
     typedef float v4tap __attribute__((ext_vector_type(4), aligned(4)));
     typedef const v4tap __attribute__((address_space(4)))* karg_tap4_p;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) win[S][i] = lum[i];
+    for (int i = 0; i < PX; ++i) win[S][i] = lum[i];
 #pragma unroll
     for (int c = FL / 2 - 1; c >= 0; --c) {
         const v4tap tc = *(karg_tap4_p)(tp + c * 16);
@@ -1172,7 +1190,7 @@ __device__ __forceinline__ void yuv_window_step(v2f (&win)[FL][4], const v2f (&l
             const int k = c * 2 + kk;
             const v2f f = v2f{tc[2 * kk], tc[2 * kk + 1]};
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < PX; ++i) {
                 if (k == FL - 1) fir_tap_first(acc_s[i], acc_t[i], win[(S - k + FL) % FL][i], f);      // oldest tap first: it sets the sums
                 else fir_tap(acc_s[i], acc_t[i], win[(S - k + FL) % FL][i], f);
             }
@@ -1180,13 +1198,13 @@ __device__ __forceinline__ void yuv_window_step(v2f (&win)[FL][4], const v2f (&l
     }
 }
 
-template <int FL>
-__device__ __forceinline__ void yuv_window_dispatch(int slot, v2f (&win)[FL][4], const v2f (&lum)[4],
-                                                    const char __attribute__((address_space(4)))* tp, v2f (&acc_s)[4], v2f (&acc_t)[4]) {
+template <int FL, int PX>
+__device__ __forceinline__ void yuv_window_dispatch(int slot, v2f (&win)[FL][PX], const v2f (&lum)[PX],
+                                                    const char __attribute__((address_space(4)))* tp, v2f (&acc_s)[PX], v2f (&acc_t)[PX]) {
     static_assert(FL <= 16, "one case per slot below");
     switch (slot) {
         default: __builtin_unreachable();
-#define FVVDP_YUV_CASE(N) case N: if constexpr (N < FL) yuv_window_step<FL, (N < FL ? N : 0)>(win, lum, tp, acc_s, acc_t); break;
+#define FVVDP_YUV_CASE(N) case N: if constexpr (N < FL) yuv_window_step<FL, (N < FL ? N : 0), PX>(win, lum, tp, acc_s, acc_t); break;
         FVVDP_YUV_CASE(0) FVVDP_YUV_CASE(1) FVVDP_YUV_CASE(2) FVVDP_YUV_CASE(3) FVVDP_YUV_CASE(4) FVVDP_YUV_CASE(5)
         FVVDP_YUV_CASE(6) FVVDP_YUV_CASE(7) FVVDP_YUV_CASE(8) FVVDP_YUV_CASE(9) FVVDP_YUV_CASE(10) FVVDP_YUV_CASE(11)
         FVVDP_YUV_CASE(12) FVVDP_YUV_CASE(13) FVVDP_YUV_CASE(14) FVVDP_YUV_CASE(15)
@@ -1194,7 +1212,7 @@ __device__ __forceinline__ void yuv_window_dispatch(int slot, v2f (&win)[FL][4],
     }
 }
 
-#define YUV_QUADS 62     // pixel quads (4 consecutive pixels) written per wave
+#define YUV_QUADS 62     // pixel groups (PX consecutive pixels, one per lane) written per wave
 #ifndef YUV_TD8
 #define YUV_TD8 2        // frames of raw samples in flight per lane, 8-slot window
 #endif
@@ -1205,16 +1223,15 @@ __device__ __forceinline__ void yuv_window_dispatch(int slot, v2f (&win)[FL][4],
 // drains).  The conversion of a frame is a few hundred instructions and exists once; the window of the last FL luminance
 // pairs stays where it is (yuv_window_step above) and only the short FIR exists FL times.
 // The FIR also runs during the history frames (its result is dropped by an out-of-range store offset).
-template <int FL, typename T, bool C420, int KIND, bool STDM>
+template <int FL, typename T, bool C420, int KIND, bool STDM, int PX>
 __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* s_t, const int lane, const int block) {
-    constexpr int PX = 4;
     constexpr int TD = FL <= 8 ? YUV_TD8 : YUV_TD16;
     typedef const int __attribute__((address_space(4)))* karg_int_p;
     typedef const char __attribute__((address_space(4)))* karg_p;
     const karg_int_p idx = (karg_int_p)((karg_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(YuvArgs, idx));
     const int HW = a.W * a.H;
     const int uvplane = a.uvw * a.uvh;
-    // lanes 1..62 own the wave's 62 pixel quads; lanes 0 and 63 convert the quads next to them, only to hand their
+    // lanes 1..62 own the wave's 62 pixel groups; lanes 0 and 63 convert the groups next to them, only to hand their
     // chroma columns to lanes 1 and 62 (quads are clamped to the frame: a clamped lane duplicates its neighbour,
     // which then sits at a row start / end and does not look at it)
     const int p0 = block * (YUV_QUADS * PX);
@@ -1236,12 +1253,12 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
             const int y0 = (int)sy, y1 = min(y0 + 1, a.uvh - 1);
             g_fy = sy - (float)y0;
             g_gy = 1.0f - g_fy;
-            const int j2 = x >> 1;                       // column of the aligned pair
+            const int j2 = x >> 1;                       // first of the lane's own PX/2 chroma columns
             g.opair[0] = y0 * a.uvw + j2;  g.opair[1] = y1 * a.uvw + j2;
             // lanes to the left / right hold the adjacent quad of the same row unless this lane starts / ends the row
             // (lanes clamped to the last quad of the frame sit at a row end as well)
             g.left_own = (j2 == 0);
-            g.right_own = (j2 + 2 > a.uvw - 1);
+            g.right_own = (j2 + PX / 2 > a.uvw - 1);
             const float sx = fmaxf(((float)x + 0.5f) * 0.5f - 0.5f, 0.0f);
             g_fx0 = sx - (float)(int)sx;                 // 0 at x == 0 (then the "left" column is column 0 itself), else .75
             g_gx0 = 1.0f - g_fx0;
@@ -1256,19 +1273,19 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
 #pragma unroll
         for (int i = 0; i < PX; ++i) win[u][i] = splat(0.0f);
     const int total = FL - 1 + a.n_out;
-    auto prefetch = [&](int v, YuvRaw<T, C420>& f0, YuvRaw<T, C420>& f1) {
+    auto prefetch = [&](int v, YuvRaw<T, C420, PX>& f0, YuvRaw<T, C420, PX>& f1) {
 #ifdef YUV_ABLATE_MEM
         const size_t off = (size_t)(idx[min(v, total - 1)] & 0) * a.frame_stride;
 #else
         const size_t off = (size_t)idx[min(v, total - 1)] * a.frame_stride;      // past the end: the last frame again (unused)
 #endif
-        f0 = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[0]) + off, g, HW, uvplane);
-        f1 = yuv_fetch<T, C420>(reinterpret_cast<const T*>(a.src[1]) + off, g, HW, uvplane);
+        f0 = yuv_fetch<T, C420, PX>(reinterpret_cast<const T*>(a.src[0]) + off, g, HW, uvplane);
+        f1 = yuv_fetch<T, C420, PX>(reinterpret_cast<const T*>(a.src[1]) + off, g, HW, uvplane);
     };
-    YuvRaw<T, C420> nx[TD][2];
+    YuvRaw<T, C420, PX> nx[TD][2];
 #pragma unroll
     for (int d = 0; d < TD; ++d) prefetch(d, nx[d][0], nx[d][1]);
-    // store i of the lane writes pixel i*64+lane of the wave's 248-pixel run (row `lane` of the LDS tile = quad lane-1)
+    // store i of the lane writes pixel i*64+lane of the wave's run of 62*PX pixels (row `lane` of the LDS tile = group lane-1)
     unsigned int soff[PX];
 #pragma unroll
     for (int i = 0; i < PX; ++i) {
@@ -1288,18 +1305,18 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
 #pragma unroll
         for (int d = 0; d < TD; ++d) {
             const int v = v0 + d;                         // v >= total (last group only): computed, not stored
-            const YuvRaw<T, C420> cur0 = nx[d][0], cur1 = nx[d][1];
+            const YuvRaw<T, C420, PX> cur0 = nx[d][0], cur1 = nx[d][1];
             prefetch(v + TD, nx[d][0], nx[d][1]);
-            v2f rgb[12];
-            yuv_pair_rgb<T, C420, STDM>(cur0, cur1, a, g, g_fy, g_gy, g_fx0, g_gx0, rgb);
-            eotf_apply_pairs<12, KIND>(rgb, a.e);
+            v2f rgb[3 * PX];
+            yuv_pair_rgb<T, C420, STDM, PX>(cur0, cur1, a, g, g_fy, g_gy, g_fx0, g_gx0, rgb);
+            eotf_apply_pairs<3 * PX, KIND>(rgb, a.e);
             v2f lum[PX];
 #pragma unroll
             for (int i = 0; i < PX; ++i) lum[i] = lum_pair(rgb[3 * i], rgb[3 * i + 1], rgb[3 * i + 2], a.w[0], a.w[1], a.w[2]);
             v2f acc_s[PX], acc_t[PX];                     // sustained / transient channel of (test, reference): set by the first tap
             karg_p tp = (karg_p)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(YuvArgs, taps2);
             if constexpr (FL > 8) asm volatile("" : "+s"(tp));      // reloaded per frame, see temporal_vec_body
-            yuv_window_dispatch<FL>(v & (FL - 1), win, lum, tp, acc_s, acc_t);
+            yuv_window_dispatch<FL, PX>(v & (FL - 1), win, lum, tp, acc_s, acc_t);
             wave_lds_order();
 #pragma unroll
             for (int i = 0; i < PX; ++i)
@@ -1323,11 +1340,23 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
     }
 }
 
+// Pixels per lane of the vector kernel, per window length (4 or 2; A/B: tools/experiments/r6/s11.sh)
+#ifndef YUV_PX8
+#define YUV_PX8 4
+#endif
+#ifndef YUV_PX16
+#define YUV_PX16 4
+#endif
+constexpr int yuv_px(int FL) { return FL == 8 ? YUV_PX8 : YUV_PX16; }
+// waves per SIMD the register allocation aims at
 #ifndef YUV_WAVES8
-#define YUV_WAVES8 3
+#define YUV_WAVES8 (YUV_PX8 == 4 ? 3 : 5)
 #endif
 #ifndef YUV_WAVES16
-#define YUV_WAVES16 2
+#define YUV_WAVES16 (YUV_PX16 == 4 ? 2 : 4)
+#endif
+#ifndef YUV_WAVES8_WIDE
+#define YUV_WAVES8_WIDE (YUV_PX8 == 4 ? 2 : 4)      // 16-bit 4:4:4 (8 raw dwords per frame pair more at PX = 4), PQ (the longest display model)
 #endif
 // KIND = display model (compile-time: the host picks the instantiation): one loop body per kernel.  With a switch over the six
 // bodies inside one kernel, scalar values of the prologue stayed alive across all of them and spilled (8 SGPRs in the 16-slot
@@ -1340,18 +1369,19 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
 #endif
 constexpr int yuv_wpb(int FL) { return FL == 8 ? YUV_WPB8 : 1; }
 template <int FL, typename T, bool C420, int KIND, bool STDM>
-__global__ __launch_bounds__(64 * yuv_wpb(FL), (FL == 8 ? (((sizeof(T) == 2 && !C420) || KIND == FVVDP_EOTF_PQ) ? 2 : YUV_WAVES8) : YUV_WAVES16))     // 16-bit 4:4:4: 8 raw dwords per frame pair more; PQ: the longest display model
+__global__ __launch_bounds__(64 * yuv_wpb(FL), (FL == 8 ? (((sizeof(T) == 2 && !C420) || KIND == FVVDP_EOTF_PQ) ? YUV_WAVES8_WIDE : YUV_WAVES8) : YUV_WAVES16))
 void temporal_yuv_vec_kernel(const YuvArgs a_byval) {
     const YuvArgs& a = *(const YuvArgs*)__builtin_amdgcn_kernarg_segment_ptr();     // see temporal_vec_kernel
     (void)a_byval;
     constexpr int WPB = yuv_wpb(FL);
-    __shared__ float4 s_t_all[WPB][64 * (4 + 1)];
+    constexpr int PX = yuv_px(FL);
+    __shared__ float4 s_t_all[WPB][64 * (PX + 1)];
     const int wave = WPB > 1 ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
-    const int block = (int)blockIdx.x * WPB + wave;           // this wave's run of 62 pixel quads
+    const int block = (int)blockIdx.x * WPB + wave;           // this wave's run of 62 pixel groups
     if constexpr (WPB > 1) {
-        if (block * (YUV_QUADS * 4) >= a.W * a.H) return;      // the last workgroup of a frame whose block count is not a multiple
+        if (block * (YUV_QUADS * PX) >= a.W * a.H) return;     // the last workgroup of a frame whose block count is not a multiple
     }
-    temporal_yuv_vec_body<FL, T, C420, KIND, STDM>(a, s_t_all[wave], (int)(threadIdx.x & 63), block);
+    temporal_yuv_vec_body<FL, T, C420, KIND, STDM, PX>(a, s_t_all[wave], (int)(threadIdx.x & 63), block);
 }
 
 // Generic (any fl, any frame size) version: one thread per pixel per output frame, the window is re-read from

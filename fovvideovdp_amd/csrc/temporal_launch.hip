@@ -154,7 +154,7 @@ static void launch_yuv_vec_kind(bool general, const YuvArgs& a, dim3 grid, hipSt
 template <int FL>
 static void launch_yuv_vec(int bytes, bool c420, bool general, const YuvArgs& a, hipStream_t st) {
     const int HW = a.W * a.H;
-    dim3 grid((HW / 4 + YUV_QUADS - 1) / YUV_QUADS);
+    dim3 grid((HW / yuv_px(FL) + YUV_QUADS - 1) / YUV_QUADS);      // one wave per run of 62 pixel groups
     if (bytes == 1) {
         if (c420) launch_yuv_vec_kind<FL, unsigned char, true>(general, a, grid, st);
         else launch_yuv_vec_kind<FL, unsigned char, false>(general, a, grid, st);
