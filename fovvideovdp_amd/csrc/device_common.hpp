@@ -49,6 +49,10 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t level_rsrc(float* base, unsigned int bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(base, 0, (int)bytes, 0x00020000);
 }
+// the same for read-only source data (a planar frame of samples)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t src_rsrc(const void* base, unsigned int bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
 // Level 0 of a context lives in ONE range, or in TWO: its even frame slots in one allocation and its odd slots in another, so that the
 // temporal kernel's writes fall on both classes of the box's physical memory at any time (place_level0 in fvvdp_hip.hip,
 // profiles/r05_k1_mode.md).  One formula serves both: slot s sits at (s odd ? hi : lo) + (s >> 1) * half_stride floats; a single range

@@ -978,36 +978,38 @@ struct YuvRaw {
 };
 
 struct YuvGeom {           // per-lane constants
-    int oy;                // element offset of the PX luma samples inside a frame
-    int opair[2];          // offsets (from the start of a chroma plane) of the lane's own columns in the two source rows
+    unsigned int oy;       // BYTE offset of the PX luma samples inside a frame (a frame is at most 3 planes of 2-byte samples: < 4 GiB up to 715 Mpixel)
+    unsigned int oc[2][2]; // BYTE offsets inside a frame of the lane's own chroma columns, [plane][source row] (4:4:4: [plane][0])
     bool left_own, right_own;   // the clamped neighbour column is one of the lane's own (image edges)
 };
 
-// BYTES consecutive bytes at p (aligned to BYTES) into the low bits of dwords
+// BYTES consecutive bytes at byte offset `off` of the frame behind the buffer resource `f` (aligned to BYTES) into the low bits of dwords.
+// Buffer loads take the frame's address from scalar registers (the resource) and the lane's offset from one 32-bit vector register:
+// no vector instruction goes into addressing (global loads: a 64-bit vector add per load, 10 per lane and frame).
 template <int BYTES>
-__device__ __forceinline__ void yuv_load_bytes(const void* p, unsigned int* out) {
-    if constexpr (BYTES == 1) out[0] = *reinterpret_cast<const unsigned char*>(p);
-    else if constexpr (BYTES == 2) out[0] = *reinterpret_cast<const unsigned short*>(p);
-    else if constexpr (BYTES == 4) out[0] = *reinterpret_cast<const unsigned int*>(p);
+__device__ __forceinline__ void yuv_load_bytes(__amdgpu_buffer_rsrc_t f, unsigned int off, unsigned int* out) {
+    if constexpr (BYTES == 1) out[0] = (unsigned int)(unsigned char)__builtin_amdgcn_raw_buffer_load_b8(f, (int)off, 0, 0);
+    else if constexpr (BYTES == 2) out[0] = (unsigned int)(unsigned short)__builtin_amdgcn_raw_buffer_load_b16(f, (int)off, 0, 0);
+    else if constexpr (BYTES == 4) out[0] = (unsigned int)__builtin_amdgcn_raw_buffer_load_b32(f, (int)off, 0, 0);
     else {
         static_assert(BYTES == 8, "1, 2, 4 or 8 bytes");
-        const uint2 t = *reinterpret_cast<const uint2*>(p);
-        out[0] = t.x; out[1] = t.y;
+        const v2i t = __builtin_bit_cast(v2i, __builtin_amdgcn_raw_buffer_load_b64(f, (int)off, 0, 0));
+        out[0] = (unsigned int)t.x; out[1] = (unsigned int)t.y;
     }
 }
 
+// f = the frame (wave-uniform); every load is the frame + a per-lane constant
 template <typename T, bool C420, int PX>
-__device__ __forceinline__ YuvRaw<T, C420, PX> yuv_fetch(const T* __restrict__ f, const YuvGeom& g, int HW, int uvplane) {
+__device__ __forceinline__ YuvRaw<T, C420, PX> yuv_fetch(__amdgpu_buffer_rsrc_t f, const YuvGeom& g) {
     YuvRaw<T, C420, PX> r;
-    yuv_load_bytes<PX * (int)sizeof(T)>(f + g.oy, r.y);
+    yuv_load_bytes<PX * (int)sizeof(T)>(f, g.oy, r.y);
 #pragma unroll
     for (int pl = 0; pl < 2; ++pl) {
-        const T* P = f + HW + pl * uvplane;
         if constexpr (C420) {
 #pragma unroll
-            for (int rr = 0; rr < 2; ++rr) yuv_load_bytes<(PX / 2) * (int)sizeof(T)>(P + g.opair[rr], &r.cp[pl][rr]);
+            for (int rr = 0; rr < 2; ++rr) yuv_load_bytes<(PX / 2) * (int)sizeof(T)>(f, g.oc[pl][rr], &r.cp[pl][rr]);
         } else {
-            yuv_load_bytes<PX * (int)sizeof(T)>(P + g.oy, r.cp[pl]);
+            yuv_load_bytes<PX * (int)sizeof(T)>(f, g.oc[pl][0], r.cp[pl]);
         }
     }
     return r;
@@ -1246,7 +1248,8 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
     float g_fx0 = 0.0f, g_gx0 = 0.0f;    // horizontal weights of pixel 0 (0/1 at the left image edge, else .75/.25)
     {
         const int y = pl / a.W, x = pl - y * a.W;
-        g.oy = pl;
+        constexpr unsigned int ES = (unsigned int)sizeof(T);
+        g.oy = (unsigned int)pl * ES;
         if constexpr (C420) {
             // torch bilinear, align_corners=False: source = (dst + 0.5)/2 - 0.5 clamped at 0 (video_source_file.py:262-266)
             const float sy = fmaxf(((float)y + 0.5f) * 0.5f - 0.5f, 0.0f);
@@ -1254,7 +1257,11 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
             g_fy = sy - (float)y0;
             g_gy = 1.0f - g_fy;
             const int j2 = x >> 1;                       // first of the lane's own PX/2 chroma columns
-            g.opair[0] = y0 * a.uvw + j2;  g.opair[1] = y1 * a.uvw + j2;
+#pragma unroll
+            for (int cpl = 0; cpl < 2; ++cpl) {
+                g.oc[cpl][0] = (unsigned int)(HW + cpl * uvplane + y0 * a.uvw + j2) * ES;
+                g.oc[cpl][1] = (unsigned int)(HW + cpl * uvplane + y1 * a.uvw + j2) * ES;
+            }
             // lanes to the left / right hold the adjacent quad of the same row unless this lane starts / ends the row
             // (lanes clamped to the last quad of the frame sit at a row end as well)
             g.left_own = (j2 == 0);
@@ -1263,7 +1270,8 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
             g_fx0 = sx - (float)(int)sx;                 // 0 at x == 0 (then the "left" column is column 0 itself), else .75
             g_gx0 = 1.0f - g_fx0;
         } else {
-            g.opair[0] = g.opair[1] = 0;
+            g.oc[0][0] = g.oc[0][1] = (unsigned int)(HW + pl) * ES;
+            g.oc[1][0] = g.oc[1][1] = (unsigned int)(HW + uvplane + pl) * ES;
             g.left_own = g.right_own = false;
         }
     }
@@ -1273,14 +1281,15 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
 #pragma unroll
         for (int i = 0; i < PX; ++i) win[u][i] = splat(0.0f);
     const int total = FL - 1 + a.n_out;
+    const unsigned int src_bytes = (unsigned int)(HW + 2 * uvplane) * (unsigned int)sizeof(T);      // one planar frame
     auto prefetch = [&](int v, YuvRaw<T, C420, PX>& f0, YuvRaw<T, C420, PX>& f1) {
 #ifdef YUV_ABLATE_MEM
         const size_t off = (size_t)(idx[min(v, total - 1)] & 0) * a.frame_stride;
 #else
         const size_t off = (size_t)idx[min(v, total - 1)] * a.frame_stride;      // past the end: the last frame again (unused)
 #endif
-        f0 = yuv_fetch<T, C420, PX>(reinterpret_cast<const T*>(a.src[0]) + off, g, HW, uvplane);
-        f1 = yuv_fetch<T, C420, PX>(reinterpret_cast<const T*>(a.src[1]) + off, g, HW, uvplane);
+        f0 = yuv_fetch<T, C420, PX>(src_rsrc(reinterpret_cast<const char*>(a.src[0]) + off * sizeof(T), src_bytes), g);
+        f1 = yuv_fetch<T, C420, PX>(src_rsrc(reinterpret_cast<const char*>(a.src[1]) + off * sizeof(T), src_bytes), g);
     };
     YuvRaw<T, C420, PX> nx[TD][2];
 #pragma unroll
@@ -1327,13 +1336,14 @@ __device__ __forceinline__ void temporal_yuv_vec_body(const YuvArgs& a, float4* 
 #else
             const bool live = (v >= FL - 1) && (v < total);
 #endif
-            const __amdgpu_buffer_rsrc_t o = level_rsrc(l0_frame(a.out, max(v - (FL - 1), 0)), frame_bytes);
+            // history frames and the steps past the end store nothing: their descriptor covers 0 bytes (a scalar select; the per-lane
+            // offsets stay as they are -- round 6: -4 vector selects per frame)
+            const __amdgpu_buffer_rsrc_t o = level_rsrc(l0_frame(a.out, max(v - (FL - 1), 0)), live ? frame_bytes : 0u);
 #pragma unroll
             for (int i = 0; i < PX; ++i) {
                 const int qq = min(i * 64 + lane, YUV_QUADS * PX - 1);
                 const float4 val = s_t[(qq / PX + 1) * (PX + 1) + (qq % PX)];
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{val.x, val.y, val.z, val.w}), o,
-                                                       live ? soff[i] : FVVDP_NO_STORE, 0, 2 /*nt*/);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i, v4f{val.x, val.y, val.z, val.w}), o, soff[i], 0, 2 /*nt*/);
             }
             __builtin_amdgcn_sched_barrier(0);
         }
