@@ -554,6 +554,9 @@ __device__ __forceinline__ void wave_lds_order() {
 #define K1_STORE_AUX 2     // cache policy of the level-0 stores: 2 = nt.  0 / 1 (sc0) / 16 (sc1) / 18: this kernel within its per-process scatter,
                            // but the pyramid pass that follows is 2 % slower behind stores that are not nt (tools/experiments/r4_session44.sh)
 #endif
+#ifndef K1_EARLY_WORDS
+#define K1_EARLY_WORDS 1   // widest sample vector (dwords per channel and lane) whose NEXT frame is requested before the current one is converted
+#endif
 template <int FL, int PX, int SRC, int TD, int CC, int KIND>
 __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const float* lutw, float4* s_t, const int block = (int)blockIdx.x) {
     // the window index lists are the only dynamically indexed members of the argument block: read them straight from the
@@ -633,7 +636,7 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
             const int u = (FL - 1 + j) % FL;         // ring slot of the newest frame (compile-time after unrolling)
             // The next frame is requested before this one is converted when a frame is a few registers (8-bit samples); wide
             // samples (12-24 registers per frame pair) are requested after the conversion has freed the registers.
-            if constexpr (RawVec<SRC, PX>::WORDS == 1) {
+            if constexpr (RawVec<SRC, PX>::WORDS <= K1_EARLY_WORDS) {
                 const RawVecFrame<SRC, PX> cur0 = nx[u % TD][0], cur1 = nx[u % TD][1];
                 prefetch(FL - 1 + t + TD, nx[u % TD][0], nx[u % TD][1]);
                 push(cur0, cur1, ring[u]);
