@@ -340,6 +340,96 @@ __device__ __forceinline__ void frame_lum(const FRAME& f, int C, const float* lu
     for (int i = 0; i < PX; ++i) L[i] = (C == 3) ? __fadd_rn(__fadd_rn(v[0][i], v[1][i]), v[2][i]) : v[0][i];
 }
 
+// ---- closed-form display model on (test, reference) PAIRS (16-bit codes / 65535 and float samples in the register-ring kernels) ----
+// eotf_one above, on both streams at once: the same operations in the same order on every component, with the affine steps as packed
+// instructions (v_pk_add / v_pk_mul / v_pk_fma), the clamps as one v_med3 per component (fminf(fmaxf()) costs three) and the selects on
+// V > 0 / r > 0 dropped where the transcendental pair yields the selected value by itself (k * log2(+0) = -inf, exp2(-inf) = +0 for
+// k > 0).  Per sample: PQ 22 -> 11.5 vector instructions (5 of them transcendental), sRGB 13 -> 7.  Rounding: every product and sum is
+// rounded on its own, as the reference's torch ops are (fvvdp_display_model.py:147-165, video_source.py:206); in eotf_one the compiler
+// fuses `scale * lin + black` and the luminance sums into multiply-adds (HIP's __fmul_rn / __fadd_rn are plain operators), so the two forms
+// differ in the last bit of a luminance.  CHECK: flag and clip samples outside [0,1] (float sources; codes / 65535 cannot leave the range).
+// No inline assembly here on purpose: an asm instruction that reads the result of v_exp / v_log / v_rcp misses the wait state the compiler
+// inserts between a transcendental and its consumer (gfx940+), and reads a stale register now and then.
+#ifndef K1_PAIRS
+#define K1_PAIRS 1
+#endif
+template <int N, int KIND, bool CHECK, typename B>
+__device__ __forceinline__ void eotf_pairs_exact(v2f (&V)[N], const EotfDev& e, B& bad) {
+#pragma clang fp contract(off)       // every product and sum rounded on its own
+    if constexpr (CHECK && (KIND == FVVDP_EOTF_SRGB || KIND == FVVDP_EOTF_GAMMA || KIND == FVVDP_EOTF_PQ)) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            note_oob(bad, V[i].x);
+            note_oob(bad, V[i].y);
+            V[i] = clamp2(V[i], 0.0f, 1.0f);
+        }
+    }
+    if constexpr (KIND == FVVDP_EOTF_SRGB) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const v2f t = (V[i] + splat(0.055f)) * splat(1.0f / 1.055f);
+            const v2f ex = v2f{fast_log2(t.x), fast_log2(t.y)} * splat(2.4f);
+            const v2f lo = V[i] * splat(1.0f / 12.92f);
+            const v2f lin = v2f{V[i].x > 0.04045f ? fast_exp2(ex.x) : lo.x, V[i].y > 0.04045f ? fast_exp2(ex.y) : lo.y};
+            V[i] = lin * splat(e.scale) + splat(e.y_black);
+        }
+    } else if constexpr (KIND == FVVDP_EOTF_GAMMA) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const v2f ex = v2f{fast_log2(V[i].x), fast_log2(V[i].y)} * splat(e.gamma);
+            // V = 0: gamma * -inf = -inf, exp2 -> +0 (gamma > 0): the value eotf_one selects
+            V[i] = v2f{fast_exp2(ex.x), fast_exp2(ex.y)} * splat(e.scale) + splat(e.y_black);
+        }
+    } else if constexpr (KIND == FVVDP_EOTF_PQ) {
+        const float m = 78.843750000000000f, n = 0.15930175781250000f;
+        const float c1 = 0.83593750000000000f, c2 = 18.851562500000000f, c3 = 18.687500000000000f;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const v2f lg = v2f{fast_log2(V[i].x), fast_log2(V[i].y)} * splat(1.0f / m);
+            const v2f im = v2f{fast_exp2(lg.x), fast_exp2(lg.y)};                        // V = 0 -> +0
+            const v2f num = clamp2(im + splat(-c1), 0.0f, 1.0f);                          // max(im - c1, 0): im <= 1, so [0,1] is the same clip
+            const v2f den = __builtin_elementwise_fma(im, splat(-c3), splat(c2));         // c2 - c3 * im, one rounding (as contracted in eotf_one)
+            const v2f r = num * v2f{fast_rcp(den.x), fast_rcp(den.y)};
+            const v2f lr = v2f{fast_log2(r.x), fast_log2(r.y)} * splat(1.0f / n);
+            const v2f L = splat(10000.0f) * v2f{fast_exp2(lr.x), fast_exp2(lr.y)};        // r = 0 -> +0
+            V[i] = clamp2(L, 0.005f, e.y_peak) + splat(e.y_black);
+        }
+    } else if constexpr (KIND == FVVDP_EOTF_LINEAR) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) V[i] = clamp2(V[i], 0.005f, e.y_peak) + splat(e.y_black);
+    } else if constexpr (KIND == FVVDP_EOTF_ABSOLUTE) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) V[i] = clamp2(V[i], e.l_min, e.l_max);
+    }
+}
+
+// (test, reference) luminance pairs of PX pixels from the raw samples of both streams: frame_lum for closed-form sources, pair by pair
+template <int SRC, int PX, int CC, int KIND, typename FRAME, typename B>
+__device__ __forceinline__ void frame_lum_pairs(const FRAME& f0, const FRAME& f1, const float (&w)[3], const EotfDev& e, v2f (&L)[PX], B& bad) {
+#pragma clang fp contract(off)       // (Lr*w0 + Lg*w1) + Lb*w2 with every product and sum rounded, as frame_lum and video_source.py:206
+    static_assert(SRC == SRC_F32 || SRC == SRC_U16, "closed-form sources");
+    v2f V[CC * PX];
+#pragma unroll
+    for (int c = 0; c < CC; ++c)
+#pragma unroll
+        for (int i = 0; i < PX; ++i) {
+            if constexpr (SRC == SRC_F32) {
+                // (the two samples are pinned as scalars: left to itself the compiler interleaves the two loaded register quads into
+                // pairs with vector shuffles that it lowers THROUGH SCRATCH MEMORY -- 112 bytes of stack, 40 scratch accesses per frame)
+                float t0 = f0.ch[c].value(i), t1 = f1.ch[c].value(i);
+                asm volatile("" : "+v"(t0), "+v"(t1));
+                V[c * PX + i] = v2f{t0, t1};
+            }
+            else V[c * PX + i] = v2f{(float)f0.ch[c].code(i), (float)f1.ch[c].code(i)} * splat(1.0f / 65535.0f);
+        }
+    eotf_pairs_exact<CC * PX, KIND, SRC == SRC_F32>(V, e, bad);
+#pragma unroll
+    for (int i = 0; i < PX; ++i) {
+        if constexpr (CC == 3) L[i] = (V[i] * splat(w[0]) + V[PX + i] * splat(w[1])) + V[2 * PX + i] * splat(w[2]);
+        else L[i] = V[i] * splat(w[0]);
+    }
+}
+
 // One filter tap on one pixel: accS += x * f.x, accT += x * f.y for the (test, reference) pair x.  The tap pair f = {sustained,
 // transient} sits in ONE scalar register pair and is broadcast by the operand selects of the packed instruction.  Written out
 // because the compiler materialises a splat {f, f} pair per tap and channel instead: 4 scalar registers per tap, 256 for a
@@ -587,14 +677,22 @@ __device__ __forceinline__ void temporal_vec_body(const TemporalArgs& a, const f
     };
     // newest frame -> ring slot u.  The pair is pinned where it is produced: the compiler otherwise sinks the channel sums
     // to their first use (many steps later), keeping three table values per pixel alive instead of one luminance.
+    // closed-form display models run on (test, reference) pairs (packed instructions; the reference's roundings)
+    constexpr bool PAIRS = (K1_PAIRS != 0) && (SRC == SRC_F32 || SRC == SRC_U16) && KIND >= 0 && KIND != FVVDP_EOTF_LUT;
     auto push = [&](const RawVecFrame<SRC, PX>& c0, const RawVecFrame<SRC, PX>& c1, v2f (&slot)[PX]) {
-        float L0[PX], L1[PX];
-        frame_lum<SRC, PX, RawVecFrame<SRC, PX>, KIND>(c0, CC, lutw, a.e.lut, w, a.e, L0, bad);
-        frame_lum<SRC, PX, RawVecFrame<SRC, PX>, KIND>(c1, CC, lutw, a.e.lut, w, a.e, L1, bad);
+        if constexpr (PAIRS) {
+            frame_lum_pairs<SRC, PX, CC, KIND>(c0, c1, w, a.e, slot, bad);
 #pragma unroll
-        for (int i = 0; i < PX; ++i) {
-            slot[i] = v2f{L0[i], L1[i]};
-            asm volatile("" : "+v"(slot[i]));
+            for (int i = 0; i < PX; ++i) asm volatile("" : "+v"(slot[i]));
+        } else {
+            float L0[PX], L1[PX];
+            frame_lum<SRC, PX, RawVecFrame<SRC, PX>, KIND>(c0, CC, lutw, a.e.lut, w, a.e, L0, bad);
+            frame_lum<SRC, PX, RawVecFrame<SRC, PX>, KIND>(c1, CC, lutw, a.e.lut, w, a.e, L1, bad);
+#pragma unroll
+            for (int i = 0; i < PX; ++i) {
+                slot[i] = v2f{L0[i], L1[i]};
+                asm volatile("" : "+v"(slot[i]));
+            }
         }
     };
     // History (no output yet, almost no arithmetic): HB frames are requested at once, otherwise this phase is one memory

@@ -17,7 +17,7 @@ for fps, N, kind in cases:
         test = test[:, 1:2].to(torch.float32) / 255; ref = ref[:, 1:2].to(torch.float32) / 255
     elif kind == "f32rgb":
         test = test.to(torch.float32) / 255; ref = ref.to(torch.float32) / 255
-    m = fv.fvvdp(display_name="standard_4k"); m.timing = True
+    m = fv.fvvdp(display_name=os.environ.get("PROBE_DISPLAY", "standard_4k")); m.timing = True      # PROBE_DISPLAY=standard_hdr_pq: the PQ display model
     best = 1e9
     for it in range(4):
         torch.cuda.synchronize(); t0 = time.perf_counter()
