@@ -1249,8 +1249,8 @@ __device__ __forceinline__ void eotf_apply_pairs(v2f (&V)[N], const EotfDev& e) 
             break;
         }
         case FVVDP_EOTF_PQ: {
-#pragma unroll
-            for (int i = 0; i < N; ++i) V[i] = v2f{eotf_one<FVVDP_EOTF_PQ>(V[i].x, e, bad), eotf_one<FVVDP_EOTF_PQ>(V[i].y, e, bad)};
+            // the packed form of eotf_one<PQ> (the same values: its one fused step, c2 - c3 * V^(1/m), is fused there as well)
+            eotf_pairs_exact<N, FVVDP_EOTF_PQ, false>(V, e, bad);
             break;
         }
         case FVVDP_EOTF_LINEAR: {

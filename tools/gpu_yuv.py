@@ -21,7 +21,7 @@ for sp in specs:
             Y.copy_((16 * (1 << (bd - 8)) + (Y.to(torch.int64) - 16 * (1 << (bd - 8))) // 24).to(a.dtype))
     if bd > 8:
         ty, ry = ty.to(torch.int16), ry.to(torch.int16)
-    m = fv.fvvdp(display_name="standard_4k")
+    m = fv.fvvdp(display_name=os.environ.get("PROBE_DISPLAY", "standard_4k"))      # PROBE_DISPLAY=standard_hdr_pq: the PQ display model
     vs = fv.fvvdp_video_source_yuv_frames(ty, ry, fps, W, H, bit_depth=bd, chroma_ss=css, color_space="bt709",
                                           display_photometry=m.display_photometry)
     m.timing = True
