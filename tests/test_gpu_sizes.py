@@ -164,3 +164,59 @@ def test_full_size_temporal_vector_kernel_equals_scalar_kernel(fps, kind, monkey
     assert float(((r_vec[:, 2:] - r_sca[:, 2:]).abs() / scale).max()) < 2e-6      # transient channels, relative to the luminance
     assert np.allclose(s_vec["Q_per_ch"], s_sca["Q_per_ch"], rtol=1e-4, atol=1e-6 * float(np.max(s_sca["Q_per_ch"])))
     assert abs(float(q_vec) - float(q_sca)) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("disp", ["standard_4k", "standard_hdr_pq", "standard_hdr_linear", "sdr_fhd_24"])
+@pytest.mark.parametrize("kind", ["u16", "f32", "f32oob", "u16gray"])
+def test_closed_form_display_model_on_pairs_equals_the_per_pixel_kernels(disp, kind, monkeypatch, caplog):
+    """Round 6: the register-ring kernels evaluate the closed-form display models (sRGB, gamma, PQ, linear) of 16-bit / float sources on
+    (test, reference) PAIRS -- packed instructions, every product and sum rounded like the reference's torch ops
+    (fvvdp_display_model.py:147-165, video_source.py:206).  Against the per-pixel kernels (FVVDP_TEMPORAL_SCALAR=1: eotf_one, one stream
+    at a time) on the same clip at 30 / 60 / 120 fps (8-, 16- and 32-slot ring): the temporal channels agree to the last bits of a
+    luminance (measured <= 2.4e-6 of the luminance, profiles/r06_k1_closed_form.md; PQ at 120 fps is the case an inline-assembly clip
+    on a transcendental's result once broke by factors of 1e4), JODs to 1e-5, and samples outside [0,1] raise the reference's warning on
+    both paths."""
+    import ctypes as C
+    import logging
+    import fovvideovdp_amd as fv
+    from fovvideovdp_amd import _native as nat
+    from fovvideovdp_amd.synth import synth_video_pair
+    N, H, W = 12, 72, 128
+    test, ref = synth_video_pair(N, H, W, device="cuda")
+    if kind.startswith("u16"):
+        test, ref = (test.to(torch.int32) * 257 + 3).clamp(0, 65535).to(torch.int16), (ref.to(torch.int32) * 257).to(torch.int16)
+        if kind == "u16gray":
+            test, ref = test[:, 1:2].contiguous(), ref[:, 1:2].contiguous()
+    else:
+        s = 900.0 if "linear" in disp else 1.0
+        test, ref = test.float() / 255 * s, ref.float() / 255 * s
+        if kind == "f32oob":
+            test = test * 1.2 - 0.1
+    for fps in (30, 60, 120):
+        m = fv.fvvdp(display_name=disp)
+
+        def run():
+            caplog.clear()
+            with caplog.at_level(logging.WARNING):
+                q, st = m.predict(test, ref, frames_per_second=fps)
+            out = torch.empty((N, 4, H, W), dtype=torch.float32, device="cuda")
+            nat.check(nat.lib().fvvdp_export_level(m._ctx.handle, 0, N, C.c_void_p(out.data_ptr()),
+                                                   C.c_void_p(torch.cuda.current_stream().cuda_stream)))
+            torch.cuda.synchronize()
+            return float(q), out, any("outside the valid range" in r.message for r in caplog.records)
+
+        q_vec, r_vec, w_vec = run()
+        monkeypatch.setenv("FVVDP_TEMPORAL_SCALAR", "1")
+        m._drop_context()          # the library reads its switches when a context is created
+        q_sca, r_sca, w_sca = run()
+        monkeypatch.delenv("FVVDP_TEMPORAL_SCALAR")
+        m._drop_context()
+        assert bool(torch.isfinite(r_vec).all())
+        lum = torch.clamp(r_sca[:, :2].abs(), min=1e-3)
+        d = (r_vec - r_sca).abs() / torch.cat([lum, lum], dim=1)
+        assert float(d.max()) < 6e-6, (disp, kind, fps, float(d.max()))      # measured <= 2.4e-6
+        assert abs(q_vec - q_sca) < 1e-5, (disp, kind, fps)
+        # the clipping models (sRGB / gamma / PQ) flag float samples outside [0,1]; linear displays and integer codes never do
+        expect = kind == "f32oob" and "linear" not in disp
+        assert w_vec == w_sca == expect, (disp, kind, fps, w_vec, w_sca)

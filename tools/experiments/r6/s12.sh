@@ -1,6 +1,6 @@
 #!/bin/bash
 # round 6, session 12: the whole GPU suite + smoke + the randomised sweeps against the oracle + the profile bundle on the final build of the round
-# (temporal kernels: entry drain, first tap as a multiply; YUV ingest: buffer loads, descriptor store gate)
+# (temporal kernels: entry drain, first tap as a multiply; YUV ingest: buffer loads, descriptor store gate, packed PQ; 16-bit / float sources: packed display model)
 set -u
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/r6s12
@@ -11,13 +11,13 @@ echo "pytest rc $?" >> $O/pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1
 echo "smoke rc $?" >> $O/smoke.log
 cd /tmp && export TMPDIR=/tmp
-python $R/tools/experiments/gpu_stress.py 500 6301 > $O/stress_default.txt 2>&1
-FVVDP_BAND_FUSE=1 python $R/tools/experiments/gpu_stress.py 400 6302 > $O/stress_fuse.txt 2>&1
-FVVDP_BAND_FUSE=1 FVVDP_BAND_INRANGE=0 python $R/tools/experiments/gpu_stress.py 200 6302 > $O/stress_fuse_clamps.txt 2>&1
-HLO=200 HHI=1100 WLO=300 WHI=2000 NMAX=5 python $R/tools/experiments/gpu_stress.py 200 6303 > $O/stress_mid.txt 2>&1
-HLO=40 HHI=400 WLO=2300 WHI=4200 NMAX=4 python $R/tools/experiments/gpu_stress.py 100 6304 > $O/stress_wide.txt 2>&1
-python $R/tools/experiments/gpu_stress_yuv.py 500 6305 > $O/stress_yuv.txt 2>&1
-python $R/tools/experiments/gpu_stress_heat.py 60 6306 > $O/stress_heat.txt 2>&1
+python $R/tools/experiments/gpu_stress.py 500 6401 > $O/stress_default.txt 2>&1
+FVVDP_BAND_FUSE=1 python $R/tools/experiments/gpu_stress.py 400 6402 > $O/stress_fuse.txt 2>&1
+FVVDP_BAND_FUSE=1 FVVDP_BAND_INRANGE=0 python $R/tools/experiments/gpu_stress.py 200 6402 > $O/stress_fuse_clamps.txt 2>&1
+HLO=200 HHI=1100 WLO=300 WHI=2000 NMAX=5 python $R/tools/experiments/gpu_stress.py 200 6403 > $O/stress_mid.txt 2>&1
+HLO=40 HHI=400 WLO=2300 WHI=4200 NMAX=4 python $R/tools/experiments/gpu_stress.py 100 6404 > $O/stress_wide.txt 2>&1
+python $R/tools/experiments/gpu_stress_yuv.py 500 6405 > $O/stress_yuv.txt 2>&1
+python $R/tools/experiments/gpu_stress_heat.py 60 6406 > $O/stress_heat.txt 2>&1
 python $R/tools/experiments/gpu_stress_shapes.py > $O/stress_shapes.txt 2>&1
 tail -n 1 $O/pytest_gpu.log $O/smoke.log $O/stress_*.txt
 cd $R
