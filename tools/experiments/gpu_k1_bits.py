@@ -27,7 +27,7 @@ for disp in ("standard_4k", "standard_hdr_pq", "standard_hdr_linear", "sdr_fhd_2
                 if kind == "f32gray":
                     test, ref = test[:, 1:2].contiguous(), ref[:, 1:2].contiguous()
                 if kind == "f32oob":
-                    test = test * 1.2 - 0.1            # samples outside [0,1]: flag + clip
+                    test = test * 1.6 - 0.3            # the synthetic clip spans 0.14 .. 0.89: samples outside [0,1] (flag + clip)
             m = fv.fvvdp(display_name=disp, quiet=True)
             try:
                 q, st = m.predict(test, ref, frames_per_second=fps)
