@@ -27,6 +27,9 @@ python $R/tools/gpu_parity_report.py > $OUT/parity.md 2>/dev/null
 ( python $R/tools/gpu_g9_report.py; python $R/tools/gpu_g10_report.py; python $R/tools/gpu_g11_report.py; python $R/tools/gpu_g12_report.py ) 2>/dev/null | grep -v Warn > $OUT/parity_goldens.txt
 python $R/tools/gpu_fps.py 30:60:u8 60:120:u8 120:120:u8 144:120:u8 240:120:u8 30:60:u16 60:60:u16 120:60:u16 144:60:u16 30:60:f32rgb 120:60:f32rgb 30:60:f32gray 2>/dev/null | grep -v Warn > $OUT/fps_probe.txt
 python $R/tools/gpu_k1_ab.py 30:60:u8:5 60:60:u8:5 120:60:u8:5 2>/dev/null | grep -v Warn >> $OUT/fps_probe.txt
+# round 6: the same probe behind the PQ display model (16-bit / float frames: closed-form display model on (test, reference) pairs)
+echo "PROBE_DISPLAY=standard_hdr_pq:" >> $OUT/fps_probe.txt
+PROBE_DISPLAY=standard_hdr_pq python $R/tools/gpu_fps.py 30:60:u8 30:60:u16 60:60:u16 120:120:u16 240:120:u16 30:60:f32rgb 120:120:f32rgb 2>/dev/null | grep -v Warn >> $OUT/fps_probe.txt
 BATCHES=None,60 python $R/tools/gpu_feeder.py 2>/dev/null | cut -c1-110 > $OUT/feeder_probe.txt
 HH=2160 WW=3840 BATCHES=None,60 python $R/tools/gpu_feeder.py 2>/dev/null | cut -c1-110 >> $OUT/feeder_probe.txt
 python $R/bench.py --pairs-per-gpu 8 --no-cpu-baseline --no-h2d > $OUT/bench_pairs8.json 2>/dev/null
@@ -38,6 +41,8 @@ STAGE=all REPS=2 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d /tmp/pw1 -o w -- p
 ( python $R/tools/pmc_query.py $(find /tmp/pf1 -name "*.db" | head -1) temporal_vec_kernel; python $R/tools/pmc_query.py $(find /tmp/pw1 -name "*.db" | head -1) temporal_vec_kernel ) > $OUT/pmc_k1.txt
 rocprofv3 --kernel-trace --stats -d /tmp/ky -o yuv -- python $R/tools/gpu_yuv.py 2160x3840x60:8:420 2160x3840x60:10:420:60 2160x3840x60:8:444 > $OUT/yuv_probe.txt 2> /tmp/ky.err
 python $R/tools/rocpd_summary.py $(find /tmp/ky -name "*.db" | head -1) --only temporal_yuv > $OUT/kernel_trace_yuv.md
+echo "PROBE_DISPLAY=standard_hdr_pq:" >> $OUT/yuv_probe.txt
+PROBE_DISPLAY=standard_hdr_pq python $R/tools/gpu_yuv.py 2160x3840x60:10:420 2160x3840x60:10:420:60 2>/dev/null | grep -v Warn >> $OUT/yuv_probe.txt
 rocprofv3 --kernel-trace --stats -d /tmp/kp -o psnr -- python $R/tools/gpu_psnr.py > $OUT/psnr_probe.txt 2> /tmp/kp.err
 python $R/tools/rocpd_summary.py $(find /tmp/kp -name "*.db" | head -1) --only pu21 > $OUT/kernel_trace_psnr.md
 rocprofv3 --kernel-trace --stats -d /tmp/kh -o heat -- python $R/tools/gpu_heatprof.py 12 threshold > /tmp/kh.out 2> /tmp/kh.err
