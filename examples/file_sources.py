@@ -153,8 +153,8 @@ class fvvdp_video_source_yuv_file(fvvdp_video_source_yuv_frames):
     """Test / reference pair of raw planar .yuv files (the reference's `fvvdp_video_source_yuv_file`,
     pyfvvdp/video_source_yuv.py:238-292, whose constructor cannot run: it logs attributes its reader does not have).
     The frames are read into host memory as they are stored (1.5 or 3 bytes per pixel and stream for 8 bit), uploaded in
-    that form and unpacked by the fused ingest kernel.  With `full_screen_resize` the frames are resized in RGB with torch (`get_*_frame`, as the
-    reference does) and the metric takes luminance frames from there."""
+    that form and unpacked by the fused ingest kernel.  With `full_screen_resize` (the CLI's --full-screen-resize) every frame is resized in RGB
+    to `resize_resolution` on the GPU (`fvvdp_video_source_yuv_frames`, `fvvdp_yuv_frame_resized`) and the metric takes luminance frames from there."""
 
     def __init__(self, test_fname, reference_fname, display_photometry='standard_4k', color_space_name='auto', frames=-1,
                  full_screen_resize=None, resize_resolution=None, verbose=False):
@@ -182,26 +182,5 @@ class fvvdp_video_source_yuv_file(fvvdp_video_source_yuv_frames):
             raise RuntimeError("The .yuv files hold no complete frame")
         super().__init__(t[:n], r[:n], tp["fps"], tp["width"], tp["height"], bit_depth=tp["bit_depth"],
                          chroma_ss=tp["chroma_ss"], color_space="bt2020nc" if tp["color_space"] == "2020" else "bt709",
-                         display_photometry=display_photometry, color_space_name=color_space_name)
-        if full_screen_resize is not None and resize_resolution is None:
-            raise RuntimeError("full_screen_resize needs resize_resolution=(width, height)")
-        self.full_screen_resize = full_screen_resize
-        self.resize_resolution = resize_resolution
-
-    def _resizing(self):
-        return self.full_screen_resize is not None and tuple(self.resize_resolution) != (self.width, self.height)
-
-    def get_video_size(self):
-        if self._resizing():
-            return (self.resize_resolution[1], self.resize_resolution[0], self.frames)
-        return (self.height, self.width, self.frames)
-
-    def _get_frame(self, frames, frame, device):
-        if not self._resizing():
-            return super()._get_frame(frames, frame, device)
-        rgb = self.unpack(frames[frame], device).permute(2, 0, 1)[None]                    # [1,3,H,W]
-        rgb = torch.nn.functional.interpolate(rgb, size=(self.resize_resolution[1], self.resize_resolution[0]),
-                                              mode=self.full_screen_resize).clip(0., 1.)
-        L = self.dm_photometry.forward(rgb[:, :, None])
-        w = self.color_to_luminance
-        return L[:, 0:1] * w[0] + L[:, 1:2] * w[1] + L[:, 2:3] * w[2]
+                         display_photometry=display_photometry, color_space_name=color_space_name,
+                         full_screen_resize=full_screen_resize, resize_resolution=resize_resolution)

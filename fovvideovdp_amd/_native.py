@@ -19,6 +19,7 @@ PSNR_SLICES = 256            # FVVDP_PSNR_SLICES
 MAX_BANDS = 16
 MAX_TAPS = 256
 LUT_N = 32
+RESIZE_MODES = {"nearest": 0, "bilinear": 1, "bicubic": 2, "area": 3}      # FVVDP_RESIZE_*
 
 
 class Params(C.Structure):
@@ -87,6 +88,8 @@ SYMBOLS = {
     "fvvdp_pu21_sse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t,
                                  C.POINTER(Eotf), C.POINTER(C.c_float), C.POINTER(Pu21), C.c_int, C.c_void_p, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
+    "fvvdp_yuv_frame_resized": (C.c_int, [C.c_void_p, C.POINTER(YuvFormat), C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                          C.POINTER(Eotf), C.POINTER(C.c_float), C.c_void_p, C.c_void_p, C.c_void_p]),
     "fvvdp_ctx_timing_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "fvvdp_ctx_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.c_int, C.c_int]),
     "fvvdp_ctx_alloc_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_float), C.c_int,

@@ -49,6 +49,7 @@ extern "C" const char* fvvdp_last_error(void) { return g_err; }
 #include "band2_kernel.hpp"
 #include "aux_kernels.hpp"
 #include "psnr_kernel.hpp"
+#include "resize_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------------------------
 // context
@@ -1006,6 +1007,53 @@ static void launch_pu21(int dtype, const Pu21Args& a, int n_frames, hipStream_t 
     if (dtype == FVVDP_U8) hipLaunchKernelGGL((pu21_sse_kernel<SRC_U8, PX>), grid, block, 0, st, a);
     else if (dtype == FVVDP_U16) hipLaunchKernelGGL((pu21_sse_kernel<SRC_U16, PX>), grid, block, 0, st, a);
     else hipLaunchKernelGGL((pu21_sse_kernel<SRC_F32, PX>), grid, block, 0, st, a);
+}
+
+extern "C" int fvvdp_yuv_frame_resized(const void* d_frame, const fvvdp_yuv_format* fmt, int W, int H, float* d_rgb_scratch,
+                                       int out_w, int out_h, int mode, const fvvdp_eotf* eotf, const float* h_rgb2y,
+                                       float* d_lum, float* d_rgb_out, void* stream) {
+    if (!d_frame || !fmt || !d_rgb_scratch || !eotf || !h_rgb2y || !d_lum) return fail(FVVDP_EINVAL, "null argument");
+    if (W < 1 || H < 1 || out_w < 1 || out_h < 1 || (long long)W * H > 0x3FFFFFFF || (long long)out_w * out_h > 0x3FFFFFFF)
+        return fail(FVVDP_EINVAL, "frame size out of range");
+    if (fmt->bit_depth < 8 || fmt->bit_depth > 16) return fail(FVVDP_EINVAL, "bit depth %d not supported", fmt->bit_depth);
+    if (fmt->chroma_420 && ((W | H) & 1)) return fail(FVVDP_EINVAL, "4:2:0 needs even frame dimensions");
+    if (mode < FVVDP_RESIZE_NEAREST || mode > FVVDP_RESIZE_AREA) return fail(FVVDP_EINVAL, "unknown resize mode %d", mode);
+    if (eotf->kind == FVVDP_EOTF_LUT) return fail(FVVDP_EINVAL, "YUV sources need a closed-form display model (RGB is fractional after the matrix)");
+    hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+    YuvRgbArgs y;
+    memset(&y, 0, sizeof(y));
+    y.src = d_frame;
+    y.W = W; y.H = H;
+    y.chroma420 = fmt->chroma_420 ? 1 : 0;
+    y.uvw = fmt->chroma_420 ? W / 2 : W;
+    y.uvh = fmt->chroma_420 ? H / 2 : H;
+    const float scale = (float)(1 << (fmt->bit_depth - 8));
+    y.wy = 1.0f / (scale * 219.0f);
+    y.wc = 1.0f / (scale * 224.0f);
+    for (int i = 0; i < 9; ++i) y.m[i] = fmt->ycbcr2rgb[i];
+    y.out = d_rgb_scratch;
+    const dim3 block(256), g1((unsigned)(((long long)W * H + 255) / 256));
+    if (fmt->bit_depth > 8) hipLaunchKernelGGL((yuv_rgb_planar_kernel<unsigned short>), g1, block, 0, st, y);
+    else hipLaunchKernelGGL((yuv_rgb_planar_kernel<unsigned char>), g1, block, 0, st, y);
+    ResizeArgs r;
+    memset(&r, 0, sizeof(r));
+    r.rgb = d_rgb_scratch;
+    r.W = W; r.H = H; r.Wo = out_w; r.Ho = out_h;
+    r.sx = (float)W / (float)out_w;
+    r.sy = (float)H / (float)out_h;
+    r.e = make_eotf(eotf);
+    r.w[0] = h_rgb2y[0]; r.w[1] = h_rgb2y[1]; r.w[2] = h_rgb2y[2];
+    r.lum = d_lum;
+    r.rgb_out = d_rgb_out;
+    const dim3 g2((unsigned)(((long long)out_w * out_h + 255) / 256));
+    switch (mode) {
+        case FVVDP_RESIZE_NEAREST: hipLaunchKernelGGL((resize_lum_kernel<FVVDP_RESIZE_NEAREST>), g2, block, 0, st, r); break;
+        case FVVDP_RESIZE_BILINEAR: hipLaunchKernelGGL((resize_lum_kernel<FVVDP_RESIZE_BILINEAR>), g2, block, 0, st, r); break;
+        case FVVDP_RESIZE_BICUBIC: hipLaunchKernelGGL((resize_lum_kernel<FVVDP_RESIZE_BICUBIC>), g2, block, 0, st, r); break;
+        default: hipLaunchKernelGGL((resize_lum_kernel<FVVDP_RESIZE_AREA>), g2, block, 0, st, r); break;
+    }
+    HIP_TRY(hipGetLastError());
+    return FVVDP_OK;
 }
 
 extern "C" int fvvdp_pu21_sse(const void* d_test, const void* d_ref, int dtype, int C, size_t chan_stride,

@@ -195,7 +195,7 @@ typedef struct fvvdp_yuv_format {
 /* Replaces video_reader_yuv_pytorch.unpack + _fixed2float_upscale (video_source_file.py:219-276),
  * fvvdp_video_source_video_file._prepare_frame (:355-363) and the temporal filter (fvvdp.py:258-300): like
  * fvvdp_temporal_channels, but the source frames are raw planar YUV.  frame_stride in elements; the display model
- * must be closed-form (kind != FVVDP_EOTF_LUT); full-screen resizing is not supported.  Up to 64 taps (256 fps): 1..32 taps in
+ * must be closed-form (kind != FVVDP_EOTF_LUT); full-screen resizing: fvvdp_yuv_frame_resized below.  Up to 64 taps (256 fps): 1..32 taps in
  * one pass, 33..64 in two (YUV frames -> luminance frames once, then the 64-slot ring), FVVDP_EINVAL above. */
 int fvvdp_temporal_channels_yuv(fvvdp_ctx* ctx, const void* d_test, const void* d_ref, const fvvdp_yuv_format* fmt,
                                 size_t frame_stride, const fvvdp_eotf* eotf, const float* h_rgb2y,
@@ -322,6 +322,21 @@ int fvvdp_pu21_sse(const void* d_test, const void* d_ref, int dtype, int channel
                    size_t frame_stride, size_t n_pixels, const fvvdp_eotf* eotf, const float* h_rgb2y,
                    const fvvdp_pu21* pu, int n_frames, double* d_partial, double* d_sse, int32_t* d_oob_flag,
                    void* stream);
+
+
+/* ---- Full-screen resize of planar YUV frames ("optional interpolate resize") ---------
+ * Replaces video_reader_yuv_pytorch.unpack WITH resize_fn (pyfvvdp/video_source_file.py:219-244: unpack to RGB without
+ * clipping, torch.nn.functional.interpolate(RGB, size=(out_h, out_w), mode=..., align_corners=False), clip to [0,1]) and
+ * fvvdp_video_source_video_file._prepare_frame (:355-363: display model, RGB -> luminance) for ONE frame of ONE stream --
+ * what the CLI's --full-screen-resize does per frame (run_fvvdp.py:84, :209-210).  Stateless.  d_frame: Y, U, V planes as
+ * in fvvdp_temporal_channels_yuv; d_rgb_scratch: workspace of 3*W*H floats (the unclipped RGB planes at the source
+ * resolution); d_lum: out_h*out_w floats, the luminance frame a video source hands to the metric (get_*_frame); d_rgb_out:
+ * optional 3*out_h*out_w floats, the clipped RGB planes [3][out_h][out_w] (= unpack's return value, for parity tests).
+ * The display model must be closed-form (kind != FVVDP_EOTF_LUT).  'area' is adaptive average pooling, as in torch.     */
+enum { FVVDP_RESIZE_NEAREST = 0, FVVDP_RESIZE_BILINEAR = 1, FVVDP_RESIZE_BICUBIC = 2, FVVDP_RESIZE_AREA = 3 };
+int fvvdp_yuv_frame_resized(const void* d_frame, const fvvdp_yuv_format* fmt, int W, int H, float* d_rgb_scratch,
+                            int out_w, int out_h, int mode, const fvvdp_eotf* eotf, const float* h_rgb2y,
+                            float* d_lum, float* d_rgb_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -249,9 +249,71 @@ def frame_luminance(arr_bcfhw, f, photometry, rgb2y):
     return L[0, 0, 0].astype(_F), oob
 
 
-def yuv_unpack(frame, W, H, bit_depth, chroma_ss, color_space):
+def torch_interpolate(img, out_h, out_w, mode):
+    """torch.nn.functional.interpolate(img[None], size=(out_h, out_w), mode=mode) for img [C,H,W] fp32 with the defaults the reference
+    uses (align_corners=False, no antialiasing; pyfvvdp/video_source_file.py:240-242) -- a restatement of ATen's index arithmetic
+    (aten/src/ATen/native/UpSample.h: area_pixel_compute_scale / _source_index, nearest_neighbor_compute_source_index,
+    guard_index_and_lambda, get_cubic_upsample_coefficients with A = -0.75; adaptive average pooling for 'area')."""
+    img = np.asarray(img, dtype=_F)
+    C, H, W = img.shape
+    sy, sx = _F(H) / _F(out_h), _F(W) / _F(out_w)
+    oy, ox = np.arange(out_h, dtype=_F), np.arange(out_w, dtype=_F)
+    if mode == "nearest":
+        iy = np.minimum(np.floor(oy * sy).astype(np.int64), H - 1)
+        ix = np.minimum(np.floor(ox * sx).astype(np.int64), W - 1)
+        return img[:, iy][:, :, ix].astype(_F)
+    if mode == "bilinear":
+        def axis(o, s, n):
+            src = np.maximum(s * (o + _F(0.5)) - _F(0.5), _F(0)).astype(_F)
+            i0 = np.minimum(src.astype(np.int64), n - 1)
+            i1 = i0 + (i0 < n - 1)
+            l1 = np.clip(src - i0.astype(_F), 0, 1).astype(_F)
+            return i0, i1, (_F(1) - l1).astype(_F), l1
+        y0, y1, ly0, ly1 = axis(oy, sy, H)
+        x0, x1, lx0, lx1 = axis(ox, sx, W)
+        ly0, ly1 = ly0[None, :, None], ly1[None, :, None]
+        top = lx0 * img[:, y0][:, :, x0] + lx1 * img[:, y0][:, :, x1]
+        bot = lx0 * img[:, y1][:, :, x0] + lx1 * img[:, y1][:, :, x1]
+        return (ly0 * top + ly1 * bot).astype(_F)
+    if mode == "bicubic":
+        A = _F(-0.75)
+
+        def coeffs(t):
+            cc1 = lambda x: ((A + _F(2)) * x - (A + _F(3))) * x * x + _F(1)
+            cc2 = lambda x: ((A * x - _F(5) * A) * x + _F(8) * A) * x - _F(4) * A
+            return [cc2(t + _F(1)), cc1(t), cc1(_F(1) - t), cc2(_F(2) - t)]
+
+        def axis(o, s, n):
+            src = (s * (o + _F(0.5)) - _F(0.5)).astype(_F)             # cubic: the coordinate is NOT clamped, every tap index is
+            fl = np.floor(src)
+            idx = [np.clip(fl.astype(np.int64) - 1 + k, 0, n - 1) for k in range(4)]
+            return idx, [c.astype(_F) for c in coeffs((src - fl).astype(_F))]
+        ys, cy = axis(oy, sy, H)
+        xs, cx = axis(ox, sx, W)
+        out = None
+        for k in range(4):                                              # x along each of the four rows, then y
+            rows = img[:, ys[k]]
+            row = ((rows[:, :, xs[0]] * cx[0] + rows[:, :, xs[1]] * cx[1]) + rows[:, :, xs[2]] * cx[2]) + rows[:, :, xs[3]] * cx[3]
+            term = row * cy[k][None, :, None]
+            out = term if out is None else out + term
+        return out.astype(_F)
+    if mode == "area":
+        def win(o, n_in, n_out):
+            return (int(np.floor(_F(o * n_in) / _F(n_out))), int(np.ceil(_F((o + 1) * n_in) / _F(n_out))))
+        out = np.empty((C, out_h, out_w), dtype=_F)
+        wy = [win(o, H, out_h) for o in range(out_h)]
+        wx = [win(o, W, out_w) for o in range(out_w)]
+        for j, (a0, a1) in enumerate(wy):
+            for i, (b0, b1) in enumerate(wx):
+                out[:, j, i] = img[:, a0:a1, b0:b1].sum(axis=(1, 2), dtype=_F) / _F((a1 - a0) * (b1 - b0))
+        return out
+    raise RuntimeError("Unknown resize method '%s'" % mode)
+
+
+def yuv_unpack(frame, W, H, bit_depth, chroma_ss, color_space, resize_fn=None, resize_hw=None):
     """video_reader_yuv_pytorch.unpack + _fixed2float_upscale, pyfvvdp/video_source_file.py:219-276.
-    frame: 1-D uint8/uint16 (Y plane, U plane, V plane) -> RGB [H,W,3] fp32 in [0,1]."""
+    frame: 1-D uint8/uint16 (Y plane, U plane, V plane) -> RGB [H,W,3] fp32 in [0,1]; with resize_fn / resize_hw = (height, width):
+    resized in RGB before the clip (:238-244)."""
     ypx = W * H
     uvh, uvw = (H // 2, W // 2) if chroma_ss == "420" else (H, W)
     x = frame.astype(_F)
@@ -277,7 +339,10 @@ def yuv_unpack(frame, W, H, bit_depth, chroma_ss, color_space):
         M = np.array([[1, 0, 1.47460], [1, -0.16455, -0.57135], [1, 1.88140, 0]], dtype=_F)
     else:
         M = np.array([[1, 0, 1.402], [1, -0.344136, -0.714136], [1, 1.772, 0]], dtype=_F)
-    return np.clip(Yuv @ M.T, 0, 1).astype(_F)                                                          # :237,244
+    RGB = (Yuv @ M.T).astype(_F)                                                                       # :237
+    if resize_fn is not None and tuple(resize_hw) != (H, W):                                           # :238-243
+        RGB = torch_interpolate(RGB.transpose(2, 0, 1), resize_hw[0], resize_hw[1], resize_fn).transpose(1, 2, 0)
+    return np.clip(RGB, 0, 1).astype(_F)                                                                # :244
 
 
 # --------------------------------------------------------------------------------------------------------
@@ -649,11 +714,15 @@ class Oracle:
         return Q
 
     def predict_yuv(self, test_yuv, ref_yuv, frames_per_second, W, H, bit_depth=8, chroma_ss="420", color_space="bt709",
-                    fixation_point=None, frames=None):
+                    fixation_point=None, frames=None, full_screen_resize=None, resize_resolution=None):
         """Raw planar YUV frames [N, frame_elems] through unpack -> photometry -> luminance
-        (fvvdp_video_source_video_file._prepare_frame, pyfvvdp/video_source_file.py:355-363), then the usual path."""
+        (fvvdp_video_source_video_file._prepare_frame, pyfvvdp/video_source_file.py:355-363), then the usual path.
+        full_screen_resize / resize_resolution = (width, height): the CLI's --full-screen-resize (run_fvvdp.py:84, :209-210)."""
+        rhw = None if full_screen_resize is None else (int(resize_resolution[1]), int(resize_resolution[0]))
+
         def to_rgb(arr):
-            vid = np.stack([yuv_unpack(arr[f], W, H, bit_depth, chroma_ss, color_space) for f in range(arr.shape[0])], 0)
+            vid = np.stack([yuv_unpack(arr[f], W, H, bit_depth, chroma_ss, color_space, full_screen_resize, rhw)
+                            for f in range(arr.shape[0])], 0)
             return np.ascontiguousarray(vid.transpose(3, 0, 1, 2)[None])           # [1,3,N,H,W] fp32
         return self.predict(to_rgb(np.asarray(test_yuv)), to_rgb(np.asarray(ref_yuv)), "BCFHW", frames_per_second,
                             fixation_point, frames)

@@ -43,7 +43,7 @@ def test_library_exports_every_declared_symbol():
     nat.build()                                    # hipcc cross-compiles for gfx950 without a GPU
     L = ctypes.CDLL(nat.LIB_PATH)
     declared = header_functions()
-    assert len(declared) == 23
+    assert len(declared) == 24
     for name in declared:
         assert hasattr(L, name), "libfvvdp_hip.so does not export " + name
     assert sorted(nat.SYMBOLS) == declared         # the ctypes binding covers exactly the header

@@ -443,6 +443,33 @@ def test_yuv_ingest_g7(tag):
     assert np.all(np.abs(q - gq) <= 4e-3 * np.abs(gq) + 1e-6 * np.max(gq))     # tiny frames: coarse bands are a few pixels
 
 
+RESIZE_CASES = {"bilinear_up": "bilinear", "bicubic_up": "bicubic", "nearest_up": "nearest", "area_down": "area",
+                "bicubic_down": "bicubic", "bilinear_down": "bilinear"}
+
+
+@pytest.mark.parametrize("tag", list(RESIZE_CASES))
+def test_yuv_full_screen_resize_g17(tag):
+    """SURVEY 8(f) rank 2, "optional interpolate resize": the oracle's restatement of torch's interpolate (bilinear, bicubic, nearest,
+    area; align_corners=False) inside unpack, against the reference's own unpack with resize_fn (video_source_file.py:238-244, run without
+    ffmpeg by tools/gen_golden.py g17): the clipped RGB of a frame, and the metric on the resized clip for the two scored cases."""
+    z = load("g17_yuv_resize")
+    N, H, W, bd, c420, c2020, fps, Ho, Wo = (int(v) for v in z[f"{tag}_cfg"])
+    css, cs = ("420" if c420 else "444"), ("bt2020nc" if c2020 else "bt709")
+    fn = RESIZE_CASES[tag]
+    t, r = yuv_arrays(N, H, W, bd, css)
+    rgb = orc.yuv_unpack(t[1], W, H, bd, css, cs, fn, (Ho, Wo))
+    assert rgb.shape == (Ho, Wo, 3)
+    # measured: nearest 0 (the same samples), area 2e-7, bilinear 1.5e-6, bicubic 2.5e-6 (torch's CPU kernels associate differently)
+    assert np.max(np.abs(rgb - z[f"{tag}_rgb_f1"])) < (1e-7 if fn == "nearest" else 8e-6), float(np.max(np.abs(rgb - z[f"{tag}_rgb_f1"])))
+    if f"{tag}_jod" in z.files:
+        disp = "standard_hdr_pq" if c2020 else "standard_fhd"
+        o = orc.Oracle(disp, color_space="BT.2020" if c2020 else "sRGB")
+        jod, st = o.predict_yuv(t, r, fps, W, H, bd, css, cs, full_screen_resize=fn, resize_resolution=(Wo, Ho))
+        assert abs(float(jod) - float(z[f"{tag}_jod"])) < 5e-5
+        q, gq = st["Q_per_ch"].astype(np.float64), z[f"{tag}_Q"].astype(np.float64)
+        assert np.all(np.abs(q - gq) <= 4e-3 * np.abs(gq) + 1e-6 * np.max(gq))
+
+
 def test_pu21_psnr_oracle_vs_reference():
     """the PU21-PSNR side metric of the oracle against values produced by the reference's
     pu_psnr.predict_video_source and PU.encode (golden g8)."""

@@ -397,6 +397,67 @@ def g7(pyfvvdp):
     save("g7_yuv_ingest", out)
 
 
+def g17(pyfvvdp):
+    """Full-screen resize of raw planar YUV frames (the CLI's --full-screen-resize, run_fvvdp.py:84, :209-210): the reference's
+    video_reader_yuv_pytorch.unpack WITH resize_fn (video_source_file.py:238-244) on synthetic frames -- the four methods, enlarging and
+    shrinking, 8-bit 4:2:0 BT.709 and 10-bit 4:4:4 BT.2020 -- through a reader object built without ffmpeg; the clipped RGB of frame 1 and
+    its luminance for every case, and the metric's JOD / Q_per_ch on the resized clip for two of them."""
+    from fovvideovdp_amd.synth import synth_yuv_pair
+    import pyfvvdp.video_source_file as vsf
+    from pyfvvdp.video_source import fvvdp_video_source_dm, reshuffle_dims
+    out = {}
+    cases = {"bilinear_up": (6, 48, 80, 8, "420", "bt709", "standard_fhd", 30, "bilinear", 90, 150, True),
+             "bicubic_up": (6, 48, 80, 8, "420", "bt709", "standard_fhd", 30, "bicubic", 96, 160, True),
+             "nearest_up": (3, 48, 80, 8, "420", "bt709", "standard_fhd", 30, "nearest", 77, 131, False),
+             "area_down": (3, 54, 96, 10, "444", "bt2020nc", "standard_hdr_pq", 60, "area", 36, 64, False),
+             "bicubic_down": (3, 54, 96, 10, "444", "bt2020nc", "standard_hdr_pq", 60, "bicubic", 40, 70, False),
+             "bilinear_down": (3, 54, 96, 10, "444", "bt2020nc", "standard_hdr_pq", 60, "bilinear", 31, 52, False)}
+    for tag, (N, H, W, bd, css, cs, disp, fps, fn, Ho, Wo, score) in cases.items():
+        ty, ry = synth_yuv_pair(N, H, W, bit_depth=bd, chroma_ss=css)
+        tnp = ty.numpy() if bd == 8 else ty.numpy().astype(np.uint16)
+        rnp = ry.numpy() if bd == 8 else ry.numpy().astype(np.uint16)
+        rd = object.__new__(vsf.video_reader_yuv_pytorch)
+        rd.width, rd.height, rd.bit_depth, rd.chroma_ss, rd.color_space = W, H, bd, css, cs
+        rd.y_pixels, rd.y_shape = W * H, (H, W)
+        rd.uv_shape = (H // 2, W // 2) if css == "420" else (H, W)
+        rd.uv_pixels = rd.uv_shape[0] * rd.uv_shape[1]
+        rd.resize_fn, rd.resize_height, rd.resize_width = fn, Ho, Wo
+
+        class Src(fvvdp_video_source_dm):
+            def __init__(self):
+                super().__init__(display_photometry=disp, color_space_name="BT.2020" if cs == "bt2020nc" else "sRGB")
+
+            def get_video_size(self):
+                return (Ho, Wo, N)
+
+            def get_frames_per_second(self):
+                return fps
+
+            def _fr(self, arr, f, device):
+                t = reshuffle_dims(rd.unpack(arr[f], device), in_dims='HWC', out_dims="BCFHW")
+                L = self.dm_photometry.forward(t)
+                c = self.color_to_luminance
+                return L[:, 0:1] * c[0] + L[:, 1:2] * c[1] + L[:, 2:3] * c[2]
+
+            def get_test_frame(self, f, device):
+                return self._fr(tnp, f, device)
+
+            def get_reference_frame(self, f, device):
+                return self._fr(rnp, f, device)
+
+        out[f"{tag}_cfg"] = np.array([N, H, W, bd, 1 if css == "420" else 0, 1 if cs == "bt2020nc" else 0, fps, Ho, Wo], dtype=np.int32)
+        out[f"{tag}_rgb_f1"] = rd.unpack(tnp[1], torch.device("cpu")).numpy()
+        out[f"{tag}_lum_f1"] = Src().get_test_frame(1, torch.device("cpu"))[0, 0, 0].numpy()
+        if score:
+            fv = pyfvvdp.fvvdp(display_name=disp, heatmap=None, device=torch.device("cpu"), quiet=True)
+            with torch.no_grad():
+                q, st = fv.predict_video_source(Src())
+            out[f"{tag}_jod"] = np.float32(q.item())
+            out[f"{tag}_Q"] = st["Q_per_ch"]
+            print("g17", tag, "JOD", out[f"{tag}_jod"])
+    save("g17_yuv_resize", out)
+
+
 def g8(pyfvvdp):
     """PU21-PSNR side metric (pupsnr.py:52-79, utils.py:157-202): the reference's pu_psnr.predict_video_source on
     array sources built by hand (its own predict() cannot run: it reads attributes that are never set, pupsnr.py:45),
@@ -692,6 +753,8 @@ def main():
             g15(pyfvvdp)
         elif w == "g16":
             g16(pyfvvdp)
+        elif w == "g17":
+            g17(pyfvvdp)
         else:
             raise SystemExit("unknown case " + w)
         print(w, "done in %.1f s" % (time.time() - t0), flush=True)
