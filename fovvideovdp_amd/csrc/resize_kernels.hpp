@@ -127,14 +127,15 @@ __global__ __launch_bounds__(256) void resize_lum_kernel(const ResizeArgs a) {
         const int y0 = (int)floorf((float)(oy * a.H) / (float)a.Ho), y1 = (int)ceilf((float)((oy + 1) * a.H) / (float)a.Ho);
         const int x0 = (int)floorf((float)(ox * a.W) / (float)a.Wo), x1 = (int)ceilf((float)((ox + 1) * a.W) / (float)a.Wo);
         const float n = (float)((y1 - y0) * (x1 - x0));
+        float acc[3] = {0.0f, 0.0f, 0.0f};
+        for (int yy = y0; yy < y1; ++yy)               // the three planes side by side: three loads in flight per step instead of one
+            for (int xx = x0; xx < x1; ++xx) {
+                const size_t q = (size_t)yy * a.W + xx;
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const float* P = a.rgb + c * HW;
-            float acc = 0.0f;
-            for (int yy = y0; yy < y1; ++yy)
-                for (int xx = x0; xx < x1; ++xx) acc += P[(size_t)yy * a.W + xx];
-            v[c] = acc / n;
-        }
+                for (int c = 0; c < 3; ++c) acc[c] += a.rgb[c * HW + q];
+            }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[c] = acc[c] / n;
     }
     const size_t OHW = (size_t)a.Wo * a.Ho;
     bool bad = false;
