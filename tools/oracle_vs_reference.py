@@ -7,7 +7,8 @@ usage: tools/oracle_vs_reference.py [cases] [seed]          (RGB / gray arrays, 
        tools/oracle_vs_reference.py yuv [cases] [seed]      (raw planar YUV through the reference's video_reader_yuv_pytorch.unpack,
                                                              generator of gpu_stress_yuv.py)
        tools/oracle_vs_reference.py shapes                  (the extreme frame shapes of gpu_stress_shapes.py, image and 5-frame video)
-       tools/oracle_vs_reference.py heat [cases] [seed]     ('raw' difference maps, generator of gpu_stress_heat.py)"""
+       tools/oracle_vs_reference.py heat [cases] [seed]     ('raw' difference maps, generator of gpu_stress_heat.py)
+       tools/oracle_vs_reference.py resize [cases] [seed]   (unpack with resize_fn: the full-screen resize, random sizes and formats)"""
 import os, sys, types, logging
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -236,6 +237,39 @@ def main_heat():
           "| worst %.2f fp16 ulp (%s) | worst mean abs %.2e (%s)" % (worst[0], worst[1], worst_m[0], worst_m[1]))
 
 
+def main_resize():
+    """The full-screen resize: oracle.yuv_unpack with resize_fn against the reference's video_reader_yuv_pytorch.unpack with resize_fn
+    (video_source_file.py:238-244) on random source / target sizes, bit depths, subsamplings and colour matrices."""
+    n_cases = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 6617
+    import_reference()
+    import pyfvvdp.video_source_file as vsf
+    from fovvideovdp_amd.synth import synth_yuv_pair
+    rng = np.random.default_rng(seed)
+    worst = {}
+    for k in range(n_cases):
+        fn = ("bilinear", "bicubic", "nearest", "area")[k % 4]
+        bd, css = ((8, "420"), (10, "444"), (12, "420"), (16, "444"))[rng.integers(0, 4)]
+        cs = ("bt709", "bt2020nc")[rng.integers(0, 2)]
+        H, W = 2 * int(rng.integers(5, 40)), 2 * int(rng.integers(5, 60))
+        Ho, Wo = int(rng.integers(7, 130)), int(rng.integers(7, 170))
+        ty, _ = synth_yuv_pair(2, H, W, bit_depth=bd, chroma_ss=css)
+        a = ty.numpy() if bd == 8 else ty.numpy().astype(np.uint16)
+        rd = object.__new__(vsf.video_reader_yuv_pytorch)
+        rd.width, rd.height, rd.bit_depth, rd.chroma_ss, rd.color_space = W, H, bd, css, cs
+        rd.y_pixels, rd.y_shape = W * H, (H, W)
+        rd.uv_shape = (H // 2, W // 2) if css == "420" else (H, W)
+        rd.uv_pixels = rd.uv_shape[0] * rd.uv_shape[1]
+        rd.resize_fn, rd.resize_height, rd.resize_width = fn, Ho, Wo
+        ref = rd.unpack(a[1], torch.device("cpu")).numpy()
+        o = orc.yuv_unpack(a[1], W, H, bd, css, cs, fn, (Ho, Wo))
+        worst[fn] = max(worst.get(fn, 0.0), float(np.abs(ref - o).max()))
+    fails = sum(v > 8e-6 for v in worst.values())
+    print("resize cases %d seed %d fails %d | worst |dRGB| per method: %s" % (
+        n_cases, seed, fails, ", ".join("%s %.2e" % kv for kv in sorted(worst.items()))))
+
+
 if __name__ == "__main__":
     mode = sys.argv[1] if len(sys.argv) > 1 else ""
-    main_yuv() if mode == "yuv" else main_shapes() if mode == "shapes" else main_heat() if mode == "heat" else main()
+    (main_yuv() if mode == "yuv" else main_shapes() if mode == "shapes" else main_heat() if mode == "heat" else
+     main_resize() if mode == "resize" else main())
