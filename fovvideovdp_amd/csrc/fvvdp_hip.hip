@@ -1013,8 +1013,8 @@ extern "C" int fvvdp_yuv_frame_resized(const void* d_frame, const fvvdp_yuv_form
                                        int out_w, int out_h, int mode, const fvvdp_eotf* eotf, const float* h_rgb2y,
                                        float* d_lum, float* d_rgb_out, void* stream) {
     if (!d_frame || !fmt || !d_rgb_scratch || !eotf || !h_rgb2y || !d_lum) return fail(FVVDP_EINVAL, "null argument");
-    if (W < 1 || H < 1 || out_w < 1 || out_h < 1 || (long long)W * H > 0x3FFFFFFF || (long long)out_w * out_h > 0x3FFFFFFF)
-        return fail(FVVDP_EINVAL, "frame size out of range");
+    if (W < 1 || H < 1 || out_w < 1 || out_h < 1 || W > 32768 || H > 32768 || out_w > 32768 || out_h > 32768)
+        return fail(FVVDP_EINVAL, "frame size out of range (1..32768 per axis)");        // index products stay inside 31 bits
     if (fmt->bit_depth < 8 || fmt->bit_depth > 16) return fail(FVVDP_EINVAL, "bit depth %d not supported", fmt->bit_depth);
     if (fmt->chroma_420 && ((W | H) & 1)) return fail(FVVDP_EINVAL, "4:2:0 needs even frame dimensions");
     if (mode < FVVDP_RESIZE_NEAREST || mode > FVVDP_RESIZE_AREA) return fail(FVVDP_EINVAL, "unknown resize mode %d", mode);

@@ -128,10 +128,15 @@ class fvvdp_video_source_yuv_frames(fvvdp_video_source_dm):
         wo, ho = self.resize_resolution
         with torch.cuda.device(device):
             x = frames[frame].to(device, non_blocking=True).contiguous()
-            ws = self._resize_ws.get(device)
-            if ws is None:                                # the unclipped RGB planes at the source resolution: reused by every frame
+            # workspace = the unclipped RGB planes at the source resolution, reused by every frame fetched on the same stream (stream order
+            # keeps two frames apart; callers that fetch on several streams get one workspace per stream)
+            wkey = (device, torch.cuda.current_stream(device).cuda_stream)
+            ws = self._resize_ws.get(wkey)
+            if ws is None:
+                if len(self._resize_ws) >= 4:
+                    self._resize_ws.clear()
                 ws = torch.empty(3 * self.height * self.width, dtype=torch.float32, device=device)
-                self._resize_ws[device] = ws
+                self._resize_ws[wkey] = ws
             lum = torch.empty((1, 1, 1, ho, wo), dtype=torch.float32, device=device)
             rgb = torch.empty((3, ho, wo), dtype=torch.float32, device=device) if want_rgb else None
             fmt = nat.YuvFormat()
